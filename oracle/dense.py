@@ -1,0 +1,175 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+CPU restatement of the dense half of the hot path, written with plain torch CPU tensor ops in
+float64 or float32 (this is the "torch fp32 reference" the floating-point kernels are compared
+against; tolerance is stated in the tests):
+
+  encoder      reference src/core/modules/temporal.py:128-147 (WaveNetBlock.forward),
+               :43-53 (WaveNetLayer.forward)
+  wrapper      reference src/mucon/models.py:746-773 (temporal_modeling_forward: GroupNorm, ReLU,
+               Dropout -- dropout is identity here: the oracle is the eval()-mode function)
+  y-head       reference src/mucon/models.py:567-582 (nearest interpolate + 1x1 conv) and the
+               log-softmax of :367-368 / :403-405
+
+Parameters are a dict keyed by the reference's state_dict names (ft.first_conv.weight, ft.l_3.
+dilated_conv.weight, ft.l_3.conv_1x1.bias, ft.last_conv.*, ft_last_gn.*, conv_classifier.*), in
+the reference's layouts ([out, in, k] for convs).  Activations here are time-major [B, T, H] --
+the layout the HIP kernels use -- instead of the reference's [B, H, T].
+
+Parity pin: tests/golden/dense_*.npz (outputs of the reference MuCon modules on seeded inputs,
+made by tools/make_golden_dense.py); checked in tests/test_oracle_dense.py.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+
+@dataclass
+class EncoderConfig:
+    """The cfg.model.ft.* keys the path depends on (reference configs/mucon/default.py:81-96)."""
+    in_dim: int = 2048
+    hidden: int = 128
+    num_classes: int = 48
+    stages: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])
+    pooling: bool = True
+    pooling_type: str = "max"
+    pooling_layers: List[int] = field(default_factory=lambda: [1, 2, 4, 8])
+    leaky_relu: bool = False
+    last_gn: bool = True
+    last_gn_num_groups: int = 32
+    last_relu: bool = True
+    gn_eps: float = 1e-5
+
+    def out_length(self, T: int) -> int:
+        for i in range(len(self.stages)):
+            if self.pooling and i in self.pooling_layers:
+                T = T // 2
+        return T
+
+
+def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
+    H, D, C = cfg.hidden, cfg.in_dim, cfg.num_classes
+    s = {"ft.first_conv.weight": (H, D, 1), "ft.first_conv.bias": (H,)}
+    for i in range(len(cfg.stages)):
+        s[f"ft.l_{i}.dilated_conv.weight"] = (H, H, 3)
+        s[f"ft.l_{i}.dilated_conv.bias"] = (H,)
+        s[f"ft.l_{i}.conv_1x1.weight"] = (H, H, 1)
+        s[f"ft.l_{i}.conv_1x1.bias"] = (H,)
+    s["ft.last_conv.weight"] = (H, H, 1)
+    s["ft.last_conv.bias"] = (H,)
+    s["ft_last_gn.weight"] = (H,)
+    s["ft_last_gn.bias"] = (H,)
+    s["conv_classifier.weight"] = (C, H, 1)
+    s["conv_classifier.bias"] = (C,)
+    return s
+
+
+def seeded_params(cfg: EncoderConfig, seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic, platform-independent parameters: uniform[-1,1) * 2^-k with 2^-k ~ 1/sqrt(fan_in)
+    (GroupNorm weight is 1 + 0.25*u so it stays positive-ish).  Same recipe in make_golden_dense.py."""
+    from mucon_amd import synth
+
+    out = {}
+    for i, (name, shape) in enumerate(param_shapes(cfg).items()):
+        u = synth.uniform_pm1(seed * 1000 + i, shape)
+        if name.endswith("weight") and len(shape) == 3:
+            fan_in = shape[1] * shape[2]
+            scale = np.float32(2.0 ** -int(round(np.log2(np.sqrt(fan_in)))))
+            out[name] = (u * scale).astype(np.float32)
+        elif name == "ft_last_gn.weight":
+            out[name] = (np.float32(1.0) + np.float32(0.25) * u).astype(np.float32)
+        else:
+            out[name] = (u * np.float32(0.125)).astype(np.float32)
+    return out
+
+
+def _act(x, leaky):
+    return torch.nn.functional.leaky_relu(x) if leaky else torch.relu(x)  # default slope 0.01
+
+
+def _conv_time_major(x, w, b, dilation=1):
+    """x [B,T,Cin], w [Cout,Cin,k] (k in {1,3}), zero padding = dilation for k=3 (temporal.py:23-29)."""
+    k = w.shape[2]
+    if k == 1:
+        return x @ w[:, :, 0].T + b
+    B, T, _ = x.shape
+    y = x @ w[:, :, 1].T + b
+    d = dilation
+    if d < T:
+        y[:, d:, :] += x[:, : T - d, :] @ w[:, :, 0].T   # tap 0 reads x[t-d]
+        y[:, : T - d, :] += x[:, d:, :] @ w[:, :, 2].T   # tap 2 reads x[t+d]
+    return y
+
+
+def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, return_intermediates=False):
+    """tape [B,T,D] -> enc [B,Tz,H].  Restates temporal.py:128-147 + models.py:759-764 (eval mode)."""
+    p = params
+    inter = {}
+    x = _act(_conv_time_major(tape, p["ft.first_conv.weight"], p["ft.first_conv.bias"]), cfg.leaky_relu)
+    inter["x0"] = x
+    for i, d in enumerate(cfg.stages):
+        h = _act(_conv_time_major(x, p[f"ft.l_{i}.dilated_conv.weight"], p[f"ft.l_{i}.dilated_conv.bias"], d),
+                 cfg.leaky_relu)
+        y = _conv_time_major(h, p[f"ft.l_{i}.conv_1x1.weight"], p[f"ft.l_{i}.conv_1x1.bias"]) + x
+        if cfg.pooling and i in cfg.pooling_layers:
+            Tl = y.shape[1] // 2
+            a, b = y[:, 0:2 * Tl:2, :], y[:, 1:2 * Tl:2, :]
+            y = torch.maximum(a, b) if cfg.pooling_type == "max" else (a + b) / 2 * 2  # avg_pool1d * 2
+        x = y
+        inter[f"x{i + 1}"] = x
+    z = _conv_time_major(_act(x, cfg.leaky_relu), p["ft.last_conv.weight"], p["ft.last_conv.bias"])
+    inter["z"] = z
+    if cfg.last_gn:
+        B, Tz, H = z.shape
+        G = cfg.last_gn_num_groups
+        zg = z.reshape(B, Tz, G, H // G)
+        mean = zg.mean(dim=(1, 3), keepdim=True)
+        var = zg.var(dim=(1, 3), unbiased=False, keepdim=True)
+        z = ((zg - mean) / torch.sqrt(var + cfg.gn_eps)).reshape(B, Tz, H) * p["ft_last_gn.weight"] + p["ft_last_gn.bias"]
+    if cfg.last_relu:
+        z = torch.relu(z)
+    return (z, inter) if return_intermediates else z
+
+
+def nearest_index(Tz: int, Tf: int) -> np.ndarray:
+    """Source index of F.interpolate(mode='nearest') (models.py:574): min(floor(i * (Tz/Tf)), Tz-1),
+    the scale and the product taken in float32 as torch does."""
+    scale = np.float32(Tz) / np.float32(Tf)
+    idx = np.floor(np.arange(Tf, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(idx, Tz - 1)
+
+
+def head_forward(enc, params, cfg: EncoderConfig, Tf: int):
+    """enc [B,Tz,H] -> (logits [B,Tf,C], logp [B,Tf,C]).  models.py:574-580 then log_softmax (:368)."""
+    idx = torch.from_numpy(nearest_index(enc.shape[1], Tf))
+    up = enc[:, idx, :]
+    logits = up @ params["conv_classifier.weight"][:, :, 0].T + params["conv_classifier.bias"]
+    return logits, torch.log_softmax(logits, dim=-1)
+
+
+def to_torch(params_np, dtype=torch.float64, requires_grad=False):
+    return {k: torch.tensor(v, dtype=dtype, requires_grad=requires_grad) for k, v in params_np.items()}
+
+
+def hot_path(tape_np, params_np, cfg: EncoderConfig, dtype=torch.float64):
+    """Convenience: numpy in, numpy out (enc, logits, logp)."""
+    p = to_torch(params_np, dtype)
+    tape = torch.tensor(tape_np, dtype=dtype)
+    enc = encoder_forward(tape, p, cfg)
+    logits, logp = head_forward(enc, p, cfg, tape.shape[1])
+    return enc.numpy(), logits.numpy(), logp.numpy()
+
+
+def hot_path_grads(tape_np, params_np, cfg: EncoderConfig, w_logp, w_enc, dtype=torch.float64):
+    """Gradients of L = sum(w_logp * logp) + sum(w_enc * enc) w.r.t. every parameter (autograd on the
+    restatement; the restatement itself is pinned by the forward goldens and by the reference's
+    gradients stored in tests/golden/dense_grads.npz)."""
+    p = to_torch(params_np, dtype, requires_grad=True)
+    tape = torch.tensor(tape_np, dtype=dtype)
+    enc = encoder_forward(tape, p, cfg)
+    _, logp = head_forward(enc, p, cfg, tape.shape[1])
+    L = (torch.tensor(w_logp, dtype=dtype) * logp).sum() + (torch.tensor(w_enc, dtype=dtype) * enc).sum()
+    L.backward()
+    return {k: v.grad.numpy() for k, v in p.items()}, float(L.detach())
