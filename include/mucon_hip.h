@@ -1,0 +1,170 @@
+/* mucon_hip.h -- C ABI of libmucon_hip.so: the MI355X (gfx950) hot path of MuCon.
+ *
+ * The reference (yassersouri/MuCon) is pure Python and has no FFI seam; its seam for this path is
+ * a Python class surface.  Each entry point below replaces the arithmetic behind
+ * one reference call site; mucon_amd/ mirrors the reference's classes on top of it and
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *     the caller owns all buffers; the library allocates nothing persistent.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work on it and returns (no host synchronisation), except where stated.
+ *   - return value: 0 on success, negative MUCON_E_* on error; mucon_last_error() gives the text.
+ *   - activations are time-major [B][T][channels] float32; weights keep the reference's
+ *     nn.Conv1d layout [out][in][k] so a reference state_dict can be passed unchanged.
+ */
+#ifndef MUCON_HIP_H
+#define MUCON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUCON_ABI_VERSION 1
+#define MUCON_MAX_LAYERS 16
+
+#define MUCON_OK 0
+#define MUCON_E_ARG (-1)        /* unsupported / inconsistent argument            */
+#define MUCON_E_WORKSPACE (-2)  /* workspace too small                            */
+#define MUCON_E_HIP (-3)        /* a HIP runtime call failed                      */
+
+/* Per-video status written by mucon_viterbi_decode_batch (mirrors the reference's behaviour) */
+#define MUCON_VIT_OK 0
+#define MUCON_VIT_INDEX_ERROR 1    /* T < frame_sampling: reference raises IndexError     (viterbi.py:87)  */
+#define MUCON_VIT_NO_HYPOTHESIS 2  /* hypothesis set empty / all NaN: AttributeError      (viterbi.py:147) */
+#define MUCON_VIT_TRUNCATED 3      /* no final-state hypothesis: score = -inf, transcript truncated        */
+
+int mucon_abi_version(void);
+const char *mucon_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder: cfg.model.ft.* (reference src/configs/mucon/default.py:81-96)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, T, D, H;                      /* batch, frames, input dim (2048), hidden (128)       */
+    int32_t n_layers;                        /* len(cfg.model.ft.stages)                            */
+    int32_t dilation[MUCON_MAX_LAYERS];      /* cfg.model.ft.stages                                 */
+    int32_t pool_after[MUCON_MAX_LAYERS];    /* 1 if i in cfg.model.ft.pooling_layers and pooling   */
+    int32_t pool_type;                       /* 0 = "max", 1 = "sum" (avg_pool1d * 2)               */
+    int32_t leaky;                           /* cfg.model.ft.leaky_relu (slope 0.01)                */
+    int32_t last_gn, gn_groups;              /* cfg.model.ft.last_gn, last_gn_num_groups            */
+    float gn_eps;                            /* nn.GroupNorm default 1e-5                           */
+    int32_t last_relu;                       /* cfg.model.ft.last_relu                              */
+    int32_t training;                        /* nn.Module.training: dropout active                  */
+    float p_drop_layer;                      /* cfg.model.ft.dropout_rate (WaveNetLayer.drop)       */
+    float p_drop_last;                       /* cfg.model.ft.last_dropout_rate if last_dropout else 0 */
+    uint64_t seed;                           /* dropout stream for this step                        */
+} mucon_encoder_cfg;
+
+/* Parameters (and, with the same shapes, their gradients).  Names = reference state_dict keys. */
+typedef struct {
+    float *first_w, *first_b;                               /* ft.first_conv.{weight[H,D,1],bias[H]}       */
+    float *dil_w[MUCON_MAX_LAYERS], *dil_b[MUCON_MAX_LAYERS]; /* ft.l_i.dilated_conv.{weight[H,H,3],bias} */
+    float *pw_w[MUCON_MAX_LAYERS], *pw_b[MUCON_MAX_LAYERS];   /* ft.l_i.conv_1x1.{weight[H,H,1],bias}     */
+    float *last_w, *last_b;                                 /* ft.last_conv.{weight[H,H,1],bias[H]}        */
+    float *gn_w, *gn_b;                                     /* ft_last_gn.{weight,bias}[H]                 */
+} mucon_encoder_params;
+
+/* Output length Tz after the pooling schedule (reference temporal.py:137-142: floor halving). */
+int32_t mucon_encoder_out_length(const mucon_encoder_cfg *cfg);
+
+/* Bytes of caller-provided scratch that fwd fills and bwd reads (saved activations, packed
+ * weights, gradient slabs).  Depends on B, T and the layer schedule only. */
+size_t mucon_encoder_workspace_bytes(const mucon_encoder_cfg *cfg);
+
+/* Replaces MuCon.temporal_modeling_forward (reference src/mucon/models.py:746-773), i.e.
+ * permute -> WaveNetBlock.forward (src/core/modules/temporal.py:128-147, :43-53) -> GroupNorm ->
+ * ReLU -> Dropout -> permute.   tape [B][T][D] -> enc [B][Tz][H]. */
+int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *params,
+                      const float *tape, float *enc, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* Replaces autograd through the above (triggered at reference src/mucon/trainers.py:131).
+ * d_enc [B][Tz][H] -> grads (every member written, not accumulated).  Must follow a fwd call
+ * with training-independent identical cfg on the same workspace. */
+int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *params,
+                      const float *tape, const float *d_enc, void *workspace,
+                      size_t workspace_bytes, const mucon_encoder_params *grads, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y-head: nearest upsample Tz -> Tf, 1x1 conv H -> C, log-softmax over C
+ * ---------------------------------------------------------------------------------------- */
+size_t mucon_head_workspace_bytes(int32_t B, int32_t Tz, int32_t H, int32_t C);
+
+/* Replaces MuCon.frame_classifier_forward (reference src/mucon/models.py:567-582) and the
+ * F.log_softmax of MuCon.predict (:367-368) / the smoothing loss (:403-405).
+ * enc [B][Tz][H], w [C][H][1], b [C] -> logits [B][Tf][C] (may be NULL), logp [B][Tf][C] (may be
+ * NULL).  workspace keeps the z-level log-probs for the backward. */
+int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc,
+                   const float *w, const float *b, float *logits, float *logp, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* d_logits / d_logp [B][Tf][C] (either may be NULL) -> d_enc [B][Tz][H], d_w [C][H], d_b [C]. */
+int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc,
+                   const float *w, const float *d_logits, const float *d_logp, float *d_enc,
+                   float *d_w, float *d_b, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Viterbi: transcript-constrained decode with a length model
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t lp_off;     /* float offset of this video's emissions [T][C] inside `lp`            */
+    int64_t tr_off;     /* int32 offset of its transcript [N] inside `transcripts`              */
+    int64_t p_off;      /* double offset of its length table [J][N] inside `length_tables`      */
+    int64_t label_off;  /* int32 offset of its output labels [T] inside `labels`                */
+    int64_t seg_off;    /* int32 offset of its output segment lengths [N] inside `seg_len`      */
+    int64_t ws_off;     /* byte offset of its scratch inside `workspace` (16-byte aligned)      */
+    int32_t T, N;
+    int32_t force_n;    /* >= 0: finalize on hypothesis (force_n, force_j) with score -inf      */
+    int32_t force_j;    /*       (the reference's degenerate outcomes, decided by the host)     */
+} mucon_viterbi_job;
+
+/* scratch bytes one video needs (frame scores [K][C] f32 + back-pointers [K][N] u8, aligned) */
+size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_t N, int32_t fs);
+
+/* Replaces Viterbi.decode (reference src/core/viterbi/viterbi.py:49-158) with
+ * SingleTranscriptGrammar (src/core/viterbi/grammar.py:196-217) and an f64 length table
+ * P[j][n] = length_model.score((j+1)*fs, a_n), J = max_len / fs rows
+ * (PoissonModel, src/core/viterbi/length_model.py:76-80), as driven by
+ * src/mucon/evaluators.py:147-180.  One workgroup per video; bit-exact (score, labels, segments).
+ * jobs: DEVICE array [n_videos].  Outputs: labels, seg_len (per job offsets), n_seg[n_videos],
+ * score[n_videos] (f64), status[n_videos] (MUCON_VIT_*). */
+int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C,
+                               int32_t fs, int32_t max_len, int32_t max_N, const float *lp,
+                               const int32_t *transcripts, const double *length_tables,
+                               int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
+                               int32_t *status, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Test / bench helpers (not part of the reference surface)
+ * ---------------------------------------------------------------------------------------- */
+/* Plain GEMM on the same MFMA core the encoder uses: out[M][128] = A[M][K] * W[128][K]^T (+bias, relu) */
+int mucon_test_gemm_nt(const float *A, const float *W, const float *bias, float *out, int32_t M,
+                       int32_t K, int32_t relu, void *stream);
+/* out[128][K] = Y[M][128]^T * X[M][K] through the weight-gradient core (slabs + reduce). */
+int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, int32_t K,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* The dropout keep-mask (1 = kept) for `site`, written as uint8 [n]. */
+int mucon_test_dropout_mask(uint8_t *mask, int64_t n, uint64_t seed, int32_t site, float p, void *stream);
+/* Times `iters` launches of the first-conv forward kernel with HIP events on `stream`;
+ * returns the average milliseconds per launch in *ms (synchronises the stream). */
+int mucon_bench_first_conv(const float *tape, const float *w, const float *b, float *out, int32_t B,
+                           int32_t T, int32_t D, int32_t iters, float *ms_host, void *stream);
+
+/* Per-launch timing of the two kernels that stream the tape, taken with HIP events on the stream
+ * the kernels run on, while the normal fwd/bwd calls execute (bench.py's roofline leg):
+ * slot 0 = first_conv forward, slot 1 = first_conv weight gradient.  begin() arms up to
+ * max_records launches per slot; end() synchronises on the recorded events and returns the
+ * summed milliseconds and the launch count per slot (arrays of 2). */
+int mucon_profile_begin(int32_t max_records);
+int mucon_profile_end(float *total_ms_host, int32_t *count_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUCON_HIP_H */

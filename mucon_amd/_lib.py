@@ -1,0 +1,128 @@
+"""ctypes binding of libmucon_hip.so -- the C ABI declared in include/mucon_hip.h.
+
+The product path has NO fallback: if the library cannot be loaded (or built with hipcc), every
+entry point raises.  Nothing under oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
+MAX_LAYERS = 16
+ABI_VERSION = 1
+
+OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
+VIT_OK, VIT_INDEX_ERROR, VIT_NO_HYPOTHESIS, VIT_TRUNCATED = 0, 1, 2, 3
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class EncoderCfg(ctypes.Structure):
+    _fields_ = [
+        ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("D", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("n_layers", ctypes.c_int32),
+        ("dilation", ctypes.c_int32 * MAX_LAYERS),
+        ("pool_after", ctypes.c_int32 * MAX_LAYERS),
+        ("pool_type", ctypes.c_int32),
+        ("leaky", ctypes.c_int32),
+        ("last_gn", ctypes.c_int32), ("gn_groups", ctypes.c_int32), ("gn_eps", ctypes.c_float),
+        ("last_relu", ctypes.c_int32),
+        ("training", ctypes.c_int32),
+        ("p_drop_layer", ctypes.c_float), ("p_drop_last", ctypes.c_float),
+        ("seed", ctypes.c_uint64),
+    ]
+
+
+class EncoderParams(ctypes.Structure):
+    _fields_ = [
+        ("first_w", ctypes.c_void_p), ("first_b", ctypes.c_void_p),
+        ("dil_w", ctypes.c_void_p * MAX_LAYERS), ("dil_b", ctypes.c_void_p * MAX_LAYERS),
+        ("pw_w", ctypes.c_void_p * MAX_LAYERS), ("pw_b", ctypes.c_void_p * MAX_LAYERS),
+        ("last_w", ctypes.c_void_p), ("last_b", ctypes.c_void_p),
+        ("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p),
+    ]
+
+
+class ViterbiJob(ctypes.Structure):
+    _fields_ = [
+        ("lp_off", ctypes.c_int64), ("tr_off", ctypes.c_int64), ("p_off", ctypes.c_int64),
+        ("label_off", ctypes.c_int64), ("seg_off", ctypes.c_int64), ("ws_off", ctypes.c_int64),
+        ("T", ctypes.c_int32), ("N", ctypes.c_int32), ("force_n", ctypes.c_int32), ("force_j", ctypes.c_int32),
+    ]
+
+
+# every symbol include/mucon_hip.h declares: (restype, argtypes)
+_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+SYMBOLS = {
+    "mucon_abi_version": (ctypes.c_int, []),
+    "mucon_last_error": (ctypes.c_char_p, []),
+    "mucon_encoder_out_length": (_i32, [ctypes.POINTER(EncoderCfg)]),
+    "mucon_encoder_workspace_bytes": (_sz, [ctypes.POINTER(EncoderCfg)]),
+    "mucon_encoder_fwd": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(EncoderParams), _vp, _vp, _vp, _sz, _vp]),
+    "mucon_encoder_bwd": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(EncoderParams), _vp, _vp, _vp, _sz,
+                                         ctypes.POINTER(EncoderParams), _vp]),
+    "mucon_head_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "mucon_head_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
+    "mucon_profile_begin": (ctypes.c_int, [_i32]),
+    "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
+    "mucon_bench_first_conv": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_float), _vp]),
+}
+
+_lib = None
+
+
+class MuconHipError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True):
+    """Load libmucon_hip.so (building it with hipcc when absent).  Raises if that is impossible.
+
+    torch must be imported first so that the HIP runtime torch ships (libamdhip64.so.7) is the
+    one the library binds to -- one runtime per process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's libamdhip64 before ours resolves its DT_NEEDED)
+
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise MuconHipError(f"{LIB_PATH} is missing: run `python -m mucon_amd.build`")
+        from . import build as _build
+
+        _build.build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mucon_abi_version() != ABI_VERSION:
+        raise MuconHipError(f"ABI version mismatch: library {lib.mucon_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != OK:
+        msg = load().mucon_last_error()
+        raise MuconHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (or NULL for None)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,55 @@
+"""Build libmucon_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m mucon_amd.build [--force]
+
+Two translation units: mucon_hip.hip (encoder / head, FMA contraction allowed) and viterbi.hip
+(-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires).
+The .so lands next to this file (git-ignored; gpurun ships it to the GPU box)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmucon_hip.so")
+ARCH = "gfx950"
+SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"])]
+DEPS = ["common.hpp", "gemm_nt.hpp", "gemm_tn.hpp", "small_kernels.hpp", "../../include/mucon_hip.h"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    files = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, d) for d in DEPS]
+    return any(os.path.getmtime(f) > t for f in files)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+               "-c", os.path.join(CSRC, src), "-o", obj] + extra
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,65 @@
+"""Length models -- host-side mirror of reference src/core/viterbi/length_model.py.
+
+PoissonModel (reference length_model.py:42-83) is the one the evaluator builds per video
+(src/mucon/evaluators.py:167).  The table is computed on the host in float64 with NumPy's `log`,
+vectorised but in the reference's exact operation order (sequential log-factorial sums, left to
+right arithmetic), so its bits equal the reference's on the same host; only the rows the decoder
+reads (lengths fs, 2fs, ...) are uploaded.  MultiPoissonModel / MeanLengthModel are out of scope:
+the former's score() raises in the reference, the latter is unused."""
+import numpy as np
+
+
+class LengthModel(object):
+    def n_classes(self):
+        return 0
+
+    def score(self, length, label):
+        return 0.0
+
+    def max_length(self):
+        return np.inf
+
+
+class PoissonModel(LengthModel):
+    def __init__(self, model, max_length=2000, renormalize=True):
+        if isinstance(model, str):
+            self.mean_lengths = np.loadtxt(model)
+        else:
+            self.mean_lengths = np.asarray(model)
+        self.num_classes = self.mean_lengths.shape[0]
+        self.max_len = int(max_length)
+        mu = self.mean_lengths
+        with np.errstate(all="ignore"):
+            # log-factorial partial sums, accumulated sequentially from 0 like `logFak += np.log(k)`
+            lf = np.concatenate(([0.0], np.cumsum(np.log(np.arange(1, max(self.max_len, 2))))))  # lf[l] = sum_{k<=l} log k
+            self.norms = np.zeros(mu.shape)
+            if renormalize:
+                self.norms = np.round(mu) * np.log(np.round(mu)) - np.round(mu)
+                kmax = int(np.nanmax(np.where(np.isfinite(mu), mu, 0))) if mu.size else 0
+                lf2 = np.concatenate(([0.0, 0.0], np.cumsum(np.log(np.arange(2, max(kmax + 1, 3))))))  # sum_{k=2..m} log k
+                m = np.where(np.isfinite(mu), mu, 0).astype(np.int64)
+                self.norms = self.norms - np.where(m >= 2, lf2[np.clip(m, 0, len(lf2) - 1)], 0)
+            ls = np.arange(self.max_len, dtype=np.int64)[:, None]
+            self.poisson = ls * np.log(mu)[None, :] - mu[None, :] - lf[: self.max_len, None] - self.norms[None, :]
+            self.poisson[0, :] = -np.inf  # length zero can not happen
+
+    def n_classes(self):
+        return self.num_classes
+
+    def score(self, length, label):
+        if length >= self.max_len:
+            return -np.inf
+        return self.poisson[length, label]
+
+    def max_length(self):
+        return self.max_len
+
+    def rows_for(self, transcript, frame_sampling):
+        """P[J x N] float64: P[j, n] = score((j+1)*fs, a_n), J = max_len // fs (what the kernel reads)."""
+        J = self.max_len // frame_sampling
+        lengths = (np.arange(J) + 1) * frame_sampling
+        tr = np.asarray(transcript, dtype=np.int64)
+        P = np.full((J, len(tr)), -np.inf, dtype=np.float64)
+        ok = lengths < self.max_len
+        P[ok, :] = self.poisson[lengths[ok]][:, tr]
+        return np.ascontiguousarray(P)

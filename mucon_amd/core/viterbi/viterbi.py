@@ -1,0 +1,163 @@
+"""Viterbi decoder with the reference's surface (src/core/viterbi/viterbi.py:10-65):
+
+    v = Viterbi(grammar, length_model, frame_sampling=30)
+    v.grammar = SingleTranscriptGrammar(transcript, n_classes)       # as evaluators.py:148-150
+    v.length_model = PoissonModel(mean_lengths)                      # as evaluators.py:167
+    score, labels, segments = v.decode(log_frame_probs)              # as evaluators.py:178-180
+
+The dynamic programme runs in the gfx950 kernels of mucon_amd/csrc/viterbi.hip through
+mucon_viterbi_decode_batch (include/mucon_hip.h); results are bit-identical to the reference's
+(score bits, labels, segments).  `log_frame_probs` may be a device tensor (the y-head's log-probs
+never leave HBM) or, as in the reference, a float32 numpy array [T x C] (uploaded first).
+
+Host logic kept here: building the length table rows the kernel reads, and resolving the
+reference's degenerate outcomes, which depend on the iteration order of its hypothesis dict:
+  * T < frame_sampling                      -> IndexError            (viterbi.py:87)
+  * all hypotheses outlived max_length      -> AttributeError        (viterbi.py:147)
+  * fewer columns than transcript states, or a NaN length model (mean length < 0.5,
+    length_model.py:56-58): every final score is -inf / NaN and the `>=` fold of
+    finalize_decoding (viterbi.py:135) returns the LAST non-NaN hypothesis in dict order with
+    score -inf and a truncated transcript.  `last_in_dict_order` reproduces that order in
+    closed form (verified against the literal oracle in tests/test_viterbi_host.py).
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .grammar import SingleTranscriptGrammar
+
+
+def last_in_dict_order(K: int, J: int, n_lim: int) -> Optional[Tuple[int, int]]:
+    """(n, j) of the last hypothesis, in the reference's dict iteration order at the final column
+    K-1, among transcript states n < n_lim; None when none is alive.
+
+    A hypothesis is (n, k0) (state n entered at column k0; k0 = 0 for n = 0, n <= k0 <= J*n
+    otherwise) and is alive at column c while c - k0 <= J-1.  decode_frame (viterbi.py:92-123)
+    rebuilds the dict every column: children keep their parents' order, and the new entry of
+    state n+1 is inserted right behind the stay-child of the FIRST hypothesis of state n, i.e. of
+    its most recent entry.  That makes the order a depth-first pre-order of the tree
+    parent(n, k0) = (n-1, min(k0-1, J*(n-1))) with later-born children first; dead hypotheses
+    keep their place in the structure.  The last alive node is then: per state the OLDEST alive
+    entry, and among states the one whose root path (c_1, c_2, ...) is smallest at the first
+    difference, a longer path winning over its own prefix."""
+    c = K - 1
+    best_key, best = None, None
+    for n in range(min(n_lim, K)):
+        if n == 0:
+            if c > J - 1:
+                continue
+            k0 = 0
+        else:
+            k0 = max(n, c - J + 1)
+            if k0 > min(J * n, c):
+                continue
+        path = [k0]
+        for m in range(n, 1, -1):  # c_{m-1} = min(c_m - 1, J*(m-1))
+            path.append(min(path[-1] - 1, J * (m - 1)))
+        key = tuple(-x for x in reversed(path)) if n >= 1 else ()
+        if best_key is None or key > best_key:
+            best_key, best = key, (n, c - k0)
+    return best
+
+
+class Viterbi(object):
+    class Segment(object):
+        def __init__(self, label, length=0):
+            self.label, self.length = label, length
+
+        def __repr__(self):
+            return f"Segment(label={self.label}, length={self.length})"
+
+    def __init__(self, grammar, length_model, frame_sampling=1, max_hypotheses=np.inf):
+        self.grammar = grammar
+        self.length_model = length_model
+        self.frame_sampling = frame_sampling
+        self.max_hypotheses = max_hypotheses
+
+    def set_multi_length(self, mode=True):  # no-op in the reference too (viterbi.py:40-41)
+        pass
+
+    # ------------------------------------------------------------------------------ host logic
+    def _table(self, transcript) -> np.ndarray:
+        lm, fs = self.length_model, self.frame_sampling
+        max_len = lm.max_length()
+        if not np.isfinite(max_len):
+            raise NotImplementedError("length models without a finite max_length() are not supported by the HIP decoder")
+        if hasattr(lm, "rows_for"):
+            return lm.rows_for(transcript, fs)
+        J = int(max_len) // fs
+        P = np.empty((J, len(transcript)), dtype=np.float64)
+        for j in range(J):
+            for n, a in enumerate(transcript):
+                P[j, n] = lm.score((j + 1) * fs, int(a))
+        return P
+
+    def _prepare(self, T: int):
+        """-> (transcript, table P[J x N], force (n, j) or None).  Raises what the reference raises."""
+        if not isinstance(self.grammar, SingleTranscriptGrammar):
+            raise NotImplementedError("the HIP decoder implements SingleTranscriptGrammar only (the one the "
+                                      "reference decodes with, evaluators.py:148-150)")
+        if np.isfinite(self.max_hypotheses):
+            raise NotImplementedError("pruning (max_hypotheses) is not implemented; the reference never enables it")
+        fs = self.frame_sampling
+        tr = np.asarray(self.grammar.transcript, dtype=np.int32)
+        N = len(tr)
+        if N == 0:
+            raise AttributeError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
+        if T < fs:
+            raise IndexError(f"index {fs - 1} is out of bounds for axis 0 with size {T}")
+        P = self._table(tr)
+        J = P.shape[0]
+        K = T // fs
+        nan_cols = np.isnan(P).any(axis=0)
+        if nan_cols.any() and not (np.isnan(P).all(axis=0) == nan_cols).all():
+            raise NotImplementedError("length table with partially-NaN columns")
+        n_lim = int(np.argmax(nan_cols)) if nan_cols.any() else N
+        force = None
+        if n_lim < N or K < N:
+            force = last_in_dict_order(K, J, n_lim)
+            if force is None:
+                raise AttributeError("'NoneType' object has no attribute 'label'")
+        elif K > J * N:
+            raise AttributeError("'NoneType' object has no attribute 'label'")
+        return tr, P, force
+
+    # ------------------------------------------------------------------------------ decode
+    def decode_batch(self, log_frame_probs: Sequence, transcripts: Sequence[Sequence[int]],
+                     length_models: Sequence) -> List[tuple]:
+        """Decode several videos in one kernel launch (one workgroup per video).  Each result is
+        what decode() returns.  Not in the reference (it decodes one video at a time)."""
+        import torch
+        from ... import _lib, ops
+
+        fs = self.frame_sampling
+        lps, trs, tabs, forces = [], [], [], []
+        max_len = None
+        for lp, tr, lm in zip(log_frame_probs, transcripts, length_models):
+            if isinstance(lp, np.ndarray):
+                lp = torch.from_numpy(np.ascontiguousarray(lp, dtype=np.float32)).cuda()
+            v = Viterbi(SingleTranscriptGrammar(tr, lp.shape[1]), lm, fs, self.max_hypotheses)
+            t, P, force = v._prepare(int(lp.shape[0]))
+            ml = int(lm.max_length())
+            if max_len is not None and ml != max_len:
+                raise ValueError("all length models of a batch must share max_length()")
+            max_len = ml
+            lps.append(lp)
+            trs.append(t)
+            tabs.append(P)
+            forces.append(force)
+        res = ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces)
+        out = []
+        for r, t in zip(res, trs):
+            if r.status == _lib.VIT_INDEX_ERROR:
+                raise IndexError("frame_sampling exceeds the sequence length")
+            if r.status == _lib.VIT_NO_HYPOTHESIS:
+                raise AttributeError("'NoneType' object has no attribute 'label'")
+            segs = [Viterbi.Segment(int(t[s]), int(r.seg_len[s])) for s in range(r.n_seg)]
+            out.append((r.score, r.labels.tolist(), segs))
+        return out
+
+    def decode(self, log_frame_probs):
+        """-> (score: np.float64, labels: list[int] of len T, segments: list of Segment(label, length))."""
+        assert log_frame_probs.shape[1] == self.grammar.n_classes()
+        return self.decode_batch([log_frame_probs], [self.grammar.transcript], [self.length_model])[0]

@@ -1,0 +1,257 @@
+"""torch.autograd wrappers over the C ABI (mucon_amd/_lib.py -> libmucon_hip.so).
+
+PyTorch is plumbing here: it owns the HBM buffers, the current HIP stream and autograd's graph;
+all arithmetic of the hot path runs in the hand-written gfx950 kernels.  Device tensors only --
+a CPU tensor raises (there is no CPU fallback in the product).
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class EncoderSpec:
+    """cfg.model.ft.* (reference src/configs/mucon/default.py:81-96) as the kernels need it."""
+    in_dim: int = 2048
+    hidden: int = 128
+    stages: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])
+    pooling: bool = True
+    pooling_type: str = "max"
+    pooling_layers: List[int] = field(default_factory=lambda: [1, 2, 4, 8])
+    leaky_relu: bool = False
+    dropout_rate: float = 0.25
+    last_gn: bool = True
+    last_gn_num_groups: int = 32
+    last_relu: bool = True
+    last_dropout: bool = True
+    last_dropout_rate: float = 0.25
+    gn_eps: float = 1e-5
+
+    def out_length(self, T: int) -> int:
+        for i in range(len(self.stages)):
+            if self.pooling and i in self.pooling_layers:
+                T //= 2
+        return T
+
+    def to_c(self, B: int, T: int, training: bool, seed: int) -> _lib.EncoderCfg:
+        if self.pooling_type not in ("max", "sum"):
+            # the reference treats every non-"max" value as avg*2 (temporal.py:138-142)
+            pool_type = 1
+        else:
+            pool_type = 0 if self.pooling_type == "max" else 1
+        if len(self.stages) > _lib.MAX_LAYERS:
+            raise ValueError(f"{len(self.stages)} stages > {_lib.MAX_LAYERS}")
+        c = _lib.EncoderCfg()
+        c.B, c.T, c.D, c.H = B, T, self.in_dim, self.hidden
+        c.n_layers = len(self.stages)
+        for i, d in enumerate(self.stages):
+            c.dilation[i] = int(d)
+            c.pool_after[i] = 1 if (self.pooling and i in self.pooling_layers) else 0
+        c.pool_type = pool_type
+        c.leaky = 1 if self.leaky_relu else 0
+        c.last_gn, c.gn_groups, c.gn_eps = (1 if self.last_gn else 0), self.last_gn_num_groups, self.gn_eps
+        c.last_relu = 1 if self.last_relu else 0
+        c.training = 1 if training else 0
+        c.p_drop_layer = float(self.dropout_rate)
+        c.p_drop_last = float(self.last_dropout_rate) if self.last_dropout else 0.0
+        c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return c
+
+
+def param_names(spec: EncoderSpec) -> List[str]:
+    """Reference state_dict keys of the encoder parameters, in the order the ops take them."""
+    names = ["ft.first_conv.weight", "ft.first_conv.bias"]
+    for i in range(len(spec.stages)):
+        names += [f"ft.l_{i}.dilated_conv.weight", f"ft.l_{i}.dilated_conv.bias",
+                  f"ft.l_{i}.conv_1x1.weight", f"ft.l_{i}.conv_1x1.bias"]
+    names += ["ft.last_conv.weight", "ft.last_conv.bias", "ft_last_gn.weight", "ft_last_gn.bias"]
+    return names
+
+
+def _pack_params(spec: EncoderSpec, tensors: Sequence[torch.Tensor]) -> _lib.EncoderParams:
+    L = len(spec.stages)
+    assert len(tensors) == 6 + 4 * L, (len(tensors), L)
+    p = _lib.EncoderParams()
+    p.first_w, p.first_b = tensors[0].data_ptr(), tensors[1].data_ptr()
+    for i in range(L):
+        p.dil_w[i], p.dil_b[i], p.pw_w[i], p.pw_b[i] = (t.data_ptr() for t in tensors[2 + 4 * i: 6 + 4 * i])
+    p.last_w, p.last_b, p.gn_w, p.gn_b = (t.data_ptr() for t in tensors[2 + 4 * L: 6 + 4 * L])
+    return p
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.MuconHipError("mucon_amd ops need device tensors: there is no CPU fallback")
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.MuconHipError(f"float32 expected, got {t.dtype}")
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tape, spec, training, seed, *params):
+        lib = _lib.load()
+        _check_dev(tape, *params)
+        tape = tape.contiguous()
+        params = [p.contiguous() for p in params]
+        B, T, D = tape.shape
+        if D != spec.in_dim:
+            raise ValueError(f"tape feature dim {D} != {spec.in_dim}")
+        cfg = spec.to_c(B, T, training, seed)
+        nbytes = lib.mucon_encoder_workspace_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            _lib.check(_lib.E_ARG, "mucon_encoder_workspace_bytes")
+        Tz = lib.mucon_encoder_out_length(ctypes.byref(cfg))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=tape.device)
+        enc = torch.empty((B, Tz, spec.hidden), dtype=torch.float32, device=tape.device)
+        cp = _pack_params(spec, params)
+        _lib.check(lib.mucon_encoder_fwd(ctypes.byref(cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(enc),
+                                         _lib.ptr(ws), nbytes, _lib.current_stream_ptr()), "mucon_encoder_fwd")
+        ctx.spec, ctx.cfg, ctx.ws, ctx.nbytes = spec, cfg, ws, nbytes
+        ctx.save_for_backward(tape, *params)
+        return enc
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        lib = _lib.load()
+        tape, *params = ctx.saved_tensors
+        d_enc = d_enc.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        cp, cg = _pack_params(ctx.spec, params), _pack_params(ctx.spec, grads)
+        _lib.check(lib.mucon_encoder_bwd(ctypes.byref(ctx.cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(d_enc),
+                                         _lib.ptr(ctx.ws), ctx.nbytes, ctypes.byref(cg), _lib.current_stream_ptr()),
+                   "mucon_encoder_bwd")
+        return (None, None, None, None, *grads)
+
+
+def encoder_forward(tape: torch.Tensor, params: Sequence[torch.Tensor], spec: EncoderSpec, training: bool = False,
+                    seed: int = 0) -> torch.Tensor:
+    """tape [B,T,D] -> enc [B,Tz,H]: MuCon.temporal_modeling_forward (reference models.py:746-773).
+    `params` in param_names(spec) order.  Differentiable w.r.t. params (the tape needs no grad)."""
+    return _EncoderFn.apply(tape, spec, bool(training), int(seed), *params)
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, w, b, Tf, want_logits, want_logp):
+        lib = _lib.load()
+        _check_dev(enc, w, b)
+        enc, w, b = enc.contiguous(), w.contiguous(), b.contiguous()
+        B, Tz, H = enc.shape
+        C = w.shape[0]
+        nbytes = lib.mucon_head_workspace_bytes(B, Tz, H, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        logits = torch.empty((B, Tf, C), dtype=torch.float32, device=enc.device) if want_logits else None
+        logp = torch.empty((B, Tf, C), dtype=torch.float32, device=enc.device) if want_logp else None
+        _lib.check(lib.mucon_head_fwd(B, Tz, Tf, H, C, _lib.ptr(enc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(logits),
+                                      _lib.ptr(logp), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+                   "mucon_head_fwd")
+        ctx.dims, ctx.ws, ctx.nbytes = (B, Tz, Tf, H, C), ws, nbytes
+        ctx.save_for_backward(enc, w)
+        ctx.set_materialize_grads(False)
+        out_logits = logits if want_logits else enc.new_empty(0)
+        out_logp = logp if want_logp else enc.new_empty(0)
+        unused = [t for t, want in ((out_logits, want_logits), (out_logp, want_logp)) if not want]
+        if unused:
+            ctx.mark_non_differentiable(*unused)
+        return out_logits, out_logp
+
+    @staticmethod
+    def backward(ctx, d_logits, d_logp):
+        lib = _lib.load()
+        enc, w = ctx.saved_tensors
+        B, Tz, Tf, H, C = ctx.dims
+        dl = d_logits.contiguous() if (d_logits is not None and d_logits.numel() == B * Tf * C) else None
+        dp = d_logp.contiguous() if (d_logp is not None and d_logp.numel() == B * Tf * C) else None
+        d_enc = torch.empty_like(enc)
+        d_w = torch.empty_like(w)
+        d_b = torch.empty(C, dtype=torch.float32, device=enc.device)
+        _lib.check(lib.mucon_head_bwd(B, Tz, Tf, H, C, _lib.ptr(enc), _lib.ptr(w), _lib.ptr(dl), _lib.ptr(dp),
+                                      _lib.ptr(d_enc), _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ctx.ws), ctx.nbytes,
+                                      _lib.current_stream_ptr()), "mucon_head_bwd")
+        return d_enc, d_w, d_b, None, None, None
+
+
+def head_forward(enc: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, Tf: int, want_logits: bool = True,
+                 want_logp: bool = True):
+    """enc [B,Tz,H] -> (logits [B,Tf,C], logp [B,Tf,C]): frame_classifier_forward + log_softmax
+    (reference models.py:567-582, :368).  weight is conv_classifier.weight [C,H,1] (or [C,H])."""
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    logits, logp = _HeadFn.apply(enc, w2, bias, int(Tf), bool(want_logits), bool(want_logp))
+    return (logits if want_logits else None), (logp if want_logp else None)
+
+
+# --------------------------------------------------------------------------------------- viterbi
+@dataclass
+class ViterbiResult:
+    score: np.float64
+    labels: np.ndarray      # int32 [T]
+    seg_len: np.ndarray     # int32 [S]
+    n_seg: int
+    status: int
+
+
+def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
+                         tables: Sequence[np.ndarray], fs: int, max_len: int,
+                         forces: Optional[Sequence[Optional[tuple]]] = None) -> List[ViterbiResult]:
+    """Decode a batch of videos in one launch (one workgroup per video).
+
+    lps[v]: device float32 [T_v, C] log-probs (stay on the device -- no D2H of emissions);
+    transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
+    forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved
+    degenerate outcomes of the reference)."""
+    lib = _lib.load()
+    nv = len(lps)
+    if nv == 0:
+        return []
+    dev = lps[0].device
+    _check_dev(*lps)
+    C = int(lps[0].shape[1])
+    J = max_len // fs
+    jobs = (_lib.ViterbiJob * nv)()
+    lp_off = tr_off = p_off = lab_off = seg_off = ws_off = 0
+    maxN = 0
+    for v in range(nv):
+        T, N = int(lps[v].shape[0]), int(len(transcripts[v]))
+        assert tables[v].shape == (J, N) and tables[v].dtype == np.float64, (tables[v].shape, J, N)
+        assert lps[v].shape[1] == C
+        j = jobs[v]
+        j.lp_off, j.tr_off, j.p_off, j.label_off, j.seg_off, j.ws_off = lp_off, tr_off, p_off, lab_off, seg_off, ws_off
+        j.T, j.N = T, N
+        f = forces[v] if forces is not None else None
+        j.force_n, j.force_j = (int(f[0]), int(f[1])) if f is not None else (-1, -1)
+        lp_off += T * C
+        tr_off += N
+        p_off += J * N
+        lab_off += max(T, 1)
+        seg_off += N
+        ws_off += (lib.mucon_viterbi_job_workspace_bytes(T, C, N, fs) + 255) // 256 * 256
+        maxN = max(maxN, N)
+    lp_all = lps[0].contiguous().reshape(-1) if nv == 1 else torch.cat([x.contiguous().reshape(-1) for x in lps])
+    tr_all = torch.from_numpy(np.concatenate([np.asarray(t, dtype=np.int32) for t in transcripts])).to(dev)
+    tb_all = torch.from_numpy(np.concatenate([np.ascontiguousarray(t, dtype=np.float64).reshape(-1) for t in tables])).to(dev)
+    jobs_dev = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(dev)
+    labels = torch.empty(lab_off, dtype=torch.int32, device=dev)
+    seg_len = torch.zeros(seg_off, dtype=torch.int32, device=dev)
+    n_seg = torch.zeros(nv, dtype=torch.int32, device=dev)
+    score = torch.zeros(nv, dtype=torch.float64, device=dev)
+    status = torch.full((nv,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(ws_off, 256), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mucon_viterbi_decode_batch(nv, _lib.ptr(jobs_dev), C, fs, max_len, maxN, _lib.ptr(lp_all),
+                                              _lib.ptr(tr_all), _lib.ptr(tb_all), _lib.ptr(labels), _lib.ptr(seg_len),
+                                              _lib.ptr(n_seg), _lib.ptr(score), _lib.ptr(status), _lib.ptr(ws),
+                                              _lib.current_stream_ptr()), "mucon_viterbi_decode_batch")
+    labels_h, seg_h = labels.cpu().numpy(), seg_len.cpu().numpy()  # the result fetch synchronises
+    nseg_h, score_h, status_h = n_seg.cpu().numpy(), score.cpu().numpy(), status.cpu().numpy()
+    out = []
+    for v in range(nv):
+        j = jobs[v]
+        ns = int(nseg_h[v])
+        out.append(ViterbiResult(score=np.float64(score_h[v]), labels=labels_h[j.label_off: j.label_off + j.T].copy(),
+                                 seg_len=seg_h[j.seg_off: j.seg_off + ns].copy(), n_seg=ns, status=int(status_h[v])))
+    return out

@@ -103,16 +103,25 @@ def _conv_time_major(x, w, b, dilation=1):
     return y
 
 
-def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, return_intermediates=False):
-    """tape [B,T,D] -> enc [B,Tz,H].  Restates temporal.py:128-147 + models.py:759-764 (eval mode)."""
+def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, return_intermediates=False,
+                    drop=None):
+    """tape [B,T,D] -> enc [B,Tz,H].  Restates temporal.py:128-147 + models.py:759-764 (eval mode).
+
+    `drop` (optional, for checking the training-mode kernels): {layer index: multiplier [B,T_l,H]}
+    applied where WaveNetLayer.drop sits (temporal.py:51) and {"last": multiplier [B,Tz,H]} for
+    ft_last_dropout (models.py:767-768); a multiplier is keep_mask / (1 - p)."""
     p = params
+    drop = drop or {}
     inter = {}
     x = _act(_conv_time_major(tape, p["ft.first_conv.weight"], p["ft.first_conv.bias"]), cfg.leaky_relu)
     inter["x0"] = x
     for i, d in enumerate(cfg.stages):
         h = _act(_conv_time_major(x, p[f"ft.l_{i}.dilated_conv.weight"], p[f"ft.l_{i}.dilated_conv.bias"], d),
                  cfg.leaky_relu)
-        y = _conv_time_major(h, p[f"ft.l_{i}.conv_1x1.weight"], p[f"ft.l_{i}.conv_1x1.bias"]) + x
+        y = _conv_time_major(h, p[f"ft.l_{i}.conv_1x1.weight"], p[f"ft.l_{i}.conv_1x1.bias"])
+        if i in drop:
+            y = y * drop[i]
+        y = y + x
         if cfg.pooling and i in cfg.pooling_layers:
             Tl = y.shape[1] // 2
             a, b = y[:, 0:2 * Tl:2, :], y[:, 1:2 * Tl:2, :]
@@ -130,6 +139,8 @@ def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, r
         z = ((zg - mean) / torch.sqrt(var + cfg.gn_eps)).reshape(B, Tz, H) * p["ft_last_gn.weight"] + p["ft_last_gn.bias"]
     if cfg.last_relu:
         z = torch.relu(z)
+    if "last" in drop:
+        z = z * drop["last"]
     return (z, inter) if return_intermediates else z
 
 

@@ -1,0 +1,276 @@
+"""GPU parity of the dense half of the hot path (encoder + GroupNorm/ReLU + y-head) through the
+C ABI, against (a) the golden vectors produced by the reference's own modules and (b) the float64
+oracle (oracle/dense.py) on seeded inputs.
+
+Tolerance (fp32 path): atol = rtol = 1e-4 on encodings / logits / log-probs;
+gradients: |g - g_ref| <= 1e-3 * ||g_ref||_inf-ish bound, stated per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mucon_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dense_cases.npz"))
+DEV = "cuda"
+
+
+def _spec(over):
+    from mucon_amd.ops import EncoderSpec
+    return EncoderSpec(**over)
+
+
+def _ocfg(over):
+    from oracle import dense as od
+    return od.EncoderConfig(**{k: v for k, v in over.items()})
+
+
+def _dev_params(params_np, names):
+    return [torch.tensor(params_np[k], device=DEV, requires_grad=True) for k in names]
+
+
+# ------------------------------------------------------------------------------------ MFMA cores
+@pytest.mark.parametrize("M,K", [(128, 128), (300, 128), (1000, 384), (257, 2048)])
+def test_mfma_nt_core_against_matmul(M, K):
+    """A = asymmetric random, W = asymmetric random: catches a transposed C-write or a wrong k map."""
+    import ctypes
+    from mucon_amd import _lib
+    lib = _lib.load()
+    A = torch.tensor(synth.uniform_pm1(1, (M, K)), device=DEV)
+    W = torch.tensor(synth.uniform_pm1(2, (128, K)), device=DEV)
+    bias = torch.tensor(synth.uniform_pm1(3, (128,)), device=DEV)
+    out = torch.full((M, 128), float("nan"), device=DEV)
+    _lib.check(lib.mucon_test_gemm_nt(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), M, K, 0,
+                                      _lib.current_stream_ptr()), "gemm_nt")
+    ref = (A.double() @ W.double().T + bias.double()).float()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-4 * (K / 128) ** 0.5)
+    _lib.check(lib.mucon_test_gemm_nt(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), M, K, 1,
+                                      _lib.current_stream_ptr()), "gemm_nt relu")
+    torch.testing.assert_close(out, torch.relu(ref), rtol=1e-5, atol=1e-4 * (K / 128) ** 0.5)
+
+
+@pytest.mark.parametrize("M,K", [(32, 128), (1000, 256), (4097, 384), (700, 2048)])
+def test_mfma_tn_core_against_matmul(M, K):
+    from mucon_amd import _lib
+    lib = _lib.load()
+    Y = torch.tensor(synth.uniform_pm1(4, (M, 128)), device=DEV)
+    X = torch.tensor(synth.uniform_pm1(5, (M, K)), device=DEV)
+    out = torch.full((128, K), float("nan"), device=DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.mucon_test_gemm_tn(_lib.ptr(Y), _lib.ptr(X), _lib.ptr(out), M, K, _lib.ptr(ws), ws.numel(),
+                                      _lib.current_stream_ptr()), "gemm_tn")
+    ref = (Y.double().T @ X.double()).float()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-4 * (M / 128) ** 0.5)
+
+
+# ------------------------------------------------------------------------------------ forward
+CASES = [("t130", {}), ("t2000", {}), ("t2097", {}), ("b2_t777", {}), ("t4096", {}),
+         ("sum_pool", {"pooling_type": "sum"}), ("leaky", {"leaky_relu": True}), ("no_gn", {"last_gn": False})]
+
+
+@pytest.mark.parametrize("name,over", CASES, ids=[c[0] for c in CASES])
+def test_forward_matches_reference_golden(name, over):
+    """HIP encoder + head vs the outputs of the reference's MuCon modules (tests/golden/dense_cases.npz)."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T, Tz, pseed, tseed = [int(x) for x in GOLD[f"{name}__meta"]]
+    spec, ocfg = _spec(over), _ocfg(over)
+    params_np = od.seeded_params(ocfg, pseed)
+    names = ops.param_names(spec)
+    P = _dev_params(params_np, names)
+    tape = torch.tensor(synth.tape(tseed, B, T, 2048), device=DEV)
+    with torch.no_grad():
+        enc = ops.encoder_forward(tape, P, spec, training=False)
+        wc = torch.tensor(params_np["conv_classifier.weight"], device=DEV)
+        bc = torch.tensor(params_np["conv_classifier.bias"], device=DEV)
+        logits, logp = ops.head_forward(enc, wc, bc, T)
+    assert enc.shape == (B, Tz, 128)
+    idx = GOLD[f"{name}__idx"]
+    np.testing.assert_allclose(enc.cpu().numpy(), GOLD[f"{name}__enc"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), GOLD[f"{name}__logits_z"][:, idx], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logp.cpu().numpy(), GOLD[f"{name}__logp_z"][:, idx], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,over", [(1, 353, {}), (3, 1201, {}), (2, 640, {"pooling_type": "sum", "leaky_relu": True}),
+                                      (1, 1500, {"last_relu": False}), (2, 333, {"last_gn_num_groups": 8})])
+def test_forward_matches_oracle_f64(B, T, over):
+    from mucon_amd import ops
+    from oracle import dense as od
+    spec, ocfg = _spec(over), _ocfg(over)
+    params_np = od.seeded_params(ocfg, 77)
+    tape_np = synth.tape(78, B, T, 2048)
+    enc_o, logits_o, logp_o = od.hot_path(tape_np, params_np, ocfg, torch.float64)
+    P = _dev_params(params_np, ops.param_names(spec))
+    with torch.no_grad():
+        enc = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec)
+        logits, logp = ops.head_forward(enc, torch.tensor(params_np["conv_classifier.weight"], device=DEV),
+                                        torch.tensor(params_np["conv_classifier.bias"], device=DEV), T)
+    np.testing.assert_allclose(enc.cpu().numpy(), enc_o, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_o, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logp.cpu().numpy(), logp_o, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ backward
+def _grad_check(grads_dev, grads_ref, names, tag):
+    worst = 0.0
+    for k, g in zip(names, grads_dev):
+        ref = grads_ref[k]
+        g = g.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(g - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 1e-3, f"{tag}: grad {k}: max err {err:.3e} relative to max |g| = {scale:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("B,T,over", [(1, 600, {}), (2, 777, {}), (1, 2097, {}), (2, 500, {"pooling_type": "sum"}),
+                                      (1, 900, {"leaky_relu": True}), (1, 640, {"last_gn": False}),
+                                      (1, 512, {"last_relu": False, "last_gn_num_groups": 16})])
+def test_backward_matches_oracle_f64(B, T, over):
+    """Gradients of L = sum(w*logp) + sum(u*logits) + sum(v*enc) w.r.t. every parameter."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    spec, ocfg = _spec(over), _ocfg(over)
+    params_np = od.seeded_params(ocfg, 91)
+    tape_np = synth.tape(92, B, T, 2048)
+    Tz = spec.out_length(T)
+    w = synth.uniform_pm1(93, (B, T, 48))
+    u = synth.uniform_pm1(95, (B, T, 48))
+    v = synth.uniform_pm1(94, (B, Tz, 128))
+    # oracle
+    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
+    enc_o = od.encoder_forward(torch.tensor(tape_np, dtype=torch.float64), p64, ocfg)
+    logits_o, logp_o = od.head_forward(enc_o, p64, ocfg, T)
+    L_o = (torch.tensor(w, dtype=torch.float64) * logp_o).sum() + (torch.tensor(u, dtype=torch.float64) * logits_o).sum() \
+        + (torch.tensor(v, dtype=torch.float64) * enc_o).sum()
+    L_o.backward()
+    ref = {k: t.grad.numpy() for k, t in p64.items()}
+    # HIP
+    names = ops.param_names(spec)
+    P = _dev_params(params_np, names)
+    wc = torch.tensor(params_np["conv_classifier.weight"], device=DEV, requires_grad=True)
+    bc = torch.tensor(params_np["conv_classifier.bias"], device=DEV, requires_grad=True)
+    enc = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec)
+    logits, logp = ops.head_forward(enc, wc, bc, T)
+    L = (torch.tensor(w, device=DEV) * logp).sum() + (torch.tensor(u, device=DEV) * logits).sum() \
+        + (torch.tensor(v, device=DEV) * enc).sum()
+    assert abs(L.item() - L_o.item()) < 1e-3 * abs(L_o.item()) + 1e-2
+    L.backward()
+    _grad_check([p.grad for p in P] + [wc.grad, bc.grad], ref, names + ["conv_classifier.weight", "conv_classifier.bias"],
+                f"B={B} T={T} {over}")
+
+
+def test_backward_matches_reference_golden():
+    """Against the gradients the REFERENCE's autograd produced (sampled entries + norms in the fixture)."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T, Tz, pseed, tseed, wseed, vseed = [int(x) for x in GOLD["grads__meta"]]
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, pseed)
+    names = ops.param_names(spec)
+    P = _dev_params(params_np, names)
+    wc = torch.tensor(params_np["conv_classifier.weight"], device=DEV, requires_grad=True)
+    bc = torch.tensor(params_np["conv_classifier.bias"], device=DEV, requires_grad=True)
+    enc = ops.encoder_forward(torch.tensor(synth.tape(tseed, B, T, 2048), device=DEV), P, spec)
+    _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
+    L = (torch.tensor(synth.uniform_pm1(wseed, (B, T, 48)), device=DEV) * logp).sum() \
+        + (torch.tensor(synth.uniform_pm1(vseed, (B, Tz, 128)), device=DEV) * enc).sum()
+    assert abs(L.item() - GOLD["grads__L"][0]) < 1e-3 * abs(GOLD["grads__L"][0])
+    L.backward()
+    for k, t in zip(names + ["conv_classifier.weight", "conv_classifier.bias"], P + [wc, bc]):
+        g = t.grad.cpu().numpy().reshape(-1).astype(np.float64)
+        norm = float(GOLD[f"grads__{k}__norm"][0])
+        assert abs(np.linalg.norm(g) - norm) <= 1e-3 * norm, k
+        sel = GOLD[f"grads__{k}__idx"]
+        np.testing.assert_allclose(g[sel], GOLD[f"grads__{k}__val"], rtol=1e-3, atol=1e-3 * norm / np.sqrt(g.size), err_msg=k)
+
+
+# ------------------------------------------------------------------------------------ dropout
+def test_training_mode_dropout_replay():
+    """Training mode: the kernels' counter-based dropout masks are read back through the C ABI and
+    injected into the oracle; forward and gradients must then agree (mask replay), and the keep
+    rate must be 1-p."""
+    from mucon_amd import _lib, ops
+    from oracle import dense as od
+    lib = _lib.load()
+    B, T, seed = 2, 700, 1234567
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 55)
+    tape_np = synth.tape(56, B, T, 2048)
+    Tz = spec.out_length(T)
+    drop, Tl = {}, T
+    for i in range(len(spec.stages) + 1):
+        last = i == len(spec.stages)
+        n = B * (Tz if last else Tl) * 128
+        m = torch.empty(n, dtype=torch.uint8, device=DEV)
+        p = spec.last_dropout_rate if last else spec.dropout_rate
+        _lib.check(lib.mucon_test_dropout_mask(_lib.ptr(m), n, seed, i, p, _lib.current_stream_ptr()), "mask")
+        keep = m.cpu().numpy().astype(np.float64)
+        assert abs(keep.mean() - (1 - p)) < 0.01, (i, keep.mean())
+        drop["last" if last else i] = torch.tensor(keep.reshape(B, -1, 128) / (1 - p))
+        if not last and spec.pooling and i in spec.pooling_layers:
+            Tl //= 2
+    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
+    enc_o = od.encoder_forward(torch.tensor(tape_np, dtype=torch.float64), p64, ocfg, drop=drop)
+    v = synth.uniform_pm1(57, (B, Tz, 128))
+    (torch.tensor(v, dtype=torch.float64) * enc_o).sum().backward()
+    names = ops.param_names(spec)
+    P = _dev_params(params_np, names)
+    enc = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec, training=True, seed=seed)
+    np.testing.assert_allclose(enc.detach().cpu().numpy(), enc_o.detach().numpy(), rtol=1e-4, atol=1e-4)
+    (torch.tensor(v, device=DEV) * enc).sum().backward()
+    _grad_check([p.grad for p in P], {k: t.grad.numpy() for k, t in p64.items()}, names, "dropout replay")
+    # a different seed gives a different mask
+    enc2 = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec, training=True, seed=seed + 1)
+    assert not torch.equal(enc2, enc)
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_full_size_batch_properties():
+    """BASELINE config 3 shape (B=8, T=4096, D=2048): size-independent properties.
+    (1) determinism: two runs are bitwise identical (no float atomics anywhere);
+    (2) batch independence: video b of the batch == the same video run alone, bitwise;
+    (3) gradient additivity: batch gradient == sum of per-video gradients (to rounding)."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T = 8, 4096
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 5)
+    names = ops.param_names(spec)
+    P = _dev_params(params_np, names)
+    wc = torch.tensor(params_np["conv_classifier.weight"], device=DEV, requires_grad=True)
+    bc = torch.tensor(params_np["conv_classifier.bias"], device=DEV, requires_grad=True)
+    tape = torch.tensor(synth.tape(6, B, T, 2048), device=DEV)
+    w = torch.tensor(synth.uniform_pm1(7, (B, T, 48)), device=DEV)
+
+    def run(tp, ww):
+        for t in P + [wc, bc]:
+            t.grad = None
+        enc = ops.encoder_forward(tp, P, spec)
+        _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
+        (ww * logp).sum().backward()
+        return enc.detach().clone(), logp.detach().clone(), [t.grad.clone() for t in P + [wc, bc]]
+
+    enc_a, logp_a, g_a = run(tape, w)
+    enc_b, logp_b, g_b = run(tape, w)
+    assert torch.equal(enc_a, enc_b) and torch.equal(logp_a, logp_b)
+    for x, y in zip(g_a, g_b):
+        assert torch.equal(x, y)
+    gsum = [torch.zeros_like(g, dtype=torch.float64) for g in g_a]
+    for b in (0, 3, 7):
+        enc_1, logp_1, _ = run(tape[b:b + 1], w[b:b + 1])
+        assert torch.equal(enc_1[0], enc_a[b]) and torch.equal(logp_1[0], logp_a[b])
+    for b in range(B):
+        _, _, g_1 = run(tape[b:b + 1], w[b:b + 1])
+        for acc, g in zip(gsum, g_1):
+            acc += g.double()
+    for k, acc, g in zip(names + ["wc", "bc"], gsum, g_a):
+        scale = acc.abs().max().item() + 1e-12
+        assert (acc - g.double()).abs().max().item() / scale < 1e-4, k
+    # and the sampled oracle check of the forward on one video of the batch
+    enc_o, _, logp_o = od.hot_path(tape[2:3].cpu().numpy(), params_np, ocfg, torch.float64)
+    np.testing.assert_allclose(enc_a[2:3].cpu().numpy(), enc_o, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logp_a[2:3].cpu().numpy(), logp_o, rtol=1e-4, atol=1e-4)

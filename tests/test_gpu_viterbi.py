@@ -1,0 +1,144 @@
+"""GPU parity of the Viterbi decode through the C ABI: bit-exact (score bits, labels, segments)
+against the golden vectors produced by the reference's Viterbi.decode, and against the literal C
+oracle on further seeded cases (batched launch, BASELINE config 5 size, small slot counts)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from mucon_amd import synth
+from helpers import C, f64_bits, load_viterbi_golden, viterbi_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+Z, META = load_viterbi_golden()
+FS, MAXLEN = META["fs"], META["max_length"]
+
+
+class TableModel:
+    """Length model backed by a golden table P[J x N] (rows = lengths fs, 2fs, ...)."""
+
+    def __init__(self, P, max_len=MAXLEN):
+        self.P, self.max_len = P, max_len
+
+    def max_length(self):
+        return self.max_len
+
+    def rows_for(self, transcript, fs):
+        return self.P
+
+
+def _decode(lp, tr, P, fs=FS, max_len=MAXLEN):
+    from mucon_amd.core.viterbi import SingleTranscriptGrammar, Viterbi
+    v = Viterbi(None, None, frame_sampling=fs)
+    v.grammar = SingleTranscriptGrammar([int(x) for x in tr], lp.shape[1])
+    v.length_model = TableModel(P, max_len)
+    return v.decode(lp)
+
+
+def _check(got, score, labels, seg_label, seg_len):
+    g_score, g_labels, g_segs = got
+    assert f64_bits(g_score) == f64_bits(score), (g_score, score)
+    np.testing.assert_array_equal(np.asarray(g_labels, dtype=np.int32), labels)
+    np.testing.assert_array_equal(np.asarray([s.label for s in g_segs], dtype=np.int32), seg_label)
+    np.testing.assert_array_equal(np.asarray([s.length for s in g_segs], dtype=np.int32), seg_len)
+
+
+@pytest.mark.parametrize("cs", META["cases"], ids=[c["name"] for c in META["cases"]])
+def test_decode_matches_reference_golden(cs):
+    nm = cs["name"]
+    lp = viterbi_case_inputs(Z, cs)
+    got = _decode(torch.from_numpy(lp).cuda(), Z[f"{nm}__transcript"], Z[f"{nm}__P"])
+    _check(got, Z[f"{nm}__score"][0], Z[f"{nm}__labels"], Z[f"{nm}__seg_label"], Z[f"{nm}__seg_len"])
+    assert isinstance(got[0], np.float64) and isinstance(got[1], list) and len(got[1]) == cs["T"]
+
+
+def test_decode_accepts_numpy_like_the_reference():
+    cs = META["cases"][4]
+    nm = cs["name"]
+    got = _decode(viterbi_case_inputs(Z, cs), Z[f"{nm}__transcript"], Z[f"{nm}__P"])
+    _check(got, Z[f"{nm}__score"][0], Z[f"{nm}__labels"], Z[f"{nm}__seg_label"], Z[f"{nm}__seg_len"])
+
+
+@pytest.mark.parametrize("er", META["errors"], ids=[e["name"] for e in META["errors"]])
+def test_error_behaviour_matches_reference(er):
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    lp = torch.from_numpy(synth.emissions(er["seed"], er["T"], C)).cuda()
+    mu = np.full(C, 300.0)
+    if er["mu_small"]:
+        mu[er["transcript"][0]] = 0.3
+    v = Viterbi(None, None, frame_sampling=FS)
+    v.grammar = SingleTranscriptGrammar(er["transcript"], C)
+    with np.errstate(all="ignore"):
+        v.length_model = PoissonModel(mu)
+    with pytest.raises({"IndexError": IndexError, "AttributeError": AttributeError}[er["exception"]]):
+        v.decode(lp)
+
+
+def test_full_pipeline_poisson_model_against_oracle():
+    """PoissonModel built by the product from mean lengths (evaluator glue) + decode, vs the oracle."""
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    for i, (T, N) in enumerate([(1500, 4), (2222, 6), (640, 3), (9000, 22)]):
+        tr = synth.transcript(50 + i, N, C)
+        gt = synth.segment_labels(60 + i, T, tr)
+        lp = synth.emissions(70 + i, T, C, labels=gt)
+        rel = synth.uniform01(80 + i, (N,)) + np.float32(0.1)
+        rel = (rel / rel.sum()).astype(np.float32)
+        mu = oracle.mean_lengths_from_s_head(rel, tr, T, C)
+        want = oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN)
+        v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], C), PoissonModel(mu), frame_sampling=FS)
+        _check(v.decode(torch.from_numpy(lp).cuda()), *want)
+
+
+def test_batched_launch_many_videos():
+    """64 ragged videos in one launch == each decoded by the oracle."""
+    from mucon_amd.core.viterbi import PoissonModel, Viterbi
+    lps, trs, lms, wants = [], [], [], []
+    for i in range(64):
+        T = 200 + int(synth.integers(900 + i, 1, 0, 3800)[0])
+        N = 1 + int(synth.integers(901 + i, 1, 0, 12)[0])
+        N = min(N, T // 30)
+        tr = synth.transcript(902 + i, N, C)
+        lp = synth.emissions(903 + i, T, C, labels=synth.segment_labels(904 + i, T, tr))
+        mu = np.full(C, float(T) / N)
+        wants.append(oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN))
+        lps.append(torch.from_numpy(lp).cuda())
+        trs.append([int(x) for x in tr])
+        lms.append(PoissonModel(mu))
+    got = Viterbi(None, None, frame_sampling=FS).decode_batch(lps, trs, lms)
+    for g, w in zip(got, wants):
+        _check(g, *w)
+
+
+def test_baseline_config5_long_video():
+    """BASELINE config 5: T = 16384, 64-state transcript (K = 546 columns, 64 x 66 hypotheses)."""
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    T, N = 16384, 64
+    tr = synth.transcript(11, N, C)
+    lp = synth.emissions(12, T, C, labels=synth.segment_labels(13, T, tr))
+    mu = np.ones(C)
+    mu[np.unique(tr)] = T / N
+    want = oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN)
+    v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], C), PoissonModel(mu), frame_sampling=FS)
+    _check(v.decode(torch.from_numpy(lp).cuda()), *want)
+    # uninformative emissions: the length model and the tie rules decide
+    lp2 = synth.emissions(14, T, C)
+    _check(v.decode(torch.from_numpy(lp2).cuda()), *oracle.viterbi_decode(lp2, tr, mu, FS, MAXLEN))
+
+
+@pytest.mark.parametrize("fs,max_len", [(1, 7), (3, 20), (10, 500), (30, 2000), (50, 6400)])
+def test_other_sampling_and_slot_counts(fs, max_len):
+    """Slot counts J = max_len // fs from 6 to 128, incl. lengths that hit max_len (score -inf)."""
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    J = max_len // fs
+    for i, N in enumerate([1, 2, 5, 9]):
+        K = max(N, min(J * N, 3 * J + i))
+        T = K * fs + (i % fs)
+        tr = synth.transcript(30 + i, N, 12)
+        lp = synth.emissions(31 + i, T, 12, labels=synth.segment_labels(32 + i, T, tr))
+        mu = np.full(12, max(1.0, T / N))
+        with np.errstate(all="ignore"):
+            P = oracle.length_rows(oracle.poisson_table(mu, max_len), tr, fs, max_len)
+        want = oracle.viterbi_decode_table(lp, tr, P, fs, max_len)
+        v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], 12), PoissonModel(mu, max_length=max_len), frame_sampling=fs)
+        _check(v.decode(torch.from_numpy(lp).cuda()), *want)

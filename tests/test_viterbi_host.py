@@ -1,0 +1,109 @@
+"""CPU: host-side logic of the product's Viterbi wrapper (no kernel is launched here).
+
+* PoissonModel (vectorised) reproduces the reference's table (golden rows + the literal oracle loop).
+* last_in_dict_order(): the closed form for the reference's degenerate outcomes is checked against
+  the LITERAL oracle (ordered-dict emulation) over a sweep of column counts, transcript lengths,
+  slot counts and NaN positions."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from mucon_amd import synth
+from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+from mucon_amd.core.viterbi.viterbi import last_in_dict_order
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_poisson_model_matches_reference_rows():
+    g = np.load(os.path.join(GOLD, "glue_cases.npz"))
+    for i in range(4):
+        mu = g[f"g{i}__mu"]
+        pm = PoissonModel(mu)
+        np.testing.assert_allclose(pm.norms, g[f"g{i}__norms"], rtol=1e-13, atol=1e-9)
+        np.testing.assert_allclose(pm.poisson[30:2000:30], g[f"g{i}__poisson_rows"], rtol=1e-13, atol=1e-9)
+        tr = g[f"g{i}__transcript"]
+        P = pm.rows_for(tr, 30)
+        assert P.shape == (66, len(tr))
+        np.testing.assert_array_equal(P, pm.poisson[30:2000:30][:, tr])
+
+
+def test_poisson_model_bits_equal_literal_loop():
+    rng = np.random.default_rng(0)
+    for it in range(10):
+        mu = rng.uniform(0.2, 2500, size=48)
+        mu[:5] = [1.0, 0.3, 0.5, 1.5, 2.0]
+        with np.errstate(all="ignore"):
+            a = oracle.poisson_table(mu, 2000)
+        b = PoissonModel(mu).poisson
+        same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), np.argwhere(~same)[:4]
+        for l in (0, 1, 30, 1999, 2000, 2500):
+            x, y = PoissonModel(mu).score(l, 7), (-np.inf if l >= 2000 else a[l, 7])
+            assert (np.isnan(x) and np.isnan(y)) or x == y
+
+
+def test_grammar_surface():
+    g = SingleTranscriptGrammar([3, 5, 5], 48)
+    assert g.n_classes() == 48 and g.start_symbol() == -1 and g.end_symbol() == -2
+    assert g.possible_successors((-1,)) == {3}
+    assert g.possible_successors((-1, 3, 5)) == {5}
+    assert g.possible_successors((-1, 3, 5, 5)) == {-2}
+    assert g.possible_successors((-1, 4)) == set()
+    assert g.score((-1, 3), 5) == 0.0 and g.score((-1, 3), 6) == -np.inf
+
+
+@pytest.mark.parametrize("J", [1, 2, 3, 5, 8])
+def test_last_in_dict_order_against_literal_oracle(J):
+    """fs = 1, max_len = J: K = T columns, J slots.  A NaN column at n* makes every state >= n*
+    incomparable, so the reference returns the last hypothesis (dict order) among states < n*."""
+    C = 6
+    checked = 0
+    for N in range(1, 7):
+        for K in range(1, J * N + 3):
+            lp = synth.emissions(1000 + 31 * N + K, K, C)
+            tr = synth.transcript(7 * N + K, N, C)
+            for nstar in [None] + list(range(N)):
+                P = np.zeros((J, N))
+                if J * 1 >= J:  # length J*fs == max_len scores -inf in the reference (length_model.py:77)
+                    P[J - 1, :] = -np.inf
+                if nstar is not None:
+                    P[:, nstar] = np.nan
+                n_lim = N if nstar is None else nstar
+                degenerate = (nstar is not None) or (K < N)
+                if not degenerate:
+                    continue
+                want = last_in_dict_order(K, J, n_lim)
+                try:
+                    score, labels, seg_label, seg_len = oracle.viterbi_decode_table(lp, tr, P, 1, J)
+                except oracle.OracleDecodeError as e:
+                    assert e.status == oracle.ST_NO_HYPOTHESIS
+                    assert want is None, (J, N, K, nstar, want)
+                    continue
+                assert want is not None, (J, N, K, nstar)
+                assert score == -np.inf
+                assert (len(seg_len) - 1, int(seg_len[-1]) - 1) == want, (J, N, K, nstar, want, seg_len)
+                checked += 1
+    assert checked > 20
+
+
+def test_wrapper_raises_like_reference():
+    v = Viterbi(None, None, frame_sampling=30)
+    v.grammar = SingleTranscriptGrammar([1, 2], 48)
+    v.length_model = PoissonModel(np.full(48, 300.0))
+    with pytest.raises(IndexError):
+        v._prepare(29)
+    with pytest.raises(AttributeError):
+        v._prepare(30 * (66 * 2 + 1))
+    tr, P, force = v._prepare(3000)
+    assert force is None and P.shape == (66, 2)
+    tr, P, force = v._prepare(45)       # K = 1 < N = 2
+    assert force == (0, 0)
+    mu = np.full(48, 300.0)
+    mu[1] = 0.3                          # NaN norms for the first transcript label
+    with np.errstate(all="ignore"):
+        v.length_model = PoissonModel(mu)
+    with pytest.raises(AttributeError):
+        v._prepare(900)
