@@ -143,6 +143,13 @@ int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, 
 /* ------------------------------------------------------------------------------------------
  * Test / bench helpers (not part of the reference surface)
  * ---------------------------------------------------------------------------------------- */
+/* Where mucon_encoder_fwd left an intermediate inside the workspace ([B][rows][128] float32):
+ * kind 0 = x[layer] (input of layer `layer`; x[0] = activated first_conv output, x[n_layers] =
+ * last_conv input), 1 = h[layer] (activated dilated_conv output), 2 = ypre[layer] (un-pooled output
+ * of a max-pooled layer), 3 = z (last_conv output).  Lets the parity tests compare gradients on the
+ * activation pattern (ReLU masks, max-pool arg-max) the kernels actually took. */
+int mucon_encoder_saved_view(const mucon_encoder_cfg *cfg, int32_t kind, int32_t layer, size_t *byte_offset,
+                             int32_t *rows_per_video);
 /* Plain GEMM on the same MFMA core the encoder uses: out[M][128] = A[M][K] * W[128][K]^T (+bias, relu) */
 int mucon_test_gemm_nt(const float *A, const float *W, const float *bias, float *out, int32_t M,
                        int32_t K, int32_t relu, void *stream);

@@ -66,6 +66,8 @@ SYMBOLS = {
     "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_encoder_saved_view": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), _i32, _i32, ctypes.POINTER(ctypes.c_size_t),
+                                                ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),

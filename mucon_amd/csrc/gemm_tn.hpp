@@ -166,20 +166,41 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
     return hipGetLastError();
 }
 
-// out = sum over slabs, in slab order (deterministic).
+// out = sum over slabs, in a fixed order (bitwise reproducible).  1024 threads = 16 slab lanes x 64
+// elements: lane group g sums slabs g, g+16, g+32, ... (eight independent loads in flight per
+// thread), then the 16 partials are combined through LDS in lane-group order.
 //   mode 0: out[e] = sum_s slabs[s*stride + e]                               (e < n_elems)
 //   mode 1: conv k=3 weight: slab element (o, tap*128 + i) -> out[(o*128 + i)*3 + tap]
-__global__ void reduce_slabs_kernel(const float *slabs, int nslabs, long stride, float *out, int n_elems,
-                                    int mode) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_elems) return;
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *slabs, int nslabs, long stride, float *out,
+                                                            int n_elems, int mode) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int i = 0; i < nslabs; ++i) s += slabs[(long)i * stride + e];
-    if (mode == 0) {
-        out[e] = s;
-    } else {
-        const int o = e / 384, r = e - o * 384;
-        const int tap = r >> 7, i = r & 127;
-        out[(o * 128 + i) * 3 + tap] = s;
+    if (e < n_elems) {
+        const float *p = slabs + e;
+        int i = g;
+        for (; i + 7 * 16 < nslabs; i += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(i + 16 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < nslabs; i += 16) s += p[(long)i * stride];
+    }
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && e < n_elems) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][lane];
+        if (mode == 0) {
+            out[e] = t;
+        } else {
+            const int o = e / 384, r = e - o * 384;
+            const int tap = r >> 7, i = r & 127;
+            out[(o * 128 + i) * 3 + tap] = t;
+        }
     }
 }

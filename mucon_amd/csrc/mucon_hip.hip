@@ -131,7 +131,7 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
 void prof_mark(int slot, bool stop, hipStream_t s);
 
 hipError_t reduce_slabs(const float *slabs, int nslabs, long stride, float *out, int n, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slabs, nslabs, stride, out, n, mode);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, slabs, nslabs, stride, out, n, mode);
     return hipGetLastError();
 }
 
@@ -228,6 +228,44 @@ size_t mucon_encoder_workspace_bytes(const mucon_encoder_cfg *cfg) {
     Plan p;
     make_plan(cfg, p);
     return p.total * sizeof(float);
+}
+
+int mucon_encoder_saved_view(const mucon_encoder_cfg *cfg, int32_t kind, int32_t layer, size_t *byte_offset,
+                             int32_t *rows_per_video) {
+    int rc = validate(cfg);
+    if (rc != MUCON_OK) return rc;
+    Plan pl;
+    make_plan(cfg, pl);
+    if (!byte_offset || !rows_per_video) return fail(MUCON_E_ARG, "null pointer argument");
+    size_t off;
+    int rows;
+    switch (kind) {
+        case 0:  // x[layer]: input of layer `layer` (x[0] = activated first_conv output, x[L] = last_conv input)
+            if (layer < 0 || layer > pl.L) return fail(MUCON_E_ARG, "saved_view: layer %d", layer);
+            off = pl.x[layer];
+            rows = pl.Tl[layer];
+            break;
+        case 1:  // h[layer]: activated dilated_conv output
+            if (layer < 0 || layer >= pl.L) return fail(MUCON_E_ARG, "saved_view: layer %d", layer);
+            off = pl.h[layer];
+            rows = pl.Tl[layer];
+            break;
+        case 2:  // ypre[layer]: un-pooled output of a max-pooled layer
+            if (layer < 0 || layer >= pl.L || !cfg->pool_after[layer] || cfg->pool_type != 0)
+                return fail(MUCON_E_ARG, "saved_view: layer %d is not max-pooled", layer);
+            off = pl.ypre[layer];
+            rows = pl.Tl[layer];
+            break;
+        case 3:  // z: last_conv output
+            off = pl.z;
+            rows = pl.Tz;
+            break;
+        default:
+            return fail(MUCON_E_ARG, "saved_view: kind %d", kind);
+    }
+    *byte_offset = off * sizeof(float);
+    *rows_per_video = rows;
+    return MUCON_OK;
 }
 
 int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *prm, const float *tape, float *enc,

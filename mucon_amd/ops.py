@@ -129,6 +129,20 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+def encoder_saved(enc: torch.Tensor, kind: str, layer: int = 0) -> torch.Tensor:
+    """Intermediate the forward left in its workspace, as a [B, rows, 128] view: kind in
+    {"x", "h", "ypre", "z"} (see mucon_encoder_saved_view).  For tests / debugging."""
+    fn = enc.grad_fn
+    if fn is None or not hasattr(fn, "ws"):
+        raise ValueError("enc is not the output of encoder_forward with autograd enabled")
+    lib = _lib.load()
+    off, rows = ctypes.c_size_t(0), ctypes.c_int32(0)
+    _lib.check(lib.mucon_encoder_saved_view(ctypes.byref(fn.cfg), {"x": 0, "h": 1, "ypre": 2, "z": 3}[kind], int(layer),
+                                            ctypes.byref(off), ctypes.byref(rows)), "mucon_encoder_saved_view")
+    n = fn.cfg.B * rows.value * fn.cfg.H
+    return fn.ws[off.value: off.value + 4 * n].view(torch.float32).view(fn.cfg.B, rows.value, fn.cfg.H)
+
+
 def encoder_forward(tape: torch.Tensor, params: Sequence[torch.Tensor], spec: EncoderSpec, training: bool = False,
                     seed: int = 0) -> torch.Tensor:
     """tape [B,T,D] -> enc [B,Tz,H]: MuCon.temporal_modeling_forward (reference models.py:746-773).

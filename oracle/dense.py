@@ -85,8 +85,13 @@ def seeded_params(cfg: EncoderConfig, seed: int) -> Dict[str, np.ndarray]:
     return out
 
 
-def _act(x, leaky):
-    return torch.nn.functional.leaky_relu(x) if leaky else torch.relu(x)  # default slope 0.01
+def _act(x, leaky, mask=None):
+    """relu / leaky_relu(0.01); with `mask` (bool, True = positive branch) the branch is forced instead
+    of read off x -- used to compare gradients on the activation pattern a kernel actually took."""
+    if mask is None:
+        return torch.nn.functional.leaky_relu(x) if leaky else torch.relu(x)  # default slope 0.01
+    m = mask.to(x.dtype)
+    return x * (m + (0.01 if leaky else 0.0) * (1 - m))
 
 
 def _conv_time_major(x, w, b, dilation=1):
@@ -104,7 +109,7 @@ def _conv_time_major(x, w, b, dilation=1):
 
 
 def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, return_intermediates=False,
-                    drop=None):
+                    drop=None, force=None):
     """tape [B,T,D] -> enc [B,Tz,H].  Restates temporal.py:128-147 + models.py:759-764 (eval mode).
 
     `drop` (optional, for checking the training-mode kernels): {layer index: multiplier [B,T_l,H]}
@@ -112,12 +117,23 @@ def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, r
     ft_last_dropout (models.py:767-768); a multiplier is keep_mask / (1 - p)."""
     p = params
     drop = drop or {}
-    inter = {}
-    x = _act(_conv_time_major(tape, p["ft.first_conv.weight"], p["ft.first_conv.bias"]), cfg.leaky_relu)
+    force = force or {}  # {"first" | ("dil", i) | "last_in" | "final": bool mask, ("pool", i): bool take-second}
+    inter = {"masks": {}}
+    margin = [float("inf")]  # distance of the closest ReLU input / max-pool pair to its kink
+
+    def note(t):
+        if return_intermediates:
+            margin[0] = min(margin[0], float(t.detach().abs().min()))
+        return t
+
+    pre = note(_conv_time_major(tape, p["ft.first_conv.weight"], p["ft.first_conv.bias"]))
+    inter["masks"]["first"] = (pre.detach(), pre.detach() > 0)
+    x = _act(pre, cfg.leaky_relu, force.get("first"))
     inter["x0"] = x
     for i, d in enumerate(cfg.stages):
-        h = _act(_conv_time_major(x, p[f"ft.l_{i}.dilated_conv.weight"], p[f"ft.l_{i}.dilated_conv.bias"], d),
-                 cfg.leaky_relu)
+        pre = note(_conv_time_major(x, p[f"ft.l_{i}.dilated_conv.weight"], p[f"ft.l_{i}.dilated_conv.bias"], d))
+        inter["masks"][("dil", i)] = (pre.detach(), pre.detach() > 0)
+        h = _act(pre, cfg.leaky_relu, force.get(("dil", i)))
         y = _conv_time_major(h, p[f"ft.l_{i}.conv_1x1.weight"], p[f"ft.l_{i}.conv_1x1.bias"])
         if i in drop:
             y = y * drop[i]
@@ -125,10 +141,20 @@ def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, r
         if cfg.pooling and i in cfg.pooling_layers:
             Tl = y.shape[1] // 2
             a, b = y[:, 0:2 * Tl:2, :], y[:, 1:2 * Tl:2, :]
-            y = torch.maximum(a, b) if cfg.pooling_type == "max" else (a + b) / 2 * 2  # avg_pool1d * 2
+            if cfg.pooling_type == "max":
+                note(a - b)
+                inter["masks"][("pool", i)] = ((b - a).detach(), (b - a).detach() > 0)
+                if ("pool", i) in force:
+                    y = torch.where(force[("pool", i)], b, a)
+                else:
+                    y = torch.maximum(a, b)
+            else:
+                y = (a + b) / 2 * 2  # avg_pool1d * 2
         x = y
         inter[f"x{i + 1}"] = x
-    z = _conv_time_major(_act(x, cfg.leaky_relu), p["ft.last_conv.weight"], p["ft.last_conv.bias"])
+    inter["masks"]["last_in"] = (x.detach(), x.detach() > 0)
+    z = _conv_time_major(_act(note(x), cfg.leaky_relu, force.get("last_in")), p["ft.last_conv.weight"],
+                         p["ft.last_conv.bias"])
     inter["z"] = z
     if cfg.last_gn:
         B, Tz, H = z.shape
@@ -138,7 +164,9 @@ def encoder_forward(tape, params: Dict[str, torch.Tensor], cfg: EncoderConfig, r
         var = zg.var(dim=(1, 3), unbiased=False, keepdim=True)
         z = ((zg - mean) / torch.sqrt(var + cfg.gn_eps)).reshape(B, Tz, H) * p["ft_last_gn.weight"] + p["ft_last_gn.bias"]
     if cfg.last_relu:
-        z = torch.relu(z)
+        inter["masks"]["final"] = (z.detach(), z.detach() > 0)
+        z = _act(note(z), False, force.get("final"))
+    inter["kink_margin"] = margin[0]
     if "last" in drop:
         z = z * drop["last"]
     return (z, inter) if return_intermediates else z

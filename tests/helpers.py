@@ -34,3 +34,22 @@ def viterbi_case_inputs(z, cs):
 
 def f64_bits(x):
     return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def dropout_keep_np(n, seed, site, p):
+    """numpy replay of the kernels' counter-based dropout (mucon_amd/csrc/common.hpp: mix32 / make_drop):
+    keep[e] for element index e of dropout site `site`."""
+    M = 0xFFFFFFFF
+    s0 = ((seed & M) ^ ((0x85EBCA6B * (site + 1)) & M)) & M
+    s1 = ((seed >> 32) + 0xC2B2AE35 * (site + 1)) & M
+    t = p * 4294967296.0
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    with np.errstate(over="ignore"):
+        x = (np.arange(n, dtype=np.uint64) ^ np.uint64(s0)) & np.uint64(M)
+        x = (x * np.uint64(0x9E3779B1) + np.uint64(s1)) & np.uint64(M)
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7feb352d)) & np.uint64(M)
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846ca68b)) & np.uint64(M)
+        x ^= x >> np.uint64(16)
+    return x >= np.uint64(thresh)

@@ -115,39 +115,77 @@ def test_forward_matches_oracle_f64(B, T, over):
 
 # ------------------------------------------------------------------------------------ backward
 def _grad_check(grads_dev, grads_ref, names, tag):
+    """fp32 kernels vs the float64 oracle ON THE SAME ACTIVATION PATTERN: relative L2 error < 1e-4 per
+    tensor and every entry within 5e-4 of the largest one (SURVEY.md 8c proposes rtol 1e-3; measured
+    ~1e-6, twice torch-CPU fp32's own distance to fp64 -- tools/gpu_diag.py prints both)."""
     worst = 0.0
     for k, g in zip(names, grads_dev):
-        ref = grads_ref[k]
-        g = g.cpu().numpy().astype(np.float64)
-        scale = np.abs(ref).max() + 1e-12
-        err = np.abs(g - ref).max() / scale
-        worst = max(worst, err)
-        assert err < 1e-3, f"{tag}: grad {k}: max err {err:.3e} relative to max |g| = {scale:.3e}"
+        g = g.cpu().numpy().astype(np.float64).reshape(-1)
+        ref = np.zeros_like(g) if grads_ref[k] is None else grads_ref[k].reshape(-1)  # unused parameter: zero gradient
+        l2 = np.linalg.norm(g - ref) / (np.linalg.norm(ref) + 1e-12)
+        mx = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-12)
+        worst = max(worst, l2)
+        assert l2 < 1e-4 and mx < 5e-4, f"{tag}: grad {k}: rel L2 err {l2:.3e}, max err {mx:.3e} of max |g|"
     return worst
 
 
-@pytest.mark.parametrize("B,T,over", [(1, 600, {}), (2, 777, {}), (1, 2097, {}), (2, 500, {"pooling_type": "sum"}),
+def _hip_pattern(enc, spec):
+    """The activation pattern the kernels took (ReLU masks, max-pool arg-max), read from the tensors the
+    forward saved in its workspace."""
+    from mucon_amd import ops
+    L = len(spec.stages)
+    f = {"first": ops.encoder_saved(enc, "x", 0) > 0, "last_in": ops.encoder_saved(enc, "x", L) > 0}
+    for i in range(L):
+        f[("dil", i)] = ops.encoder_saved(enc, "h", i) > 0
+        if spec.pooling and i in spec.pooling_layers and spec.pooling_type == "max":
+            y = ops.encoder_saved(enc, "ypre", i)
+            Th = y.shape[1] // 2
+            f[("pool", i)] = y[:, 1:2 * Th:2] > y[:, 0:2 * Th:2]
+    if spec.last_relu:
+        f["final"] = enc.detach() > 0
+    return {k: v.cpu() for k, v in f.items()}
+
+
+def _pattern_agrees(hip, oracle_masks, only=None, tol=2e-5):
+    """A ReLU input (or max-pool pair) that lies within fp32 rounding of its kink may legitimately take
+    the other branch in ANY fp32 evaluation; everywhere else the kernels' pattern must equal the
+    float64 oracle's.  Returns the number of such near-kink flips."""
+    flips = 0
+    for k, m in hip.items():
+        pre, om = oracle_masks[k]
+        diff = m != om
+        if only is not None and k in only:
+            diff &= only[k]
+        n = int(diff.sum())
+        if n:
+            assert float(pre[diff].abs().max()) < tol, (k, n, float(pre[diff].abs().max()))
+            flips += n
+    assert flips <= 8, flips
+    return flips
+
+
+@pytest.mark.parametrize("B,T,over", [(1, 600, {}), (2, 777, {}), (1, 2097, {}), (3, 1201, {}),
+                                      (2, 500, {"pooling_type": "sum"}),
                                       (1, 900, {"leaky_relu": True}), (1, 640, {"last_gn": False}),
                                       (1, 512, {"last_relu": False, "last_gn_num_groups": 16})])
 def test_backward_matches_oracle_f64(B, T, over):
-    """Gradients of L = sum(w*logp) + sum(u*logits) + sum(v*enc) w.r.t. every parameter."""
+    """Gradients of L = sum(w*logp) + sum(u*logits) + sum(v*enc) w.r.t. every parameter.
+
+    An fp32 forward and an fp64 forward disagree on the sign of the handful of ReLU inputs that are
+    ~1e-7 from zero, and each such flip re-routes one gradient entry (~5e-3 relative on a bias
+    gradient) -- so the gradients are compared on the pattern the kernels took: (1) that pattern must
+    equal the oracle's except at inputs within 2e-5 of a kink, (2) the oracle's autograd, forced onto
+    that pattern, must match the kernels' gradients to 1e-4."""
     from mucon_amd import ops
     from oracle import dense as od
+    seed = 91
     spec, ocfg = _spec(over), _ocfg(over)
-    params_np = od.seeded_params(ocfg, 91)
-    tape_np = synth.tape(92, B, T, 2048)
+    params_np = od.seeded_params(ocfg, seed)
+    tape_np = synth.tape(seed + 1, B, T, 2048)
     Tz = spec.out_length(T)
-    w = synth.uniform_pm1(93, (B, T, 48))
-    u = synth.uniform_pm1(95, (B, T, 48))
-    v = synth.uniform_pm1(94, (B, Tz, 128))
-    # oracle
-    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
-    enc_o = od.encoder_forward(torch.tensor(tape_np, dtype=torch.float64), p64, ocfg)
-    logits_o, logp_o = od.head_forward(enc_o, p64, ocfg, T)
-    L_o = (torch.tensor(w, dtype=torch.float64) * logp_o).sum() + (torch.tensor(u, dtype=torch.float64) * logits_o).sum() \
-        + (torch.tensor(v, dtype=torch.float64) * enc_o).sum()
-    L_o.backward()
-    ref = {k: t.grad.numpy() for k, t in p64.items()}
+    w = synth.uniform_pm1(seed + 2, (B, T, 48))
+    u = synth.uniform_pm1(seed + 4, (B, T, 48))
+    v = synth.uniform_pm1(seed + 3, (B, Tz, 128))
     # HIP
     names = ops.param_names(spec)
     P = _dev_params(params_np, names)
@@ -157,8 +195,20 @@ def test_backward_matches_oracle_f64(B, T, over):
     logits, logp = ops.head_forward(enc, wc, bc, T)
     L = (torch.tensor(w, device=DEV) * logp).sum() + (torch.tensor(u, device=DEV) * logits).sum() \
         + (torch.tensor(v, device=DEV) * enc).sum()
-    assert abs(L.item() - L_o.item()) < 1e-3 * abs(L_o.item()) + 1e-2
     L.backward()
+    pattern = _hip_pattern(enc, spec)
+    # oracle: free forward (pattern check), then forced onto the kernels' pattern (gradient check)
+    tape64 = torch.tensor(tape_np, dtype=torch.float64)
+    _, inter = od.encoder_forward(tape64, od.to_torch(params_np, torch.float64), ocfg, return_intermediates=True)
+    _pattern_agrees(pattern, inter["masks"])
+    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
+    enc_o = od.encoder_forward(tape64, p64, ocfg, force=pattern)
+    logits_o, logp_o = od.head_forward(enc_o, p64, ocfg, T)
+    L_o = (torch.tensor(w, dtype=torch.float64) * logp_o).sum() + (torch.tensor(u, dtype=torch.float64) * logits_o).sum() \
+        + (torch.tensor(v, dtype=torch.float64) * enc_o).sum()
+    L_o.backward()
+    assert abs(L.item() - L_o.item()) < 1e-4 * abs(L_o.item()) + 1e-3
+    ref = {k: (None if t.grad is None else t.grad.numpy()) for k, t in p64.items()}
     _grad_check([p.grad for p in P] + [wc.grad, bc.grad], ref, names + ["conv_classifier.weight", "conv_classifier.bias"],
                 f"B={B} T={T} {over}")
 
@@ -190,39 +240,49 @@ def test_backward_matches_reference_golden():
 
 # ------------------------------------------------------------------------------------ dropout
 def test_training_mode_dropout_replay():
-    """Training mode: the kernels' counter-based dropout masks are read back through the C ABI and
-    injected into the oracle; forward and gradients must then agree (mask replay), and the keep
-    rate must be 1-p."""
+    """Training mode: the kernels' counter-based dropout masks (read back through the C ABI, and
+    replayed bit-for-bit by tests/helpers.dropout_keep_np) are injected into the oracle; forward and
+    gradients must then agree, and the keep rate must be 1-p."""
     from mucon_amd import _lib, ops
     from oracle import dense as od
+    from helpers import dropout_keep_np
     lib = _lib.load()
     B, T, seed = 2, 700, 1234567
     spec, ocfg = _spec({}), _ocfg({})
     params_np = od.seeded_params(ocfg, 55)
     tape_np = synth.tape(56, B, T, 2048)
     Tz = spec.out_length(T)
-    drop, Tl = {}, T
+    drop, dropped, Tl = {}, {}, T
     for i in range(len(spec.stages) + 1):
         last = i == len(spec.stages)
         n = B * (Tz if last else Tl) * 128
         m = torch.empty(n, dtype=torch.uint8, device=DEV)
         p = spec.last_dropout_rate if last else spec.dropout_rate
         _lib.check(lib.mucon_test_dropout_mask(_lib.ptr(m), n, seed, i, p, _lib.current_stream_ptr()), "mask")
-        keep = m.cpu().numpy().astype(np.float64)
+        keep = m.cpu().numpy()
+        np.testing.assert_array_equal(keep.astype(bool), dropout_keep_np(n, seed, i, p))
         assert abs(keep.mean() - (1 - p)) < 0.01, (i, keep.mean())
-        drop["last" if last else i] = torch.tensor(keep.reshape(B, -1, 128) / (1 - p))
+        drop["last" if last else i] = torch.tensor(keep.astype(np.float64).reshape(B, -1, 128) / (1 - p))
         if not last and spec.pooling and i in spec.pooling_layers:
             Tl //= 2
-    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
-    enc_o = od.encoder_forward(torch.tensor(tape_np, dtype=torch.float64), p64, ocfg, drop=drop)
     v = synth.uniform_pm1(57, (B, Tz, 128))
-    (torch.tensor(v, dtype=torch.float64) * enc_o).sum().backward()
     names = ops.param_names(spec)
     P = _dev_params(params_np, names)
     enc = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec, training=True, seed=seed)
-    np.testing.assert_allclose(enc.detach().cpu().numpy(), enc_o.detach().numpy(), rtol=1e-4, atol=1e-4)
     (torch.tensor(v, device=DEV) * enc).sum().backward()
-    _grad_check([p.grad for p in P], {k: t.grad.numpy() for k, t in p64.items()}, names, "dropout replay")
+    pattern = _hip_pattern(enc, spec)
+    tape64 = torch.tensor(tape_np, dtype=torch.float64)
+    enc_free, inter = od.encoder_forward(tape64, od.to_torch(params_np, torch.float64), ocfg, return_intermediates=True,
+                                         drop=drop)
+    # a dropped output reads enc == 0 whatever the sign of its GroupNorm value: ignore those positions
+    _pattern_agrees(pattern, inter["masks"], only={"final": drop["last"] != 0})
+    pattern["final"] = torch.where(drop["last"] != 0, pattern["final"], inter["masks"]["final"][1])
+    np.testing.assert_allclose(enc.detach().cpu().numpy(), enc_free.numpy(), rtol=1e-4, atol=1e-4)
+    p64 = od.to_torch(params_np, torch.float64, requires_grad=True)
+    enc_o = od.encoder_forward(tape64, p64, ocfg, drop=drop, force=pattern)
+    (torch.tensor(v, dtype=torch.float64) * enc_o).sum().backward()
+    _grad_check([p.grad for p in P], {k: (None if t.grad is None else t.grad.numpy()) for k, t in p64.items()}, names,
+                "dropout replay")
     # a different seed gives a different mask
     enc2 = ops.encoder_forward(torch.tensor(tape_np, device=DEV), P, spec, training=True, seed=seed + 1)
     assert not torch.equal(enc2, enc)

@@ -97,7 +97,7 @@ def test_batched_launch_many_videos():
     for i in range(64):
         T = 200 + int(synth.integers(900 + i, 1, 0, 3800)[0])
         N = 1 + int(synth.integers(901 + i, 1, 0, 12)[0])
-        N = min(N, T // 30)
+        N = max(min(N, T // 30), -(-(T // 30) // 66))  # 1 <= N <= K, and K <= 66 N so that hypotheses survive
         tr = synth.transcript(902 + i, N, C)
         lp = synth.emissions(903 + i, T, C, labels=synth.segment_labels(904 + i, T, tr))
         mu = np.full(C, float(T) / N)
