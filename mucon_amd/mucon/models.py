@@ -1,0 +1,293 @@
+"""MuCon model with the reference's surface (src/mucon/models.py): create_model, MuCon.forward /
+predict / loss / set_teacher_forcing, encode_params / decode_params, the MuConLoss /
+MuConForwardOut / MuConPredictOut records, and the reference's parameter names, so a reference
+state_dict loads unchanged.
+
+What runs where
+  * temporal_modeling_forward (reference models.py:746-773), frame_classifier_forward (:567-582)
+    and the per-frame log-softmax (:368, :405): the hand-written gfx950 kernels, via mucon_amd.ops.
+  * the s-head (biLSTM encoder + attention LSTM decoder, :585-744) and the losses (:376-565):
+    PyTorch-ROCm ops.  They are rows "next" of SURVEY.md 8f, kept here so that forward/loss are
+    complete; their arithmetic follows the reference statement by statement.
+"""
+import math
+from dataclasses import dataclass
+from typing import List
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.nn import functional as F
+
+from .. import ops
+from ..core.datasets import Batch
+from ..core.modules.temporal import WaveNetBlock
+from .masks import create_masks, project_lengths_softmax
+
+
+@dataclass(repr=False)
+class GeneralLoss:
+    main: Tensor
+
+
+@dataclass(repr=False)
+class MuConLoss(GeneralLoss):
+    transcript_loss: Tensor
+    mucon_loss: Tensor
+    length_loss: Tensor
+    smoothing_loss: Tensor
+
+
+@dataclass(repr=False)
+class MuConForwardOut:
+    transcript: Tensor    # [(N + 1) x (M + 1)] log-probs of the s-head, EOS included
+    lengths: Tensor       # [N] un-normalised log length estimates
+    segmentation: Tensor  # [Tf x M] y-head logits
+
+
+@dataclass(repr=False)
+class MuConPredictOut:
+    transcript: List[int]         # N + 1 labels, EOS included
+    lengths: Tensor               # [N] softmaxed relative lengths
+    segmentation_logits: Tensor   # [T x M] log-softmaxed y-head output (Viterbi input)
+
+
+def rand_t(*sz):
+    return torch.randn(sz) / math.sqrt(sz[0])
+
+
+def rand_p(*sz):
+    return nn.Parameter(rand_t(*sz), requires_grad=True)
+
+
+def create_model(cfg, num_classes: int, max_decoding_steps: int, input_feature_size: int) -> "MuCon":
+    if cfg.model.name == "mucon":
+        return MuCon(cfg=cfg, input_feature_size=input_feature_size, num_classes=num_classes,
+                     max_decoding_steps=max_decoding_steps)
+    raise Exception("Invalid model name")
+
+
+class MuCon(nn.Module):
+    def __init__(self, cfg, input_feature_size: int, num_classes: int, max_decoding_steps: int):
+        super().__init__()
+        self.cfg = cfg
+        self.input_feature_size, self.num_classes, self.max_decoding_steps = input_feature_size, num_classes, max_decoding_steps
+        self.teacher_forcing = True
+        self.EOS_token_id = num_classes
+        m = cfg.model
+        self.loss_mul_mucon, self.loss_mul_transcript = m.loss.mul_mucon, m.loss.mul_transcript
+        self.loss_mul_smoothing, self.loss_mul_length = m.loss.mul_smoothing, m.loss.mul_length
+
+        if m.ft.type != "wavenet":
+            raise NotImplementedError(f"ft type {m.ft.type!r}: only the default 'wavenet' encoder has HIP kernels")
+        H = m.ft.hidden_size
+        self.ft = WaveNetBlock(in_channels=input_feature_size, stages=m.ft.stages, out_dims=H, pooling=m.ft.pooling,
+                               pooling_type=m.ft.pooling_type, pooling_layers=m.ft.pooling_layers,
+                               leaky=m.ft.leaky_relu, dropout_rate=m.ft.dropout_rate)
+        self.ft_last_gn = nn.GroupNorm(num_groups=m.ft.last_gn_num_groups, num_channels=H)
+        self.ft_last_dropout = nn.Dropout(p=m.ft.last_dropout_rate)
+
+        E, Dd = m.fs.encoder.hidden_size, m.fs.decoder.hidden_size
+        bi = m.fs.encoder.bidirectional
+        enc_out = 2 * E if bi else E
+        self.fs_encoder_lstm = nn.LSTM(input_size=H, hidden_size=E, batch_first=True, dropout=m.fs.encoder.dropout,
+                                       bidirectional=bi)
+        self.fs_encoder_hidden_out = nn.Linear(enc_out, E)
+        self.fs_encoder_cn_out = nn.Linear(enc_out, E)
+        self.fs_decoder_attention_W1 = rand_p(E * 2, Dd)
+        self.fs_decoder_attention_l2 = nn.Linear(Dd, Dd)
+        self.fs_decoder_attention_l3 = nn.Linear(Dd + Dd, Dd)  # present (unused) in the reference too
+        self.fs_decoder_attention_V = rand_p(Dd)
+        self.fs_decoder_embedding = nn.Embedding(num_embeddings=num_classes + 2, embedding_dim=Dd)
+        self.fs_decoder_embedding_drop = nn.Dropout(p=m.fs.decoder.embedding_dropout)
+        self.fs_decoder_attn_combine = nn.Linear(enc_out + Dd, Dd)
+        self.fs_decoder_lstm = nn.LSTM(input_size=Dd, hidden_size=Dd, dropout=m.fs.decoder.dropout)
+        self.fs_decoder_transcript = nn.Sequential(nn.Linear(Dd, Dd), nn.ReLU(), nn.Linear(Dd, num_classes + 1))
+        self.fs_decoder_length = nn.Sequential(nn.Linear(Dd + num_classes + 1, int(Dd / 2)), nn.ReLU(),
+                                               nn.Linear(int(Dd / 2), 1))
+        self.conv_classifier = nn.Conv1d(H, num_classes, kernel_size=1)
+
+        # two parameter sets, clipped separately by the trainer (reference models.py:284-317)
+        def flat(items):
+            out = []
+            for it in items:
+                out.extend(list(it.parameters()) if isinstance(it, nn.Module) else [it])
+            return out
+
+        self.encode_params = flat([self.ft, self.ft_last_gn, self.fs_encoder_lstm, self.fs_encoder_hidden_out,
+                                   self.fs_encoder_cn_out])
+        self.decode_params = flat([self.fs_decoder_attention_W1, self.fs_decoder_attention_l2,
+                                   self.fs_decoder_attention_l3, self.fs_decoder_attention_V, self.fs_decoder_embedding,
+                                   self.fs_decoder_attn_combine, self.fs_decoder_lstm, self.fs_decoder_transcript,
+                                   self.fs_decoder_length, self.conv_classifier])
+        self._step = 0  # dropout stream counter for the HIP encoder
+
+    def get_params(self, original_lr):  # fandak.Model.get_params
+        return [{"params": self.parameters(), "lr": original_lr}]
+
+    # ------------------------------------------------------------------------------ hot path
+    def _encoder_spec(self) -> ops.EncoderSpec:
+        ft = self.cfg.model.ft
+        return self.ft.spec(last_gn=ft.last_gn, last_gn_num_groups=ft.last_gn_num_groups, last_relu=ft.last_relu,
+                            last_dropout=ft.last_dropout, last_dropout_rate=ft.last_dropout_rate)
+
+    def temporal_modeling_forward(self, input: Tensor) -> Tensor:
+        """[B x T x D] -> [B x T' x D'] (reference models.py:746-773): one fused HIP pipeline --
+        no permute, no transposed copy of the tape."""
+        self._step += 1
+        seed = (int(self.cfg.system.seed) << 32) ^ self._step if self.training else 0
+        return self.ft.forward_time_major(input, self.ft_last_gn.weight, self.ft_last_gn.bias, self._encoder_spec(), seed)
+
+    def frame_classifier_forward(self, temporal_encoded: Tensor, target_length: int) -> Tensor:
+        """[1 x Ds x Tz] -> [1 x num_classes x Tf] (reference models.py:567-582)."""
+        enc = temporal_encoded.permute(0, 2, 1)
+        logits, _ = ops.head_forward(enc, self.conv_classifier.weight, self.conv_classifier.bias, target_length,
+                                     want_logits=True, want_logp=False)
+        return logits.permute(0, 2, 1)
+
+    def _segmentation_and_logp(self, temporal_encoded: Tensor, Tf: int):
+        """logits [Tf x M] and log-probs [Tf x M] from one kernel launch."""
+        logits, logp = ops.head_forward(temporal_encoded, self.conv_classifier.weight, self.conv_classifier.bias, Tf)
+        return logits[0], logp[0]
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, batch: Batch) -> MuConForwardOut:
+        features = batch.feats                       # [1 x T x D]
+        Tf = features.shape[1]
+        temporal_encoded = self.temporal_modeling_forward(input=features)      # [1 x Tz x Dt]
+        transcripts, lengths = self.sequence_generation_forward(
+            temporal_encoded=temporal_encoded, tf_transcript_target_length=batch.transcript_tf_target.shape[0],
+            transcript_tf_input=batch.transcript_tf_input, transcript_tf_target=batch.transcript_tf_target)
+        segmentation, logp = self._segmentation_and_logp(temporal_encoded, Tf)  # [Tf x M] each
+        out = MuConForwardOut(transcript=torch.cat(transcripts, dim=0), lengths=torch.stack(lengths[:-1]),
+                              segmentation=segmentation)
+        out._logp = logp  # the kernel's log-softmax, reused by predict() and the smoothing loss
+        return out
+
+    def predict(self, batch: Batch, forward_out: MuConForwardOut) -> MuConPredictOut:
+        if self.teacher_forcing:
+            transcript = batch.transcript_tf_target.detach().cpu().numpy().tolist()
+        else:
+            transcript = [w.argmax().item() for w in forward_out.transcript]
+        logp = getattr(forward_out, "_logp", None)
+        if logp is None:
+            logp = F.log_softmax(forward_out.segmentation, dim=1)
+        return MuConPredictOut(transcript=transcript, lengths=F.softmax(forward_out.lengths, dim=0),
+                               segmentation_logits=logp)
+
+    # ------------------------------------------------------------------------------ s-head
+    def sequence_generation_forward(self, temporal_encoded: Tensor, tf_transcript_target_length: int,
+                                    transcript_tf_input: Tensor, transcript_tf_target: Tensor):
+        """biLSTM encoder over [1 x Tz x D'], additive attention, LSTM decoder (reference models.py:585-728)."""
+        enc_out, (h_n, c_n) = self.fs_encoder_lstm(temporal_encoded)
+        dec_h = self.fs_encoder_hidden_out(h_n.view(1, -1)).unsqueeze(0)   # [1 x 1 x D'']
+        dec_c = self.fs_encoder_cn_out(c_n.view(1, -1)).unsqueeze(0)
+        memory = enc_out[0]                                               # [Tz x 2D']
+        memory_proj = memory @ self.fs_decoder_attention_W1               # [Tz x D'']
+        steps = tf_transcript_target_length if (self.teacher_forcing or self.training) else self.max_decoding_steps
+        lengths, transcripts = [], []
+        dec_in = transcript_tf_input[0].unsqueeze(0)
+        for step in range(steps):
+            if self.teacher_forcing:
+                dec_in = transcript_tf_input[step].unsqueeze(0)
+            emb = self.fs_decoder_embedding_drop(F.relu(self.fs_decoder_embedding(dec_in)))      # [1 x Ds]
+            attn = self._calculate_attention(dec_h, memory_proj)                                  # [Tz]
+            context = (attn.unsqueeze(1) * memory).sum(dim=0, keepdim=True)                       # [1 x 2Ds]
+            mixed = F.relu(self.fs_decoder_attn_combine(torch.cat((emb, context), 1)).unsqueeze(0))  # [1 x 1 x Ds]
+            dec_out, (dec_h, dec_c) = self.fs_decoder_lstm(mixed, (dec_h, dec_c))
+            word_logits = self.fs_decoder_transcript(dec_out)                                     # [1 x 1 x M+1]
+            length = self.fs_decoder_length(F.relu(torch.cat((mixed, word_logits), 2))).squeeze()
+            word_logp = F.log_softmax(word_logits.squeeze(0), dim=1)                              # [1 x M+1]
+            transcripts.append(word_logp)
+            lengths.append(length)
+            word = word_logp.argmax(dim=1)
+            if not self.teacher_forcing and not self.training and word.item() == self.EOS_token_id:
+                break
+            if not self.teacher_forcing:
+                dec_in = word
+        return transcripts, lengths
+
+    def _calculate_attention(self, current_hidden_state: Tensor, encoder_result_ready_for_attention: Tensor) -> Tensor:
+        q = self.fs_decoder_attention_l2(current_hidden_state.view(1, -1))
+        u = torch.tanh(encoder_result_ready_for_attention + q)
+        return F.softmax(u @ self.fs_decoder_attention_V, dim=0)
+
+    # ------------------------------------------------------------------------------ losses
+    def loss(self, batch: Batch, forward_out: MuConForwardOut) -> MuConLoss:
+        t = self.transcript_loss(batch, forward_out)
+        ln = self.length_loss(batch, forward_out)
+        mu = self.mucon_loss(batch, forward_out)
+        sm = self.smoothing_loss(batch, forward_out)
+        main = self.loss_mul_transcript * t + self.loss_mul_length * ln + self.loss_mul_mucon * mu + self.loss_mul_smoothing * sm
+        return MuConLoss(main=main, transcript_loss=t, length_loss=ln, mucon_loss=mu, smoothing_loss=sm)
+
+    def smoothing_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
+        sm = self.cfg.model.loss.smoothing
+        logp = getattr(forward_out, "_logp", None) if sm.log_softmax_before else None
+        if logp is not None:
+            return self._smoothing_from(logp)
+        return self.calculate_smoothing_loss_for_logits(forward_out.segmentation)
+
+    def _smoothing_from(self, x: Tensor) -> Tensor:
+        sm = self.cfg.model.loss.smoothing
+        values = F.mse_loss(x[1:, :], x[:-1, :].detach())
+        if sm.clamp:
+            values = torch.clamp(values, min=sm.clamp_min, max=sm.clamp_max)
+        return torch.mean(values)
+
+    def calculate_smoothing_loss_for_logits(self, logits):
+        if self.cfg.model.loss.smoothing.log_softmax_before:
+            logits = F.log_softmax(logits, dim=1)
+        return self._smoothing_from(logits)
+
+    def mucon_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
+        if self.teacher_forcing:
+            target = batch.transcript
+        else:
+            target = torch.tensor([w.argmax().item() for w in forward_out.transcript[:-1]], dtype=torch.long,
+                                  device=batch.transcript.device)
+            target[target >= self.num_classes] = 0
+        T = forward_out.segmentation.shape[0]
+        absolute_lengths = project_lengths_softmax(T=T, L=forward_out.lengths)
+        mc = self.cfg.model.loss.mucon
+        masks = create_masks(T=T, L=absolute_lengths, template=mc.template, overlap=mc.overlap)   # [N x T]
+        return self.calculate_mucon_loss_using_masks(absolute_lengths, masks, forward_out.segmentation, target)
+
+    def _bg_weight(self, n, index, value, device):
+        w = torch.ones(n, dtype=torch.float32, device=device)
+        w[index] = value
+        return w
+
+    def calculate_mucon_loss_using_masks(self, absolute_lengths, masks, segmentation, target_transcript):
+        lc = self.cfg.model.loss
+        weight = (self._bg_weight(self.num_classes, lc.mucon_weight_background_index, lc.mucon_weight_background_value,
+                                  absolute_lengths.device) if lc.mucon_weight_background else None)
+        kind = lc.mucon.type
+        if kind == "flint":
+            # mean of the masked logits per segment == (masks @ segmentation) / length, then log-softmax
+            windows = (masks @ segmentation) / absolute_lengths.unsqueeze(1)                 # [N x M]
+            return F.nll_loss(F.log_softmax(windows, dim=1), target_transcript, weight=weight, reduction="mean")
+        if kind == "arithmetic":
+            T = segmentation.size(0)
+            total = 0
+            for i in range(absolute_lengths.shape[0]):
+                tgt = target_transcript[i].clone().detach().repeat(T).long().to(segmentation.device)
+                total = total + (F.cross_entropy(segmentation, tgt, reduction="none", weight=weight) * masks[i]).sum()
+            return total / T
+        raise Exception(f"Invalid mucon type ({kind})")
+
+    def length_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
+        w = self.cfg.model.loss.length_width
+        s = forward_out.lengths
+        return F.relu(s - w).sum() + F.relu(-w - s).sum()
+
+    def transcript_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
+        lc = self.cfg.model.loss
+        weight = (self._bg_weight(self.num_classes + 1, lc.transcript_weight_background_index,
+                                  lc.transcript_weight_background_value, forward_out.transcript.device)
+                  if lc.transcript_weight_background else None)
+        return F.nll_loss(input=forward_out.transcript, target=batch.transcript_tf_target,
+                          reduction="mean" if lc.transcript_average else "sum", weight=weight)
+
+    def set_teacher_forcing(self, teacher_forcing: bool = True):
+        self.teacher_forcing = teacher_forcing

@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange of the N>1 path -- one flat gradient
+all-reduce per step (mucon_amd/mucon/trainers.all_reduce_gradients; bench.py uses the same
+flatten / all-reduce / scatter-back pattern), disjoint video shards per rank, and the all-reduced
+MoF counters of the evaluator.  The kernels themselves need a GPU; everything around them is
+exercised here with a stand-in model."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mucon_amd.mucon.trainers import all_reduce_gradients
+
+    torch.manual_seed(0)  # identical replicas
+    model = nn.Sequential(nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 4), nn.Linear(4, 2))
+    for p in model[2].parameters():      # a parameter set that receives no gradient on rank 1
+        p.requires_grad_(True)
+    x = torch.randn(5, 16, generator=torch.Generator().manual_seed(100 + rank))
+    h = model[1](model[0](x))
+    y = model[3](model[2](h)) if rank == 0 else h[:, :2] * 1.0
+    y.sum().backward()
+    local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    all_reduce_gradients(model, world)
+    torch.save({"local": local, "avg": [p.grad.clone() for p in model.parameters()]}, os.path.join(out_dir, f"r{rank}.pt"))
+
+    # shard arithmetic of SimpleTrainer.train_epoch: disjoint, same count on every rank
+    n = 11
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(1)).tolist()
+    steps = n // world
+    mine = [order[s * world + rank] for s in range(steps)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        flat = sum(gathered, [])
+        assert len(flat) == len(set(flat)) == steps * world
+    # evaluator counters: a few scalars summed over ranks
+    counts = torch.tensor([3.0 + rank, 10.0], dtype=torch.float64)
+    dist.all_reduce(counts)
+    assert counts.tolist() == [7.0, 20.0]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
+        assert torch.equal(a0, a1)                      # every rank ends with the same averaged gradient
+        z = torch.zeros_like(a0)
+        want = ((l0 if l0 is not None else z) + (l1 if l1 is not None else z)) / 2
+        torch.testing.assert_close(a0, want, rtol=1e-6, atol=1e-7)
