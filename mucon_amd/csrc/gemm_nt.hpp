@@ -16,10 +16,11 @@
 #pragma once
 #include "common.hpp"
 
-constexpr int NT_BM = 128;
 constexpr int NT_BK = 32;
 constexpr int NT_LDS = 36;  // padded row length (floats)
-constexpr int NT_SMEM_BYTES = 2 * 2 * NT_BM * NT_LDS * 4;  // A and W tiles, double buffered
+// workgroup tile = BM time steps x 128 channels; BM in {128, 64, 32}: 4 waves arranged WAVES_M x (4/WAVES_M),
+// each owning WM x WN MFMA tiles of 32x32.  Small BM = more, shorter workgroups for the coarse levels.
+constexpr int nt_smem_bytes(int BM) { return 2 * (BM + 128) * NT_LDS * 4; }  // A and W tiles, double buffered
 
 struct NtParams {
     const float *A;     // [B][Ta][lda] source rows
@@ -38,18 +39,22 @@ struct NtParams {
     DropCfg drop;       // element index (b*Trows + t)*128 + c
 };
 
-template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
 __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WN = 4 / WAVES_N;            // 32-wide column tiles per wave (128 columns in all)
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int NQA = BM / 32;               // A-tile float4 loads per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
-    float *Bs = smem + 2 * NT_BM * NT_LDS;
+    float *Bs = smem + 2 * BM * NT_LDS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * NT_BM;
+    const int t0 = blockIdx.x * BM;
     const int ktiles_per_tap = p.Kc >> 5;
     const int nkt = p.taps * ktiles_per_tap;
     const int Ktot = p.taps * p.Kc;
@@ -57,14 +62,17 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     const int lc4 = (tid & 7) * 4;
     const float *Ab = p.A + (long)b * p.a_bstride;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NQA], rb[4];
 
     auto gload = [&](int kt) {
         const int tap = kt / ktiles_per_tap;
         const int kk = (kt - tap * ktiles_per_tap) * 32;
         const int off = (tap - (p.taps >> 1)) * p.tap_step;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q)
+            rb[q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + 32 * q) * Ktot + kt * 32 + lc4);
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
             const int r = lrow + 32 * q;
             const int t = t0 + r;
             const int ts = t + off;
@@ -84,31 +92,29 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                 }
             }
             ra[q] = v;
-            rb[q] = *reinterpret_cast<const f32x4 *>(p.W + (long)r * Ktot + kt * 32 + lc4);
         }
     };
     auto sstore = [&](int buf) {
-        float *a = As + buf * NT_BM * NT_LDS;
-        float *w = Bs + buf * NT_BM * NT_LDS;
+        float *a = As + buf * BM * NT_LDS;
+        float *w = Bs + buf * 128 * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = ra[q];
-            *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[q];
-        }
+        for (int q = 0; q < NQA; ++q) *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[q];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // lane (i = lane&31, h = lane>>5) feeds row i of its tile and k = 16h + s at MFMA step s:
     // both operands use the same k permutation inside the 32-wide tile, so the sum is unchanged.
-    const int a_off = (wr * 64 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
-    const int b_off = (wc * 64 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
+    const int a_off = (wr * WM * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
+    const int b_off = (wc * WN * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
 
     gload(0);
     sstore(0);
@@ -116,26 +122,29 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
-        const float *Aw = As + cur * NT_BM * NT_LDS + a_off;
-        const float *Bw = Bs + cur * NT_BM * NT_LDS + b_off;
+        const float *Aw = As + cur * BM * NT_LDS + a_off;
+        const float *Bw = Bs + cur * 128 * NT_LDS + b_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f32x4 av[2][2], bv[2][2];
+            f32x4 av[WM][2], bv[WN][2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < WM; ++m) {
                 av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * NT_LDS + ks * 8);
                 av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * NT_LDS + ks * 8 + 4);
-                bv[m][0] = *reinterpret_cast<const f32x4 *>(Bw + m * 32 * NT_LDS + ks * 8);
-                bv[m][1] = *reinterpret_cast<const f32x4 *>(Bw + m * 32 * NT_LDS + ks * 8 + 4);
+            }
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8);
+                bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8 + 4);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const float a0 = av[0][s >> 2][s & 3], a1 = av[1][s >> 2][s & 3];
-                const float b0 = bv[0][s >> 2][s & 3], b1 = bv[1][s >> 2][s & 3];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3],
+                                                                         acc[m][n], 0, 0, 0);
             }
         }
         if (kt + 1 < nkt) sstore(cur ^ 1);
@@ -146,10 +155,10 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     // registers (4q, 4q+1) and (4q+2, 4q+3) hold time steps (2i, 2i+1): max_pool1d(2) pairs.
     const long vbase = (long)b * p.Trows;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WM; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = wc * 64 + nt * 32 + (lane & 31);
+        for (int nt = 0; nt < WN; ++nt) {
+            const int col = (wc * WN + nt) * 32 + (lane & 31);
             const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int reg = rp * 2 + u;
-                    const int row = wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const int row = (wr * WM + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                     const int t = t0 + row;
                     tt[u] = t;
                     float x = acc[mt][nt][reg] + bias;
@@ -188,17 +197,37 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     }
 }
 
-template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
-static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
-    auto k = nt_gemm_kernel<PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>;
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 32;
+    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, nt_smem_bytes(BM));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((p.Trows + NT_BM - 1) / NT_BM, B);
-    hipLaunchKernelGGL(k, grid, dim3(256), NT_SMEM_BYTES, s, p);
+    dim3 grid((p.Trows + BM - 1) / BM, B);
+    hipLaunchKernelGGL(k, grid, dim3(256), nt_smem_bytes(BM), s, p);
     return hipGetLastError();
+}
+
+// Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it.
+extern int g_nt_force_bm;  // 0 = automatic (tuning hook: MUCON_NT_BM)
+static inline int nt_pick_bm(int B, int Trows) {
+    if (g_nt_force_bm) return g_nt_force_bm;
+    const long rows = (long)B * Trows;
+    if (rows >= 512L * 128) return 128;
+    if (rows >= 512L * 64) return 64;
+    return 32;
+}
+
+template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
+    switch (nt_pick_bm(B, p.Trows)) {
+        case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
+        case 64: return launch_nt_cfg<1, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
+        default: return launch_nt_cfg<1, 1, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
+    }
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mucon_hip.h"
@@ -11,6 +12,8 @@
 #include "gemm_nt.hpp"
 #include "gemm_tn.hpp"
 #include "small_kernels.hpp"
+
+int g_nt_force_bm = 0;
 
 namespace {
 
@@ -213,7 +216,15 @@ void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), 
 
 extern "C" {
 
-int mucon_abi_version(void) { return MUCON_ABI_VERSION; }
+int mucon_abi_version(void) {
+    static bool once = false;
+    if (!once) {  // tuning hook: force the NT tile height (32 / 64 / 128)
+        const char *e = getenv("MUCON_NT_BM");
+        if (e) g_nt_force_bm = atoi(e);
+        once = true;
+    }
+    return MUCON_ABI_VERSION;
+}
 const char *mucon_last_error(void) { return g_err; }
 
 int32_t mucon_encoder_out_length(const mucon_encoder_cfg *cfg) {
