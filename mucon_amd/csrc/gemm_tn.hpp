@@ -17,24 +17,31 @@
 
 constexpr int TN_SMEM_BYTES = 2 * 2 * 32 * 128 * 4;  // Y and X tiles, double buffered = 64 KiB
 
+// One launch covers every weight gradient of a residual layer: k-chunks [0, nk0) use operand set 0
+// (Y0 = gradient at the dilated conv's pre-activation, X0 = the layer input gathered per tap ->
+// dilated_conv.weight), and with DUAL the extra k-chunk nk0 uses set 1 (Y1 = gradient at the layer
+// output with the dropout mask replayed, X1 = the activated dilated-conv output -> conv_1x1.weight).
 struct TnParams {
-    const float *Y;   // [B][Trows][128]
     int Trows;
-    const float *X;   // [B][Tx][ldx]
+    const float *Y0;  // [B][Trows][128]
+    const float *X0;  // [B][Tx][ldx]
     long x_bstride;
     int ldx, Tx;
     int taps;         // 3: k-chunk kc is tap kc (row offset (kc-1)*tap_step), columns 0..127
-    int tap_step;     // 1: k-chunk kc is columns kc*128.. of X
-    int Ktot;         // number of k columns overall (multiple of 128)
-    float *slabs;     // [n_time_chunks][128][Ktot]
-    float *bias_slabs;  // [n_time_chunks][128] column sums of Y, or null
+    int tap_step;     // 1: k-chunk kc is columns kc*128.. of X0
+    int nk0;          // k-chunks of set 0
+    const float *Y1;  // DUAL: [B][Trows][128], multiplied by the dropout mask
+    const float *X1;  // DUAL: [B][Trows][128]
+    int Ktot;         // slab row length = 128 * (nk0 + DUAL)
+    float *slabs;       // [n_time_chunks][128][Ktot]
+    float *bias_slabs;  // [n_time_chunks][2][128]: column sums of Y0 (and of Y1 with DUAL)
     int MC;           // time steps per chunk (multiple of 32)
     int chunks_per_video;
     float slope;
-    DropCfg drop;     // Y_DROP: Y element index (b*Trows + t)*128 + n
+    DropCfg drop;     // set 1: Y1 element index (b*Trows + t)*128 + n
 };
 
-template <bool Y_DROP, bool X_ACT>
+template <bool X0_ACT, bool DUAL>
 __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ys = smem;
@@ -50,10 +57,13 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
     const int tend = min(tbeg + p.MC, p.Trows);
     const int ntiles = (tend - tbeg + 31) >> 5;
-    const int xoff = (p.taps == 3) ? (kc - 1) * p.tap_step : 0;
-    const int xcol = (p.taps == 3) ? 0 : kc * 128;
-    const float *Yb = p.Y + (long)b * p.Trows * 128;
-    const float *Xb = p.X + (long)b * p.x_bstride + xcol;
+    const bool second = DUAL && kc >= p.nk0;   // workgroup-uniform
+    const int xoff = (!second && p.taps == 3) ? (kc - 1) * p.tap_step : 0;
+    const int xcol = (second || p.taps == 3) ? 0 : kc * 128;
+    const float *Yb = (second ? p.Y1 : p.Y0) + (long)b * p.Trows * 128;
+    const float *Xb = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;
+    const int ldx = second ? 128 : p.ldx;
+    const int Tx = second ? p.Trows : p.Tx;
 
     f32x4 ry[4], rx[4];
     auto gload = [&](int mtile) {
@@ -66,16 +76,16 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
             f32x4 y = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
             if (t < tend) {
                 y = *reinterpret_cast<const f32x4 *>(Yb + (long)t * 128 + c4);
-                if (Y_DROP) {
-                    if (p.drop.thresh) {
+                if (DUAL) {
+                    if (second && p.drop.thresh) {
                         const uint32_t idx = (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)c4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] *= drop_mul(p.drop, idx + e);
                     }
                 }
-                if (ts >= 0 && ts < p.Tx) {
-                    x = *reinterpret_cast<const f32x4 *>(Xb + (long)ts * p.ldx + c4);
-                    if (X_ACT) {
+                if (ts >= 0 && ts < Tx) {
+                    x = *reinterpret_cast<const f32x4 *>(Xb + (long)ts * ldx + c4);
+                    if (X0_ACT) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
                     }
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float bsum = 0.f;
-    const bool do_bias = (p.bias_slabs != nullptr) && (kc == 0) && (tid < 128);
+    const bool do_bias = (p.bias_slabs != nullptr) && (kc == 0 || (DUAL && kc == p.nk0)) && (tid < 128);
 
     // lane (i = lane&31, h = lane>>5): MFMA step s consumes time step 16h + s of the tile.
     const int y_off = (lane >> 5) * 16 * 128 + wr * 64 + (lane & 31);
@@ -148,12 +158,12 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
                 slab[(long)row * p.Ktot + col] = acc[mt][nt][reg];
             }
         }
-    if (do_bias) p.bias_slabs[(long)mc * 128 + tid] = bsum;
+    if (do_bias) p.bias_slabs[(long)mc * 256 + (second ? 128 : 0) + tid] = bsum;
 }
 
-template <bool Y_DROP, bool X_ACT>
+template <bool X0_ACT, bool DUAL>
 static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
-    auto k = tn_gemm_kernel<Y_DROP, X_ACT>;
+    auto k = tn_gemm_kernel<X0_ACT, DUAL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -166,41 +176,81 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
     return hipGetLastError();
 }
 
-// out = sum over slabs, in a fixed order (bitwise reproducible).  1024 threads = 16 slab lanes x 64
-// elements: lane group g sums slabs g, g+16, g+32, ... (eight independent loads in flight per
-// thread), then the 16 partials are combined through LDS in lane-group order.
-//   mode 0: out[e] = sum_s slabs[s*stride + e]                               (e < n_elems)
-//   mode 1: conv k=3 weight: slab element (o, tap*128 + i) -> out[(o*128 + i)*3 + tap]
-__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *slabs, int nslabs, long stride, float *out,
-                                                            int n_elems, int mode) {
-    __shared__ float part[16][64];
+// ------------------------------------------------------------------------------------------
+// Batched slab reduction: ONE launch sums every gradient's partial slabs of a backward pass, in a
+// fixed order (bitwise reproducible -- no float atomics).  1024 threads = 16 slab lanes x 64
+// elements: lane group g sums slabs g, g+16, ... (eight independent loads in flight per thread),
+// then the 16 partials are combined through LDS in lane-group order.
+//   element (row, col) of a job reads slabs[s*slab_stride + row*ld + coff + col]
+//   mode 0: out[row*ncols + col]      mode 1 (conv k=3 weight, ncols = 384): col = tap*128 + i ->
+//   out[(row*128 + i)*3 + tap], the reference's [out][in][k] layout
+// ------------------------------------------------------------------------------------------
+constexpr int REDUCE_MAX_JOBS = 64;
+struct ReduceJob {
+    const float *slabs;
+    float *out;
+    long slab_stride;
+    int nslabs, ld, coff, ncols, n_elems, mode;
+    int block0;  // first workgroup of this job
+    int vec;     // 1: ncols, coff, ld, slab_stride and n_elems are multiples of 4 (float4 path)
+};
+struct ReduceBatch {
+    ReduceJob j[REDUCE_MAX_JOBS];
+    int njobs, nblocks;
+};
+
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb) {
+    // a workgroup owns 256 consecutive elements of one job: 64 lanes x float4, 16 slab lanes
+    __shared__ f32x4 part[16][64];
+    int ji = 0;
+    while (ji + 1 < rb.njobs && (int)blockIdx.x >= rb.j[ji + 1].block0) ++ji;
+    const ReduceJob &J = rb.j[ji];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (e < n_elems) {
-        const float *p = slabs + e;
-        int i = g;
-        for (; i + 7 * 16 < nslabs; i += 8 * 16) {
-            float v[8];
+    const int e = (((int)blockIdx.x - J.block0) * 64 + lane) * 4;   // ncols, coff, ld are multiples of 4
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int row = 0, col = 0;
+    if (!J.vec) {  // odd shapes (e.g. a class count that is not a multiple of 4): element-wise
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(long)(i + 16 * u) * stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+        for (int k = 0; k < 4; ++k) {
+            const int ek = e + k;
+            if (ek < J.n_elems) {
+                const int r = ek / J.ncols, c = ek - r * J.ncols;
+                const float *p = J.slabs + (long)r * J.ld + J.coff + c;
+                float a = 0.f;
+                for (int i = g; i < J.nslabs; i += 16) a += p[(long)i * J.slab_stride];
+                s[k] = a;
+            }
         }
-        for (; i < nslabs; i += 16) s += p[(long)i * stride];
+    } else if (e < J.n_elems) {
+        row = e / J.ncols;
+        col = e - row * J.ncols;
+        const float *p = J.slabs + (long)row * J.ld + J.coff + col;
+        int i = g;
+        for (; i + 3 * 16 < J.nslabs; i += 4 * 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + 16 * u) * J.slab_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; i < J.nslabs; i += 16) s += *reinterpret_cast<const f32x4 *>(p + (long)i * J.slab_stride);
     }
     part[g][lane] = s;
     __syncthreads();
-    if (g == 0 && e < n_elems) {
-        float t = part[0][lane];
+    if (g == 0 && e < J.n_elems) {
+        f32x4 t = part[0][lane];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t += part[k][lane];
-        if (mode == 0) {
-            out[e] = t;
+        if (!J.vec) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < J.n_elems) J.out[e + k] = t[k];
+        } else if (J.mode == 0) {
+            *reinterpret_cast<f32x4 *>(J.out + e) = t;
         } else {
-            const int o = e / 384, r = e - o * 384;
-            const int tap = r >> 7, i = r & 127;
-            out[(o * 128 + i) * 3 + tap] = t;
+            const int tap = col >> 7, i = col & 127;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) J.out[(row * 128 + i + k) * 3 + tap] = t[k];
         }
     }
 }

@@ -34,11 +34,12 @@ int fail(int code, const char *fmt, ...) {
 
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats: 256-byte alignment
 
-// time-chunk length for a weight-gradient launch: aim at ~512 workgroups
+// time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
+// time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 inline int pick_mc(int B, int Trows, int kchunks) {
-    long want = ((long)B * Trows * kchunks + 511) / 512;
+    long want = ((long)B * Trows * kchunks + 255) / 256;
     long mc = ((want + 31) / 32) * 32;
-    if (mc < 32) mc = 32;
+    if (mc < 128) mc = 128;
     if (mc > 1024) mc = 1024;
     return (int)mc;
 }
@@ -110,19 +111,17 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.gB = take(full);
     p.dpre = take(full);
     p.dyd = take(full);
-    // slabs: the largest weight-gradient launch
+    // slab arena: every weight-gradient launch of a backward pass keeps its own slabs until the
+    // single batched reduction at the end
     size_t sf = 0, bf = 0;
     auto consider = [&](int Trows, int Ktot) {
         const int mc = pick_mc(p.B, Trows, Ktot / 128);
         const size_t nmc = (size_t)p.B * ((Trows + mc - 1) / mc);
-        sf = sf > nmc * 128 * Ktot ? sf : nmc * 128 * Ktot;
-        bf = bf > nmc * 128 ? bf : nmc * 128;
+        sf += align64(nmc * 128 * Ktot);
+        bf += align64(nmc * 256);
     };
     consider(p.T, p.D);
-    for (int l = 0; l < p.L; ++l) {
-        consider(p.Tl[l], 384);
-        consider(p.Tl[l], 128);
-    }
+    for (int l = 0; l < p.L; ++l) consider(p.Tl[l], 512);
     consider(p.Tz, 128);
     p.slab_floats = sf;
     p.bslab_floats = bf;
@@ -133,39 +132,97 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
 
 void prof_mark(int slot, bool stop, hipStream_t s);
 
-hipError_t reduce_slabs(const float *slabs, int nslabs, long stride, float *out, int n, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, slabs, nslabs, stride, out, n, mode);
-    return hipGetLastError();
-}
+// Collects the slab reductions of one backward pass; run() sums them all in one launch.
+struct Reducer {
+    ReduceBatch rb;
+    hipStream_t stream;
+    explicit Reducer(hipStream_t s) : stream(s) {
+        rb.njobs = 0;
+        rb.nblocks = 0;
+    }
+    bool add(const float *slabs, int nslabs, long slab_stride, int ld, int coff, int nrows, int ncols, float *out,
+             int mode) {
+        if (rb.njobs >= REDUCE_MAX_JOBS && run() != hipSuccess) return false;  // table full: flush what is queued
+        ReduceJob &j = rb.j[rb.njobs++];
+        j.slabs = slabs;
+        j.out = out;
+        j.slab_stride = slab_stride;
+        j.nslabs = nslabs;
+        j.ld = ld;
+        j.coff = coff;
+        j.ncols = ncols;
+        j.n_elems = nrows * ncols;
+        j.mode = mode;
+        j.vec = ((ncols | coff | ld | j.n_elems) % 4 == 0 && slab_stride % 4 == 0) ? 1 : 0;
+        j.block0 = rb.nblocks;
+        rb.nblocks += (j.n_elems + 255) / 256;
+        return true;
+    }
+    hipError_t run() {
+        if (rb.njobs == 0) return hipSuccess;
+        hipLaunchKernelGGL(reduce_batch_kernel, dim3(rb.nblocks), dim3(1024), 0, stream, rb);
+        rb.njobs = 0;
+        rb.nblocks = 0;
+        return hipGetLastError();
+    }
+};
 
-// weight gradient through the TN core: out_w (mode 0: [128][Ktot], mode 1: conv3 layout), out_b [128]
-template <bool Y_DROP, bool X_ACT>
-int wgrad(const Plan &pl, float *ws, const float *Y, int Trows, const float *X, long x_bstride, int ldx, int Tx,
-          int taps, int tap_step, int Ktot, float slope, DropCfg drop, float *out_w, int mode, float *out_b,
-          hipStream_t s, int prof_slot = -1) {
+// One weight-gradient launch through the TN core.  Slabs are carved from the arena at *arena / *barena
+// (floats, advanced); the reductions are queued on `red`.
+//   set 0: Y0 x X0 (taps / column chunks) -> out_w0 (mode0: 0 = [128][nk0*128], 1 = conv3 layout), out_b0
+//   set 1 (dual): (Y1 * dropout) x X1    -> out_w1 [128][128], out_b1
+struct WgradArgs {
+    const float *Y0, *X0;
+    long x_bstride;
+    int ldx, Tx, taps, tap_step, nk0;
+    bool x0_act;
+    const float *Y1, *X1;  // null: single set
+    float *out_w0, *out_b0, *out_w1, *out_b1;
+    int mode0;
+    DropCfg drop;
+};
+int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, const WgradArgs &a, float slope,
+          Reducer &red, hipStream_t s, int prof_slot = -1) {
+    const bool dual = a.Y1 != nullptr;
     TnParams t;
-    t.Y = Y;
+    memset(&t, 0, sizeof(t));
     t.Trows = Trows;
-    t.X = X;
-    t.x_bstride = x_bstride;
-    t.ldx = ldx;
-    t.Tx = Tx;
-    t.taps = taps;
-    t.tap_step = tap_step;
-    t.Ktot = Ktot;
-    t.slabs = ws + pl.slabs;
-    t.bias_slabs = out_b ? ws + pl.bslabs : nullptr;
-    t.MC = pick_mc(pl.B, Trows, Ktot / 128);
+    t.Y0 = a.Y0;
+    t.X0 = a.X0;
+    t.x_bstride = a.x_bstride;
+    t.ldx = a.ldx;
+    t.Tx = a.Tx;
+    t.taps = a.taps;
+    t.tap_step = a.tap_step;
+    t.nk0 = a.nk0;
+    t.Y1 = a.Y1;
+    t.X1 = a.X1;
+    t.Ktot = 128 * (a.nk0 + (dual ? 1 : 0));
+    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128);
     t.chunks_per_video = (Trows + t.MC - 1) / t.MC;
     t.slope = slope;
-    t.drop = drop;
+    t.drop = a.drop;
     const int nmc = pl.B * t.chunks_per_video;
-    if ((size_t)nmc * 128 * Ktot > pl.slab_floats) return fail(MUCON_E_WORKSPACE, "internal: slab region too small");
+    const size_t need = align64((size_t)nmc * 128 * t.Ktot), bneed = align64((size_t)nmc * 256);
+    if (arena + need > pl.slab_floats || barena + bneed > pl.bslab_floats)
+        return fail(MUCON_E_WORKSPACE, "internal: slab arena too small");
+    t.slabs = ws + pl.slabs + arena;
+    t.bias_slabs = ws + pl.bslabs + barena;
+    arena += need;
+    barena += bneed;
     if (prof_slot >= 0) prof_mark(prof_slot, false, s);
-    HIPCHK((launch_tn<Y_DROP, X_ACT>(t, pl.B, s)));
+    if (dual) HIPCHK((launch_tn<false, true>(t, pl.B, s)));
+    else if (a.x0_act) HIPCHK((launch_tn<true, false>(t, pl.B, s)));
+    else HIPCHK((launch_tn<false, false>(t, pl.B, s)));
     if (prof_slot >= 0) prof_mark(prof_slot, true, s);
-    HIPCHK(reduce_slabs(t.slabs, nmc, (long)128 * Ktot, out_w, 128 * Ktot, mode, s));
-    if (out_b) HIPCHK(reduce_slabs(t.bias_slabs, nmc, 128, out_b, 128, 0, s));
+    const long ss = (long)128 * t.Ktot;
+    bool ok = red.add(t.slabs, nmc, ss, t.Ktot, 0, 128, a.nk0 * 128, a.out_w0, a.mode0);
+    if (a.out_b0) ok = ok && red.add(t.bias_slabs, nmc, 256, 256, 0, 1, 128, a.out_b0, 0);
+    if (dual) {
+        ok = ok && red.add(t.slabs, nmc, ss, t.Ktot, a.nk0 * 128, 128, 128, a.out_w1, 0);
+        if (a.out_b1) ok = ok && red.add(t.bias_slabs, nmc, 256, 256, 128, 1, 128, a.out_b1, 0);
+    }
+    if (!ok) return fail(MUCON_E_ARG, "internal: too many reduction jobs");
     return MUCON_OK;
 }
 
@@ -381,6 +438,8 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
 
     float *cur = ws + pl.gA;   // gradient w.r.t. the current activation
     float *other = ws + pl.gB;
+    Reducer red(s);
+    size_t arena = 0, barena = 0;
 
     {   // GroupNorm / ReLU / Dropout backward -> dz in `cur`
         GnBwdArgs g;
@@ -399,16 +458,28 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(B), dim3(256), 0, s, g);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
-            HIPCHK(reduce_slabs(ws + pl.gnpart, B, 256, gr->gn_w, 128, 0, s));
-            HIPCHK(reduce_slabs(ws + pl.gnpart + 128, B, 256, gr->gn_b, 128, 0, s));
+            red.add(ws + pl.gnpart, B, 256, 256, 0, 1, 128, gr->gn_w, 0);
+            red.add(ws + pl.gnpart, B, 256, 256, 128, 1, 128, gr->gn_b, 0);
         } else {
             HIPCHK(hipMemsetAsync(gr->gn_w, 0, 128 * sizeof(float), s));
             HIPCHK(hipMemsetAsync(gr->gn_b, 0, 128 * sizeof(float), s));
         }
     }
     {   // last_conv backward
-        rc = wgrad<false, true>(pl, ws, cur, Tz, ws + pl.x[L], (long)Tz * 128, 128, Tz, 1, 0, 128, slope, nodrop,
-                                gr->last_w, 0, gr->last_b, s);
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.Y0 = cur;
+        a.X0 = ws + pl.x[L];
+        a.x_bstride = (long)Tz * 128;
+        a.ldx = 128;
+        a.Tx = Tz;
+        a.taps = 1;
+        a.nk0 = 1;
+        a.x0_act = true;
+        a.out_w0 = gr->last_w;
+        a.out_b0 = gr->last_b;
+        a.drop = nodrop;
+        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, s);
         if (rc != MUCON_OK) return rc;
         NtParams p = nt_base(cur, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, other, slope);
         p.mask = ws + pl.x[L];
@@ -430,22 +501,36 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             HIPCHK(hipGetLastError());
             dyd = u;
         }
-        // conv_1x1: weight/bias gradient, then data gradient through the dilated conv's non-linearity
-        rc = wgrad<true, false>(pl, ws, dyd, Tl, ws + pl.h[l], (long)Tl * 128, 128, Tl, 1, 0, 128, slope, dl,
-                                gr->pw_w[l], 0, gr->pw_b[l], s);
-        if (rc != MUCON_OK) return rc;
-        {
+        {   // gradient at the dilated conv's pre-activation: through conv_1x1 (dropout replayed) and the non-linearity
             NtParams p = nt_base(dyd, (long)Tl * 128, 128, Tl, Tl, 1, 0, 128, ws + pl.W2t + (size_t)l * 16384, nullptr,
                                  ws + pl.dpre, slope);
             p.mask = ws + pl.h[l];
             p.drop = dl;
             HIPCHK((launch_nt<false, true, false, false, false, true, 0>(p, B, s)));
         }
-        // dilated_conv: weight/bias gradient, then data gradient + residual
-        rc = wgrad<false, false>(pl, ws, ws + pl.dpre, Tl, ws + pl.x[l], (long)Tl * 128, 128, Tl, 3, cfg->dilation[l],
-                                 384, slope, nodrop, gr->dil_w[l], 1, gr->dil_b[l], s);
-        if (rc != MUCON_OK) return rc;
-        {
+        {   // all four parameter gradients of the layer in one launch
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.Y0 = ws + pl.dpre;
+            a.X0 = ws + pl.x[l];
+            a.x_bstride = (long)Tl * 128;
+            a.ldx = 128;
+            a.Tx = Tl;
+            a.taps = 3;
+            a.tap_step = cfg->dilation[l];
+            a.nk0 = 3;
+            a.Y1 = dyd;
+            a.X1 = ws + pl.h[l];
+            a.out_w0 = gr->dil_w[l];
+            a.out_b0 = gr->dil_b[l];
+            a.mode0 = 1;
+            a.out_w1 = gr->pw_w[l];
+            a.out_b1 = gr->pw_b[l];
+            a.drop = dl;
+            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, s);
+            if (rc != MUCON_OK) return rc;
+        }
+        {   // data gradient of the dilated conv + the residual branch
             float *dst = (dyd == cur) ? other : cur;
             NtParams p = nt_base(ws + pl.dpre, (long)Tl * 128, 128, Tl, Tl, 3, -cfg->dilation[l], 128,
                                  ws + pl.W1b + (size_t)l * 49152, nullptr, dst, slope);
@@ -458,10 +543,24 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
-    // first_conv: the tape needs no gradient; weight gradient streams the tape once more
-    rc = wgrad<false, false>(pl, ws, cur, pl.T, tape, (long)pl.T * pl.D, pl.D, pl.T, 1, 0, pl.D, slope, nodrop,
-                             gr->first_w, 0, gr->first_b, s, 1);
-    return rc;
+    {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.Y0 = cur;
+        a.X0 = tape;
+        a.x_bstride = (long)pl.T * pl.D;
+        a.ldx = pl.D;
+        a.Tx = pl.T;
+        a.taps = 1;
+        a.nk0 = pl.D / 128;
+        a.out_w0 = gr->first_w;
+        a.out_b0 = gr->first_b;
+        a.drop = nodrop;
+        rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1);
+        if (rc != MUCON_OK) return rc;
+    }
+    HIPCHK(red.run());
+    return MUCON_OK;
 }
 
 // ------------------------------------------------------------------------------------------ head
@@ -544,8 +643,10 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     }
     hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
     HIPCHK(hipGetLastError());
-    HIPCHK(reduce_slabs(a.w_slabs, (int)nblk, (long)C * H, d_w, C * H, 0, s));
-    HIPCHK(reduce_slabs(a.b_slabs, (int)nblk, C, d_b, C, 0, s));
+    Reducer red(s);
+    red.add(a.w_slabs, (int)nblk, (long)C * H, C * H, 0, 1, C * H, d_w, 0);
+    red.add(a.b_slabs, (int)nblk, C, C, 0, 1, C, d_b, 0);
+    HIPCHK(red.run());
     return MUCON_OK;
 }
 
@@ -569,11 +670,27 @@ int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, in
     const int mc = pick_mc(1, M, K / 128);
     const size_t nmc = (M + mc - 1) / mc;
     pl.slabs = 0;
-    pl.slab_floats = nmc * 128 * K;
-    pl.bslabs = align64(pl.slab_floats);
-    if (workspace_bytes < (pl.bslabs + nmc * 128) * sizeof(float)) return fail(MUCON_E_WORKSPACE, "test_gemm_tn workspace");
-    return wgrad<false, false>(pl, static_cast<float *>(workspace), Y, M, X, 0, K, M, 1, 0, K, 0.f,
-                               make_drop(0, 0, 0.f, false), out, 0, nullptr, static_cast<hipStream_t>(stream));
+    pl.slab_floats = align64(nmc * 128 * K);
+    pl.bslabs = pl.slab_floats;
+    pl.bslab_floats = align64(nmc * 256);
+    if (workspace_bytes < (pl.slab_floats + pl.bslab_floats) * sizeof(float)) return fail(MUCON_E_WORKSPACE, "test_gemm_tn workspace");
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Y0 = Y;
+    a.X0 = X;
+    a.ldx = K;
+    a.Tx = M;
+    a.taps = 1;
+    a.nk0 = K / 128;
+    a.out_w0 = out;
+    a.drop = make_drop(0, 0, 0.f, false);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Reducer red(s);
+    size_t arena = 0, barena = 0;
+    int rc = wgrad(pl, static_cast<float *>(workspace), arena, barena, M, a, 0.f, red, s);
+    if (rc != MUCON_OK) return rc;
+    HIPCHK(red.run());
+    return MUCON_OK;
 }
 
 int mucon_test_dropout_mask(uint8_t *mask, int64_t n, uint64_t seed, int32_t site, float p, void *stream) {

@@ -1,0 +1,28 @@
+"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals (hot-path kernels only) and the
+per-launch timeline of the last benchmark step."""
+import csv, sys, collections
+f = sys.argv[1]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+hp = [r for r in rows if 'viterbi' not in r['Kernel_Name']]
+idx = [i for i, r in enumerate(hp) if 'pack_weights' in r['Kernel_Name']]
+s, e = idx[-2], idx[-1]
+step = hp[s:e]
+t0 = int(step[0]['Start_Timestamp'])
+agg = collections.OrderedDict()
+prev_end = t0
+gap_total = 0
+for r in step:
+    st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    nm = r['Kernel_Name'].replace('void ', '').split('(')[0][:70]
+    a = agg.setdefault(nm, [0, 0.0])
+    a[0] += 1; a[1] += (en - st) / 1e3
+    gap_total += max(0, st - prev_end) / 1e3
+    prev_end = max(prev_end, en)
+print(f"one step: {(prev_end - t0)/1e3:.1f} us wall on the GPU timeline, {len(step)} launches, gaps {gap_total:.1f} us")
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {t:9.1f} us  {n:4d}x  {k}")
+if len(sys.argv) > 2:
+    for r in step:
+        st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        print(f"{(st-t0)/1e3:9.1f} {(en-st)/1e3:8.1f}us grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}x{r['Grid_Size_Y']} {r['Kernel_Name'].replace('void ','')[:64]}")
