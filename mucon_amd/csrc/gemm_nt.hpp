@@ -29,7 +29,8 @@ struct NtParams {
     int Trows;          // output rows per video (before pooling)
     int taps, tap_step; // 1 or 3 taps; signed row offset between taps
     int Kc;             // channels per tap (multiple of 32)
-    const float *W;     // [128][taps*Kc]
+    const float *W;     // [128][ldw]: columns tap*Kc + c
+    int ldw;            // row stride of W (floats); taps*Kc unless a tap subset is used
     const float *bias;  // [128] or null
     float *out;         // [B][Tout][128]; Tout = Trows (POOL 0) or Trows/2 (POOL 1,2)
     float *out_pre;     // POOL 1: un-pooled rows [B][Trows][128], kept for the max-pool backward
@@ -39,7 +40,8 @@ struct NtParams {
     DropCfg drop;       // element index (b*Trows + t)*128 + c
 };
 
-template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+// TAG only names the instantiation (TAG 1 = first_conv forward, so that profilers list it separately)
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG>
 __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WN = 4 / WAVES_N;            // 32-wide column tiles per wave (128 columns in all)
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     const int t0 = blockIdx.x * BM;
     const int ktiles_per_tap = p.Kc >> 5;
     const int nkt = p.taps * ktiles_per_tap;
-    const int Ktot = p.taps * p.Kc;
+    const int Ktot = p.ldw;
     const int lrow = tid >> 3;
     const int lc4 = (tid & 7) * 4;
     const float *Ab = p.A + (long)b * p.a_bstride;
@@ -197,10 +199,10 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     }
 }
 
-template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG>
 static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32;
-    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>;
+    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -223,11 +225,11 @@ static inline int nt_pick_bm(int B, int Trows) {
     return 32;
 }
 
-template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL>
+template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG = 0>
 static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
     switch (nt_pick_bm(B, p.Trows)) {
-        case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
-        case 64: return launch_nt_cfg<1, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
-        default: return launch_nt_cfg<1, 1, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL>(p, B, s);
+        case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
+        case 64: return launch_nt_cfg<1, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
+        default: return launch_nt_cfg<1, 1, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
     }
 }

@@ -239,6 +239,7 @@ NtParams nt_base(const float *A, long a_bstride, int lda, int Ta, int Trows, int
     p.tap_step = tap_step;
     p.Kc = Kc;
     p.W = W;
+    p.ldw = taps * Kc;
     p.bias = bias;
     p.out = out;
     p.slope = slope;
@@ -370,14 +371,18 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         NtParams p = nt_base(tape, (long)pl.T * pl.D, pl.D, pl.T, pl.T, 1, 0, pl.D, prm->first_w, prm->first_b,
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
-        HIPCHK((launch_nt<false, false, true, false, false, false, 0>(p, B, s)));
+        HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
         prof_mark(0, true, s);
     }
     for (int l = 0; l < L; ++l) {
         const int Tl = pl.Tl[l];
-        {   // dilated_conv + non-linearity (temporal.py:48-49)
-            NtParams p = nt_base(ws + pl.x[l], (long)Tl * 128, 128, Tl, Tl, 3, cfg->dilation[l], 128,
-                                 ws + pl.W1f + (size_t)l * 49152, prm->dil_b[l], ws + pl.h[l], slope);
+        {   // dilated_conv + non-linearity (temporal.py:48-49).  When the dilation reaches past the sequence
+            // (d >= T_l, e.g. d = 512, 1024 at T/16) the outer taps only ever read zero padding: centre tap alone.
+            const bool centre_only = cfg->dilation[l] >= Tl;
+            NtParams p = nt_base(ws + pl.x[l], (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, cfg->dilation[l], 128,
+                                 ws + pl.W1f + (size_t)l * 49152 + (centre_only ? 128 : 0), prm->dil_b[l],
+                                 ws + pl.h[l], slope);
+            p.ldw = 384;
             HIPCHK((launch_nt<false, false, true, false, false, false, 0>(p, B, s)));
         }
         {   // conv_1x1, dropout, residual (temporal.py:50-52) and the pooling of WaveNetBlock (:137-142)
@@ -414,7 +419,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
-        hipLaunchKernelGGL(gn_fwd_kernel, dim3(B), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(gn_fwd_kernel, dim3(B), dim3(GN_THREADS), 0, s, g);
         HIPCHK(hipGetLastError());
     }
     return MUCON_OK;
@@ -455,7 +460,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
-        hipLaunchKernelGGL(gn_bwd_kernel, dim3(B), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(B), dim3(GN_THREADS), 0, s, g);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
             red.add(ws + pl.gnpart, B, 256, 256, 0, 1, 128, gr->gn_w, 0);
@@ -532,8 +537,10 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         }
         {   // data gradient of the dilated conv + the residual branch
             float *dst = (dyd == cur) ? other : cur;
-            NtParams p = nt_base(ws + pl.dpre, (long)Tl * 128, 128, Tl, Tl, 3, -cfg->dilation[l], 128,
-                                 ws + pl.W1b + (size_t)l * 49152, nullptr, dst, slope);
+            const bool centre_only = cfg->dilation[l] >= Tl;
+            NtParams p = nt_base(ws + pl.dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128,
+                                 ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0), nullptr, dst, slope);
+            p.ldw = 384;
             p.res = dyd;
             p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
             HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
@@ -741,9 +748,9 @@ int mucon_bench_first_conv(const float *tape, const float *w, const float *b, fl
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    HIPCHK((launch_nt<false, false, true, false, false, false, 0>(p, B, s)));  // warm-up
+    HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));  // warm-up
     HIPCHK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) HIPCHK((launch_nt<false, false, true, false, false, false, 0>(p, B, s)));
+    for (int i = 0; i < iters; ++i) HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -90,20 +90,23 @@ struct GnArgs {
     DropCfg drop;
 };
 
+constexpr int GN_ROWS = 32;               // row slots per workgroup
+constexpr int GN_THREADS = 32 * GN_ROWS;   // x 32 float4 columns
+
 __device__ __forceinline__ float block_group_sum(float v, float *red, int c4, int trow, int lanes_per_group) {
-    // sum over the float4 columns of one group (adjacent c4) and over the 8 row-slots
+    // sum over the float4 columns of one group (adjacent c4) and over the row slots
     for (int o = 1; o < lanes_per_group; o <<= 1) v += __shfl_xor(v, o);
     __syncthreads();
     red[trow * 32 + c4] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += red[r * 32 + c4];
+    for (int r = 0; r < GN_ROWS; ++r) s += red[r * 32 + c4];
     return s;
 }
 
-__global__ __launch_bounds__(256) void gn_fwd_kernel(const GnArgs a) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const GnArgs a) {
+    __shared__ float red[GN_THREADS];
     const int b = blockIdx.x;
     const int c4 = threadIdx.x & 31, trow = threadIdx.x >> 5;
     const int cpg = 128 / a.G;           // channels per group (>= 4)
@@ -114,13 +117,13 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const GnArgs a) {
     if (a.use_gn) {
         const float n = (float)a.Tz * (float)cpg;
         float s = 0.f;
-        for (int t = trow; t < a.Tz; t += 8) {
+        for (int t = trow; t < a.Tz; t += GN_ROWS) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
         mean = block_group_sum(s, red, c4, trow, lpg) / n;
         float q = 0.f;
-        for (int t = trow; t < a.Tz; t += 8) {
+        for (int t = trow; t < a.Tz; t += GN_ROWS) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const GnArgs a) {
         be = *reinterpret_cast<const f32x4 *>(a.beta + c4 * 4);
     }
     float *eb = a.enc + (long)b * a.Tz * 128 + c4 * 4;
-    for (int t = trow; t < a.Tz; t += 8) {
+    for (int t = trow; t < a.Tz; t += GN_ROWS) {
         f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
         const uint32_t idx = (uint32_t)(b * a.Tz + t) * 128u + (uint32_t)(c4 * 4);
 #pragma unroll
@@ -167,9 +170,9 @@ struct GnBwdArgs {
     DropCfg drop;
 };
 
-__global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdArgs a) {
-    __shared__ float red[256];
-    __shared__ float cred[2][8][128];
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
+    __shared__ float red[GN_THREADS];
+    __shared__ float cred[2][GN_ROWS][128];
     const int b = blockIdx.x;
     const int c4 = threadIdx.x & 31, trow = threadIdx.x >> 5;
     const int cpg = 128 / a.G, lpg = cpg >> 2;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdArgs a) {
         }
     };
     if (!a.use_gn) {
-        for (int t = trow; t < a.Tz; t += 8) {
+        for (int t = trow; t < a.Tz; t += GN_ROWS) {
             f32x4 xh, dg;
             dgn_at(t, xh, dg);
             *reinterpret_cast<f32x4 *>(ob + (long)t * 128) = dg;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdArgs a) {
     }
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
-    for (int t = trow; t < a.Tz; t += 8) {
+    for (int t = trow; t < a.Tz; t += GN_ROWS) {
         f32x4 xh, dg;
         dgn_at(t, xh, dg);
 #pragma unroll
@@ -231,14 +234,14 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdArgs a) {
         cred[1][trow][c4 * 4 + k] = sb[k];
     }
     __syncthreads();
-    {
+    if (threadIdx.x < 256) {
         const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += cred[which][r][c];
+        for (int r = 0; r < GN_ROWS; ++r) s += cred[which][r][c];
         a.part[((long)b * 2 + which) * 128 + c] = s;
     }
-    for (int t = trow; t < a.Tz; t += 8) {
+    for (int t = trow; t < a.Tz; t += GN_ROWS) {
         f32x4 xh, dg, o;
         dgn_at(t, xh, dg);
 #pragma unroll
