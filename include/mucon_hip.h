@@ -8,7 +8,9 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / C++ types.
  *   - every data pointer is a DEVICE pointer (HBM) unless the name ends in _host;
- *     the caller owns all buffers; the library allocates nothing persistent.
+ *     the caller owns all buffers; the library allocates no device memory (it creates one auxiliary
+ *     HIP stream and a few events on first use: weight-gradient launches overlap the data-gradient chain
+ *     and are joined back into `stream` before the call's last kernel; MUCON_NO_OVERLAP=1 disables it).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
  *     enqueues work on it and returns (no host synchronisation), except where stated.
  *   - return value: 0 on success, negative MUCON_E_* on error; mucon_last_error() gives the text.

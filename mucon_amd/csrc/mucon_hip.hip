@@ -36,8 +36,9 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
+int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 inline int pick_mc(int B, int Trows, int kchunks) {
-    long want = ((long)B * Trows * kchunks + 255) / 256;
+    long want = ((long)B * Trows * kchunks + g_tn_target - 1) / g_tn_target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
     if (mc > 1024) mc = 1024;
@@ -50,7 +51,7 @@ struct Plan {
     size_t W1f, W1b, W2t, Wlt;
     size_t x[MUCON_MAX_LAYERS + 1], h[MUCON_MAX_LAYERS], ypre[MUCON_MAX_LAYERS];
     size_t z, gnstat, gnpart;
-    size_t gA, gB, dpre, dyd;
+    size_t gz, g[MUCON_MAX_LAYERS + 1], dpre[MUCON_MAX_LAYERS], dyd[MUCON_MAX_LAYERS];
     size_t slabs, slab_floats, bslabs, bslab_floats;
     size_t total;  // floats
 };
@@ -106,11 +107,14 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.z = take((size_t)p.B * p.Tz * 128);
     p.gnstat = take((size_t)p.B * 128 * 2);
     p.gnpart = take((size_t)p.B * 256);
-    const size_t full = (size_t)p.B * p.T * 128;
-    p.gA = take(full);
-    p.gB = take(full);
-    p.dpre = take(full);
-    p.dyd = take(full);
+    // backward buffers, one per layer (no ping-pong): the weight-gradient launches run on a second
+    // stream and may still be reading a layer's tensors while the data-gradient chain moves on
+    p.gz = take((size_t)p.B * p.Tz * 128);
+    for (int l = 0; l <= p.L; ++l) p.g[l] = take((size_t)p.B * p.Tl[l] * 128);     // gradient w.r.t. x[l]
+    for (int l = 0; l < p.L; ++l) {
+        p.dpre[l] = take((size_t)p.B * p.Tl[l] * 128);                             // at the dilated conv's pre-activation
+        p.dyd[l] = c->pool_after[l] ? take((size_t)p.B * p.Tl[l] * 128) : 0;       // un-pooled gradient of a pooled layer
+    }
     // slab arena: every weight-gradient launch of a backward pass keeps its own slabs until the
     // single batched reduction at the end
     size_t sf = 0, bf = 0;
@@ -131,6 +135,45 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
 }
 
 void prof_mark(int slot, bool stop, hipStream_t s);
+
+// Second stream for the weight-gradient launches (they hang off the data-gradient chain and are not on its
+// critical path; the coarse levels leave most CUs idle).  Created on first use; MUCON_NO_OVERLAP=1 disables it.
+struct SideStream {
+    bool init = false, enabled = true;
+    hipStream_t s = nullptr;
+    hipEvent_t ev[2 * MUCON_MAX_LAYERS + 8];
+    int next = 0;
+    int ensure() {
+        if (init) return MUCON_OK;
+        const char *e = getenv("MUCON_NO_OVERLAP");
+        enabled = !(e && atoi(e) != 0);
+        if (enabled) {
+            HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            for (auto &x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        }
+        init = true;
+        return MUCON_OK;
+    }
+    hipEvent_t fresh() {
+        hipEvent_t x = ev[next];
+        next = (next + 1) % (int)(sizeof(ev) / sizeof(ev[0]));
+        return x;
+    }
+    // side stream continues after everything enqueued so far on `from`
+    int fork(hipStream_t from) {
+        hipEvent_t x = fresh();
+        HIPCHK(hipEventRecord(x, from));
+        HIPCHK(hipStreamWaitEvent(s, x, 0));
+        return MUCON_OK;
+    }
+    // `to` continues after everything enqueued so far on the side stream
+    int join(hipStream_t to) {
+        hipEvent_t x = fresh();
+        HIPCHK(hipEventRecord(x, s));
+        HIPCHK(hipStreamWaitEvent(to, x, 0));
+        return MUCON_OK;
+    }
+} g_side;
 
 // Collects the slab reductions of one backward pass; run() sums them all in one launch.
 struct Reducer {
@@ -279,6 +322,8 @@ int mucon_abi_version(void) {
     if (!once) {  // tuning hook: force the NT tile height (32 / 64 / 128)
         const char *e = getenv("MUCON_NT_BM");
         if (e) g_nt_force_bm = atoi(e);
+        e = getenv("MUCON_TN_TARGET");
+        if (e && atoi(e) > 0) g_tn_target = atoi(e);
         once = true;
     }
     return MUCON_ABI_VERSION;
@@ -441,16 +486,19 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     const int B = pl.B, L = pl.L, Tz = pl.Tz;
     DropCfg nodrop = make_drop(0, 0, 0.f, false);
 
-    float *cur = ws + pl.gA;   // gradient w.r.t. the current activation
-    float *other = ws + pl.gB;
+    rc = g_side.ensure();
+    if (rc != MUCON_OK) return rc;
+    const bool overlap = g_side.enabled;
+    hipStream_t sw = overlap ? g_side.s : s;   // stream of the weight-gradient launches
     Reducer red(s);
     size_t arena = 0, barena = 0;
+    float *gz = ws + pl.gz;
 
-    {   // GroupNorm / ReLU / Dropout backward -> dz in `cur`
+    {   // GroupNorm / ReLU / Dropout backward -> dz
         GnBwdArgs g;
         g.z = ws + pl.z;
         g.denc = d_enc;
-        g.dz = cur;
+        g.dz = gz;
         g.gamma = prm->gn_w;
         g.beta = prm->gn_b;
         g.stats = ws + pl.gnstat;
@@ -470,10 +518,11 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             HIPCHK(hipMemsetAsync(gr->gn_b, 0, 128 * sizeof(float), s));
         }
     }
-    {   // last_conv backward
+    {   // last_conv backward: weight gradient on the side stream, data gradient on the chain
+        if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
         WgradArgs a;
         memset(&a, 0, sizeof(a));
-        a.Y0 = cur;
+        a.Y0 = gz;
         a.X0 = ws + pl.x[L];
         a.x_bstride = (long)Tz * 128;
         a.ldx = 128;
@@ -484,39 +533,38 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.out_w0 = gr->last_w;
         a.out_b0 = gr->last_b;
         a.drop = nodrop;
-        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, s);
+        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw);
         if (rc != MUCON_OK) return rc;
-        NtParams p = nt_base(cur, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, other, slope);
+        NtParams p = nt_base(gz, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, ws + pl.g[L], slope);
         p.mask = ws + pl.x[L];
         HIPCHK((launch_nt<false, false, false, false, false, true, 0>(p, B, s)));
-        float *t = cur;
-        cur = other;
-        other = t;
     }
     for (int l = L - 1; l >= 0; --l) {
         const int Tl = pl.Tl[l];
         const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
-        const float *dyd = cur;
+        const float *dyd = ws + pl.g[l + 1];   // gradient at the layer output
         if (cfg->pool_after[l]) {
-            float *u = ws + pl.dyd;
+            float *u = ws + pl.dyd[l];
             const long n4 = (long)B * Tl * 32;
             const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
-            hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, cur,
+            hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, ws + pl.g[l + 1],
                                cfg->pool_type == 0 ? ws + pl.ypre[l] : nullptr, u, B, Tl, cfg->pool_type);
             HIPCHK(hipGetLastError());
             dyd = u;
         }
+        float *dpre = ws + pl.dpre[l];
         {   // gradient at the dilated conv's pre-activation: through conv_1x1 (dropout replayed) and the non-linearity
             NtParams p = nt_base(dyd, (long)Tl * 128, 128, Tl, Tl, 1, 0, 128, ws + pl.W2t + (size_t)l * 16384, nullptr,
-                                 ws + pl.dpre, slope);
+                                 dpre, slope);
             p.mask = ws + pl.h[l];
             p.drop = dl;
             HIPCHK((launch_nt<false, true, false, false, false, true, 0>(p, B, s)));
         }
-        {   // all four parameter gradients of the layer in one launch
+        {   // all four parameter gradients of the layer in one launch, off the critical path
+            if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
             WgradArgs a;
             memset(&a, 0, sizeof(a));
-            a.Y0 = ws + pl.dpre;
+            a.Y0 = dpre;
             a.X0 = ws + pl.x[l];
             a.x_bstride = (long)Tl * 128;
             a.ldx = 128;
@@ -532,28 +580,23 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             a.out_w1 = gr->pw_w[l];
             a.out_b1 = gr->pw_b[l];
             a.drop = dl;
-            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, s);
+            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, sw);
             if (rc != MUCON_OK) return rc;
         }
-        {   // data gradient of the dilated conv + the residual branch
-            float *dst = (dyd == cur) ? other : cur;
+        {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
             const bool centre_only = cfg->dilation[l] >= Tl;
-            NtParams p = nt_base(ws + pl.dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128,
-                                 ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0), nullptr, dst, slope);
+            NtParams p = nt_base(dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128,
+                                 ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0), nullptr, ws + pl.g[l], slope);
             p.ldw = 384;
             p.res = dyd;
             p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
             HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
-            if (dst == other) {
-                other = cur;
-                cur = dst;
-            }
         }
     }
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
-        a.Y0 = cur;
+        a.Y0 = ws + pl.g[0];
         a.X0 = tape;
         a.x_bstride = (long)pl.T * pl.D;
         a.ldx = pl.D;
@@ -566,6 +609,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1);
         if (rc != MUCON_OK) return rc;
     }
+    if (overlap && (rc = g_side.join(s)) != MUCON_OK) return rc;
     HIPCHK(red.run());
     return MUCON_OK;
 }
