@@ -10,10 +10,13 @@
 #include "../../include/mucon_hip.h"
 #include "common.hpp"
 #include "gemm_nt.hpp"
+#include "gemm_fused.hpp"
 #include "gemm_tn.hpp"
 #include "small_kernels.hpp"
 
 int g_nt_force_bm = 0;
+int g_fused_bm = 0;
+int g_no_fuse = 0;
 
 namespace {
 
@@ -322,6 +325,10 @@ int mucon_abi_version(void) {
     if (!once) {  // tuning hook: force the NT tile height (32 / 64 / 128)
         const char *e = getenv("MUCON_NT_BM");
         if (e) g_nt_force_bm = atoi(e);
+        e = getenv("MUCON_FUSED_BM");
+        if (e) g_fused_bm = atoi(e);
+        e = getenv("MUCON_NO_FUSE");
+        if (e) g_no_fuse = atoi(e);
         e = getenv("MUCON_TN_TARGET");
         if (e && atoi(e) > 0) g_tn_target = atoi(e);
         once = true;
@@ -421,9 +428,37 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     for (int l = 0; l < L; ++l) {
         const int Tl = pl.Tl[l];
-        {   // dilated_conv + non-linearity (temporal.py:48-49).  When the dilation reaches past the sequence
-            // (d >= T_l, e.g. d = 512, 1024 at T/16) the outer taps only ever read zero padding: centre tap alone.
-            const bool centre_only = cfg->dilation[l] >= Tl;
+        // When the dilation reaches past the sequence (d >= T_l, e.g. d = 512, 1024 at T/16) the outer taps only
+        // ever read zero padding: centre tap alone.
+        const bool centre_only = cfg->dilation[l] >= Tl;
+        const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
+        const int pool = !cfg->pool_after[l] ? 0 : (cfg->pool_type == 0 ? 1 : 2);
+        if (!g_no_fuse) {
+            // one launch per residual layer: dilated_conv + non-linearity (temporal.py:48-49), then conv_1x1,
+            // dropout, residual (:50-52) and the pooling of WaveNetBlock (:137-142); h crosses through LDS
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.Trows = Tl;
+            f.A = ws + pl.x[l];
+            f.taps = centre_only ? 1 : 3;
+            f.tap_step = cfg->dilation[l];
+            f.W1 = ws + pl.W1f + (size_t)l * 49152 + (centre_only ? 128 : 0);
+            f.ldw1 = 384;
+            f.bias1 = prm->dil_b[l];
+            f.out1 = ws + pl.h[l];
+            f.W2 = prm->pw_w[l];
+            f.bias2 = prm->pw_b[l];
+            f.res2 = ws + pl.x[l];
+            f.out2 = ws + pl.x[l + 1];
+            f.out_pre = pool == 1 ? ws + pl.ypre[l] : nullptr;
+            f.slope = slope;
+            f.drop = dl;
+            if (pool == 0) HIPCHK((launch_fused<false, 0>(f, B, s)));
+            else if (pool == 1) HIPCHK((launch_fused<false, 1>(f, B, s)));
+            else HIPCHK((launch_fused<false, 2>(f, B, s)));
+            continue;
+        }
+        {   // dilated_conv + non-linearity (temporal.py:48-49)
             NtParams p = nt_base(ws + pl.x[l], (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, cfg->dilation[l], 128,
                                  ws + pl.W1f + (size_t)l * 49152 + (centre_only ? 128 : 0), prm->dil_b[l],
                                  ws + pl.h[l], slope);
@@ -434,10 +469,10 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             NtParams p = nt_base(ws + pl.h[l], (long)Tl * 128, 128, Tl, Tl, 1, 0, 128, prm->pw_w[l], prm->pw_b[l],
                                  ws + pl.x[l + 1], slope);
             p.res = ws + pl.x[l];
-            p.drop = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
-            if (!cfg->pool_after[l]) {
+            p.drop = dl;
+            if (pool == 0) {
                 HIPCHK((launch_nt<false, false, false, true, true, false, 0>(p, B, s)));
-            } else if (cfg->pool_type == 0) {
+            } else if (pool == 1) {
                 p.out_pre = ws + pl.ypre[l];
                 HIPCHK((launch_nt<false, false, false, true, true, false, 1>(p, B, s)));
             } else {
@@ -518,6 +553,17 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             HIPCHK(hipMemsetAsync(gr->gn_b, 0, 128 * sizeof(float), s));
         }
     }
+    // Data-gradient chain.  Stage pairs that meet at a layer boundary without a pooling step run as one fused
+    // launch: (last_conv or layer l+1's dilated conv) data gradient -> gradient at layer l's output ->
+    // through layer l's conv_1x1 and non-linearity -> dpre_l.
+    auto fused_tail = [&](FusedParams &f, int l) {  // stage 2 = conv_1x1 backward of layer l
+        f.W2 = ws + pl.W2t + (size_t)l * 16384;
+        f.mask2 = ws + pl.h[l];
+        f.out2 = ws + pl.dpre[l];
+        f.slope = slope;
+        f.drop = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
+    };
+    bool have_dpre = false;  // dpre[l] already produced by the previous (fused) launch
     {   // last_conv backward: weight gradient on the side stream, data gradient on the chain
         if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
         WgradArgs a;
@@ -535,25 +581,41 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.drop = nodrop;
         rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw);
         if (rc != MUCON_OK) return rc;
-        NtParams p = nt_base(gz, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, ws + pl.g[L], slope);
-        p.mask = ws + pl.x[L];
-        HIPCHK((launch_nt<false, false, false, false, false, true, 0>(p, B, s)));
+        if (!g_no_fuse && !cfg->pool_after[L - 1]) {
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.Trows = Tz;
+            f.A = gz;
+            f.taps = 1;
+            f.W1 = ws + pl.Wlt;
+            f.ldw1 = 128;
+            f.mask1 = ws + pl.x[L];
+            f.out1 = ws + pl.g[L];
+            fused_tail(f, L - 1);
+            HIPCHK((launch_fused<true, 0>(f, B, s)));
+            have_dpre = true;
+        } else {
+            NtParams p = nt_base(gz, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, ws + pl.g[L], slope);
+            p.mask = ws + pl.x[L];
+            HIPCHK((launch_nt<false, false, false, false, false, true, 0>(p, B, s)));
+        }
     }
     for (int l = L - 1; l >= 0; --l) {
         const int Tl = pl.Tl[l];
         const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
         const float *dyd = ws + pl.g[l + 1];   // gradient at the layer output
-        if (cfg->pool_after[l]) {
-            float *u = ws + pl.dyd[l];
-            const long n4 = (long)B * Tl * 32;
-            const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
-            hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, ws + pl.g[l + 1],
-                               cfg->pool_type == 0 ? ws + pl.ypre[l] : nullptr, u, B, Tl, cfg->pool_type);
-            HIPCHK(hipGetLastError());
-            dyd = u;
-        }
         float *dpre = ws + pl.dpre[l];
-        {   // gradient at the dilated conv's pre-activation: through conv_1x1 (dropout replayed) and the non-linearity
+        if (!have_dpre) {
+            if (cfg->pool_after[l]) {
+                float *u = ws + pl.dyd[l];
+                const long n4 = (long)B * Tl * 32;
+                const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+                hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, ws + pl.g[l + 1],
+                                   cfg->pool_type == 0 ? ws + pl.ypre[l] : nullptr, u, B, Tl, cfg->pool_type);
+                HIPCHK(hipGetLastError());
+                dyd = u;
+            }
+            // gradient at the dilated conv's pre-activation: through conv_1x1 (dropout replayed) and the non-linearity
             NtParams p = nt_base(dyd, (long)Tl * 128, 128, Tl, Tl, 1, 0, 128, ws + pl.W2t + (size_t)l * 16384, nullptr,
                                  dpre, slope);
             p.mask = ws + pl.h[l];
@@ -585,12 +647,30 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         }
         {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
             const bool centre_only = cfg->dilation[l] >= Tl;
-            NtParams p = nt_base(dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128,
-                                 ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0), nullptr, ws + pl.g[l], slope);
-            p.ldw = 384;
-            p.res = dyd;
-            p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
-            HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
+            const float *W1b = ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0);
+            have_dpre = false;
+            if (!g_no_fuse && l >= 1 && !cfg->pool_after[l - 1]) {
+                FusedParams f;
+                memset(&f, 0, sizeof(f));
+                f.Trows = Tl;
+                f.A = dpre;
+                f.taps = centre_only ? 1 : 3;
+                f.tap_step = -cfg->dilation[l];
+                f.W1 = W1b;
+                f.ldw1 = 384;
+                f.res1 = dyd;
+                f.out1 = ws + pl.g[l];
+                fused_tail(f, l - 1);
+                HIPCHK((launch_fused<true, 0>(f, B, s)));
+                have_dpre = true;
+            } else {
+                NtParams p = nt_base(dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128, W1b,
+                                     nullptr, ws + pl.g[l], slope);
+                p.ldw = 384;
+                p.res = dyd;
+                p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
+                HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
+            }
         }
     }
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
