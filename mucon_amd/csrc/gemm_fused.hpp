@@ -12,6 +12,8 @@
 // Why: the coarse levels (T/8, T/16: <= 64 workgroups) are latency-bound -- every launch costs its own
 // prologue, k-loop ramp and epilogue, and the K = 128 GEMMs alone reach < 25 % MFMA utilisation.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "gemm_nt.hpp"
 
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
     const long vbase = (long)b * p.Trows;
 
     f32x4 ra[NQA], rb[4];
+    bool ra_ok[NQA];  // padding rows are zeroed at the LDS store, so that the loads stay in flight (see gemm_nt.hpp)
     f32x16 acc[WM][WN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -90,15 +93,20 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
         for (int q = 0; q < NQA; ++q) {
             const int t = t0 + lrow + 32 * q;
             const int ts = t + off;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t < p.Trows && ts >= 0 && ts < p.Trows) v = *reinterpret_cast<const f32x4 *>(Ab + (long)ts * 128 + kk + lc4);
-            ra[q] = v;
+            ra_ok[q] = (t < p.Trows) && (ts >= 0) && (ts < p.Trows);   // branch-free load from a clamped row
+            const int tc = ts < 0 ? 0 : (ts >= p.Trows ? p.Trows - 1 : ts);
+            ra[q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tc * 128 + kk + lc4);
         }
     };
     auto storeA = [&](int buf) {
         float *a = As + buf * BM * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < NQA; ++q) *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = ra[q];
+        for (int q = 0; q < NQA; ++q) {
+            f32x4 v = ra[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ra_ok[q] ? v[e] : 0.f;
+            *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = v;
+        }
     };
     // 32-deep k-tile of MFMAs: A fragments from `Aw` (row stride lda floats), W fragments from the staging buffer
     auto mfma_tile = [&](const float *Aw, int lda, const float *Bw) {
@@ -152,34 +160,50 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
     }
     const int w2buf0 = nkt1 & 1;  // staging buffer that now holds W2 k-tile 0
 
-    // stage-1 epilogue: global copy (saved / consumed later) + LDS copy (stage-2 A operand)
+    // stage-1 epilogue: global copy (saved / consumed later) + LDS copy (stage-2 A operand).  FULL tiles run
+    // straight-line code (loads, math, stores batched per 32x32 tile; see gemm_nt.hpp).
+    const bool full_tile = t0 + BM <= p.Trows;
+    auto epilogue1 = [&](auto FULLT) {
+        constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
+        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int col = (wc * WN + nt) * 32 + (lane & 31);
-            const float bias = (!BWD && p.bias1) ? p.bias1[col] : 0.f;
+            for (int nt = 0; nt < WN; ++nt) {
+                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const float bias = (!BWD && p.bias1) ? p.bias1[col] : 0.f;
+                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
+                float rres[16], rmask[16];
+                if (BWD) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = (wr * WM + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int t = t0 + row;
-                float x = acc[mt][nt][reg] + bias;
-                float xl = 0.f;
-                if (t < p.Trows) {
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                        const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                        rres[reg] = p.res1 ? p.res1[g] : 0.f;
+                        rmask[reg] = p.mask1 ? p.mask1[g] : 1.f;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+                    const int t = t0 + row;
                     const long g = (vbase + t) * 128 + col;
+                    float x = acc[mt][nt][reg] + bias;
+                    float xl;
                     if (!BWD) {
                         x = act_f(x, p.slope);
                         xl = x;
                     } else {
-                        if (p.res1) x += p.res1[g];
-                        if (p.mask1) x *= act_grad(p.mask1[g], p.slope);
+                        x += rres[reg];
+                        if (p.mask1) x *= act_grad(rmask[reg], p.slope);
                         xl = p.drop.thresh ? x * drop_mul(p.drop, (uint32_t)g) : x;
                     }
-                    p.out1[g] = x;
+                    if (FULL || t < p.Trows) p.out1[g] = x;
+                    Hs[row * FUSED_HS + col] = (FULL || t < p.Trows) ? xl : 0.f;
                 }
-                Hs[row * FUSED_HS + col] = xl;
             }
-        }
+    };
+    if (full_tile) epilogue1(std::true_type{});
+    else epilogue1(std::false_type{});
     __syncthreads();
 
     // ---------------------------------------------------------------- stage 2 (K = 128: 4 k-tiles, A from Hs)
@@ -193,45 +217,59 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
     }
 
     // stage-2 epilogue
+    auto epilogue2 = [&](auto FULLT) {
+        constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
+        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int col = (wc * WN + nt) * 32 + (lane & 31);
-            const float bias = (!BWD && p.bias2) ? p.bias2[col] : 0.f;
+            for (int nt = 0; nt < WN; ++nt) {
+                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const float bias = (!BWD && p.bias2) ? p.bias2[col] : 0.f;
+                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
+                float raux[16];   // FWD: residual x; BWD: h (mask)
 #pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                float v[2];
-                int tt[2];
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                    raux[reg] = BWD ? p.mask2[g] : p.res2[g];
+                }
+                float v[16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int reg = rp * 2 + u;
-                    const int row = (wr * WM + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    const int t = t0 + row;
-                    tt[u] = t;
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + t) * 128 + col;
                     float x = acc[mt][nt][reg] + bias;
-                    if (t < p.Trows) {
-                        const long g = (vbase + t) * 128 + col;
-                        if (!BWD) {
-                            if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
-                            x += p.res2[g];
-                            if (POOL == 0) p.out2[g] = x;
-                            if (POOL == 1) p.out_pre[g] = x;
-                        } else {
-                            x *= act_grad(p.mask2[g], p.slope);
-                            p.out2[g] = x;
-                        }
+                    if (!BWD) {
+                        if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
+                        x += raux[reg];
+                    } else {
+                        x *= act_grad(raux[reg], p.slope);
                     }
-                    v[u] = x;
+                    v[reg] = x;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + t) * 128 + col;
+                    if (FULL || t < p.Trows) {
+                        if (BWD || POOL == 0) p.out2[g] = v[reg];
+                        if (!BWD && POOL == 1) p.out_pre[g] = v[reg];
+                    }
                 }
                 if (!BWD && POOL != 0) {
-                    if (tt[1] < p.Trows) {
-                        const long g = ((long)b * (p.Trows >> 1) + (tt[0] >> 1)) * 128 + col;
-                        p.out2[g] = (POOL == 1) ? fmaxf(v[0], v[1]) : (v[0] + v[1]);
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp) {
+                        const int te = t0 + rbase + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);
+                        if (FULL || te + 1 < p.Trows) {
+                            const long g = ((long)b * (p.Trows >> 1) + (te >> 1)) * 128 + col;
+                            p.out2[g] = (POOL == 1) ? fmaxf(v[2 * rp], v[2 * rp + 1]) : (v[2 * rp] + v[2 * rp + 1]);
+                        }
                     }
                 }
             }
-        }
+    };
+    if (full_tile) epilogue2(std::true_type{});
+    else epilogue2(std::false_type{});
 }
 
 template <int WM, int WAVES_M, bool BWD, int POOL>

@@ -14,6 +14,8 @@
 //   conv_1x1 (:50)     taps=1 Kc=128         last_conv (:145)   taps=1 Kc=128, ReLU on the input
 // and, with transposed / re-packed weights, their data gradients.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 constexpr int NT_BK = 32;
@@ -64,46 +66,63 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     const int lc4 = (tid & 7) * 4;
     const float *Ab = p.A + (long)b * p.a_bstride;
 
-    f32x4 ra[NQA], rb[4];
+    // two register sets: tile kt+2 is requested while tile kt is being multiplied and tile kt+1 (requested one
+    // iteration earlier) waits in the other set -- with 32-row tiles one k-tile of MFMAs (1024 cycles) is
+    // shorter than an L2 round trip, so a single tile of look-ahead leaves the loop latency-bound
+    f32x4 ra[2][NQA], rb[2][4];
+    int rt[2][NQA];   // time step of each staged A row, or -1 when the row is padding (zeroed at the LDS store)
+    int rkk[2];       // channel offset of the staged k-tile (dropout replay)
 
-    auto gload = [&](int kt) {
+    // gload only ISSUES loads (always, from a clamped valid row: a load under a divergent `if` makes hipcc wait
+    // vmcnt(0) around it); every use of the loaded values -- zeroing of padding rows, ReLU / dropout prologues --
+    // happens in sstore, one or two k-tiles later, so the loads stay in flight under the MFMAs.
+    auto gload = [&](int kt, auto SET) {
+        constexpr int S = decltype(SET)::value;
         const int tap = kt / ktiles_per_tap;
         const int kk = (kt - tap * ktiles_per_tap) * 32;
         const int off = (tap - (p.taps >> 1)) * p.tap_step;
+        rkk[S] = kk;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            rb[q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + 32 * q) * Ktot + kt * 32 + lc4);
+            rb[S][q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + 32 * q) * Ktot + kt * 32 + lc4);
 #pragma unroll
         for (int q = 0; q < NQA; ++q) {
-            const int r = lrow + 32 * q;
-            const int t = t0 + r;
+            const int t = t0 + lrow + 32 * q;
             const int ts = t + off;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t < p.Trows && ts >= 0 && ts < p.Ta) {
-                v = *reinterpret_cast<const f32x4 *>(Ab + (long)ts * p.lda + kk + lc4);
-                if (PRO_ACT) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.slope);
-                }
-                if (PRO_DROP) {
-                    if (p.drop.thresh) {
-                        const uint32_t idx = (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)(kk + lc4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, idx + e);
-                    }
-                }
-            }
-            ra[q] = v;
+            const bool ok = (t < p.Trows) && (ts >= 0) && (ts < p.Ta);
+            const int tc = ts < 0 ? 0 : (ts >= p.Ta ? p.Ta - 1 : ts);
+            ra[S][q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tc * p.lda + kk + lc4);
+            rt[S][q] = ok ? t : -1;
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
         float *a = As + buf * BM * NT_LDS;
         float *w = Bs + buf * 128 * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < NQA; ++q) *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = ra[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[S][q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[q];
+        for (int q = 0; q < NQA; ++q) {
+            f32x4 v = ra[S][q];
+            const int t = rt[S][q];
+            if (PRO_ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.slope);
+            }
+            if (PRO_DROP) {
+                if (p.drop.thresh) {
+                    const uint32_t idx = (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)(rkk[S] + lc4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, idx + e);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t >= 0 ? v[e] : 0.f;
+            *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = v;
+        }
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -118,12 +137,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     const int a_off = (wr * WM * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
     const int b_off = (wc * WN * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+    auto compute = [&](int cur) {
         const float *Aw = As + cur * BM * NT_LDS + a_off;
         const float *Bw = Bs + cur * 128 * NT_LDS + b_off;
 #pragma unroll
@@ -149,54 +163,99 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                                                                          acc[m][n], 0, 0, 0);
             }
         }
-        if (kt + 1 < nkt) sstore(cur ^ 1);
+    };
+
+    // nkt is even (Kc is a multiple of 64).  The loop body is ONE basic block -- no guards around the loads or
+    // the LDS stores (the tail re-loads the last tile and stores it where nobody reads it) -- so that hipcc
+    // can count its vmcnt waits exactly: at sstore(set) only that set's loads must have landed while the
+    // other set's five loads, issued one half-iteration later, stay in flight under the MFMAs.
+    const int last = nkt - 1;
+    gload(0, S0{});
+    gload(1, S1{});
+    sstore(0, S0{});
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // sched_barrier pins the three phases: hipcc otherwise sinks the loads below the MFMAs and hoists the
+        // first use of their data (the padding select) to the loop top, i.e. a vmcnt(0) stall per half-iteration
+        gload(min(kt + 2, last), S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(1, S1{});
+        __syncthreads();
+        gload(min(kt + 3, last), S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(0, S0{});
         __syncthreads();
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
     // registers (4q, 4q+1) and (4q+2, 4q+3) hold time steps (2i, 2i+1): max_pool1d(2) pairs.
+    // Two instantiations, chosen by a workgroup-uniform branch: FULL tiles (every row inside the video, the
+    // common case) run straight-line code -- all residual / mask loads of a 32x32 tile first, then the math,
+    // then the stores -- because per-element bounds checks put every load and store under a divergent branch
+    // and hipcc then separates them with vmcnt(0) waits, which serialises the whole epilogue.
     const long vbase = (long)b * p.Trows;
+    auto epilogue = [&](auto FULLT) {
+        constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
+        for (int mt = 0; mt < WM; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int col = (wc * WN + nt) * 32 + (lane & 31);
-            const float bias = p.bias ? p.bias[col] : 0.f;
+            for (int nt = 0; nt < WN; ++nt) {
+                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const float bias = p.bias ? p.bias[col] : 0.f;
+                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
+                float rres[16], rmask[16];
+                const bool use_mask = EPI_MASK && (p.mask != nullptr);
 #pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                float v[2];
-                int tt[2];
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                    if (EPI_RES) rres[reg] = p.res[g];
+                    if (EPI_MASK) rmask[reg] = use_mask ? p.mask[g] : 1.f;
+                }
+                float v[16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int reg = rp * 2 + u;
-                    const int row = (wr * WM + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    const int t = t0 + row;
-                    tt[u] = t;
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + t) * 128 + col;
                     float x = acc[mt][nt][reg] + bias;
-                    if (t < p.Trows) {
-                        const long g = (vbase + t) * 128 + col;
-                        if (EPI_ACT) x = act_f(x, p.slope);
-                        if (EPI_DROP) {
-                            if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
-                        }
-                        if (EPI_RES) x += p.res[g];
-                        if (EPI_MASK) {
-                            if (p.mask) x *= act_grad(p.mask[g], p.slope);
-                        }
-                        if (POOL == 0) p.out[g] = x;
-                        if (POOL == 1) p.out_pre[g] = x;
+                    if (EPI_ACT) x = act_f(x, p.slope);
+                    if (EPI_DROP) {
+                        if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
                     }
-                    v[u] = x;
+                    if (EPI_RES) x += rres[reg];
+                    if (EPI_MASK) {
+                        if (use_mask) x *= act_grad(rmask[reg], p.slope);
+                    }
+                    v[reg] = x;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    const long g = (vbase + t) * 128 + col;
+                    if (FULL || t < p.Trows) {
+                        if (POOL == 0) p.out[g] = v[reg];
+                        if (POOL == 1) p.out_pre[g] = v[reg];
+                    }
                 }
                 if (POOL != 0) {
-                    if (tt[1] < p.Trows) {  // floor pooling drops an odd last step
-                        const long g = ((long)b * (p.Trows >> 1) + (tt[0] >> 1)) * 128 + col;
-                        p.out[g] = (POOL == 1) ? fmaxf(v[0], v[1]) : (v[0] + v[1]);
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp) {
+                        const int te = t0 + rbase + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);   // even time step of the pair
+                        if (FULL || te + 1 < p.Trows) {  // floor pooling drops an odd last step
+                            const long g = ((long)b * (p.Trows >> 1) + (te >> 1)) * 128 + col;
+                            p.out[g] = (POOL == 1) ? fmaxf(v[2 * rp], v[2 * rp + 1]) : (v[2 * rp] + v[2 * rp + 1]);
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (t0 + BM <= p.Trows) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG>

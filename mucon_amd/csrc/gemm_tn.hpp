@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     const int Tx = second ? p.Trows : p.Tx;
 
     f32x4 ry[4], rx[4];
+    int rty[4];      // time step of the staged Y row, -1 = padding
+    bool rokx[4];
+    // loads are only ISSUED here (always, from clamped rows); zeroing, dropout replay and the ReLU prologue are
+    // applied at the LDS store one m-tile later, so the loads stay in flight under the MFMAs
     auto gload = [&](int mtile) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -73,34 +77,39 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
             const int row = f >> 5, c4 = (f & 31) * 4;
             const int t = tbeg + mtile * 32 + row;
             const int ts = t + xoff;
-            f32x4 y = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
-            if (t < tend) {
-                y = *reinterpret_cast<const f32x4 *>(Yb + (long)t * 128 + c4);
-                if (DUAL) {
-                    if (second && p.drop.thresh) {
-                        const uint32_t idx = (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)c4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] *= drop_mul(p.drop, idx + e);
-                    }
-                }
-                if (ts >= 0 && ts < Tx) {
-                    x = *reinterpret_cast<const f32x4 *>(Xb + (long)ts * ldx + c4);
-                    if (X0_ACT) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
-                    }
-                }
-            }
-            ry[q] = y;
-            rx[q] = x;
+            const bool oky = t < tend;
+            rty[q] = oky ? t : -1;
+            rokx[q] = oky && ts >= 0 && ts < Tx;
+            const int tyc = t < p.Trows ? t : p.Trows - 1;
+            const int txc = ts < 0 ? 0 : (ts >= Tx ? Tx - 1 : ts);
+            ry[q] = *reinterpret_cast<const f32x4 *>(Yb + (long)tyc * 128 + c4);
+            rx[q] = *reinterpret_cast<const f32x4 *>(Xb + (long)txc * ldx + c4);
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f = tid + 256 * q;
-            *reinterpret_cast<f32x4 *>(Ys + buf * 4096 + f * 4) = ry[q];
-            *reinterpret_cast<f32x4 *>(Xs + buf * 4096 + f * 4) = rx[q];
+            const int c4 = (f & 31) * 4;
+            f32x4 y = ry[q], x = rx[q];
+            if (DUAL) {
+                if (second && p.drop.thresh) {
+                    const uint32_t idx = (uint32_t)(b * p.Trows + rty[q]) * 128u + (uint32_t)c4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] *= drop_mul(p.drop, idx + e);
+                }
+            }
+            if (X0_ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = rty[q] >= 0 ? y[e] : 0.f;
+                x[e] = rokx[q] ? x[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(Ys + buf * 4096 + f * 4) = y;
+            *reinterpret_cast<f32x4 *>(Xs + buf * 4096 + f * 4) = x;
         }
     };
 

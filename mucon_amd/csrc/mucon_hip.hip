@@ -16,7 +16,7 @@
 
 int g_nt_force_bm = 0;
 int g_fused_bm = 0;
-int g_no_fuse = 0;
+int g_no_fuse = 1;  // the fused two-stage layer kernels (gemm_fused.hpp) are opt-in: MUCON_FUSE=1
 
 namespace {
 
@@ -327,8 +327,8 @@ int mucon_abi_version(void) {
         if (e) g_nt_force_bm = atoi(e);
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
-        e = getenv("MUCON_NO_FUSE");
-        if (e) g_no_fuse = atoi(e);
+        e = getenv("MUCON_FUSE");
+        if (e) g_no_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_TN_TARGET");
         if (e && atoi(e) > 0) g_tn_target = atoi(e);
         once = true;
