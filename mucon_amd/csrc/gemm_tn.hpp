@@ -127,14 +127,16 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     const int y_off = (lane >> 5) * 16 * 128 + wr * 64 + (lane & 31);
     const int x_off = (lane >> 5) * 16 * 128 + wc * 64 + (lane & 31);
 
-    if (ntiles > 0) {
-        gload(0);
-        sstore(0);
-    }
+    // ntiles >= 1.  Guard-free loop body (the tail re-loads the last tile into the buffer nobody reads) with the
+    // phases pinned: loads issued first, MFMAs, then the first use of the loaded data at the LDS store -- so the
+    // loads of m-tile mt+1 are in flight under the 64 MFMAs of tile mt and hipcc can count its vmcnt waits.
+    gload(0);
+    sstore(0);
     __syncthreads();
     for (int mt = 0; mt < ntiles; ++mt) {
         const int cur = mt & 1;
-        if (mt + 1 < ntiles) gload(mt + 1);
+        gload(min(mt + 1, ntiles - 1));
+        __builtin_amdgcn_sched_barrier(0);
         const float *Yw = Ys + cur * 4096 + y_off;
         const float *Xw = Xs + cur * 4096 + x_off;
 #pragma unroll
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
 #pragma unroll 8
             for (int m = 0; m < 32; ++m) bsum += Yc[m * 128];
         }
-        if (mt + 1 < ntiles) sstore(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(cur ^ 1);
         __syncthreads();
     }
 

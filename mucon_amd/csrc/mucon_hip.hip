@@ -622,8 +622,11 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             p.drop = dl;
             HIPCHK((launch_nt<false, true, false, false, false, true, 0>(p, B, s)));
         }
-        {   // all four parameter gradients of the layer in one launch, off the critical path
-            if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
+        {   // all four parameter gradients of the layer in one launch -- off the critical path (second stream) at the
+            // coarse levels, where neither this launch nor the data-gradient chain fills the chip; at the fine
+            // levels both do, and running them side by side only makes them thrash
+            const bool side = overlap && (long)B * Tl < 512L * 64;
+            if (side && (rc = g_side.fork(s)) != MUCON_OK) return rc;
             WgradArgs a;
             memset(&a, 0, sizeof(a));
             a.Y0 = dpre;
@@ -642,7 +645,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             a.out_w1 = gr->pw_w[l];
             a.out_b1 = gr->pw_b[l];
             a.drop = dl;
-            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, sw);
+            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, side ? sw : s);
             if (rc != MUCON_OK) return rc;
         }
         {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
