@@ -32,35 +32,100 @@ namespace {
 constexpr int VIT_THREADS = 1024;
 constexpr int VIT_FCHUNK = 16;  // columns of frame scores staged in LDS at a time
 
-__global__ __launch_bounds__(64) void viterbi_framescore_kernel(const mucon_viterbi_job *jobs, const float *lp,
-                                                                char *ws, int C, int fs) {
+// Phase 1.  The cumulative sum is a strictly sequential float32 chain per class (np.cumsum; a parallel scan
+// would round differently), so one wave adds -- lane c owns class c -- while the whole workgroup keeps it fed:
+// 256 threads stream the emissions in chunks of FS_ROWS frames into a double-buffered LDS tile, wave 0
+// walks the tile row by row.  Column boundaries are wave-uniform (scalar branch, no divergence).
+constexpr int FS_ROWS = 256;
+constexpr int FS_THREADS = 256;
+typedef float vit_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mucon_viterbi_job *jobs, const float *lp,
+                                                                        char *ws, int C, int fs) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][FS_ROWS * C]
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
     if (K < 1) return;
     float *F = reinterpret_cast<float *>(ws + job.ws_off);
-    const int n = K * fs;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float *p = lp + job.lp_off + c;
-        float run = 0.f, prev = 0.f;
-        int until = fs;  // frames left in the current column
-        int k = 0;
-        for (int t0 = 0; t0 < n; t0 += 8) {
-            float v[8];
+    const int n = K * fs;                       // frames that enter the decode
+    const int tid = threadIdx.x;
+    const float *src = lp + job.lp_off;
+    const int chunk = FS_ROWS * C;              // floats per chunk: a contiguous range of the [T][C] array
+    const int nchunks = (n + FS_ROWS - 1) / FS_ROWS;
+    const long total = (long)n * C;
+    const bool vec = (C & 3) == 0;              // float4 path: every offset is a multiple of 4 floats
+    const int nper = C >> 2;                    // float4 per thread per chunk = chunk / 4 / FS_THREADS  (<= 16)
+
+    vit_f32x4 r[16];
+    auto gload = [&](int ci) {                  // issue only; clamped so that no load needs a branch
+        const long base4 = ((long)ci * chunk) >> 2;
+        const long last4 = (total >> 2) - 1;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (t0 + u < n) ? p[(long)(t0 + u) * C] : 0.f;
+        for (int u = 0; u < 16; ++u)
+            if (u < nper) {
+                long e = base4 + u * FS_THREADS + tid;
+                e = e < last4 ? e : last4;
+                r[u] = reinterpret_cast<const vit_f32x4 *>(src)[e];
+            }
+    };
+    auto sstore = [&](int buf) {
+        vit_f32x4 *dst = reinterpret_cast<vit_f32x4 *>(fs_smem + buf * chunk);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (t0 + u < n) {
-                    run = (t0 + u == 0) ? v[u] : run + v[u];  // sequential float32 chain
-                    if (--until == 0) {
-                        F[(long)k * C + c] = (k == 0) ? run : run - prev;
-                        prev = run;
-                        until = fs;
-                        ++k;
-                    }
+        for (int u = 0; u < 16; ++u)
+            if (u < nper) dst[u * FS_THREADS + tid] = r[u];
+    };
+    auto copy_scalar = [&](int ci, int buf) {   // odd class counts: plain element-wise staging
+        float *dst = fs_smem + buf * chunk;
+        const long base = (long)ci * chunk;
+        for (int i = tid; i < chunk; i += FS_THREADS) {
+            const long e = base + i;
+            dst[i] = src[e < total ? e : total - 1];
+        }
+    };
+
+    // -0.0f is the additive identity of IEEE float addition for EVERY x (incl. both zeros), so starting the chain
+    // there reproduces cs[0] = lp[0], cs[t] = cs[t-1] + lp[t] bit for bit without a first-row special case
+    float run = -0.0f, prev = 0.f;
+    int until = fs, k = 0;
+    if (vec) {
+        gload(0);
+        sstore(0);
+    } else {
+        copy_scalar(0, 0);
+    }
+    __syncthreads();
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int cur = ci & 1;
+        const int nxt = ci + 1 < nchunks ? ci + 1 : ci;
+        if (vec) gload(nxt);
+        if (tid < 64) {   // wave 0: the sequential chain, lane = class; column bookkeeping is wave-uniform
+            const float *col = fs_smem + cur * chunk + (tid < C ? tid : C - 1);
+            const int rows = min(FS_ROWS, n - ci * FS_ROWS);
+            int rr = 0;
+            while (rr < rows) {
+                const int take = min(until, rows - rr);   // rows of the current column inside this chunk
+                int q = 0;
+                for (; q + 6 <= take; q += 6) {
+                    float v[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) v[u] = col[(rr + q + u) * C];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) run = run + v[u];      // sequential float32 chain
+                }
+                for (; q < take; ++q) run = run + col[(rr + q) * C];
+                rr += take;
+                until -= take;
+                if (until == 0) {                                      // end of column k
+                    if (tid < C) F[(long)k * C + tid] = (k == 0) ? run : run - prev;
+                    prev = run;
+                    until = fs;
+                    ++k;
                 }
             }
         }
+        if (vec) sstore(cur ^ 1);
+        else copy_scalar(nxt, cur ^ 1);
+        __syncthreads();
     }
 }
 
@@ -73,15 +138,43 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
     const bool take = (b.v > a.v) || (b.v == a.v && b.j > a.j);
     return take ? b : a;
 }
+// Wave-wide arg-max with the reference's tie rule, on the DPP crossbar (no LDS round trips): first the
+// maximum score (six DPP steps of v_max_f64), then the largest length index among the lanes that hold it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // lanes whose DPP source is disabled / out of range keep their own value (old = self): max(v, v) = v
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ Cand wave_best(Cand c) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        Cand d;
-        d.v = __shfl_xor(c.v, o);
-        d.j = __shfl_xor(c.j, o);
-        c = better(c, d);
-    }
-    return c;
+    // candidates are never NaN here: NaN length tables are resolved on the host (mucon_amd/core/viterbi/viterbi.py)
+    double m = c.v;
+    m = dpp_max_f64<0xB1, 0xF>(m);    // quad_perm [1,0,3,2]
+    m = dpp_max_f64<0x4E, 0xF>(m);    // quad_perm [2,3,0,1]
+    m = dpp_max_f64<0x141, 0xF>(m);   // row_half_mirror
+    m = dpp_max_f64<0x140, 0xF>(m);   // row_mirror: every lane of a 16-lane row holds the row maximum
+    m = dpp_max_f64<0x142, 0xA>(m);   // row_bcast15 into rows 1 and 3
+    m = dpp_max_f64<0x143, 0xC>(m);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+    const int mlo = __builtin_amdgcn_readlane(__double2loint(m), 63);
+    const int mhi = __builtin_amdgcn_readlane(__double2hiint(m), 63);
+    const double vmax = __hiloint2double(mhi, mlo);
+    int j = (c.v == vmax) ? c.j : -1;  // `<=` in HypDict.update keeps the LAST of equal candidates: the largest j
+    j = dpp_max_i32<0xB1, 0xF>(j);
+    j = dpp_max_i32<0x4E, 0xF>(j);
+    j = dpp_max_i32<0x141, 0xF>(j);
+    j = dpp_max_i32<0x140, 0xF>(j);
+    j = dpp_max_i32<0x142, 0xA>(j);
+    j = dpp_max_i32<0x143, 0xC>(j);
+    Cand r;
+    r.v = vmax;
+    r.j = __builtin_amdgcn_readlane(j, 63);
+    return r;
 }
 __device__ __forceinline__ bool alive_at(int n, int k0, int J) {
     return k0 >= 0 && (n == 0 ? (k0 == 0) : (k0 >= n && k0 <= J * n));
@@ -89,13 +182,15 @@ __device__ __forceinline__ bool alive_at(int n, int k0, int J) {
 // hyp.score + frame_score (viterbi.py:99,113): float32 + float32 while in the first transcript
 // state, float64 + float32 afterwards (NumPy 2 promotion; the length table makes later states f64)
 __device__ __forceinline__ double add_frame(double s, float f, int n) {
-    if (n == 0) {
-        const float t = (float)s + f;
-        return (double)t;
-    }
-    return s + (double)f;
+    const float t32 = (float)s + f;          // state 0: s is float32-valued, the add rounds to float32
+    const double t64 = s + (double)f;
+    return n == 0 ? (double)t32 : t64;
 }
 
+// SPW = transcript states per wave (a wave owns states wave, wave+16, ...): the per-state work of a column is
+// written out SPW times in straight-line code -- all LDS reads first, then the adds, then the SPW independent
+// DPP reductions, then the writes -- so that the LDS and DPP latencies of the states overlap instead of adding up.
+template <int SPW>
 __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
@@ -164,6 +259,19 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     const bool has0 = lane < J, has1 = lane + 64 < J;  // J <= 128 slots per state
     float fpre = 0.f;
 
+    // per-wave state set, hoisted out of the column loop
+    int sm[SPW], sam[SPW], sapm[SPW];
+    bool sv[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+        const int m = wave + nwaves * i;
+        sv[i] = m < N;
+        sm[i] = sv[i] ? m : 0;
+        sam[i] = a[sm[i]];
+        sapm[i] = a[sm[i] >= 1 ? sm[i] - 1 : 0];
+    }
+    const int l0 = has0 ? lane : J - 1, l1 = has1 ? lane + 64 : J - 1;   // clamped slot indices (reads stay in bounds)
+
     for (int k = 1; k < K; ++k) {
         double *So = S + (size_t)((k - 1) & 1) * N * J;
         double *Sn = S + (size_t)(k & 1) * N * J;
@@ -182,36 +290,54 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
         const int kslot = k % J;
         const int k00 = c_old - jr0, k01 = c_old - jr1;  // entry columns of this lane's two slots
 
-        for (int m = wave; m < N; m += nwaves) {
-            // (1) stay in state m (viterbi.py:96-104)
-            const float fm = Fk[a[m]];
-            if (has0 && alive_at(m, k00, J) && jr0 + 1 < J) Sn[m * J + lane] = add_frame(So[m * J + lane], fm, m);
-            if (has1 && alive_at(m, k01, J) && jr1 + 1 < J)
-                Sn[m * J + lane + 64] = add_frame(So[m * J + lane + 64], fm, m);
-            // (2) enter state m from state m-1 (viterbi.py:105-121): the frame score is the OLD label's
-            if (m >= 1 && k >= m && k <= J * m) {
-                const int pm = m - 1;
-                const float fp = Fk[a[pm]];
-                Cand best;
-                best.v = -INFINITY;
-                best.j = -1;
-                if (has0 && alive_at(pm, k00, J)) {
-                    Cand c;
-                    c.v = (add_frame(So[pm * J + lane], fp, pm) + Pl[pm * J + jr0]) + 0.0;
-                    c.j = jr0;
-                    best = better(best, c);
-                }
-                if (has1 && alive_at(pm, k01, J)) {
-                    Cand c;
-                    c.v = (add_frame(So[pm * J + lane + 64], fp, pm) + Pl[pm * J + jr1]) + 0.0;
-                    c.j = jr1;
-                    best = better(best, c);
-                }
-                best = wave_best(best);
-                if (lane == 0) {
-                    Sn[m * J + kslot] = best.v;
-                    bp[(size_t)k * N + m] = (uint8_t)best.j;
-                }
+        // ---- all LDS reads of the column (unconditional; out-of-range work reads a clamped, valid address)
+        float fm[SPW], fp[SPW];
+        double own0[SPW], own1[SPW], prv0[SPW], prv1[SPW], pl0[SPW], pl1[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int m = sm[i], pm = m >= 1 ? m - 1 : 0;
+            fm[i] = Fk[sam[i]];
+            fp[i] = Fk[sapm[i]];
+            own0[i] = So[m * J + l0];
+            own1[i] = So[m * J + l1];
+            prv0[i] = So[pm * J + l0];
+            prv1[i] = So[pm * J + l1];
+            pl0[i] = Pl[pm * J + jr0];
+            pl1[i] = Pl[pm * J + jr1];
+        }
+        // ---- (1) stay in state m (viterbi.py:96-104) and (2) the candidates for entering m from m-1
+        //      (viterbi.py:105-121; the frame score is the OLD label's)
+        Cand best[SPW];
+        bool enter[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int m = sm[i], pm = m >= 1 ? m - 1 : 0;
+            if (sv[i] && has0 && alive_at(m, k00, J) && jr0 + 1 < J) Sn[m * J + lane] = add_frame(own0[i], fm[i], m);
+            if (sv[i] && has1 && alive_at(m, k01, J) && jr1 + 1 < J) Sn[m * J + lane + 64] = add_frame(own1[i], fm[i], m);
+            enter[i] = sv[i] && m >= 1 && k >= m && k <= J * m;
+            Cand c0, c1;
+            c0.v = (add_frame(prv0[i], fp[i], pm) + pl0[i]) + 0.0;
+            c0.j = jr0;
+            c1.v = (add_frame(prv1[i], fp[i], pm) + pl1[i]) + 0.0;
+            c1.j = jr1;
+            const bool a0 = has0 && alive_at(pm, k00, J), a1 = has1 && alive_at(pm, k01, J);
+            if (!a0) {
+                c0.v = -INFINITY;
+                c0.j = -1;
+            }
+            if (!a1) {
+                c1.v = -INFINITY;
+                c1.j = -1;
+            }
+            best[i] = better(c0, c1);
+        }
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) best[i] = wave_best(best[i]);
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            if (enter[i] && lane == 0) {
+                Sn[sm[i] * J + kslot] = best[i].v;
+                bp[(size_t)k * N + sm[i]] = (uint8_t)best[i].j;
             }
         }
         jr0 = (jr0 + 1 == J) ? 0 : jr0 + 1;
@@ -360,18 +486,40 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     hipStream_t s = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_dp_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
+        const void *ks[4] = {reinterpret_cast<const void *>(viterbi_dp_kernel<1>), reinterpret_cast<const void *>(viterbi_dp_kernel<2>),
+                             reinterpret_cast<const void *>(viterbi_dp_kernel<4>), reinterpret_cast<const void *>(viterbi_dp_kernel<8>)};
+        for (const void *kp : ks)
+            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
+                snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
+                VIT_FAIL(MUCON_E_HIP);
+            }
+        attr_set = true;
+    }
+    static bool fs_attr = false;
+    const size_t fs_smem = (size_t)2 * FS_ROWS * C * sizeof(float);
+    if (!fs_attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
             VIT_FAIL(MUCON_E_HIP);
         }
-        attr_set = true;
+        fs_attr = true;
     }
-    hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(64), 0, s, jobs, lp,
+    hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
                        static_cast<char *>(workspace), C, fs);
-    hipLaunchKernelGGL(viterbi_dp_kernel, dim3(n_videos), dim3(VIT_THREADS), smem, s, jobs, transcripts,
-                       length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C,
-                       fs, J);
+    const int spw = (max_N + 15) / 16;   // transcript states per wave
+#define VIT_LAUNCH(SPW)                                                                                              \
+    hipLaunchKernelGGL(viterbi_dp_kernel<SPW>, dim3(n_videos), dim3(VIT_THREADS), smem, s, jobs, transcripts,          \
+                       length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J)
+    if (spw <= 1) VIT_LAUNCH(1);
+    else if (spw <= 2) VIT_LAUNCH(2);
+    else if (spw <= 4) VIT_LAUNCH(4);
+    else if (spw <= 8) VIT_LAUNCH(8);
+    else {
+        snprintf(g_err, sizeof(g_err), "viterbi: transcripts longer than 128 states are not supported (max_N=%d)", max_N);
+        VIT_FAIL(MUCON_E_ARG);
+    }
+#undef VIT_LAUNCH
     if (hipGetLastError() != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
         VIT_FAIL(MUCON_E_HIP);

@@ -247,21 +247,41 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
         ws_off += (lib.mucon_viterbi_job_workspace_bytes(T, C, N, fs) + 255) // 256 * 256
         maxN = max(maxN, N)
     lp_all = lps[0].contiguous().reshape(-1) if nv == 1 else torch.cat([x.contiguous().reshape(-1) for x in lps])
-    tr_all = torch.from_numpy(np.concatenate([np.asarray(t, dtype=np.int32) for t in transcripts])).to(dev)
-    tb_all = torch.from_numpy(np.concatenate([np.ascontiguousarray(t, dtype=np.float64).reshape(-1) for t in tables])).to(dev)
-    jobs_dev = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(dev)
-    labels = torch.empty(lab_off, dtype=torch.int32, device=dev)
-    seg_len = torch.zeros(seg_off, dtype=torch.int32, device=dev)
-    n_seg = torch.zeros(nv, dtype=torch.int32, device=dev)
-    score = torch.zeros(nv, dtype=torch.float64, device=dev)
-    status = torch.full((nv,), -1, dtype=torch.int32, device=dev)
+
+    def up8(n):
+        return (n + 7) // 8 * 8
+
+    # ONE host->device copy (jobs | length tables | transcripts) and ONE device->host copy
+    # (score | labels | segment lengths | n_seg | status): the decode of a short video is latency-bound
+    jobs_b = np.frombuffer(bytes(jobs), dtype=np.uint8)
+    tb_b = np.concatenate([np.ascontiguousarray(t, dtype=np.float64).reshape(-1) for t in tables]).view(np.uint8)
+    tr_b = np.concatenate([np.asarray(t, dtype=np.int32) for t in transcripts]).view(np.uint8)
+    o_jobs, o_tb = 0, up8(jobs_b.size)
+    o_tr = o_tb + up8(tb_b.size)
+    h_in = np.zeros(o_tr + up8(tr_b.size), dtype=np.uint8)
+    h_in[o_jobs: o_jobs + jobs_b.size] = jobs_b
+    h_in[o_tb: o_tb + tb_b.size] = tb_b
+    h_in[o_tr: o_tr + tr_b.size] = tr_b
+    d_in = torch.from_numpy(h_in).to(dev)
+    o_score, o_lab = 0, up8(8 * nv)
+    o_seg = o_lab + up8(4 * lab_off)
+    o_nseg = o_seg + up8(4 * seg_off)
+    o_stat = o_nseg + up8(4 * nv)
+    d_out = torch.zeros(o_stat + up8(4 * nv), dtype=torch.uint8, device=dev)
     ws = torch.empty(max(ws_off, 256), dtype=torch.uint8, device=dev)
-    _lib.check(lib.mucon_viterbi_decode_batch(nv, _lib.ptr(jobs_dev), C, fs, max_len, maxN, _lib.ptr(lp_all),
-                                              _lib.ptr(tr_all), _lib.ptr(tb_all), _lib.ptr(labels), _lib.ptr(seg_len),
-                                              _lib.ptr(n_seg), _lib.ptr(score), _lib.ptr(status), _lib.ptr(ws),
-                                              _lib.current_stream_ptr()), "mucon_viterbi_decode_batch")
-    labels_h, seg_h = labels.cpu().numpy(), seg_len.cpu().numpy()  # the result fetch synchronises
-    nseg_h, score_h, status_h = n_seg.cpu().numpy(), score.cpu().numpy(), status.cpu().numpy()
+    base_in, base_out = d_in.data_ptr(), d_out.data_ptr()
+    vp = ctypes.c_void_p
+    _lib.check(lib.mucon_viterbi_decode_batch(nv, vp(base_in + o_jobs), C, fs, max_len, maxN, _lib.ptr(lp_all),
+                                              vp(base_in + o_tr), vp(base_in + o_tb), vp(base_out + o_lab),
+                                              vp(base_out + o_seg), vp(base_out + o_nseg), vp(base_out + o_score),
+                                              vp(base_out + o_stat), _lib.ptr(ws), _lib.current_stream_ptr()),
+               "mucon_viterbi_decode_batch")
+    h_out = d_out.cpu().numpy()  # the result fetch synchronises
+    score_h = h_out[o_score: o_score + 8 * nv].view(np.float64)
+    labels_h = h_out[o_lab: o_lab + 4 * lab_off].view(np.int32)
+    seg_h = h_out[o_seg: o_seg + 4 * seg_off].view(np.int32)
+    nseg_h = h_out[o_nseg: o_nseg + 4 * nv].view(np.int32)
+    status_h = h_out[o_stat: o_stat + 4 * nv].view(np.int32)
     out = []
     for v in range(nv):
         j = jobs[v]
