@@ -104,14 +104,37 @@ def viterbi_bench(dev, C=48):
     from mucon_amd import ops
     from mucon_amd.core.viterbi import PoissonModel
 
-    T, N, fs, max_len = 16384, 64, 30, 2000
+    fs, max_len = 30, 2000
     g = torch.Generator(device="cpu").manual_seed(7)
+    out = {}
+    # a Breakfast-typical video first (T ~ 2000 frames, 6 actions), single stream
+    T, N = 2000, 6
     tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
     mu = np.ones(C)
     mu[np.unique(tr)] = T / N
     P = PoissonModel(mu).rows_for(tr, fs)
     lp = torch.log_softmax(3 * torch.randn(T, C, generator=g), dim=1).to(dev)
-    out = {}
+    for _ in range(3):
+        ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len)
+    torch.cuda.synchronize()
+    out["ms_per_video_T2000_N6_single"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    lp_h = lp.cpu().numpy()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        oracle.viterbi_decode_table(lp_h, tr, P, fs, max_len)
+    out["cpu_oracle_ms_per_video_T2000_N6"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    out["reference_python_ms_per_video_T2000_N6"] = 68.0   # measured in the build container, context only
+
+    T, N = 16384, 64
+    tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
+    mu = np.ones(C)
+    mu[np.unique(tr)] = T / N
+    P = PoissonModel(mu).rows_for(tr, fs)
+    lp = torch.log_softmax(3 * torch.randn(T, C, generator=g), dim=1).to(dev)
     for label, nv, reps in (("single", 1, 10), ("batch64", 64, 3)):
         lps = [lp] * nv if nv == 1 else [torch.log_softmax(3 * torch.randn(T, C, device=dev), dim=1) for _ in range(nv)]
         ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)  # warm-up
@@ -125,7 +148,8 @@ def viterbi_bench(dev, C=48):
     t0 = time.perf_counter()
     oracle.viterbi_decode_table(lp_h, tr, P, fs, max_len)
     out["cpu_oracle_ms_per_video"] = round((time.perf_counter() - t0) * 1e3, 3)
-    out["config"] = f"T={T}, N={N}, C={C}, fs={fs}: K=546 columns, 64x66 hypotheses; timings include the result D2H"
+    out["config"] = (f"ms_per_video_single/batch64 and cpu_oracle_ms_per_video: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
+                     f"(K=546 columns, 64x66 hypotheses); every timing includes the upload of the job table and the result D2H")
     out["algorithmic_bytes_per_video"] = T * C * 4 + T * 4
     return out
 
@@ -142,10 +166,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("MUCON_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path even with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mucon_amd import _lib, ops
 
@@ -167,21 +194,18 @@ def main():
         _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
         logp.backward(dlogp)
         grads = [p.grad for p in flat_params]
-        if world > 1:
-            flat = torch.cat([g_.reshape(-1) for g_ in grads])
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for g_ in grads:
-                g_.copy_(flat[off: off + g_.numel()].view_as(g_))
-                off += g_.numel()
+        if dist is not None:
+            # the one exchange step: sum the gradients over ranks (the encoder's gradients are views of one flat
+            # buffer, the two head tensors ride in a second tiny call), then average
+            for buf in ops.flat_grad_buffers(flat_params):
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG)
         with torch.no_grad():
             torch._foreach_add_(grads, flat_params, alpha=wd)
             torch._foreach_add_(flat_params, grads, alpha=-lr)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -197,7 +221,7 @@ def main():
     tot_ms = (ctypes.c_float * 2)()
     cnt = (ctypes.c_int32 * 2)()
     _lib.check(lib.mucon_profile_end(tot_ms, cnt), "profile_end")
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -210,6 +234,12 @@ def main():
         flops = 2.0 * B * T * spec.in_dim * spec.hidden            # per launch, either kernel
         dom = ("first_conv_fwd nt_gemm_kernel", k_fwd_ms) if k_fwd_ms >= k_wg_ms else ("first_conv_wgrad tn_gemm_kernel", k_wg_ms)
         achieved = flops / (dom[1] * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from the rocprofv3 --pmc passes of tools/profile_round.sh (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["first_conv_fwd" if k_fwd_ms >= k_wg_ms else "first_conv_wgrad"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "frames/sec fwd+bwd (Breakfast I3D Tx2048)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,7 +250,8 @@ def main():
                                    f"(dropout on), fwd+bwd+SGD, tapes resident in HBM",
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": B * T * (spec.in_dim + spec.hidden) * 4,
                          "avg_launch_ms": round(dom[1], 4), "flops_per_launch": flops,
                          "first_conv_fwd_ms": round(k_fwd_ms, 4), "first_conv_wgrad_ms": round(k_wg_ms, 4)},
             "roofline_hbm_whole_path": {"bound": "hbm", "achieved": round(value / world * BYTES_PER_FRAME_FWD_BWD / 1e9, 1),
@@ -234,10 +265,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
         if not args.no_viterbi:
             out["viterbi"] = viterbi_bench(dev, C)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio buffers: get it out before the result line
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

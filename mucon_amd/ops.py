@@ -121,12 +121,35 @@ class _EncoderFn(torch.autograd.Function):
         lib = _lib.load()
         tape, *params = ctx.saved_tensors
         d_enc = d_enc.contiguous()
-        grads = [torch.empty_like(p) for p in params]
+        # one flat gradient buffer, the per-parameter gradients are views into it: data-parallel training
+        # all-reduces the flat buffer directly (flat_grad_buffers), no gather / scatter copies
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]   # 256-byte aligned slots
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=tape.device)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off: off + p.numel()].view(p.shape))
+            off += n
         cp, cg = _pack_params(ctx.spec, params), _pack_params(ctx.spec, grads)
         _lib.check(lib.mucon_encoder_bwd(ctypes.byref(ctx.cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(d_enc),
                                          _lib.ptr(ctx.ws), ctx.nbytes, ctypes.byref(cg), _lib.current_stream_ptr()),
                    "mucon_encoder_bwd")
         return (None, None, None, None, *grads)
+
+
+def flat_grad_buffers(params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """The distinct underlying buffers of the parameters' .grad tensors (the encoder's gradients live in ONE
+    flat buffer, see _EncoderFn.backward).  All-reducing these in place all-reduces every gradient."""
+    seen, out = set(), []
+    for p in params:
+        g = p.grad
+        if g is None:
+            continue
+        st = g.untyped_storage()
+        key = st.data_ptr()
+        if key not in seen:
+            seen.add(key)
+            out.append(torch.empty(0, dtype=g.dtype, device=g.device).set_(st))   # 1-D tensor over the whole storage
+    return out
 
 
 def encoder_saved(enc: torch.Tensor, kind: str, layer: int = 0) -> torch.Tensor:
