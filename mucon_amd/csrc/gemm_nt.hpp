@@ -2,12 +2,19 @@
 //
 //     out[t][n] = epilogue( sum_{tap, c} A[t + (tap - taps/2) * tap_step][c] * W[n][tap*Kc + c] )
 //
-// One workgroup = 256 threads = 4 waves computes 128 time steps x 128 output channels of one
-// video; each wave owns a 64x64 quadrant as 2x2 MFMA tiles (64 accumulator VGPRs).  A and W
-// tiles (128 rows x 32 k) are staged global -> registers -> LDS, double buffered, one barrier
-// per k-tile; the global loads of tile k+1 are in flight under the 64 MFMAs of tile k.
-// LDS rows are padded to 36 floats so that the 16-lane groups of ds_read_b128 hit 64 distinct
-// banks (rows r, r+1.. map to bank offsets 36r mod 64: a permutation of the multiples of 4).
+// One workgroup = 256 threads = 4 waves computes BM time steps x 128 output channels of one video, BM in
+// {128, 64, 32} picked per level (nt_pick_bm: the coarse levels get many short workgroups, the fine ones two
+// workgroups per CU).  A and W tiles (BM / 128 rows x 32 k) are staged global -> registers -> LDS, double
+// buffered, one barrier per k-tile, with TWO register sets so that the loads of k-tile kt+2 are in flight
+// while kt is multiplied and kt+1 waits in the other set.  LDS rows are padded to 36 floats so that the
+// 16-lane groups of ds_read_b128 hit 64 distinct banks (row r -> bank offset 36r mod 64: a permutation of the
+// multiples of 4).
+//
+// Three things keep hipcc from serialising the memory pipeline (each was worth 5-10 % of the step):
+//   * loads are never under a divergent `if`: padding rows load from a clamped valid row and are zeroed later;
+//   * every USE of loaded data (zeroing, ReLU / dropout prologue) sits in the LDS-store phase, and the
+//     phases load / MFMA / store are pinned with sched_barrier, so waits are counted vmcnt(N), never vmcnt(0);
+//   * full tiles take a straight-line epilogue (16 residual / mask loads, math, 16 stores per 32x32 tile).
 //
 // It serves every convolution of the reference's encoder (src/core/modules/temporal.py):
 //   first_conv (:133)  taps=1 Kc=2048        dilated_conv (:48) taps=3 Kc=128 (zero pad = dilation)
