@@ -154,6 +154,40 @@ def viterbi_bench(dev, C=48):
     return out
 
 
+def end_to_end_bench(dev, steps=40):
+    """Second timed scope of SURVEY.md 8d: the reference's whole training step (_train_1_batch: forward incl. the
+    PyTorch-ROCm s-head, losses, backward, two clip_grad_norm_, SGD) on one Breakfast-typical synthetic video,
+    batch size 1 as in the reference (README: 14.67-16.23 it/s on the authors' GPU)."""
+    from mucon_amd import synth
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.core.datasets import Batch
+    from mucon_amd.mucon.models import create_model
+    from mucon_amd.mucon.trainers import SimpleTrainer
+
+    T, N, C = 2000, 6, 48
+    cfg = update_config(get_cfg_defaults(), [], [])
+    torch.manual_seed(0)
+    model = create_model(cfg, C, 31, 2048).to(dev)
+    trainer = SimpleTrainer(cfg, model, dev)
+    trainer.on_start_epoch(0)
+    model.train()
+    tr = synth.transcript(3, N, C, allow_repeats=False)
+    batch = Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(4, T, tr)),
+                  transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
+                  transcript_tf_target=torch.tensor(tr.tolist() + [C]), video_name="synthetic").to(dev)
+    for i in range(5):
+        trainer._train_1_batch(i, batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer._train_1_batch(5 + i, batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"videos_per_s": round(1.0 / dt, 1), "frames_per_s": round(T / dt, 1), "ms_per_video": round(dt * 1e3, 3),
+            "config": f"full MuCon train step, batch 1, T={T}, N={N}: HIP hot path + PyTorch-ROCm s-head/losses/clip/SGD",
+            "reference_readme_it_per_s": [14.67, 16.23]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -265,6 +299,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
         if not args.no_viterbi:
             out["viterbi"] = viterbi_bench(dev, C)
+            out["end_to_end"] = end_to_end_bench(dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
