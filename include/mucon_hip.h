@@ -173,6 +173,28 @@ int mucon_bench_first_conv(const float *tape, const float *w, const float *b, fl
 int mucon_profile_begin(int32_t max_records);
 int mucon_profile_end(float *total_ms_host, int32_t *count_host);
 
+/* ---- s-head sequence encoder: bidirectional LSTM --------------------------------
+ * Replaces torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True) as the reference's s-head calls
+ * it (reference src/mucon/models.py:195-201 construction, :605-611 call: batch 1, zero initial state).
+ * Parameter layout is torch's: w_ih [4H][I], w_hh [4H][H], b_ih [4H], b_hh [4H], gate order i,f,g,o;
+ * index 0 = forward direction, 1 = reverse (weight_*_l0_reverse).  x [T][I], out [T][ndir*H]
+ * (forward half first), hn / cn [ndir][H].  I = H = 128 only.  All pointers are device pointers. */
+typedef struct mucon_lstm_params {
+    const float *w_ih[2];
+    const float *w_hh[2];
+    const float *b_ih[2];
+    const float *b_hh[2];
+} mucon_lstm_params;
+size_t mucon_lstm_workspace_bytes(int32_t T, int32_t ndir);
+/* Forward; keeps the gate activations and cell states in `workspace` for mucon_lstm_bwd. */
+int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
+                   float *out, float *hn, float *cn, void *workspace, size_t workspace_bytes, void *stream);
+/* Backward through time from d_out [T][ndir*H], d_hn, d_cn [ndir][H] (each may be NULL = zero) with the
+ * workspace the forward filled.  Writes (not accumulates) d_x [T][I] and every tensor of d_params. */
+int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
+                   const float *out, const float *d_out, const float *d_hn, const float *d_cn, float *d_x,
+                   const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

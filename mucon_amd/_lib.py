@@ -51,6 +51,11 @@ class ViterbiJob(ctypes.Structure):
     ]
 
 
+class LstmParams(ctypes.Structure):
+    _fields_ = [("w_ih", ctypes.c_void_p * 2), ("w_hh", ctypes.c_void_p * 2),
+                ("b_ih", ctypes.c_void_p * 2), ("b_hh", ctypes.c_void_p * 2)]
+
+
 # every symbol include/mucon_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
@@ -74,6 +79,10 @@ SYMBOLS = {
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "mucon_bench_first_conv": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_float), _vp]),
+    "mucon_lstm_workspace_bytes": (_sz, [_i32, _i32]),
+    "mucon_lstm_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_lstm_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _vp,
+                                      ctypes.POINTER(LstmParams), _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -2,8 +2,9 @@
 
     python -m mucon_amd.build [--force]
 
-Two translation units: mucon_hip.hip (encoder / head, FMA contraction allowed) and viterbi.hip
-(-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires).
+Three translation units: mucon_hip.hip (encoder / head, FMA contraction allowed), viterbi.hip
+(-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires) and
+shead.hip (the s-head's bidirectional LSTM).
 The .so lands next to this file (git-ignored; gpurun ships it to the GPU box)."""
 import os
 import subprocess
@@ -13,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmucon_hip.so")
 ARCH = "gfx950"
-SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"])]
-DEPS = ["common.hpp", "gemm_nt.hpp", "gemm_tn.hpp", "small_kernels.hpp", "../../include/mucon_hip.h"]
+SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shead.hip", [])]
+DEPS = ["common.hpp", "gemm_nt.hpp", "gemm_tn.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "../../include/mucon_hip.h"]
 
 
 def _stale():

@@ -121,6 +121,7 @@ class MuCon(nn.Module):
                                    self.fs_decoder_attn_combine, self.fs_decoder_lstm, self.fs_decoder_transcript,
                                    self.fs_decoder_length, self.conv_classifier])
         self._step = 0  # dropout stream counter for the HIP encoder
+        self.native_lstm = True  # s-head biLSTM through the HIP kernels (False: torch's nn.LSTM / MIOpen)
 
     def get_params(self, original_lr):  # fandak.Model.get_params
         return [{"params": self.parameters(), "lr": original_lr}]
@@ -179,7 +180,7 @@ class MuCon(nn.Module):
     def sequence_generation_forward(self, temporal_encoded: Tensor, tf_transcript_target_length: int,
                                     transcript_tf_input: Tensor, transcript_tf_target: Tensor):
         """biLSTM encoder over [1 x Tz x D'], additive attention, LSTM decoder (reference models.py:585-728)."""
-        enc_out, (h_n, c_n) = self.fs_encoder_lstm(temporal_encoded)
+        enc_out, h_n, c_n = self._sequence_encoder(temporal_encoded)
         dec_h = self.fs_encoder_hidden_out(h_n.view(1, -1)).unsqueeze(0)   # [1 x 1 x D'']
         dec_c = self.fs_encoder_cn_out(c_n.view(1, -1)).unsqueeze(0)
         memory = enc_out[0]                                               # [Tz x 2D']
@@ -206,6 +207,18 @@ class MuCon(nn.Module):
             if not self.teacher_forcing:
                 dec_in = word
         return transcripts, lengths
+
+    def _sequence_encoder(self, temporal_encoded: Tensor):
+        """fs_encoder_lstm over [1 x Tz x D'] (reference models.py:605-611).  On the GPU, at the reference's
+        sizes (input = hidden = 128, one layer), this is the persistent HIP LSTM (ops.lstm_forward, csrc/lstm.hpp)
+        on the module's own parameters; other sizes -- and the CPU-side surface tests -- run torch's nn.LSTM."""
+        lstm = self.fs_encoder_lstm
+        if (temporal_encoded.is_cuda and temporal_encoded.shape[0] == 1 and lstm.input_size == 128
+                and lstm.hidden_size == 128 and lstm.num_layers == 1 and self.native_lstm):
+            out, h_n, c_n = ops.lstm_forward(temporal_encoded[0], list(lstm.parameters()), lstm.bidirectional)
+            return out.unsqueeze(0), h_n, c_n
+        enc_out, (h_n, c_n) = lstm(temporal_encoded)
+        return enc_out, h_n, c_n
 
     def _calculate_attention(self, current_hidden_state: Tensor, encoder_result_ready_for_attention: Tensor) -> Tensor:
         q = self.fs_decoder_attention_l2(current_hidden_state.view(1, -1))

@@ -223,6 +223,66 @@ def head_forward(enc: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, Tf
     return (logits if want_logits else None), (logp if want_logp else None)
 
 
+# --------------------------------------------------------------------------------------- s-head LSTM
+class _LstmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ndir, *weights):
+        lib = _lib.load()
+        _check_dev(x, *weights)
+        x = x.contiguous()
+        weights = [w.contiguous() for w in weights]
+        T, I = x.shape
+        H = weights[1].shape[1]
+        nbytes = lib.mucon_lstm_workspace_bytes(T, ndir)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+        out = torch.empty((T, ndir * H), dtype=torch.float32, device=x.device)
+        hn = torch.empty((ndir, H), dtype=torch.float32, device=x.device)
+        cn = torch.empty((ndir, H), dtype=torch.float32, device=x.device)
+        _lib.check(lib.mucon_lstm_fwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_lstm_params(weights, ndir)), _lib.ptr(out),
+                                      _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+                   "mucon_lstm_fwd")
+        ctx.dims, ctx.ws, ctx.nbytes = (T, I, H, ndir), ws, nbytes
+        ctx.save_for_backward(x, out, *weights)
+        ctx.set_materialize_grads(False)
+        return out, hn, cn
+
+    @staticmethod
+    def backward(ctx, d_out, d_hn, d_cn):
+        lib = _lib.load()
+        x, out, *weights = ctx.saved_tensors
+        T, I, H, ndir = ctx.dims
+        d_out = d_out.contiguous() if d_out is not None else None
+        d_hn = d_hn.contiguous() if d_hn is not None else None
+        d_cn = d_cn.contiguous() if d_cn is not None else None
+        d_x = torch.empty_like(x)
+        grads = [torch.empty_like(w) for w in weights]
+        _lib.check(lib.mucon_lstm_bwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_lstm_params(weights, ndir)), _lib.ptr(out),
+                                      _lib.ptr(d_out), _lib.ptr(d_hn), _lib.ptr(d_cn), _lib.ptr(d_x),
+                                      ctypes.byref(_lstm_params(grads, ndir)), _lib.ptr(ctx.ws), ctx.nbytes,
+                                      _lib.current_stream_ptr()), "mucon_lstm_bwd")
+        return (d_x, None, *grads)
+
+
+def _lstm_params(weights, ndir):
+    """weights in torch.nn.LSTM._flat_weights order: (w_ih, w_hh, b_ih, b_hh) per direction."""
+    p = _lib.LstmParams()
+    for d in range(ndir):
+        w_ih, w_hh, b_ih, b_hh = weights[4 * d:4 * d + 4]
+        p.w_ih[d], p.w_hh[d], p.b_ih[d], p.b_hh[d] = _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(b_ih), _lib.ptr(b_hh)
+    return p
+
+
+def lstm_forward(x: torch.Tensor, weights: Sequence[torch.Tensor], bidirectional: bool = True):
+    """x [T, 128] -> (out [T, ndir*128], h_n [ndir, 128], c_n [ndir, 128]): torch.nn.LSTM(128, 128,
+    bidirectional) at batch 1 with zero initial state, as the s-head calls it (reference models.py:605-611).
+    `weights` = the module's parameters in its own order (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0
+    [, *_reverse])."""
+    ndir = 2 if bidirectional else 1
+    if len(weights) != 4 * ndir:
+        raise ValueError(f"lstm_forward: expected {4 * ndir} weight tensors, got {len(weights)}")
+    return _LstmFn.apply(x, ndir, *weights)
+
+
 # --------------------------------------------------------------------------------------- viterbi
 @dataclass
 class ViterbiResult:

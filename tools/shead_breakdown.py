@@ -21,3 +21,13 @@ def shead_fb():
 print("biLSTM fwd", t(lstm_f)); print("biLSTM fwd+bwd", t(lstm_fb)); print("s-head fwd", t(shead_f)); print("s-head fwd+bwd", t(shead_fb))
 with torch.backends.cudnn.flags(enabled=False):
     print("native biLSTM fwd", t(lstm_f)); print("native biLSTM fwd+bwd", t(lstm_fb))
+from mucon_amd import ops
+W=list(m.fs_encoder_lstm.parameters())
+def hip_f(): return ops.lstm_forward(enc[0],W)
+def hip_fb():
+    o,h,c=ops.lstm_forward(enc[0],W); (o.sum()+h.sum()+c.sum()).backward()
+print("HIP biLSTM fwd", t(hip_f)); print("HIP biLSTM fwd+bwd", t(hip_fb))
+m.native_lstm=True
+print("s-head (HIP lstm) fwd", t(shead_f)); print("s-head (HIP lstm) fwd+bwd", t(shead_fb))
+m.native_lstm=False
+print("s-head (MIOpen lstm) fwd", t(shead_f)); print("s-head (MIOpen lstm) fwd+bwd", t(shead_fb))
