@@ -195,6 +195,54 @@ int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x
                    const float *out, const float *d_out, const float *d_hn, const float *d_cn, float *d_x,
                    const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- s-head attention decoder ---------------------------------------------------
+ * Replaces the decoding loop of reference src/mucon/models.py:612-728 (sequence_generation_forward after
+ * the encoder LSTM) and :730-744 (_calculate_attention): initial state from h_n / c_n through
+ * fs_encoder_hidden_out / fs_encoder_cn_out, then per step embedding -> additive attention over `memory`
+ * -> attn_combine -> one LSTM cell -> transcript MLP + length MLP -> log-softmax -> arg-max feedback.
+ * One persistent workgroup walks all steps.  Tensors keep torch's layouts (Linear weight [out][in]);
+ * every pointer is a device pointer. */
+typedef struct mucon_decoder_cfg {
+    int32_t Tz;              /* encoder states attended over */
+    int32_t ME;              /* memory width = directions * encoder hidden (256) */
+    int32_t D;               /* decoder width: embedding = hidden = attention size; must be 128 */
+    int32_t NC;              /* transcript outputs = num_classes + 1 (EOS) */
+    int32_t n_emb;           /* embedding rows = num_classes + 2 */
+    int32_t max_steps;       /* steps to run (and the workspace layout) */
+    int32_t teacher_forcing; /* 1: step input = tf_input[step]; 0: tf_input[0], then the previous arg-max */
+    int32_t stop_on_eos;     /* 1: stop after the step whose arg-max is `eos` (models.py:718-721) */
+    int32_t eos;
+} mucon_decoder_cfg;
+typedef struct mucon_decoder_params {
+    const float *hidden_out_w, *hidden_out_b;   /* fs_encoder_hidden_out   [D][ME], [D] */
+    const float *cn_out_w, *cn_out_b;           /* fs_encoder_cn_out       [D][ME], [D] */
+    const float *attention_W1;                  /* fs_decoder_attention_W1 [ME][D] */
+    const float *attention_l2_w, *attention_l2_b; /* fs_decoder_attention_l2 [D][D], [D] */
+    const float *attention_V;                   /* fs_decoder_attention_V  [D] */
+    const float *embedding;                     /* fs_decoder_embedding    [n_emb][D] */
+    const float *attn_combine_w, *attn_combine_b; /* fs_decoder_attn_combine [D][D+ME], [D] */
+    const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh; /* fs_decoder_lstm [4D][D] x2, [4D] x2 */
+    const float *transcript0_w, *transcript0_b; /* fs_decoder_transcript[0] [D][D], [D] */
+    const float *transcript2_w, *transcript2_b; /* fs_decoder_transcript[2] [NC][D], [NC] */
+    const float *length0_w, *length0_b;         /* fs_decoder_length[0]     [D/2][D+NC], [D/2] */
+    const float *length2_w, *length2_b;         /* fs_decoder_length[2]     [1][D/2], [1] */
+} mucon_decoder_params;
+size_t mucon_decoder_workspace_bytes(const mucon_decoder_cfg *cfg);
+/* memory [Tz][ME] (encoder LSTM output), hn / cn [ME] (h_n.view(1,-1)), tf_input int64 [>= max_steps when
+ * teacher forcing, >= 1 otherwise], dropmask [max_steps][D] = the embedding-dropout keep mask already scaled
+ * by 1/(1-p), or NULL.  Writes logp [max_steps][NC], lengths [max_steps] and *n_steps (device int32: rows
+ * valid).  Keeps the activations in `workspace` for mucon_decoder_bwd. */
+int mucon_decoder_fwd(const mucon_decoder_cfg *cfg, const mucon_decoder_params *params, const float *memory,
+                      const float *hn, const float *cn, const int64_t *tf_input, const float *dropmask,
+                      float *logp, float *lengths, int32_t *n_steps, void *workspace, size_t workspace_bytes,
+                      void *stream);
+/* Backward over the n_steps the forward ran, from d_logp [n_steps][NC] and d_lengths [n_steps] (each may be
+ * NULL = zero).  Writes d_memory [Tz][ME], d_hn / d_cn [ME] and every tensor of d_params. */
+int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, const mucon_decoder_params *params,
+                      const float *memory, const float *hn, const float *cn, const float *logp, const float *d_logp,
+                      const float *d_lengths, const float *dropmask, float *d_memory, float *d_hn, float *d_cn,
+                      const mucon_decoder_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

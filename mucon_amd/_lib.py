@@ -56,6 +56,21 @@ class LstmParams(ctypes.Structure):
                 ("b_ih", ctypes.c_void_p * 2), ("b_hh", ctypes.c_void_p * 2)]
 
 
+class DecoderCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("Tz", "ME", "D", "NC", "n_emb", "max_steps", "teacher_forcing",
+                                              "stop_on_eos", "eos")]
+
+
+DECODER_PARAM_FIELDS = (
+    "hidden_out_w", "hidden_out_b", "cn_out_w", "cn_out_b", "attention_W1", "attention_l2_w", "attention_l2_b",
+    "attention_V", "embedding", "attn_combine_w", "attn_combine_b", "lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh",
+    "transcript0_w", "transcript0_b", "transcript2_w", "transcript2_b", "length0_w", "length0_b", "length2_w", "length2_b")
+
+
+class DecoderParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in DECODER_PARAM_FIELDS]
+
+
 # every symbol include/mucon_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
@@ -83,6 +98,11 @@ SYMBOLS = {
     "mucon_lstm_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_lstm_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _vp,
                                       ctypes.POINTER(LstmParams), _vp, _sz, _vp]),
+    "mucon_decoder_workspace_bytes": (_sz, [ctypes.POINTER(DecoderCfg)]),
+    "mucon_decoder_fwd": (ctypes.c_int, [ctypes.POINTER(DecoderCfg), ctypes.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_decoder_bwd": (ctypes.c_int, [ctypes.POINTER(DecoderCfg), _i32, ctypes.POINTER(DecoderParams), _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(DecoderParams), _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,546 @@
+// The s-head's attention decoder as two persistent kernels (reference
+// src/mucon/models.py:585-744: sequence_generation_forward + _calculate_attention).
+//
+// Per decoding step the reference runs ~30 small torch ops on 128-wide vectors (embedding, additive
+// attention over the Tz encoder states, attn_combine, one LSTM cell, the transcript MLP, the length MLP,
+// log-softmax, arg-max feedback): ~600 launches per training step, 11.5 ms of pure launch latency.  Here ONE
+// workgroup (1024 threads) walks all steps: the recurrent state stays in LDS, weights stream from L2
+// (~1 MB per step), the memory [Tz x 2E] and its projection are read once per step.
+//   dec_memproj_kernel   mp = memory @ W1                                        (all Tz rows, many workgroups)
+//   decoder_fwd_kernel   the step loop; saves every activation the backward needs
+//   decoder_bwd_kernel   back-propagation through the steps; per-step "delta" vectors go to the workspace
+//   dec_outer_kernel     every weight gradient = sum over steps of delta (x) input: one batched launch
+//   dec_memgrad_kernel   d_memory += d_mp @ W1^T
+// Vector width D = 128 (embedding = hidden = attention size: the reference's only configuration).
+#pragma once
+#include "common.hpp"
+
+constexpr int DEC_D = 128;
+constexpr int DEC_THREADS = 1024;
+constexpr int DEC_WAVES = DEC_THREADS / 64;
+constexpr int DEC_MAXNC = 128;   // transcript classes + 1 (EOS)
+constexpr int DEC_MAXME = 256;   // memory width (2E)
+constexpr int DEC_NL = 64;       // hidden width of the length MLP (D / 2)
+
+struct DecParams {  // torch layouts: Linear weight [out][in]
+    const float *ho_w, *ho_b;    // fs_encoder_hidden_out  [D][ME]
+    const float *co_w, *co_b;    // fs_encoder_cn_out      [D][ME]
+    const float *w1;             // fs_decoder_attention_W1 [ME][D]
+    const float *l2_w, *l2_b;    // fs_decoder_attention_l2 [D][D]
+    const float *v;              // fs_decoder_attention_V  [D]
+    const float *emb;            // fs_decoder_embedding    [n_emb][D]
+    const float *cmb_w, *cmb_b;  // fs_decoder_attn_combine [D][D+ME]
+    const float *w_ih, *w_hh, *b_ih, *b_hh;  // fs_decoder_lstm [4D][D] x2, [4D] x2
+    const float *t1_w, *t1_b;    // fs_decoder_transcript[0] [D][D]
+    const float *t2_w, *t2_b;    // fs_decoder_transcript[2] [NC][D]
+    const float *n1_w, *n1_b;    // fs_decoder_length[0]     [D/2][D+NC]
+    const float *n2_w, *n2_b;    // fs_decoder_length[2]     [1][D/2]
+};
+constexpr int DEC_NPARAMS = 23;
+
+struct DecDims {
+    int Tz, ME, NC, S, n_emb;
+    int teacher_forcing;  // 1: step input = tf_input[step]; 0: previous arg-max (tf_input[0] first)
+    int stop_on_eos;      // 1: stop after the step whose arg-max is `eos` (evaluation without teacher forcing)
+    int eos;
+};
+
+struct DecSaved {   // forward activations (workspace)
+    float *mp;      // [Tz][D]       memory @ W1
+    float *h, *c;   // [S+1][D]      row 0 = initial state
+    float *q;       // [S][D]
+    float *cat;     // [S][D+ME]     dropout(relu(emb)) | context
+    float *attn;    // [S][Tz]
+    float *mixed;   // [S][D]
+    float *gates;   // [S][4D]       post-activation i,f,g,o
+    float *t1;      // [S][D]
+    float *lencat;  // [S][D+NC]     relu(cat(mixed, logits))
+    float *l1;      // [S][D/2]
+    int *toks;      // [S]           the token each step consumed
+};
+struct DecDeltas {  // backward: gradients at the pre-activations (workspace)
+    float *mp;      // [Tz][D]
+    float *q, *mixed, *gates, *t1, *logits, *l1, *len;  // [S][...]
+    float *h0, *c0; // [D]
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float *red) {  // red: DEC_WAVES + 1 floats of LDS
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = threadIdx.x < DEC_WAVES ? red[threadIdx.x] : 0.f;
+        t = wave_sum(t);
+        if (threadIdx.x == 0) red[DEC_WAVES] = t;
+    }
+    __syncthreads();
+    return red[DEC_WAVES];
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = threadIdx.x < DEC_WAVES ? red[threadIdx.x] : -INFINITY;
+        t = wave_max(t);
+        if (threadIdx.x == 0) red[DEC_WAVES] = t;
+    }
+    __syncthreads();
+    return red[DEC_WAVES];
+}
+
+// out[r] = act((ACC ? out[r] : 0) + b[r] + W[r][:] . x) for r < rows: four rows per wave at a time, lanes
+// across the columns, wave reduction.  The row -> thread mapping depends only on `rows`, so an ACC call
+// after a plain call with the same `rows` needs no barrier in between.
+template <int ACT, bool ACC>
+__device__ __forceinline__ void matvec_rows(const float *__restrict__ W, const float *__restrict__ b, int rows, int cols,
+                                            const float *x, float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = wave * 4; r0 < rows; r0 += DEC_WAVES * 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int nr = rows - r0;
+        const float *w0 = W + (long)r0 * cols;
+        const float *w1 = W + (long)(nr > 1 ? r0 + 1 : r0) * cols;
+        const float *w2 = W + (long)(nr > 2 ? r0 + 2 : r0) * cols;
+        const float *w3 = W + (long)(nr > 3 ? r0 + 3 : r0) * cols;
+        for (int j = lane; j < cols; j += 64) {
+            const float xv = x[j];
+            a0 += w0[j] * xv;
+            a1 += w1[j] * xv;
+            a2 += w2[j] * xv;
+            a3 += w3[j] * xv;
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        a3 = wave_sum(a3);
+        if (lane < 4 && lane < nr) {
+            const int r = r0 + lane;
+            float v = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
+            v += b ? b[r] : 0.f;
+            if (ACC) v += out[r];
+            out[r] = ACT ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// out[j] = (ACC ? out[j] : 0) + sum_i W[i][j] d[i] for j < cols (W^T d): thread groups split the rows,
+// lanes run along a row (coalesced), partial sums meet in `scratch` (DEC_THREADS floats).  Two barriers
+// inside; the caller synchronises before reading `out`.
+template <bool ACC>
+__device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int rows, int cols, const float *d, float *out,
+                                            float *scratch) {
+    const int cp = cols <= 128 ? 128 : cols <= 256 ? 256 : 512;
+    const int ng = DEC_THREADS / cp;
+    const int g = threadIdx.x / cp, j = threadIdx.x - g * cp;
+    float acc = 0.f;
+    if (j < cols)
+        for (int i = g; i < rows; i += ng) acc += W[(long)i * cols + j] * d[i];
+    __syncthreads();  // scratch may still be read by the previous user
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        float s = 0.f;
+        for (int gg = 0; gg < ng; ++gg) s += scratch[gg * cp + threadIdx.x];
+        out[threadIdx.x] = ACC ? out[threadIdx.x] + s : s;
+    }
+}
+
+// mp[t][k] = sum_j memory[t][j] W1[j][k]; grid (ceil(Tz/4)), 512 threads = 4 rows x 128 columns
+__global__ __launch_bounds__(512) void dec_memproj_kernel(const float *memory, const float *w1, float *mp, int Tz, int ME) {
+    __shared__ float ms[4][DEC_MAXME];
+    const int t0 = blockIdx.x * 4;
+    for (int e = threadIdx.x; e < 4 * ME; e += 512) {
+        const int t = t0 + e / ME;
+        ms[e / ME][e % ME] = t < Tz ? memory[(long)t * ME + e % ME] : 0.f;
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 7, k = threadIdx.x & 127;
+    if (t0 + r >= Tz) return;
+    float acc = 0.f;
+    for (int j = 0; j < ME; ++j) acc += ms[r][j] * w1[(long)j * DEC_D + k];
+    mp[(long)(t0 + r) * DEC_D + k] = acc;
+}
+
+// dynamic LDS: Tz floats (attention scores / weights)
+__global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, DecParams p, DecSaved sv, const float *memory,
+                                                                  const float *hn, const float *cn, const long *tf_input,
+                                                                  const float *dropmask, float *logp_out, float *len_out,
+                                                                  int *nsteps_out) {
+    extern __shared__ float s_score[];
+    __shared__ float s_h[DEC_D], s_c[DEC_D], s_q[DEC_D], s_cat[DEC_D + DEC_MAXME], s_mixed[DEC_D], s_gates[4 * DEC_D];
+    __shared__ float s_t1[DEC_D], s_logits[DEC_MAXNC], s_lencat[DEC_D + DEC_MAXNC], s_l1[DEC_NL], s_scr[DEC_THREADS];
+    __shared__ float s_hc[2 * DEC_MAXME], s_red[DEC_WAVES + 1];
+    __shared__ int s_tok, s_stop;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Tz = dm.Tz, ME = dm.ME, NC = dm.NC, CW = DEC_D + ME, LW = DEC_D + NC;
+
+    // initial state: dec_h = hidden_out(h_n.view(1,-1)), dec_c = cn_out(c_n.view(1,-1))   (models.py:612-617)
+    if (tid < ME) {
+        s_hc[tid] = hn[tid];
+        s_hc[DEC_MAXME + tid] = cn[tid];
+    }
+    if (tid == 0) {
+        s_tok = (int)tf_input[0];
+        s_stop = 0;
+    }
+    __syncthreads();
+    matvec_rows<0, false>(p.ho_w, p.ho_b, DEC_D, ME, s_hc, s_h);
+    matvec_rows<0, false>(p.co_w, p.co_b, DEC_D, ME, s_hc + DEC_MAXME, s_c);
+    __syncthreads();
+    if (tid < DEC_D) {
+        sv.h[tid] = s_h[tid];
+        sv.c[tid] = s_c[tid];
+    }
+    int s = 0;
+    for (; s < dm.S; ++s) {
+        int tok = dm.teacher_forcing ? (int)tf_input[s] : s_tok;
+        tok = tok < 0 ? 0 : tok >= dm.n_emb ? dm.n_emb - 1 : tok;  // host validated; keeps a bad arg-max in range
+        // embedded = dropout(relu(embedding(input)));  q = attention_l2(dec_h)
+        if (tid < DEC_D) {
+            float e = fmaxf(p.emb[(long)tok * DEC_D + tid], 0.f);
+            if (dropmask) e *= dropmask[s * DEC_D + tid];
+            s_cat[tid] = e;
+        }
+        if (tid == 0) sv.toks[s] = tok;
+        matvec_rows<0, false>(p.l2_w, p.l2_b, DEC_D, DEC_D, s_h, s_q);
+        __syncthreads();
+        if (tid < DEC_D) sv.q[s * DEC_D + tid] = s_q[tid];
+        // score[t] = V . tanh(mp[t] + q)
+        {
+            const float q0 = s_q[lane], q1 = s_q[lane + 64], v0 = p.v[lane], v1 = p.v[lane + 64];
+            for (int t = wave; t < Tz; t += DEC_WAVES) {
+                const float *m = sv.mp + (long)t * DEC_D;
+                float a = v0 * tanhf(m[lane] + q0) + v1 * tanhf(m[lane + 64] + q1);
+                a = wave_sum(a);
+                if (lane == 0) s_score[t] = a;
+            }
+        }
+        __syncthreads();
+        // attention weights = softmax(score)
+        {
+            float mx = -INFINITY;
+            for (int t = tid; t < Tz; t += DEC_THREADS) mx = fmaxf(mx, s_score[t]);
+            mx = block_max(mx, s_red);
+            float sum = 0.f;
+            for (int t = tid; t < Tz; t += DEC_THREADS) {
+                const float e = expf(s_score[t] - mx);
+                s_score[t] = e;
+                sum += e;
+            }
+            sum = block_sum(sum, s_red);
+            const float inv = 1.f / sum;
+            for (int t = tid; t < Tz; t += DEC_THREADS) {
+                const float a = s_score[t] * inv;
+                s_score[t] = a;
+                sv.attn[(long)s * Tz + t] = a;
+            }
+        }
+        __syncthreads();
+        // context = sum_t attn[t] memory[t]
+        {
+            const int g = tid >> 8, j = tid & 255;
+            float acc = 0.f;
+            if (j < ME)
+                for (int t = g; t < Tz; t += 4) acc += s_score[t] * memory[(long)t * ME + j];
+            s_scr[tid] = acc;
+            __syncthreads();
+            if (tid < ME) s_cat[DEC_D + tid] = (s_scr[tid] + s_scr[256 + tid]) + (s_scr[512 + tid] + s_scr[768 + tid]);
+        }
+        __syncthreads();
+        if (tid < CW) sv.cat[(long)s * CW + tid] = s_cat[tid];
+        // mixed = relu(attn_combine(cat(embedded, context)))
+        matvec_rows<1, false>(p.cmb_w, p.cmb_b, DEC_D, CW, s_cat, s_mixed);
+        __syncthreads();
+        // one LSTM cell
+        matvec_rows<0, false>(p.w_ih, p.b_ih, 4 * DEC_D, DEC_D, s_mixed, s_gates);
+        matvec_rows<0, true>(p.w_hh, p.b_hh, 4 * DEC_D, DEC_D, s_h, s_gates);
+        __syncthreads();
+        if (tid < DEC_D) {
+            const float gi = sigmoid_f(s_gates[tid]), gf = sigmoid_f(s_gates[DEC_D + tid]);
+            const float gg = tanhf(s_gates[2 * DEC_D + tid]), go = sigmoid_f(s_gates[3 * DEC_D + tid]);
+            const float c = gf * s_c[tid] + gi * gg;
+            const float h = go * tanhf(c);
+            s_c[tid] = c;
+            s_h[tid] = h;
+            float *gs = sv.gates + (long)s * 4 * DEC_D;
+            gs[tid] = gi;
+            gs[DEC_D + tid] = gf;
+            gs[2 * DEC_D + tid] = gg;
+            gs[3 * DEC_D + tid] = go;
+            sv.c[(s + 1) * DEC_D + tid] = c;
+            sv.h[(s + 1) * DEC_D + tid] = h;
+            sv.mixed[s * DEC_D + tid] = s_mixed[tid];
+        }
+        __syncthreads();
+        // word logits = transcript MLP(dec_out)
+        matvec_rows<1, false>(p.t1_w, p.t1_b, DEC_D, DEC_D, s_h, s_t1);
+        __syncthreads();
+        if (tid < DEC_D) sv.t1[s * DEC_D + tid] = s_t1[tid];
+        matvec_rows<0, false>(p.t2_w, p.t2_b, NC, DEC_D, s_t1, s_logits);
+        __syncthreads();
+        // length = length MLP(relu(cat(mixed, word logits)))
+        if (tid < LW) {
+            const float v = tid < DEC_D ? s_mixed[tid] : fmaxf(s_logits[tid - DEC_D], 0.f);
+            s_lencat[tid] = v;
+            sv.lencat[(long)s * LW + tid] = v;
+        }
+        __syncthreads();
+        matvec_rows<1, false>(p.n1_w, p.n1_b, DEC_NL, LW, s_lencat, s_l1);
+        __syncthreads();
+        if (wave == 0) {
+            sv.l1[s * DEC_NL + lane] = s_l1[lane];
+            const float a = wave_sum(p.n2_w[lane] * s_l1[lane]);
+            if (lane == 0) len_out[s] = a + p.n2_b[0];
+        } else if (wave == 1) {  // log-softmax + arg-max (lowest index on ties)
+            const float x0 = lane < NC ? s_logits[lane] : -INFINITY, x1 = lane + 64 < NC ? s_logits[lane + 64] : -INFINITY;
+            const float mx = wave_max(fmaxf(x0, x1));
+            const float se = wave_sum((lane < NC ? expf(x0 - mx) : 0.f) + (lane + 64 < NC ? expf(x1 - mx) : 0.f));
+            const float lse = mx + logf(se);
+            if (lane < NC) logp_out[(long)s * NC + lane] = x0 - lse;
+            if (lane + 64 < NC) logp_out[(long)s * NC + lane + 64] = x1 - lse;
+            int cand = x0 == mx ? lane : x1 == mx ? lane + 64 : 1 << 20;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+            if (lane == 0) {
+                s_tok = cand;
+                if (dm.stop_on_eos && cand == dm.eos) s_stop = 1;
+            }
+        }
+        __syncthreads();
+        if (s_stop) {
+            ++s;
+            break;
+        }
+    }
+    if (tid == 0) *nsteps_out = s;
+}
+
+// dynamic LDS: Tz floats.  dm.S = the number of steps the forward ran.  d_logp [S][NC] / d_len [S] may be null.
+// d_memory [Tz][ME] and d_emb [n_emb][D] are zeroed here; d_v [D]; d_hn / d_cn [ME].
+__global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl,
+                                                                  const float *memory, const float *logp, const float *d_logp,
+                                                                  const float *d_len, const float *dropmask, float *d_memory,
+                                                                  float *d_emb, float *d_v, float *d_hn, float *d_cn) {
+    extern __shared__ float s_ds[];  // d_attn, then d_score
+    __shared__ float s_dh[DEC_D], s_dc[DEC_D], s_dlogits[DEC_MAXNC], s_dl1[DEC_NL], s_dlencat[DEC_D + DEC_MAXNC];
+    __shared__ float s_dt1[DEC_D], s_dgates[4 * DEC_D], s_dmixed[DEC_D], s_dcat[DEC_D + DEC_MAXME], s_dq[DEC_D];
+    __shared__ float s_scr[DEC_THREADS], s_red[DEC_WAVES + 1], s_out[DEC_MAXME];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Tz = dm.Tz, ME = dm.ME, NC = dm.NC, CW = DEC_D + ME, LW = DEC_D + NC;
+
+    for (long e = tid; e < (long)Tz * DEC_D; e += DEC_THREADS) dl.mp[e] = 0.f;
+    for (long e = tid; e < (long)Tz * ME; e += DEC_THREADS) d_memory[e] = 0.f;
+    for (long e = tid; e < (long)dm.n_emb * DEC_D; e += DEC_THREADS) d_emb[e] = 0.f;
+    if (tid < DEC_D) {
+        s_dh[tid] = 0.f;
+        s_dc[tid] = 0.f;
+    }
+    float dv_acc = 0.f;  // thread (g = tid >> 7, k = tid & 127): partial dV[k]
+    __syncthreads();
+
+    for (int s = dm.S - 1; s >= 0; --s) {
+        // log-softmax backward; length MLP output layer backward
+        if (wave == 0) {
+            const float g0 = (d_logp && lane < NC) ? d_logp[(long)s * NC + lane] : 0.f;
+            const float g1 = (d_logp && lane + 64 < NC) ? d_logp[(long)s * NC + lane + 64] : 0.f;
+            const float tot = wave_sum(g0 + g1);
+            if (lane < NC) s_dlogits[lane] = g0 - expf(logp[(long)s * NC + lane]) * tot;
+            if (lane + 64 < NC) s_dlogits[lane + 64] = g1 - expf(logp[(long)s * NC + lane + 64]) * tot;
+        } else if (wave == 1) {
+            const float dlen = d_len ? d_len[s] : 0.f;
+            const float v = sv.l1[s * DEC_NL + lane] > 0.f ? dlen * p.n2_w[lane] : 0.f;
+            s_dl1[lane] = v;
+            dl.l1[s * DEC_NL + lane] = v;
+            if (lane == 0) dl.len[s] = dlen;
+        }
+        __syncthreads();
+        matvec_cols<false>(p.n1_w, DEC_NL, LW, s_dl1, s_dlencat, s_scr);
+        __syncthreads();
+        if (tid < DEC_D) s_dmixed[tid] = sv.lencat[(long)s * LW + tid] > 0.f ? s_dlencat[tid] : 0.f;
+        if (tid < NC) {
+            const float v = s_dlogits[tid] + (sv.lencat[(long)s * LW + DEC_D + tid] > 0.f ? s_dlencat[DEC_D + tid] : 0.f);
+            s_dlogits[tid] = v;
+            dl.logits[(long)s * NC + tid] = v;
+        }
+        __syncthreads();
+        // transcript MLP backward -> d dec_out (added to the recurrent dh)
+        matvec_cols<false>(p.t2_w, NC, DEC_D, s_dlogits, s_dt1, s_scr);
+        __syncthreads();
+        if (tid < DEC_D) {
+            const float v = sv.t1[s * DEC_D + tid] > 0.f ? s_dt1[tid] : 0.f;
+            s_dt1[tid] = v;
+            dl.t1[s * DEC_D + tid] = v;
+        }
+        __syncthreads();
+        matvec_cols<true>(p.t1_w, DEC_D, DEC_D, s_dt1, s_dh, s_scr);
+        __syncthreads();
+        // LSTM cell backward
+        if (tid < DEC_D) {
+            const float *gs = sv.gates + (long)s * 4 * DEC_D;
+            const float gi = gs[tid], gf = gs[DEC_D + tid], gg = gs[2 * DEC_D + tid], go = gs[3 * DEC_D + tid];
+            const float ct = sv.c[(s + 1) * DEC_D + tid], cp = sv.c[s * DEC_D + tid];
+            const float dh = s_dh[tid], th = tanhf(ct);
+            const float dct = s_dc[tid] + dh * go * (1.f - th * th);
+            const float dpi = dct * gg * gi * (1.f - gi), dpf = dct * cp * gf * (1.f - gf);
+            const float dpg = dct * gi * (1.f - gg * gg), dpo = dh * th * go * (1.f - go);
+            s_dc[tid] = dct * gf;
+            s_dgates[tid] = dpi;
+            s_dgates[DEC_D + tid] = dpf;
+            s_dgates[2 * DEC_D + tid] = dpg;
+            s_dgates[3 * DEC_D + tid] = dpo;
+            float *o = dl.gates + (long)s * 4 * DEC_D;
+            o[tid] = dpi;
+            o[DEC_D + tid] = dpf;
+            o[2 * DEC_D + tid] = dpg;
+            o[3 * DEC_D + tid] = dpo;
+        }
+        __syncthreads();
+        matvec_cols<true>(p.w_ih, 4 * DEC_D, DEC_D, s_dgates, s_dmixed, s_scr);
+        matvec_cols<false>(p.w_hh, 4 * DEC_D, DEC_D, s_dgates, s_dh, s_scr);  // dh w.r.t. the previous hidden state
+        __syncthreads();
+        if (tid < DEC_D) {
+            const float v = sv.mixed[s * DEC_D + tid] > 0.f ? s_dmixed[tid] : 0.f;
+            s_dmixed[tid] = v;
+            dl.mixed[s * DEC_D + tid] = v;
+        }
+        __syncthreads();
+        matvec_cols<false>(p.cmb_w, DEC_D, CW, s_dmixed, s_dcat, s_scr);
+        __syncthreads();
+        // embedding row gradient (this workgroup is the only writer; thread tid owns column tid)
+        if (tid < DEC_D) {
+            const int tok = sv.toks[s];
+            float g = p.emb[(long)tok * DEC_D + tid] > 0.f ? s_dcat[tid] : 0.f;
+            if (dropmask) g *= dropmask[s * DEC_D + tid];
+            d_emb[(long)tok * DEC_D + tid] += g;
+        }
+        // context backward: d_attn[t] = memory[t] . d_ctx;  d_memory[t] += attn[t] d_ctx
+        {
+            const float *dctx = s_dcat + DEC_D;
+            for (int t = wave; t < Tz; t += DEC_WAVES) {
+                const float a = sv.attn[(long)s * Tz + t];
+                float acc = 0.f;
+                for (int j = lane; j < ME; j += 64) {
+                    const float dc = dctx[j];
+                    acc += memory[(long)t * ME + j] * dc;
+                    d_memory[(long)t * ME + j] += a * dc;
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) s_ds[t] = acc;
+            }
+        }
+        __syncthreads();
+        {
+            float part = 0.f;
+            for (int t = tid; t < Tz; t += DEC_THREADS) part += sv.attn[(long)s * Tz + t] * s_ds[t];
+            const float dot = block_sum(part, s_red);
+            for (int t = tid; t < Tz; t += DEC_THREADS) s_ds[t] = sv.attn[(long)s * Tz + t] * (s_ds[t] - dot);
+        }
+        __syncthreads();
+        // score backward through tanh: d_mp, d_q, dV
+        {
+            const int g = tid >> 7, k = tid & 127;
+            const float qk = sv.q[s * DEC_D + k], vk = p.v[k];
+            float dq = 0.f;
+            for (int t = g; t < Tz; t += DEC_THREADS / DEC_D) {
+                const float u = tanhf(sv.mp[(long)t * DEC_D + k] + qk);
+                const float ds = s_ds[t];
+                dv_acc += ds * u;
+                const float dp = ds * vk * (1.f - u * u);
+                dl.mp[(long)t * DEC_D + k] += dp;
+                dq += dp;
+            }
+            s_scr[tid] = dq;
+            __syncthreads();
+            if (tid < DEC_D) {
+                float v = 0.f;
+                for (int gg = 0; gg < DEC_THREADS / DEC_D; ++gg) v += s_scr[gg * DEC_D + tid];
+                s_dq[tid] = v;
+                dl.q[s * DEC_D + tid] = v;
+            }
+        }
+        __syncthreads();
+        matvec_cols<true>(p.l2_w, DEC_D, DEC_D, s_dq, s_dh, s_scr);
+        __syncthreads();
+    }
+    // initial state -> h_n / c_n through hidden_out / cn_out
+    if (tid < DEC_D) {
+        dl.h0[tid] = s_dh[tid];
+        dl.c0[tid] = s_dc[tid];
+    }
+    matvec_cols<false>(p.ho_w, DEC_D, ME, s_dh, s_out, s_scr);
+    __syncthreads();
+    if (tid < ME) d_hn[tid] = s_out[tid];
+    matvec_cols<false>(p.co_w, DEC_D, ME, s_dc, s_out, s_scr);
+    __syncthreads();
+    if (tid < ME) d_cn[tid] = s_out[tid];
+    __syncthreads();
+    s_scr[tid] = dv_acc;
+    __syncthreads();
+    if (tid < DEC_D) {
+        float v = 0.f;
+        for (int gg = 0; gg < DEC_THREADS / DEC_D; ++gg) v += s_scr[gg * DEC_D + tid];
+        d_v[tid] = v;
+    }
+}
+
+// out[i][j] = sum_n A[n*lda + i] B[n*ldb + j];  bias[i] = sum_n A[n*lda + i]
+struct OuterJob {
+    const float *A, *B;
+    float *out, *bias, *bias2;
+    int lda, ldb, ra, cb, n, block0;
+};
+constexpr int DEC_MAXJOBS = 12;
+struct OuterBatch {
+    OuterJob job[DEC_MAXJOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void dec_outer_kernel(OuterBatch ob) {
+    int ji = 0;
+    while (ji + 1 < ob.njobs && (int)blockIdx.x >= ob.job[ji + 1].block0) ++ji;
+    const OuterJob &jb = ob.job[ji];
+    const long e = (long)(blockIdx.x - jb.block0) * 256 + threadIdx.x;
+    if (e >= (long)jb.ra * jb.cb) return;
+    const int i = (int)(e / jb.cb), j = (int)(e - (long)i * jb.cb);
+    float acc = 0.f, accb = 0.f;
+    for (int n = 0; n < jb.n; ++n) {
+        const float a = jb.A[(long)n * jb.lda + i];
+        acc += a * jb.B[(long)n * jb.ldb + j];
+        accb += a;
+    }
+    jb.out[e] = acc;
+    if (j == 0) {
+        if (jb.bias) jb.bias[i] = accb;
+        if (jb.bias2) jb.bias2[i] = accb;
+    }
+}
+
+// d_memory[t][j] += sum_k d_mp[t][k] W1[j][k]; grid (Tz), 256 threads
+__global__ __launch_bounds__(256) void dec_memgrad_kernel(const float *dmp, const float *w1, float *d_memory, int ME) {
+    __shared__ __attribute__((aligned(16))) float ds[DEC_D];
+    const int t = blockIdx.x, j = threadIdx.x;
+    if (j < DEC_D) ds[j] = dmp[(long)t * DEC_D + j];
+    __syncthreads();
+    if (j >= ME) return;
+    float acc = 0.f;
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(w1 + (long)j * DEC_D);
+#pragma unroll 8
+    for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
+        const f32x4 wv = w[k4];
+        const f32x4 dv = *reinterpret_cast<const f32x4 *>(&ds[k4 * 4]);
+        acc += wv[0] * dv[0] + wv[1] * dv[1] + wv[2] * dv[2] + wv[3] * dv[3];
+    }
+    d_memory[(long)t * ME + j] += acc;
+}

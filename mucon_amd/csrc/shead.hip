@@ -1,11 +1,12 @@
-// C-ABI entry points of the s-head's sequence encoder (bidirectional LSTM), SURVEY.md 8f row 1.
-// Kernels in lstm.hpp; declared in include/mucon_hip.h.
+// C-ABI entry points of the s-head: the sequence encoder (bidirectional LSTM, lstm.hpp)
+// and the attention decoder (decoder.hpp).  Declared in include/mucon_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 
 #include "../../include/mucon_hip.h"
 #include "lstm.hpp"
+#include "decoder.hpp"
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 
@@ -103,6 +104,165 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir);
     hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(LSTM_G / 4, ndir), dim3(512), 0, s, dG, x, out, g, T, ndir);
     hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(128), 0, s, dG, w, d_x, T, ndir);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------ decoder
+constexpr int DEC_MAXTZ = 8192;
+
+static int dec_check(const mucon_decoder_cfg *c) {
+    if (!c) return sfail(MUCON_E_ARG, "decoder: null cfg");
+    if (c->Tz < 1 || c->Tz > DEC_MAXTZ) return sfail(MUCON_E_ARG, "decoder: Tz=%d unsupported (1..%d)", c->Tz, DEC_MAXTZ);
+    if (c->D != DEC_D) return sfail(MUCON_E_ARG, "decoder: width %d unsupported (must be %d)", c->D, DEC_D);
+    if (c->ME < 1 || c->ME > DEC_MAXME) return sfail(MUCON_E_ARG, "decoder: memory width %d unsupported (max %d)", c->ME, DEC_MAXME);
+    if (c->NC < 1 || c->NC > DEC_MAXNC) return sfail(MUCON_E_ARG, "decoder: %d output classes unsupported (max %d)", c->NC, DEC_MAXNC);
+    if (c->max_steps < 1) return sfail(MUCON_E_ARG, "decoder: max_steps=%d", c->max_steps);
+    if (c->n_emb < 1) return sfail(MUCON_E_ARG, "decoder: n_emb=%d", c->n_emb);
+    return MUCON_OK;
+}
+
+struct DecLayout {
+    DecSaved sv;
+    DecDeltas dl;
+    size_t floats;
+};
+static DecLayout dec_layout(const mucon_decoder_cfg *c, float *base) {
+    DecLayout L;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float *p = base ? base + off : nullptr;
+        off += al64(n);
+        return p;
+    };
+    const size_t S = c->max_steps, Tz = c->Tz, CW = DEC_D + c->ME, LW = DEC_D + c->NC;
+    L.sv.mp = take(Tz * DEC_D);
+    L.sv.h = take((S + 1) * DEC_D);
+    L.sv.c = take((S + 1) * DEC_D);
+    L.sv.q = take(S * DEC_D);
+    L.sv.cat = take(S * CW);
+    L.sv.attn = take(S * Tz);
+    L.sv.mixed = take(S * DEC_D);
+    L.sv.gates = take(S * 4 * DEC_D);
+    L.sv.t1 = take(S * DEC_D);
+    L.sv.lencat = take(S * LW);
+    L.sv.l1 = take(S * DEC_NL);
+    L.sv.toks = reinterpret_cast<int *>(take(S));
+    L.dl.mp = take(Tz * DEC_D);
+    L.dl.q = take(S * DEC_D);
+    L.dl.mixed = take(S * DEC_D);
+    L.dl.gates = take(S * 4 * DEC_D);
+    L.dl.t1 = take(S * DEC_D);
+    L.dl.logits = take(S * c->NC);
+    L.dl.l1 = take(S * DEC_NL);
+    L.dl.len = take(S);
+    L.dl.h0 = take(DEC_D);
+    L.dl.c0 = take(DEC_D);
+    L.floats = off;
+    return L;
+}
+
+extern "C" size_t mucon_decoder_workspace_bytes(const mucon_decoder_cfg *cfg) {
+    if (dec_check(cfg) != MUCON_OK) return 0;
+    return dec_layout(cfg, nullptr).floats * sizeof(float);
+}
+
+static int dec_params(DecParams &p, const mucon_decoder_params *q, const char *what) {
+    const float *const *src = reinterpret_cast<const float *const *>(q);
+    const float **dst = reinterpret_cast<const float **>(&p);
+    static_assert(sizeof(DecParams) == DEC_NPARAMS * sizeof(float *), "DecParams layout");
+    static_assert(sizeof(mucon_decoder_params) == DEC_NPARAMS * sizeof(float *), "mucon_decoder_params layout");
+    for (int i = 0; i < DEC_NPARAMS; ++i) {
+        if (!src[i]) return sfail(MUCON_E_ARG, "decoder: null %s pointer (#%d)", what, i);
+        dst[i] = src[i];
+    }
+    return MUCON_OK;
+}
+
+static DecDims dec_dims(const mucon_decoder_cfg *c, int S) {
+    DecDims d;
+    d.Tz = c->Tz;
+    d.ME = c->ME;
+    d.NC = c->NC;
+    d.S = S;
+    d.n_emb = c->n_emb;
+    d.teacher_forcing = c->teacher_forcing;
+    d.stop_on_eos = c->stop_on_eos;
+    d.eos = c->eos;
+    return d;
+}
+
+extern "C" int mucon_decoder_fwd(const mucon_decoder_cfg *cfg, const mucon_decoder_params *params, const float *memory,
+                                 const float *hn, const float *cn, const int64_t *tf_input, const float *dropmask,
+                                 float *logp, float *lengths, int32_t *n_steps, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
+    int rc = dec_check(cfg);
+    if (rc != MUCON_OK) return rc;
+    if (!params || !memory || !hn || !cn || !tf_input || !logp || !lengths || !n_steps || !workspace)
+        return sfail(MUCON_E_ARG, "decoder: null pointer argument");
+    if (workspace_bytes < mucon_decoder_workspace_bytes(cfg)) return sfail(MUCON_E_WORKSPACE, "decoder workspace too small");
+    DecParams p;
+    if ((rc = dec_params(p, params, "parameter")) != MUCON_OK) return rc;
+    const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dec_memproj_kernel, dim3((cfg->Tz + 3) / 4), dim3(512), 0, s, memory, p.w1, L.sv.mp, cfg->Tz, cfg->ME);
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(1), dim3(DEC_THREADS), sizeof(float) * cfg->Tz, s, dec_dims(cfg, cfg->max_steps), p,
+                       L.sv, memory, hn, cn, reinterpret_cast<const long *>(tf_input), dropmask, logp, lengths, n_steps);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, const mucon_decoder_params *params,
+                                 const float *memory, const float *hn, const float *cn, const float *logp, const float *d_logp,
+                                 const float *d_lengths, const float *dropmask, float *d_memory, float *d_hn, float *d_cn,
+                                 const mucon_decoder_params *d_params, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = dec_check(cfg);
+    if (rc != MUCON_OK) return rc;
+    if (n_steps < 1 || n_steps > cfg->max_steps) return sfail(MUCON_E_ARG, "decoder: n_steps=%d outside 1..%d", n_steps, cfg->max_steps);
+    if (!params || !memory || !hn || !cn || !logp || !d_memory || !d_hn || !d_cn || !d_params || !workspace)
+        return sfail(MUCON_E_ARG, "decoder: null pointer argument");
+    if (workspace_bytes < mucon_decoder_workspace_bytes(cfg)) return sfail(MUCON_E_WORKSPACE, "decoder workspace too small");
+    DecParams p, g;
+    if ((rc = dec_params(p, params, "parameter")) != MUCON_OK) return rc;
+    if ((rc = dec_params(g, d_params, "gradient")) != MUCON_OK) return rc;
+    auto W = [](const float *q) { return const_cast<float *>(q); };
+    const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int S = n_steps, Tz = cfg->Tz, ME = cfg->ME, NC = cfg->NC, CW = DEC_D + ME, LW = DEC_D + NC;
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), sizeof(float) * Tz, s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
+                       logp, d_logp, d_lengths, dropmask, d_memory, W(g.emb), W(g.v), d_hn, d_cn);
+    OuterBatch ob;
+    int nj = 0, blocks = 0;
+    auto job = [&](const float *A, int lda, int ra, const float *B, int ldb, int cb, int n, const float *out, const float *bias,
+                   const float *bias2) {
+        OuterJob &j = ob.job[nj++];
+        j.A = A;
+        j.B = B;
+        j.out = W(out);
+        j.bias = W(bias);
+        j.bias2 = W(bias2);
+        j.lda = lda;
+        j.ldb = ldb;
+        j.ra = ra;
+        j.cb = cb;
+        j.n = n;
+        j.block0 = blocks;
+        blocks += (ra * cb + 255) / 256;
+    };
+    job(L.dl.q, DEC_D, DEC_D, L.sv.h, DEC_D, DEC_D, S, g.l2_w, g.l2_b, nullptr);
+    job(L.dl.mixed, DEC_D, DEC_D, L.sv.cat, CW, CW, S, g.cmb_w, g.cmb_b, nullptr);
+    job(L.dl.gates, 4 * DEC_D, 4 * DEC_D, L.sv.mixed, DEC_D, DEC_D, S, g.w_ih, g.b_ih, g.b_hh);
+    job(L.dl.gates, 4 * DEC_D, 4 * DEC_D, L.sv.h, DEC_D, DEC_D, S, g.w_hh, nullptr, nullptr);
+    job(L.dl.t1, DEC_D, DEC_D, L.sv.h + DEC_D, DEC_D, DEC_D, S, g.t1_w, g.t1_b, nullptr);
+    job(L.dl.logits, NC, NC, L.sv.t1, DEC_D, DEC_D, S, g.t2_w, g.t2_b, nullptr);
+    job(L.dl.l1, DEC_NL, DEC_NL, L.sv.lencat, LW, LW, S, g.n1_w, g.n1_b, nullptr);
+    job(L.dl.len, 1, 1, L.sv.l1, DEC_NL, DEC_NL, S, g.n2_w, g.n2_b, nullptr);
+    job(L.dl.h0, DEC_D, DEC_D, hn, ME, ME, 1, g.ho_w, g.ho_b, nullptr);
+    job(L.dl.c0, DEC_D, DEC_D, cn, ME, ME, 1, g.co_w, g.co_b, nullptr);
+    job(memory, ME, ME, L.dl.mp, DEC_D, DEC_D, Tz, g.w1, nullptr, nullptr);
+    ob.njobs = nj;
+    hipLaunchKernelGGL(dec_outer_kernel, dim3(blocks), dim3(256), 0, s, ob);
+    hipLaunchKernelGGL(dec_memgrad_kernel, dim3(Tz), dim3(256), 0, s, L.dl.mp, p.w1, d_memory, ME);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

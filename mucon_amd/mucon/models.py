@@ -121,7 +121,8 @@ class MuCon(nn.Module):
                                    self.fs_decoder_attn_combine, self.fs_decoder_lstm, self.fs_decoder_transcript,
                                    self.fs_decoder_length, self.conv_classifier])
         self._step = 0  # dropout stream counter for the HIP encoder
-        self.native_lstm = True  # s-head biLSTM through the HIP kernels (False: torch's nn.LSTM / MIOpen)
+        self.native_lstm = True     # s-head biLSTM through the HIP kernels (False: torch's nn.LSTM / MIOpen)
+        self.native_decoder = True  # s-head decoding loop as one persistent HIP kernel (False: the torch loop)
 
     def get_params(self, original_lr):  # fandak.Model.get_params
         return [{"params": self.parameters(), "lr": original_lr}]
@@ -181,11 +182,13 @@ class MuCon(nn.Module):
                                     transcript_tf_input: Tensor, transcript_tf_target: Tensor):
         """biLSTM encoder over [1 x Tz x D'], additive attention, LSTM decoder (reference models.py:585-728)."""
         enc_out, h_n, c_n = self._sequence_encoder(temporal_encoded)
+        steps = tf_transcript_target_length if (self.teacher_forcing or self.training) else self.max_decoding_steps
+        if self._native_decoder_ok(enc_out):
+            return self._native_decoder(enc_out[0], h_n, c_n, steps, transcript_tf_input)
         dec_h = self.fs_encoder_hidden_out(h_n.view(1, -1)).unsqueeze(0)   # [1 x 1 x D'']
         dec_c = self.fs_encoder_cn_out(c_n.view(1, -1)).unsqueeze(0)
         memory = enc_out[0]                                               # [Tz x 2D']
         memory_proj = memory @ self.fs_decoder_attention_W1               # [Tz x D'']
-        steps = tf_transcript_target_length if (self.teacher_forcing or self.training) else self.max_decoding_steps
         lengths, transcripts = [], []
         dec_in = transcript_tf_input[0].unsqueeze(0)
         for step in range(steps):
@@ -207,6 +210,36 @@ class MuCon(nn.Module):
             if not self.teacher_forcing:
                 dec_in = word
         return transcripts, lengths
+
+    def _decoder_param_list(self):
+        """The 23 tensors of _lib.DECODER_PARAM_FIELDS, in that order."""
+        return [self.fs_encoder_hidden_out.weight, self.fs_encoder_hidden_out.bias, self.fs_encoder_cn_out.weight,
+                self.fs_encoder_cn_out.bias, self.fs_decoder_attention_W1, self.fs_decoder_attention_l2.weight,
+                self.fs_decoder_attention_l2.bias, self.fs_decoder_attention_V, self.fs_decoder_embedding.weight,
+                self.fs_decoder_attn_combine.weight, self.fs_decoder_attn_combine.bias, *self.fs_decoder_lstm.parameters(),
+                self.fs_decoder_transcript[0].weight, self.fs_decoder_transcript[0].bias,
+                self.fs_decoder_transcript[2].weight, self.fs_decoder_transcript[2].bias,
+                self.fs_decoder_length[0].weight, self.fs_decoder_length[0].bias,
+                self.fs_decoder_length[2].weight, self.fs_decoder_length[2].bias]
+
+    def _native_decoder_ok(self, enc_out: Tensor) -> bool:
+        d = self.fs_decoder_lstm
+        return (self.native_decoder and enc_out.is_cuda and d.input_size == 128 and d.hidden_size == 128
+                and d.num_layers == 1 and enc_out.shape[2] <= 256 and self.num_classes + 1 <= 128
+                and self.fs_decoder_embedding.embedding_dim == 128 and enc_out.shape[1] <= 8192)
+
+    def _native_decoder(self, memory: Tensor, h_n: Tensor, c_n: Tensor, steps: int, transcript_tf_input: Tensor):
+        """The decoding loop below as one persistent HIP kernel (ops.decoder_forward, csrc/decoder.hpp); returns
+        the same per-step lists.  The embedding dropout mask is drawn with torch's generator."""
+        p = self.fs_decoder_embedding_drop.p
+        mask = None
+        if self.training and p > 0:
+            mask = (torch.rand((steps, 128), device=memory.device) >= p).to(torch.float32) / (1.0 - p)
+        stop = not self.teacher_forcing and not self.training
+        logp, lengths = ops.decoder_forward(memory, h_n, c_n, transcript_tf_input, self._decoder_param_list(), steps,
+                                            self.teacher_forcing, stop, self.EOS_token_id, mask)
+        n = logp.shape[0]
+        return [logp[i:i + 1] for i in range(n)], [lengths[i] for i in range(n)]
 
     def _sequence_encoder(self, temporal_encoded: Tensor):
         """fs_encoder_lstm over [1 x Tz x D'] (reference models.py:605-611).  On the GPU, at the reference's

@@ -283,6 +283,96 @@ def lstm_forward(x: torch.Tensor, weights: Sequence[torch.Tensor], bidirectional
     return _LstmFn.apply(x, ndir, *weights)
 
 
+# --------------------------------------------------------------------------------------- s-head decoder
+# the reference's state_dict names of the 23 decoder tensors, in _lib.DECODER_PARAM_FIELDS order
+DECODER_STATE_NAMES = (
+    "fs_encoder_hidden_out.weight", "fs_encoder_hidden_out.bias", "fs_encoder_cn_out.weight", "fs_encoder_cn_out.bias",
+    "fs_decoder_attention_W1", "fs_decoder_attention_l2.weight", "fs_decoder_attention_l2.bias", "fs_decoder_attention_V",
+    "fs_decoder_embedding.weight", "fs_decoder_attn_combine.weight", "fs_decoder_attn_combine.bias",
+    "fs_decoder_lstm.weight_ih_l0", "fs_decoder_lstm.weight_hh_l0", "fs_decoder_lstm.bias_ih_l0", "fs_decoder_lstm.bias_hh_l0",
+    "fs_decoder_transcript.0.weight", "fs_decoder_transcript.0.bias", "fs_decoder_transcript.2.weight",
+    "fs_decoder_transcript.2.bias", "fs_decoder_length.0.weight", "fs_decoder_length.0.bias",
+    "fs_decoder_length.2.weight", "fs_decoder_length.2.bias")
+LSTM_STATE_NAMES = tuple(f"fs_encoder_lstm.{n}_l0{s}" for s in ("", "_reverse")
+                         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+
+
+def _decoder_params(tensors):
+    p = _lib.DecoderParams()
+    for name, t in zip(_lib.DECODER_PARAM_FIELDS, tensors):
+        setattr(p, name, _lib.ptr(t))
+    return p
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, memory, hn, cn, tf_input, dropmask, opts, *params):
+        lib = _lib.load()
+        _check_dev(memory, hn, cn, dropmask, *params)
+        if not tf_input.is_cuda:
+            raise _lib.MuconHipError("mucon_amd ops need device tensors: there is no CPU fallback")
+        memory, hn, cn = memory.contiguous(), hn.contiguous(), cn.contiguous()
+        params = [w.contiguous() for w in params]
+        tf_input = tf_input.contiguous().to(torch.int64)
+        if dropmask is not None:
+            dropmask = dropmask.contiguous()
+        max_steps, teacher_forcing, stop_on_eos, eos = opts
+        Tz, ME = memory.shape
+        cfg = _lib.DecoderCfg(Tz=Tz, ME=ME, D=params[7].shape[0], NC=params[17].shape[0], n_emb=params[8].shape[0],
+                              max_steps=max_steps, teacher_forcing=int(teacher_forcing), stop_on_eos=int(stop_on_eos), eos=eos)
+        need = max_steps if teacher_forcing else 1
+        if tf_input.numel() < need:
+            raise ValueError(f"decoder_forward: tf_input has {tf_input.numel()} tokens, {need} needed")
+        nbytes = lib.mucon_decoder_workspace_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            _lib.check(_lib.E_ARG, "mucon_decoder_workspace_bytes")
+        dev = memory.device
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        logp = torch.empty((max_steps, cfg.NC), dtype=torch.float32, device=dev)
+        lengths = torch.empty(max_steps, dtype=torch.float32, device=dev)
+        n_steps = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mucon_decoder_fwd(ctypes.byref(cfg), ctypes.byref(_decoder_params(params)), _lib.ptr(memory), _lib.ptr(hn),
+                                         _lib.ptr(cn), _lib.ptr(tf_input), _lib.ptr(dropmask), _lib.ptr(logp), _lib.ptr(lengths),
+                                         _lib.ptr(n_steps), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+                   "mucon_decoder_fwd")
+        n = int(n_steps.item()) if stop_on_eos else max_steps
+        logp, lengths = logp[:n], lengths[:n]
+        ctx.cfg, ctx.n, ctx.ws, ctx.nbytes, ctx.dropmask = cfg, n, ws, nbytes, dropmask
+        ctx.save_for_backward(memory, hn, cn, logp, *params)
+        ctx.set_materialize_grads(False)
+        return logp, lengths
+
+    @staticmethod
+    def backward(ctx, d_logp, d_len):
+        lib = _lib.load()
+        memory, hn, cn, logp, *params = ctx.saved_tensors
+        d_logp = d_logp.contiguous() if d_logp is not None else None
+        d_len = d_len.contiguous() if d_len is not None else None
+        d_memory, d_hn, d_cn = torch.empty_like(memory), torch.empty_like(hn), torch.empty_like(cn)
+        grads = [torch.empty_like(w) for w in params]
+        _lib.check(lib.mucon_decoder_bwd(ctypes.byref(ctx.cfg), ctx.n, ctypes.byref(_decoder_params(params)), _lib.ptr(memory),
+                                         _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(logp), _lib.ptr(d_logp), _lib.ptr(d_len),
+                                         _lib.ptr(ctx.dropmask), _lib.ptr(d_memory), _lib.ptr(d_hn), _lib.ptr(d_cn),
+                                         ctypes.byref(_decoder_params(grads)), _lib.ptr(ctx.ws), ctx.nbytes,
+                                         _lib.current_stream_ptr()), "mucon_decoder_bwd")
+        return (d_memory, d_hn, d_cn, None, None, None, *grads)
+
+
+def decoder_forward(memory: torch.Tensor, h_n: torch.Tensor, c_n: torch.Tensor, tf_input: torch.Tensor,
+                    params: Sequence[torch.Tensor], max_steps: int, teacher_forcing: bool, stop_on_eos: bool, eos: int,
+                    dropmask: Optional[torch.Tensor] = None):
+    """The s-head's decoding loop (reference models.py:612-744) in one persistent kernel.
+
+    memory [Tz, 2E] (encoder LSTM output), h_n / c_n [ndir, E]; tf_input int64 tokens; params = the 23 tensors
+    named by _lib.DECODER_PARAM_FIELDS in that order; dropmask [max_steps, 128] = the embedding-dropout keep mask
+    already divided by (1 - p), or None.  Returns (logp [n, NC], lengths [n]) with n = max_steps, or the number of
+    steps up to and including the first EOS arg-max when stop_on_eos."""
+    if len(params) != len(_lib.DECODER_PARAM_FIELDS):
+        raise ValueError(f"decoder_forward: expected {len(_lib.DECODER_PARAM_FIELDS)} parameter tensors, got {len(params)}")
+    return _DecoderFn.apply(memory, h_n.reshape(-1), c_n.reshape(-1), tf_input, dropmask,
+                            (int(max_steps), bool(teacher_forcing), bool(stop_on_eos), int(eos)), *params)
+
+
 # --------------------------------------------------------------------------------------- viterbi
 @dataclass
 class ViterbiResult:

@@ -53,3 +53,62 @@ def dropout_keep_np(n, seed, site, p):
         x = (x * np.uint64(0x846ca68b)) & np.uint64(M)
         x ^= x >> np.uint64(16)
     return x >= np.uint64(thresh)
+
+
+# ---------------------------------------------------------------------------- s-head goldens
+def seeded_model_value(name, shape):
+    """Parameter recipe of tools/make_golden_model.py / make_golden_shead.py (seed = crc32 of the name)."""
+    import zlib
+    from mucon_amd import synth
+    u = synth.uniform_pm1(zlib.crc32(name.encode()), tuple(shape))
+    if name == "ft_last_gn.weight":
+        return np.float32(1.0) + np.float32(0.25) * u
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return u * np.float32(2.0 ** -int(round(np.log2(np.sqrt(max(fan_in, 1))))))
+    return u * np.float32(0.125)
+
+
+SHEAD_SHAPES = {
+    "fs_decoder_attention_W1": (256, 128), "fs_decoder_attention_V": (128,),
+    **{f"fs_encoder_lstm.{n}_l0{s}": sh for s in ("", "_reverse")
+       for n, sh in (("weight_ih", (512, 128)), ("weight_hh", (512, 128)), ("bias_ih", (512,)), ("bias_hh", (512,)))},
+    "fs_encoder_hidden_out.weight": (128, 256), "fs_encoder_hidden_out.bias": (128,),
+    "fs_encoder_cn_out.weight": (128, 256), "fs_encoder_cn_out.bias": (128,),
+    "fs_decoder_attention_l2.weight": (128, 128), "fs_decoder_attention_l2.bias": (128,),
+    "fs_decoder_embedding.weight": (50, 128),
+    "fs_decoder_attn_combine.weight": (128, 384), "fs_decoder_attn_combine.bias": (128,),
+    "fs_decoder_lstm.weight_ih_l0": (512, 128), "fs_decoder_lstm.weight_hh_l0": (512, 128),
+    "fs_decoder_lstm.bias_ih_l0": (512,), "fs_decoder_lstm.bias_hh_l0": (512,),
+    "fs_decoder_transcript.0.weight": (128, 128), "fs_decoder_transcript.0.bias": (128,),
+    "fs_decoder_transcript.2.weight": (49, 128), "fs_decoder_transcript.2.bias": (49,),
+    "fs_decoder_length.0.weight": (64, 177), "fs_decoder_length.0.bias": (64,),
+    "fs_decoder_length.2.weight": (1, 64), "fs_decoder_length.2.bias": (1,),
+}
+
+
+def shead_params(gold, case):
+    """The s-head parameters of a tests/golden/shead_cases.npz case, as float32 torch tensors by state_dict name."""
+    import torch
+    scale = np.float32(gold[f"{case}__scale"])
+    out = {}
+    for name, shape in SHEAD_SHAPES.items():
+        v = seeded_model_value(name, shape).astype(np.float32)
+        if name.startswith("fs_decoder") and v.ndim >= 2:
+            v = v * scale
+        out[name] = torch.from_numpy(v)
+    return out
+
+
+def shead_case(gold, case):
+    import torch
+    from mucon_amd import synth
+    Tz, N, seed, eos = [int(x) for x in gold[f"{case}__meta"]]
+    tr = synth.transcript(seed + 1, N, 48, allow_repeats=True)
+    return {
+        "Tz": Tz, "N": N, "eos": eos,
+        "enc": torch.from_numpy(synth.uniform_pm1(seed, (1, Tz, 128)).astype(np.float32))[0],
+        "tf_in": torch.tensor([49] + tr.tolist()),
+        "R1": torch.from_numpy(synth.uniform_pm1(seed + 2, (N + 1, 49)).astype(np.float32)),
+        "r2": torch.from_numpy(synth.uniform_pm1(seed + 3, (N + 1,)).astype(np.float32)),
+    }
