@@ -243,6 +243,40 @@ int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, const mucon
                       const float *d_lengths, const float *dropmask, float *d_memory, float *d_hn, float *d_cn,
                       const mucon_decoder_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the four MuCon losses, forward and gradients --------------------------------
+ * Replaces MuCon.loss (reference src/mucon/models.py:376-565) together with project_lengths_softmax and
+ * create_masks (reference src/mucon/masks.py:8-74) for one video:
+ *   main = mul_transcript * transcript + mul_length * length + mul_mucon * mucon + mul_smoothing * smoothing.
+ * The loss is a scalar, so one call returns the five values AND d main / d input for every input. */
+typedef struct mucon_loss_cfg {
+    int32_t T;                  /* frames (rows of segmentation) */
+    int32_t M;                  /* classes (<= 64) */
+    int32_t N;                  /* segments = number of length logits (<= 64) */
+    int32_t S;                  /* transcript steps (rows of transcript_logp) */
+    int32_t NC;                 /* transcript outputs (M + 1) */
+    int32_t mucon_type;         /* 0 "flint", 1 "arithmetic"  (cfg.model.loss.mucon.type) */
+    int32_t smoothing_clamp;    /* cfg.model.loss.smoothing.clamp */
+    int32_t transcript_average; /* cfg.model.loss.transcript_average */
+    float overlap;              /* cfg.model.loss.mucon.overlap */
+    float clamp_min, clamp_max; /* cfg.model.loss.smoothing.clamp_min / clamp_max */
+    float length_width;         /* cfg.model.loss.length_width */
+    float mul_transcript, mul_length, mul_mucon, mul_smoothing; /* cfg.model.loss.mul_* */
+} mucon_loss_cfg;
+size_t mucon_loss_workspace_bytes(const mucon_loss_cfg *cfg);
+/* segmentation [T][M] logits; smoothing_input [T][M] = what the smoothing loss runs on (log_softmax(segmentation)
+ * when cfg.model.loss.smoothing.log_softmax_before, else the logits themselves; may alias segmentation);
+ * transcript_logp [S][NC]; lengths [N]; mucon_target int64 [N]; transcript_target int64 [S]; mask_template [100]
+ * (masks.py:26-41: box / gaussian / trapezoid); the class-weight vectors [M] / [NC] may be NULL (= ones).
+ * Writes losses[5] = {main, transcript, length, mucon, smoothing} and the gradients of `main`:
+ * d_segmentation [T][M] (mucon part), d_smoothing_input [T][M] (smoothing part; never aliases d_segmentation),
+ * d_transcript_logp [S][NC], d_lengths [N]. */
+int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmentation, const float *smoothing_input,
+                       const float *transcript_logp, const float *lengths, const int64_t *mucon_target,
+                       const int64_t *transcript_target, const float *mask_template, const float *mucon_class_weight,
+                       const float *transcript_class_weight, float *losses, float *d_segmentation,
+                       float *d_smoothing_input, float *d_transcript_logp, float *d_lengths, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,12 @@ class DecoderParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in DECODER_PARAM_FIELDS]
 
 
+class LossCfg(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("T", "M", "N", "S", "NC", "mucon_type", "smoothing_clamp", "transcript_average")]
+                + [(n, ctypes.c_float) for n in ("overlap", "clamp_min", "clamp_max", "length_width", "mul_transcript",
+                                                 "mul_length", "mul_mucon", "mul_smoothing")])
+
+
 # every symbol include/mucon_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
@@ -98,6 +104,8 @@ SYMBOLS = {
     "mucon_lstm_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_lstm_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _vp,
                                       ctypes.POINTER(LstmParams), _vp, _sz, _vp]),
+    "mucon_loss_workspace_bytes": (_sz, [ctypes.POINTER(LossCfg)]),
+    "mucon_loss_fwd_bwd": (ctypes.c_int, [ctypes.POINTER(LossCfg)] + [_vp] * 15 + [_sz, _vp]),
     "mucon_decoder_workspace_bytes": (_sz, [ctypes.POINTER(DecoderCfg)]),
     "mucon_decoder_fwd": (ctypes.c_int, [ctypes.POINTER(DecoderCfg), ctypes.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1,5 +1,5 @@
 // C-ABI entry points of the s-head: the sequence encoder (bidirectional LSTM, lstm.hpp)
-// and the attention decoder (decoder.hpp).  Declared in include/mucon_hip.h.
+// and the attention decoder (decoder.hpp); and of the fused losses (8f row 2, loss.hpp).  Declared in include/mucon_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -7,6 +7,7 @@
 #include "../../include/mucon_hip.h"
 #include "lstm.hpp"
 #include "decoder.hpp"
+#include "loss.hpp"
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 
@@ -263,6 +264,100 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     ob.njobs = nj;
     hipLaunchKernelGGL(dec_outer_kernel, dim3(blocks), dim3(256), 0, s, ob);
     hipLaunchKernelGGL(dec_memgrad_kernel, dim3(Tz), dim3(256), 0, s, L.dl.mp, p.w1, d_memory, ME);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------ losses
+static int loss_check(const mucon_loss_cfg *c) {
+    if (!c) return sfail(MUCON_E_ARG, "loss: null cfg");
+    if (c->T < 2) return sfail(MUCON_E_ARG, "loss: T=%d (at least 2 frames)", c->T);
+    if (c->M < 1 || c->M > LOSS_MAXM) return sfail(MUCON_E_ARG, "loss: %d classes unsupported (max %d)", c->M, LOSS_MAXM);
+    if (c->N < 1 || c->N > LOSS_MAXN) return sfail(MUCON_E_ARG, "loss: %d segments unsupported (1..%d)", c->N, LOSS_MAXN);
+    if (c->S < 1 || c->NC < 1) return sfail(MUCON_E_ARG, "loss: S=%d NC=%d", c->S, c->NC);
+    if (c->mucon_type != 0 && c->mucon_type != 1) return sfail(MUCON_E_ARG, "loss: mucon_type %d (0 flint, 1 arithmetic)", c->mucon_type);
+    return MUCON_OK;
+}
+
+static size_t loss_layout(const mucon_loss_cfg *c, float *base, LossBufs *b) {
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float *p = base ? base + off : nullptr;
+        off += al64(n);
+        return p;
+    };
+    const size_t chunks = (c->T + LOSS_FB - 1) / LOSS_FB, NM = (size_t)c->N * c->M;
+    float *geo = take(6 * LOSS_MAXN), *small = take(8), *slab = take(chunks * (NM + 2)), *gwin = take(NM);
+    float *glwin = take(LOSS_MAXN), *gsm = take(1), *gslab = take(chunks * c->N * 2);
+    if (b) {
+        b->geo = geo;
+        b->small = small;
+        b->slab = slab;
+        b->gwin = gwin;
+        b->glwin = glwin;
+        b->gsm = gsm;
+        b->gslab = gslab;
+    }
+    return off;
+}
+
+extern "C" size_t mucon_loss_workspace_bytes(const mucon_loss_cfg *cfg) {
+    if (loss_check(cfg) != MUCON_OK) return 0;
+    return loss_layout(cfg, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmentation, const float *smoothing_input,
+                                  const float *transcript_logp, const float *lengths, const int64_t *mucon_target,
+                                  const int64_t *transcript_target, const float *mask_template, const float *mucon_class_weight,
+                                  const float *transcript_class_weight, float *losses, float *d_segmentation,
+                                  float *d_smoothing_input, float *d_transcript_logp, float *d_lengths, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    int rc = loss_check(cfg);
+    if (rc != MUCON_OK) return rc;
+    if (!segmentation || !smoothing_input || !transcript_logp || !lengths || !mucon_target || !transcript_target || !mask_template ||
+        !losses || !d_segmentation || !d_smoothing_input || !d_transcript_logp || !d_lengths || !workspace)
+        return sfail(MUCON_E_ARG, "loss: null pointer argument");
+    if (workspace_bytes < mucon_loss_workspace_bytes(cfg)) return sfail(MUCON_E_WORKSPACE, "loss workspace too small");
+    LossDims d;
+    d.T = cfg->T;
+    d.M = cfg->M;
+    d.N = cfg->N;
+    d.S = cfg->S;
+    d.NC = cfg->NC;
+    d.mucon_type = cfg->mucon_type;
+    d.smoothing_clamp = cfg->smoothing_clamp;
+    d.transcript_average = cfg->transcript_average;
+    d.overlap = cfg->overlap;
+    d.clamp_min = cfg->clamp_min;
+    d.clamp_max = cfg->clamp_max;
+    d.length_width = cfg->length_width;
+    d.mul_transcript = cfg->mul_transcript;
+    d.mul_length = cfg->mul_length;
+    d.mul_mucon = cfg->mul_mucon;
+    d.mul_smoothing = cfg->mul_smoothing;
+    LossBufs b;
+    loss_layout(cfg, static_cast<float *>(workspace), &b);
+    b.seg = segmentation;
+    b.sx = smoothing_input;
+    b.tlogp = transcript_logp;
+    b.lengths = lengths;
+    b.mtarget = reinterpret_cast<const long *>(mucon_target);
+    b.ttarget = reinterpret_cast<const long *>(transcript_target);
+    b.tmpl = mask_template;
+    b.mweight = mucon_class_weight;
+    b.tweight = transcript_class_weight;
+    b.losses = losses;
+    b.d_seg = d_segmentation;
+    b.d_sx = d_smoothing_input;
+    b.d_tlogp = d_transcript_logp;
+    b.d_lengths = d_lengths;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunks = (cfg->T + LOSS_FB - 1) / LOSS_FB;
+    hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(64), 0, s, d, b);
+    hipLaunchKernelGGL(loss_acc_kernel, dim3(chunks), dim3(256), 0, s, d, b);
+    hipLaunchKernelGGL(loss_mid_kernel, dim3(1), dim3(256), 0, s, d, b, chunks);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks), dim3(256), 0, s, d, b);
+    hipLaunchKernelGGL(loss_fin_kernel, dim3(1), dim3(64), 0, s, d, b, chunks);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

@@ -123,6 +123,7 @@ class MuCon(nn.Module):
         self._step = 0  # dropout stream counter for the HIP encoder
         self.native_lstm = True     # s-head biLSTM through the HIP kernels (False: torch's nn.LSTM / MIOpen)
         self.native_decoder = True  # s-head decoding loop as one persistent HIP kernel (False: the torch loop)
+        self.native_loss = True     # the four losses + gradients in the fused HIP kernels (False: the torch formulation)
 
     def get_params(self, original_lr):  # fandak.Model.get_params
         return [{"params": self.parameters(), "lr": original_lr}]
@@ -260,12 +261,55 @@ class MuCon(nn.Module):
 
     # ------------------------------------------------------------------------------ losses
     def loss(self, batch: Batch, forward_out: MuConForwardOut) -> MuConLoss:
+        if self._native_loss_ok(forward_out):
+            return self._native_loss(batch, forward_out)
         t = self.transcript_loss(batch, forward_out)
         ln = self.length_loss(batch, forward_out)
         mu = self.mucon_loss(batch, forward_out)
         sm = self.smoothing_loss(batch, forward_out)
         main = self.loss_mul_transcript * t + self.loss_mul_length * ln + self.loss_mul_mucon * mu + self.loss_mul_smoothing * sm
         return MuConLoss(main=main, transcript_loss=t, length_loss=ln, mucon_loss=mu, smoothing_loss=sm)
+
+    def _native_loss_ok(self, forward_out: MuConForwardOut) -> bool:
+        seg = forward_out.segmentation
+        return (self.native_loss and seg.is_cuda and seg.shape[0] >= 2 and seg.shape[1] <= 64
+                and 1 <= forward_out.lengths.shape[0] <= 64 and self.cfg.model.loss.mucon.type in ("flint", "arithmetic"))
+
+    def _native_loss(self, batch: Batch, forward_out: MuConForwardOut) -> MuConLoss:
+        """All four losses and their gradients through the fused HIP kernels (ops.losses_forward, csrc/loss.hpp); the
+        torch formulation below stays as the path for CPU tensors and unsupported sizes."""
+        lc = self.cfg.model.loss
+        seg, dev = forward_out.segmentation, forward_out.segmentation.device
+        if self.teacher_forcing:
+            target = batch.transcript
+        else:   # reference models.py:417-428
+            target = forward_out.transcript[:-1].argmax(dim=1)
+            target = torch.where(target >= self.num_classes, torch.zeros_like(target), target)
+        if lc.smoothing.log_softmax_before:
+            logp = getattr(forward_out, "_logp", None)
+            sx = logp if logp is not None else F.log_softmax(seg, dim=1)
+        else:
+            sx = seg
+        key = (lc.mucon.template, str(dev))
+        if getattr(self, "_loss_consts_key", None) != key:
+            from .masks import _template
+            self._loss_tmpl = _template(lc.mucon.template, 1, torch.zeros(1, device=dev)).reshape(-1).contiguous()
+            self._loss_mw = (self._bg_weight(self.num_classes, lc.mucon_weight_background_index,
+                                             lc.mucon_weight_background_value, dev) if lc.mucon_weight_background else None)
+            self._loss_tw = (self._bg_weight(self.num_classes + 1, lc.transcript_weight_background_index,
+                                             lc.transcript_weight_background_value, dev)
+                             if lc.transcript_weight_background else None)
+            self._loss_consts_key = key
+        spec = ops.LossSpec(mucon_type=lc.mucon.type, overlap=float(lc.mucon.overlap), smoothing_clamp=bool(lc.smoothing.clamp),
+                            clamp_min=float(lc.smoothing.clamp_min), clamp_max=float(lc.smoothing.clamp_max),
+                            length_width=float(lc.length_width), transcript_average=bool(lc.transcript_average),
+                            mul_transcript=float(self.loss_mul_transcript), mul_length=float(self.loss_mul_length),
+                            mul_mucon=float(self.loss_mul_mucon), mul_smoothing=float(self.loss_mul_smoothing))
+        main, parts = ops.losses_forward(seg, sx, forward_out.transcript, forward_out.lengths, spec, target.to(torch.int64),
+                                         batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw,
+                                         self._loss_tw)
+        return MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2],
+                         smoothing_loss=parts[3])
 
     def smoothing_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
         sm = self.cfg.model.loss.smoothing

@@ -373,6 +373,82 @@ def decoder_forward(memory: torch.Tensor, h_n: torch.Tensor, c_n: torch.Tensor, 
                             (int(max_steps), bool(teacher_forcing), bool(stop_on_eos), int(eos)), *params)
 
 
+# --------------------------------------------------------------------------------------- losses
+@dataclass
+class LossSpec:
+    """cfg.model.loss.* as the fused loss kernels take it (include/mucon_hip.h: mucon_loss_cfg)."""
+    mucon_type: str = "flint"
+    overlap: float = 0.0
+    smoothing_clamp: bool = True
+    clamp_min: float = 0.0
+    clamp_max: float = 16.0
+    length_width: float = 2.0
+    transcript_average: bool = False
+    mul_transcript: float = 1.0
+    mul_length: float = 0.1
+    mul_mucon: float = 1.0
+    mul_smoothing: float = 0.1
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, sx, tlogp, lengths, spec, mtarget, ttarget, tmpl, mweight, tweight):
+        lib = _lib.load()
+        _check_dev(seg, sx, tlogp, lengths, tmpl, mweight, tweight)
+        for t in (mtarget, ttarget):
+            if not t.is_cuda or t.dtype != torch.int64:
+                raise _lib.MuconHipError("loss targets must be int64 device tensors")
+        seg, sx, tlogp, lengths = seg.contiguous(), sx.contiguous(), tlogp.contiguous(), lengths.contiguous()
+        mtarget, ttarget = mtarget.contiguous(), ttarget.contiguous()
+        T, M = seg.shape
+        S, NC = tlogp.shape
+        N = lengths.shape[0]
+        if mtarget.numel() != N or ttarget.numel() != S or sx.shape != seg.shape or tmpl.numel() != 100:
+            raise ValueError("losses_forward: inconsistent shapes")
+        types = {"flint": 0, "arithmetic": 1}
+        if spec.mucon_type not in types:
+            raise Exception(f"Invalid mucon type ({spec.mucon_type})")   # the reference's error (models.py:513-515)
+        cfg = _lib.LossCfg(T=T, M=M, N=N, S=S, NC=NC, mucon_type=types[spec.mucon_type],
+                           smoothing_clamp=int(spec.smoothing_clamp), transcript_average=int(spec.transcript_average),
+                           overlap=spec.overlap, clamp_min=spec.clamp_min, clamp_max=spec.clamp_max,
+                           length_width=spec.length_width, mul_transcript=spec.mul_transcript, mul_length=spec.mul_length,
+                           mul_mucon=spec.mul_mucon, mul_smoothing=spec.mul_smoothing)
+        nbytes = lib.mucon_loss_workspace_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            _lib.check(_lib.E_ARG, "mucon_loss_workspace_bytes")
+        dev = seg.device
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        d_seg, d_sx, d_tlogp, d_len = torch.empty_like(seg), torch.empty_like(sx), torch.empty_like(tlogp), torch.empty_like(lengths)
+        _lib.check(lib.mucon_loss_fwd_bwd(ctypes.byref(cfg), _lib.ptr(seg), _lib.ptr(sx), _lib.ptr(tlogp), _lib.ptr(lengths),
+                                          _lib.ptr(mtarget), _lib.ptr(ttarget), _lib.ptr(tmpl.contiguous()),
+                                          _lib.ptr(mweight), _lib.ptr(tweight), _lib.ptr(losses), _lib.ptr(d_seg), _lib.ptr(d_sx),
+                                          _lib.ptr(d_tlogp), _lib.ptr(d_len), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+                   "mucon_loss_fwd_bwd")
+        ctx.save_for_backward(d_seg, d_sx, d_tlogp, d_len)
+        parts = losses[1:].clone()
+        ctx.mark_non_differentiable(parts)
+        return losses[0], parts
+
+    @staticmethod
+    def backward(ctx, g_main, _g_parts):
+        d_seg, d_sx, d_tlogp, d_len = ctx.saved_tensors
+        return (d_seg * g_main, d_sx * g_main, d_tlogp * g_main, d_len * g_main, None, None, None, None, None, None)
+
+
+def losses_forward(segmentation: torch.Tensor, smoothing_input: torch.Tensor, transcript_logp: torch.Tensor,
+                   lengths: torch.Tensor, spec: LossSpec, mucon_target: torch.Tensor, transcript_target: torch.Tensor,
+                   mask_template: torch.Tensor, mucon_class_weight: Optional[torch.Tensor] = None,
+                   transcript_class_weight: Optional[torch.Tensor] = None):
+    """MuCon.loss for one video in five launches (reference models.py:376-565 + masks.py:8-74).
+
+    segmentation [T, M] logits; smoothing_input [T, M] (log-probs or the logits, per smoothing.log_softmax_before);
+    transcript_logp [S, M+1]; lengths [N]; targets int64.  Returns (main, parts) with parts = [transcript, length, mucon,
+    smoothing] (detached); main.backward() delivers the gradients computed in the same launches."""
+    return _LossFn.apply(segmentation, smoothing_input, transcript_logp, lengths, spec, mucon_target, transcript_target,
+                         mask_template, mucon_class_weight, transcript_class_weight)
+
+
 # --------------------------------------------------------------------------------------- viterbi
 @dataclass
 class ViterbiResult:

@@ -112,3 +112,17 @@ def shead_case(gold, case):
         "R1": torch.from_numpy(synth.uniform_pm1(seed + 2, (N + 1, 49)).astype(np.float32)),
         "r2": torch.from_numpy(synth.uniform_pm1(seed + 3, (N + 1,)).astype(np.float32)),
     }
+
+
+# ---------------------------------------------------------------------------- loss goldens
+def loss_inputs(T, N, seed):
+    """Seeded head outputs of tools/make_golden_loss.py: (segmentation [T,48], transcript logits [N+1,49], length
+    logits [N], transcript [N]) as numpy."""
+    from mucon_amd import synth
+    seg = synth.uniform_pm1(seed, (T, 48)).astype(np.float32) * np.float32(3.0)
+    tl = synth.uniform_pm1(seed + 1, (N + 1, 49)).astype(np.float32) * np.float32(2.0)
+    ln = synth.uniform_pm1(seed + 2, (N,)).astype(np.float32) * np.float32(3.0)
+    tr = synth.transcript(seed + 3, N, 48, allow_repeats=True)
+    if N >= 2:
+        tr[0] = 0
+    return seg, tl, ln, tr
