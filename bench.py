@@ -156,7 +156,7 @@ def viterbi_bench(dev, C=48):
 
 def end_to_end_bench(dev, steps=40):
     """Second timed scope of SURVEY.md 8d: the reference's whole training step (_train_1_batch: forward incl. the
-    PyTorch-ROCm s-head, losses, backward, two clip_grad_norm_, SGD) on one Breakfast-typical synthetic video,
+    s-head, losses, backward, two clip_grad_norm_, SGD) on one Breakfast-typical synthetic video,
     batch size 1 as in the reference (README: 14.67-16.23 it/s on the authors' GPU)."""
     from mucon_amd import synth
     from mucon_amd.config import get_cfg_defaults, update_config
@@ -184,7 +184,7 @@ def end_to_end_bench(dev, steps=40):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"videos_per_s": round(1.0 / dt, 1), "frames_per_s": round(T / dt, 1), "ms_per_video": round(dt * 1e3, 3),
-            "config": f"full MuCon train step, batch 1, T={T}, N={N}: HIP hot path + HIP s-head (persistent LSTM / decoder) + PyTorch-ROCm losses/clip/SGD",
+            "config": f"full MuCon train step, batch 1, T={T}, N={N}: all-HIP: hot path, s-head (persistent LSTM / decoder), fused losses, fused clip+SGD; torch = autograd glue only",
             "reference_readme_it_per_s": [14.67, 16.23]}
 
 

@@ -277,6 +277,27 @@ int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmentation, con
                        float *d_smoothing_input, float *d_transcript_logp, float *d_lengths, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* ---- gradient clipping + SGD step (the tail of the training step) ------------------------------------
+ * Replaces, for one optimizer step, reference src/mucon/trainers.py:137-140:
+ *   clip_grad_norm_(model.encode_params, max_norm); clip_grad_norm_(model.decode_params, max_norm);
+ *   optimizer.step()     with torch.optim.SGD(lr, momentum, weight_decay) (trainers.py:18-30)
+ * Per clipping group g: norm_g = ||all gradients of the group||_2, coef = min(max_norm[g] / (norm_g + 1e-6), 1)
+ * (max_norm[g] <= 0: no clipping); then per element  grad *= coef (written back),  u = grad + weight_decay * param,
+ * buf = momentum * buf + u and u = buf (when momentum != 0),  param -= lr * u.   `tensors` is a HOST array;
+ * the pointers in it are device pointers.  group_norms [n_groups] (device, may be NULL) receives the norms. */
+typedef struct mucon_sgd_tensor {
+    float *param;
+    float *grad;
+    float *momentum_buf; /* NULL when momentum == 0 */
+    int64_t n;           /* elements */
+    int32_t group;       /* clipping group, 0 .. n_groups-1 */
+    int32_t reserved;
+} mucon_sgd_tensor;
+size_t mucon_sgd_workspace_bytes(int32_t n_tensors, int64_t total_elements);
+int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *tensors, int32_t n_groups, const float *max_norm,
+                        float lr, float weight_decay, float momentum, float *group_norms, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

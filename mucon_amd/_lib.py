@@ -77,6 +77,11 @@ class LossCfg(ctypes.Structure):
                                                  "mul_length", "mul_mucon", "mul_smoothing")])
 
 
+class SgdTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("momentum_buf", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # every symbol include/mucon_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
@@ -106,6 +111,9 @@ SYMBOLS = {
                                       ctypes.POINTER(LstmParams), _vp, _sz, _vp]),
     "mucon_loss_workspace_bytes": (_sz, [ctypes.POINTER(LossCfg)]),
     "mucon_loss_fwd_bwd": (ctypes.c_int, [ctypes.POINTER(LossCfg)] + [_vp] * 15 + [_sz, _vp]),
+    "mucon_sgd_workspace_bytes": (_sz, [_i32, _i64]),
+    "mucon_sgd_clip_step": (ctypes.c_int, [_i32, ctypes.POINTER(SgdTensor), _i32, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_float, _vp, _vp, _sz, _vp]),
     "mucon_decoder_workspace_bytes": (_sz, [ctypes.POINTER(DecoderCfg)]),
     "mucon_decoder_fwd": (ctypes.c_int, [ctypes.POINTER(DecoderCfg), ctypes.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _sz, _vp]),

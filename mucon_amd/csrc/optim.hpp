@@ -1,0 +1,94 @@
+// Gradient clipping + SGD step over a list of tensors in two launches (the tail of the reference's training step:
+// src/mucon/trainers.py:137-140 -- clip_grad_norm_(encode_params), clip_grad_norm_(decode_params), optimizer.step()
+// with torch.optim.SGD(lr, momentum, weight_decay), trainers.py:18-30).  torch runs this as ~25 small multi-tensor
+// launches (0.86 ms of launch latency per step for a 1.6 M-parameter model).
+//   sgd_norm_kernel    sum of squares per 4096-float chunk -> partial[block]
+//   sgd_apply_kernel   every block re-reduces the partials of its clipping group in a fixed order (so all blocks
+//                      agree bitwise), coef = min(max_norm / (norm + 1e-6), 1)  [torch.nn.utils.clip_grad_norm_],
+//                      g *= coef (written back, as torch clips in place), g' = g + wd * p,
+//                      buf = momentum * buf + g' (optional), p -= lr * g'
+#pragma once
+#include "common.hpp"
+
+constexpr int SGD_CHUNK = 4096;
+constexpr int SGD_MAXGROUPS = 8;
+
+struct SgdTensor {   // mirrors mucon_sgd_tensor + the launch bookkeeping
+    float *p, *g, *mom;
+    long n;
+    int group, block0;
+};
+
+__device__ __forceinline__ int sgd_find(const SgdTensor *tab, int nt, int block) {
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block0 <= block) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float sgd_block_sum(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sgd_norm_kernel(const SgdTensor *tab, int nt, float *partial) {
+    __shared__ float red[4];
+    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
+    const long b1 = min(t.n, b0 + SGD_CHUNK);
+    float acc = 0.f;
+    for (long e = b0 + threadIdx.x; e < b1; e += 256) {
+        const float g = t.g[e];
+        acc += g * g;
+    }
+    acc = sgd_block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+struct SgdHyper {
+    float max_norm[SGD_MAXGROUPS];   // <= 0: no clipping for the group
+    float lr, weight_decay, momentum;
+    int ngroups, nblocks;
+};
+
+__global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, int nt, const float *partial, SgdHyper h,
+                                                        float *norms_out) {
+    __shared__ float red[4];
+    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    // squared norm of this block's group: partials of every tensor of the group, strided over the threads
+    float acc = 0.f;
+    for (int i = 0; i < nt; ++i) {
+        if (tab[i].group != t.group) continue;
+        const int e0 = tab[i].block0, e1 = i + 1 < nt ? tab[i + 1].block0 : h.nblocks;
+        for (int b = e0 + threadIdx.x; b < e1; b += 256) acc += partial[b];
+    }
+    const float norm = sqrtf(sgd_block_sum(acc, red));
+    const float mx = h.max_norm[t.group];
+    const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
+    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
+        // the first block of the group's first tensor reports the norm
+        bool first = true;
+        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
+        if (first) norms_out[t.group] = norm;
+    }
+    const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
+    const long b1 = min(t.n, b0 + SGD_CHUNK);
+    for (long e = b0 + threadIdx.x; e < b1; e += 256) {
+        const float g = t.g[e] * coef;
+        t.g[e] = g;
+        const float p = t.p[e];
+        float u = g + h.weight_decay * p;
+        if (t.mom) {
+            u = h.momentum * t.mom[e] + u;
+            t.mom[e] = u;
+        }
+        t.p[e] = p - h.lr * u;
+    }
+}

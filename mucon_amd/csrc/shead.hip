@@ -1,5 +1,6 @@
 // C-ABI entry points of the s-head: the sequence encoder (bidirectional LSTM, lstm.hpp)
-// and the attention decoder (decoder.hpp); and of the fused losses (8f row 2, loss.hpp).  Declared in include/mucon_hip.h.
+// and the attention decoder (decoder.hpp); of the fused losses (8f row 2, loss.hpp) and of the
+// clip + SGD step (optim.hpp).  Declared in include/mucon_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -8,6 +9,8 @@
 #include "lstm.hpp"
 #include "decoder.hpp"
 #include "loss.hpp"
+#include "optim.hpp"
+#include <vector>
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 
@@ -358,6 +361,53 @@ extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmen
     hipLaunchKernelGGL(loss_mid_kernel, dim3(1), dim3(256), 0, s, d, b, chunks);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks), dim3(256), 0, s, d, b);
     hipLaunchKernelGGL(loss_fin_kernel, dim3(1), dim3(64), 0, s, d, b, chunks);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------ clip + SGD
+extern "C" size_t mucon_sgd_workspace_bytes(int32_t n_tensors, int64_t total_elements) {
+    if (n_tensors < 1 || total_elements < 1) return 0;
+    const size_t blocks = (size_t)(total_elements / SGD_CHUNK) + n_tensors;   // upper bound on the chunk count
+    return al64(sizeof(SgdTensor) * n_tensors) + sizeof(float) * al64(blocks);
+}
+
+extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *tensors, int32_t n_groups, const float *max_norm,
+                                   float lr, float weight_decay, float momentum, float *group_norms, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (n_tensors < 1 || !tensors || !workspace) return sfail(MUCON_E_ARG, "sgd: no tensors");
+    if (n_groups < 1 || n_groups > SGD_MAXGROUPS || !max_norm) return sfail(MUCON_E_ARG, "sgd: %d clipping groups (1..%d)", n_groups, SGD_MAXGROUPS);
+    std::vector<SgdTensor> tab(n_tensors);
+    long total = 0;
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const mucon_sgd_tensor &t = tensors[i];
+        if (!t.param || !t.grad || t.n < 1) return sfail(MUCON_E_ARG, "sgd: tensor %d: null pointer or empty", i);
+        if (t.group < 0 || t.group >= n_groups) return sfail(MUCON_E_ARG, "sgd: tensor %d: group %d outside 0..%d", i, t.group, n_groups - 1);
+        if (momentum != 0.f && !t.momentum_buf) return sfail(MUCON_E_ARG, "sgd: tensor %d: momentum %g needs a momentum buffer", i, momentum);
+        tab[i].p = t.param;
+        tab[i].g = t.grad;
+        tab[i].mom = momentum != 0.f ? t.momentum_buf : nullptr;
+        tab[i].n = t.n;
+        tab[i].group = t.group;
+        tab[i].block0 = blocks;
+        blocks += (int)((t.n + SGD_CHUNK - 1) / SGD_CHUNK);
+        total += t.n;
+    }
+    if (workspace_bytes < mucon_sgd_workspace_bytes(n_tensors, total)) return sfail(MUCON_E_WORKSPACE, "sgd workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SgdTensor *dtab = static_cast<SgdTensor *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + al64(sizeof(SgdTensor) * n_tensors));
+    SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+    SgdHyper h;
+    for (int g = 0; g < SGD_MAXGROUPS; ++g) h.max_norm[g] = g < n_groups ? max_norm[g] : 0.f;
+    h.lr = lr;
+    h.weight_decay = weight_decay;
+    h.momentum = momentum;
+    h.ngroups = n_groups;
+    h.nblocks = blocks;
+    hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
+    hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial, h, group_norms);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

@@ -58,6 +58,32 @@ class SimpleTrainer:
         self.scheduler = create_scheduler(cfg, self.optimizer)
         self.clip_grad_norm: Optional[float] = cfg.trainer.clip_grad_norm_value if cfg.trainer.clip_grad_norm else None
         self.iter_num = 0
+        self.fused_step = self._make_fused_step()
+
+    def _make_fused_step(self):
+        """The two clip_grad_norm_ calls + SGD.step() as ops.FusedClipSGD (two launches) when the configuration is the
+        one those kernels implement: SGD on the GPU, no gradient accumulation, group-wise or global clipping."""
+        from .. import ops
+        t = self.cfg.trainer
+        if not isinstance(self.optimizer, optim.SGD) or (t.accumulate_grad_every or 1) != 1:
+            return None
+        if not str(self.device).startswith("cuda") or len(self.optimizer.param_groups) != 1:
+            return None
+        pg = self.optimizer.param_groups[0]
+        if pg.get("nesterov") or pg.get("dampening") or pg.get("maximize"):
+            return None
+        if self.clip_grad_norm is None:
+            groups, mx = [list(self.model.parameters())], None
+        elif t.clip_grad_norm_separate:
+            groups, mx = [self.model.encode_params, self.model.decode_params], self.clip_grad_norm
+            covered = {id(p) for g in groups for p in g}
+            if any(id(p) not in covered for p in self.model.parameters()):   # a parameter outside both lists: torch path
+                return None
+        elif t.clip_grad_norm_every_param:
+            return None
+        else:
+            groups, mx = [list(self.model.parameters())], self.clip_grad_norm
+        return ops.FusedClipSGD(groups, mx, self.optimizer)
 
     def on_start_epoch(self, epoch_num: int):
         self.model.set_teacher_forcing(self.cfg.model.teacher_forcing)
@@ -74,6 +100,9 @@ class SimpleTrainer:
         last_of_group = iter_num % acc == (acc - 1)
         if last_of_group and self.world_size > 1:
             all_reduce_gradients(self.model, self.world_size)
+        if self.fused_step is not None:
+            self.fused_step.step()
+            return loss, forward_out
         if self.clip_grad_norm is not None:
             t = self.cfg.trainer
             if t.clip_grad_norm_separate:

@@ -449,6 +449,62 @@ def losses_forward(segmentation: torch.Tensor, smoothing_input: torch.Tensor, tr
                          mask_template, mucon_class_weight, transcript_class_weight)
 
 
+# --------------------------------------------------------------------------------------- clip + SGD
+class FusedClipSGD:
+    """clip_grad_norm_ per parameter group + torch.optim.SGD.step() in two launches (reference trainers.py:137-140).
+
+    groups: lists of parameters, one list per clipping group (the reference's model.encode_params /
+    model.decode_params); max_norm: one value for all groups, or None for no clipping.  lr / weight_decay / momentum are
+    read from `optimizer.param_groups[0]` at every step, so schedulers keep working.  Parameters whose .grad is None are
+    skipped, as torch does."""
+
+    def __init__(self, groups, max_norm, optimizer):
+        self.groups, self.max_norm, self.optimizer = [list(g) for g in groups], max_norm, optimizer
+        if not 1 <= len(self.groups) <= 8:
+            raise ValueError("FusedClipSGD: 1..8 clipping groups")
+        self._mom = {}
+        self._ws = None
+        self.last_norms = None
+
+    def step(self):
+        lib = _lib.load()
+        pg = self.optimizer.param_groups[0]
+        lr, wd, mom = float(pg["lr"]), float(pg["weight_decay"]), float(pg["momentum"])
+        entries = []
+        for gi, params in enumerate(self.groups):
+            for p in params:
+                if p.grad is None:
+                    continue
+                _check_dev(p, p.grad)
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
+                buf = None
+                if mom != 0.0:
+                    buf = self._mom.get(id(p))
+                    if buf is None:
+                        buf = self._mom[id(p)] = torch.zeros_like(p)   # buf = 0 -> first step gives buf = grad, as torch
+                entries.append((p, p.grad, buf, gi))
+        if not entries:
+            return
+        n = len(entries)
+        tab = (_lib.SgdTensor * n)()
+        total = 0
+        for i, (p, g, buf, gi) in enumerate(entries):
+            tab[i].param, tab[i].grad = p.data_ptr(), g.data_ptr()
+            tab[i].momentum_buf = buf.data_ptr() if buf is not None else None
+            tab[i].n, tab[i].group = p.numel(), gi
+            total += p.numel()
+        nbytes = lib.mucon_sgd_workspace_bytes(n, total)
+        dev = entries[0][0].device
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.last_norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
+        mx = (ctypes.c_float * len(self.groups))(*[float(self.max_norm) if self.max_norm is not None else 0.0] * len(self.groups))
+        _lib.check(lib.mucon_sgd_clip_step(n, tab, len(self.groups), mx, lr, wd, mom, _lib.ptr(self.last_norms),
+                                           _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream_ptr()),
+                   "mucon_sgd_clip_step")
+
+
 # --------------------------------------------------------------------------------------- viterbi
 @dataclass
 class ViterbiResult:

@@ -1,0 +1,101 @@
+"""GPU: ops.FusedClipSGD (csrc/optim.hpp: two launches) against what it replaces -- torch.nn.utils.clip_grad_norm_
+per group followed by torch.optim.SGD.step() (reference src/mucon/trainers.py:137-140, :18-30).  float32 both
+sides; the only difference is the summation order of the norm: 2e-6 relative."""
+import pytest
+import torch
+from torch.nn.utils import clip_grad_norm_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SIZES = [(1,), (7, 3), (4095,), (4096,), (4097,), (128, 2048, 1), (512, 128), (50, 128), (3, 5, 7)]
+
+
+def _params(seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in SIZES]
+    grads = [(torch.randn(s, generator=g) * scale).to(DEV) for s in SIZES]
+    return ps, grads
+
+
+@pytest.mark.parametrize("scale,momentum,max_norm", [(1.0, 0.0, 100.0), (0.001, 0.0, 100.0), (1.0, 0.9, 5.0), (1.0, 0.0, None)])
+def test_fused_clip_sgd_matches_torch(scale, momentum, max_norm):
+    from mucon_amd import ops
+    pa, ga = _params(1, scale)
+    pb, _ = _params(1, scale)
+    split = 4
+    opt_a = torch.optim.SGD(pa, lr=0.01, weight_decay=0.005, momentum=momentum)
+    opt_b = torch.optim.SGD(pb, lr=0.01, weight_decay=0.005, momentum=momentum)
+    fused = ops.FusedClipSGD([pb[:split], pb[split:]], max_norm, opt_b)
+    for step in range(3):
+        for p, q, g in zip(pa, pb, ga):
+            p.grad = g.clone() * (step + 1)
+            q.grad = g.clone() * (step + 1)
+        pb[2].grad = None   # a parameter without a gradient is skipped
+        pa[2].grad = None
+        norms = []
+        if max_norm is not None:
+            norms = [clip_grad_norm_(pa[:split], max_norm), clip_grad_norm_(pa[split:], max_norm)]
+        opt_a.step()
+        fused.step()
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (step, i)
+            if p.grad is not None:
+                assert torch.allclose(p.grad, q.grad, rtol=2e-6, atol=1e-9), (step, i)   # clipped in place, as torch
+        if norms:
+            assert torch.allclose(torch.stack(norms), fused.last_norms, rtol=2e-6)
+
+
+def test_fused_step_follows_the_scheduler_and_is_deterministic():
+    from mucon_amd import ops
+    outs = []
+    for _ in range(2):
+        ps, gs = _params(3, 1.0)
+        opt = torch.optim.SGD(ps, lr=0.01, weight_decay=0.0)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+        fused = ops.FusedClipSGD([ps], 1e9, opt)
+        before = [p.detach().clone() for p in ps]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        fused.step()
+        d1 = (ps[3].detach() - before[3]).abs().max().item()
+        opt.step = lambda *a, **k: None
+        sched.step()
+        mid = ps[3].detach().clone()
+        fused.step()
+        d2 = (ps[3].detach() - mid).abs().max().item()
+        assert abs(d2 / d1 - 0.1) < 1e-3
+        outs.append([p.detach().clone() for p in ps])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_trainer_uses_the_fused_step_and_matches_the_torch_tail():
+    """Two SimpleTrainers from the same seed, one with the fused tail, one forced onto torch's clip + SGD: same
+    parameters after three steps on the same video (dropout off: eval-mode forward inside train step is not possible, so
+    dropout rates are set to 0)."""
+    import numpy as np
+    from test_gpu_model import make_batch, seeded_value
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.models import create_model
+    from mucon_amd.mucon.trainers import SimpleTrainer
+    cfg = update_config(get_cfg_defaults(), [], [["model.ft.dropout_rate", "0.0", "model.ft.last_dropout_rate", "0.0",
+                                                   "model.fs.decoder.embedding_dropout", "0.0"]])
+    finals = []
+    for fused in (True, False):
+        model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(torch.from_numpy(seeded_value(name, p.shape).astype(np.float32)))
+        model = model.cuda()
+        tr = SimpleTrainer(cfg, model, "cuda")
+        assert tr.fused_step is not None
+        if not fused:
+            tr.fused_step = None
+        tr.on_start_epoch(0)
+        model.train()
+        batch = make_batch(640, 5).to("cuda")
+        for it in range(3):
+            tr._train_1_batch(it, batch)
+        finals.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in finals[0]:
+        a, b = finals[0][n].double(), finals[1][n].double()
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7, n

@@ -25,9 +25,8 @@ for it in range(25):
     fo=MuConForwardOut(transcript=torch.cat(trs,0),lengths=torch.stack(lens[:-1]),segmentation=seg); fo._logp=logp
     loss=model.loss(batch,fo); t4=sync()
     loss.main.backward(); t5=sync()
-    clip_grad_norm_(model.encode_params,100.); clip_grad_norm_(model.decode_params,100.); t6=sync()
-    trainer.optimizer.step(); t7=sync()
+    t6=sync(); trainer.fused_step.step(); t7=sync()
     if it>=5:
-        for k,v in (("encoder_fwd",t1-t0),("s_head_fwd",t2-t1),("y_head_fwd",t3-t2),("loss",t4-t3),("backward",t5-t4),("clip",t6-t5),("sgd",t7-t6)):
+        for k,v in (("encoder_fwd",t1-t0),("s_head_fwd",t2-t1),("y_head_fwd",t3-t2),("loss",t4-t3),("backward",t5-t4),("clip+sgd",t7-t6)):
             acc[k]=acc.get(k,0)+v
 for k,v in acc.items(): print(f"{k:12s} {v/20*1e3:8.3f} ms")
