@@ -101,36 +101,81 @@ __device__ __forceinline__ float block_max(float v, float *red) {
     return red[DEC_WAVES];
 }
 
-// out[r] = act((ACC ? out[r] : 0) + b[r] + W[r][:] . x) for r < rows: four rows per wave at a time, lanes
-// across the columns, wave reduction.  The row -> thread mapping depends only on `rows`, so an ACC call
-// after a plain call with the same `rows` needs no barrier in between.
-template <int ACT, bool ACC>
+// Sum R (8 or 4) per-lane values across the wave with 10 (7) shuffles instead of R x 6: after the call, the lanes
+// with (lane >> 3) & 7 == r  (R = 8)  or  (lane >> 4) & 3 == r  (R = 4)  hold the wave-wide sum of v[r].
+template <int R>
+__device__ __forceinline__ float wave_sum_rows(float *v) {
+    const int lane = threadIdx.x & 63;
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    float c;
+    if (R == 8) {
+        float a[4], b2[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (h5 ? v[i + 4] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 4], 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b2[i] = (h4 ? a[i + 2] : a[i]) + __shfl_xor(h4 ? a[i] : a[i + 2], 16);
+        c = (h3 ? b2[1] : b2[0]) + __shfl_xor(h3 ? b2[0] : b2[1], 8);
+    } else {
+        float a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = (h5 ? v[i + 2] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 2], 32);
+        c = (h4 ? a[1] : a[0]) + __shfl_xor(h4 ? a[0] : a[1], 16);
+        c += __shfl_xor(c, 8);
+    }
+    c += __shfl_xor(c, 4);
+    c += __shfl_xor(c, 2);
+    c += __shfl_xor(c, 1);
+    return c;
+}
+
+// out[r] = act(b[r] + W[r][:] . x  [+ b2[r] + W2[r][:] . x2]) for r < rows: R rows per wave at a time, lanes across the
+// columns -- all of an iteration's loads (R rows x COLS/64, both matrices) are issued before the first use, so an
+// iteration costs about one L2 round trip -- then one tree reduction for the R rows.  COLS is a multiple of 64, or 0 for
+// a run-time column count (`cols`, one round trip per 64 columns).
+template <int ACT, int R, int COLS, bool DUAL>
 __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, const float *__restrict__ b, int rows, int cols,
-                                            const float *x, float *out) {
+                                            const float *x, float *out, const float *__restrict__ W2 = nullptr,
+                                            const float *__restrict__ b2 = nullptr, const float *x2 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r0 = wave * 4; r0 < rows; r0 += DEC_WAVES * 4) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const int nr = rows - r0;
-        const float *w0 = W + (long)r0 * cols;
-        const float *w1 = W + (long)(nr > 1 ? r0 + 1 : r0) * cols;
-        const float *w2 = W + (long)(nr > 2 ? r0 + 2 : r0) * cols;
-        const float *w3 = W + (long)(nr > 3 ? r0 + 3 : r0) * cols;
-        for (int j = lane; j < cols; j += 64) {
-            const float xv = x[j];
-            a0 += w0[j] * xv;
-            a1 += w1[j] * xv;
-            a2 += w2[j] * xv;
-            a3 += w3[j] * xv;
+    const int nc = COLS ? COLS : cols;
+    for (int r0 = wave * R; r0 < rows; r0 += DEC_WAVES * R) {
+        float acc[R];
+        if (COLS) {
+            constexpr int NJ = COLS ? COLS / 64 : 1;
+            float w[R][NJ], w2[R][DUAL ? NJ : 1];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = min(r0 + i, rows - 1);
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    w[i][jj] = W[(long)r * COLS + jj * 64 + lane];
+                    if (DUAL) w2[i][jj] = W2[(long)r * COLS + jj * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    a += w[i][jj] * x[jj * 64 + lane];
+                    if (DUAL) a += w2[i][jj] * x2[jj * 64 + lane];
+                }
+                acc[i] = a;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] = 0.f;
+            for (int j = lane; j < nc; j += 64) {
+                const float xv = x[j];
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] += W[(long)min(r0 + i, rows - 1) * nc + j] * xv;
+            }
         }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
-        a3 = wave_sum(a3);
-        if (lane < 4 && lane < nr) {
-            const int r = r0 + lane;
-            float v = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
-            v += b ? b[r] : 0.f;
-            if (ACC) v += out[r];
+        const float sum = wave_sum_rows<R>(acc);
+        const int r = r0 + (R == 8 ? (lane >> 3) & 7 : (lane >> 4) & 3);
+        if ((lane & (R == 8 ? 7 : 15)) == 0 && r < rows) {
+            float v = sum + (b ? b[r] : 0.f);
+            if (DUAL && b2) v += b2[r];
             out[r] = ACT ? fmaxf(v, 0.f) : v;
         }
     }
@@ -146,8 +191,10 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int row
     const int ng = DEC_THREADS / cp;
     const int g = threadIdx.x / cp, j = threadIdx.x - g * cp;
     float acc = 0.f;
-    if (j < cols)
+    if (j < cols) {
+#pragma unroll 8
         for (int i = g; i < rows; i += ng) acc += W[(long)i * cols + j] * d[i];
+    }
     __syncthreads();  // scratch may still be read by the previous user
     scratch[threadIdx.x] = acc;
     __syncthreads();
@@ -155,6 +202,32 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int row
         float s = 0.f;
         for (int gg = 0; gg < ng; ++gg) s += scratch[gg * cp + threadIdx.x];
         out[threadIdx.x] = ACC ? out[threadIdx.x] + s : s;
+    }
+}
+
+// Two transposed mat-vecs with the same d in one pass over the rows (128 columns each):
+// out_a += Wa^T d,  out_b = Wb^T d.   scratch: 2 * DEC_THREADS floats.
+__device__ __forceinline__ void matvec_cols_pair(const float *__restrict__ Wa, const float *__restrict__ Wb, int rows,
+                                                 const float *d, float *out_a, float *out_b, float *scratch) {
+    constexpr int ng = DEC_THREADS / DEC_D;
+    const int g = threadIdx.x / DEC_D, j = threadIdx.x - g * DEC_D;
+    float a = 0.f, b = 0.f;
+#pragma unroll 8
+    for (int i = g; i < rows; i += ng) {
+        const float dv = d[i];
+        a += Wa[(long)i * DEC_D + j] * dv;
+        b += Wb[(long)i * DEC_D + j] * dv;
+    }
+    __syncthreads();
+    scratch[threadIdx.x] = a;
+    scratch[DEC_THREADS + threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < 2 * DEC_D) {
+        const int which = threadIdx.x >> 7, jj = threadIdx.x & 127;
+        float s = 0.f;
+        for (int gg = 0; gg < ng; ++gg) s += scratch[which * DEC_THREADS + gg * DEC_D + jj];
+        if (which == 0) out_a[jj] += s;
+        else out_b[jj] = s;
     }
 }
 
@@ -197,8 +270,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
         s_stop = 0;
     }
     __syncthreads();
-    matvec_rows<0, false>(p.ho_w, p.ho_b, DEC_D, ME, s_hc, s_h);
-    matvec_rows<0, false>(p.co_w, p.co_b, DEC_D, ME, s_hc + DEC_MAXME, s_c);
+    matvec_rows<0, 4, 0, false>(p.ho_w, p.ho_b, DEC_D, ME, s_hc, s_h);
+    matvec_rows<0, 4, 0, false>(p.co_w, p.co_b, DEC_D, ME, s_hc + DEC_MAXME, s_c);
     __syncthreads();
     if (tid < DEC_D) {
         sv.h[tid] = s_h[tid];
@@ -215,17 +288,25 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
             s_cat[tid] = e;
         }
         if (tid == 0) sv.toks[s] = tok;
-        matvec_rows<0, false>(p.l2_w, p.l2_b, DEC_D, DEC_D, s_h, s_q);
+        matvec_rows<0, 8, DEC_D, false>(p.l2_w, p.l2_b, DEC_D, DEC_D, s_h, s_q);
         __syncthreads();
         if (tid < DEC_D) sv.q[s * DEC_D + tid] = s_q[tid];
-        // score[t] = V . tanh(mp[t] + q)
+        // score[t] = V . tanh(mp[t] + q): 8 encoder states per wave at a time (16 loads in flight)
         {
             const float q0 = s_q[lane], q1 = s_q[lane + 64], v0 = p.v[lane], v1 = p.v[lane + 64];
-            for (int t = wave; t < Tz; t += DEC_WAVES) {
-                const float *m = sv.mp + (long)t * DEC_D;
-                float a = v0 * tanhf(m[lane] + q0) + v1 * tanhf(m[lane + 64] + q1);
-                a = wave_sum(a);
-                if (lane == 0) s_score[t] = a;
+            for (int t0 = wave * 8; t0 < Tz; t0 += DEC_WAVES * 8) {
+                float m0[8], m1[8], a[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float *m = sv.mp + (long)min(t0 + i, Tz - 1) * DEC_D;
+                    m0[i] = m[lane];
+                    m1[i] = m[lane + 64];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = v0 * tanhf(m0[i] + q0) + v1 * tanhf(m1[i] + q1);
+                const float sum = wave_sum_rows<8>(a);
+                const int t = t0 + ((lane >> 3) & 7);
+                if ((lane & 7) == 0 && t < Tz) s_score[t] = sum;
             }
         }
         __syncthreads();
@@ -253,8 +334,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
         {
             const int g = tid >> 8, j = tid & 255;
             float acc = 0.f;
-            if (j < ME)
+            if (j < ME) {
+#pragma unroll 8
                 for (int t = g; t < Tz; t += 4) acc += s_score[t] * memory[(long)t * ME + j];
+            }
             s_scr[tid] = acc;
             __syncthreads();
             if (tid < ME) s_cat[DEC_D + tid] = (s_scr[tid] + s_scr[256 + tid]) + (s_scr[512 + tid] + s_scr[768 + tid]);
@@ -262,11 +345,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
         __syncthreads();
         if (tid < CW) sv.cat[(long)s * CW + tid] = s_cat[tid];
         // mixed = relu(attn_combine(cat(embedded, context)))
-        matvec_rows<1, false>(p.cmb_w, p.cmb_b, DEC_D, CW, s_cat, s_mixed);
+        if (ME == 256) matvec_rows<1, 4, DEC_D + 256, false>(p.cmb_w, p.cmb_b, DEC_D, CW, s_cat, s_mixed);
+        else if (ME == 128) matvec_rows<1, 4, DEC_D + 128, false>(p.cmb_w, p.cmb_b, DEC_D, CW, s_cat, s_mixed);
+        else matvec_rows<1, 4, 0, false>(p.cmb_w, p.cmb_b, DEC_D, CW, s_cat, s_mixed);
         __syncthreads();
         // one LSTM cell
-        matvec_rows<0, false>(p.w_ih, p.b_ih, 4 * DEC_D, DEC_D, s_mixed, s_gates);
-        matvec_rows<0, true>(p.w_hh, p.b_hh, 4 * DEC_D, DEC_D, s_h, s_gates);
+        matvec_rows<0, 8, DEC_D, true>(p.w_ih, p.b_ih, 4 * DEC_D, DEC_D, s_mixed, s_gates, p.w_hh, p.b_hh, s_h);
         __syncthreads();
         if (tid < DEC_D) {
             const float gi = sigmoid_f(s_gates[tid]), gf = sigmoid_f(s_gates[DEC_D + tid]);
@@ -286,10 +370,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
         }
         __syncthreads();
         // word logits = transcript MLP(dec_out)
-        matvec_rows<1, false>(p.t1_w, p.t1_b, DEC_D, DEC_D, s_h, s_t1);
+        matvec_rows<1, 8, DEC_D, false>(p.t1_w, p.t1_b, DEC_D, DEC_D, s_h, s_t1);
         __syncthreads();
         if (tid < DEC_D) sv.t1[s * DEC_D + tid] = s_t1[tid];
-        matvec_rows<0, false>(p.t2_w, p.t2_b, NC, DEC_D, s_t1, s_logits);
+        matvec_rows<0, 4, DEC_D, false>(p.t2_w, p.t2_b, NC, DEC_D, s_t1, s_logits);
         __syncthreads();
         // length = length MLP(relu(cat(mixed, word logits)))
         if (tid < LW) {
@@ -298,7 +382,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
             sv.lencat[(long)s * LW + tid] = v;
         }
         __syncthreads();
-        matvec_rows<1, false>(p.n1_w, p.n1_b, DEC_NL, LW, s_lencat, s_l1);
+        matvec_rows<1, 4, 0, false>(p.n1_w, p.n1_b, DEC_NL, LW, s_lencat, s_l1);
         __syncthreads();
         if (wave == 0) {
             sv.l1[s * DEC_NL + lane] = s_l1[lane];
@@ -337,7 +421,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
     extern __shared__ float s_ds[];  // d_attn, then d_score
     __shared__ float s_dh[DEC_D], s_dc[DEC_D], s_dlogits[DEC_MAXNC], s_dl1[DEC_NL], s_dlencat[DEC_D + DEC_MAXNC];
     __shared__ float s_dt1[DEC_D], s_dgates[4 * DEC_D], s_dmixed[DEC_D], s_dcat[DEC_D + DEC_MAXME], s_dq[DEC_D];
-    __shared__ float s_scr[DEC_THREADS], s_red[DEC_WAVES + 1], s_out[DEC_MAXME];
+    __shared__ float s_scr[2 * DEC_THREADS], s_red[DEC_WAVES + 1], s_out[DEC_MAXME];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tz = dm.Tz, ME = dm.ME, NC = dm.NC, CW = DEC_D + ME, LW = DEC_D + NC;
 
@@ -408,8 +492,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             o[3 * DEC_D + tid] = dpo;
         }
         __syncthreads();
-        matvec_cols<true>(p.w_ih, 4 * DEC_D, DEC_D, s_dgates, s_dmixed, s_scr);
-        matvec_cols<false>(p.w_hh, 4 * DEC_D, DEC_D, s_dgates, s_dh, s_scr);  // dh w.r.t. the previous hidden state
+        // d mixed += W_ih^T dgates;  dh w.r.t. the previous hidden state = W_hh^T dgates
+        matvec_cols_pair(p.w_ih, p.w_hh, 4 * DEC_D, s_dgates, s_dmixed, s_dh, s_scr);
         __syncthreads();
         if (tid < DEC_D) {
             const float v = sv.mixed[s * DEC_D + tid] > 0.f ? s_dmixed[tid] : 0.f;
