@@ -30,6 +30,9 @@ if trace:
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_summary.py"), trace, "v"], capture_output=True, text=True).stdout
     open(os.path.join(dst, f"{tag}_step_timeline.txt"), "w").write(out)
     print(out.split("\n")[0])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "e2e_trace_summary.py"), trace, "v"], capture_output=True, text=True).stdout
+    open(os.path.join(dst, f"{tag}_e2e_step_timeline.txt"), "w").write(out)
+    print(out.split("\n")[0])
 
 def pmc(pattern, counter):
     f = one(pattern)

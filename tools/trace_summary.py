@@ -5,7 +5,9 @@ f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 hp = [r for r in rows if 'viterbi' not in r['Kernel_Name']]
-idx = [i for i, r in enumerate(hp) if 'pack_weights' in r['Kernel_Name']]
+# a hot-path bench step starts at a pack_weights launch followed by the first conv of a B > 1 batch (grid y = B);
+# bench.py's end-to-end leg (batch 1) is summarised separately by tools/e2e_trace_summary.py
+idx = [i for i, r in enumerate(hp) if 'pack_weights' in r['Kernel_Name'] and i + 1 < len(hp) and int(hp[i + 1]['Grid_Size_Y']) > 1]
 s, e = idx[-2], idx[-1]
 step = hp[s:e]
 t0 = int(step[0]['Start_Timestamp'])
