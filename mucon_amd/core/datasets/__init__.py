@@ -103,6 +103,12 @@ def handel_dataset(cfg, train: bool) -> GeneralDataset:  # (sic) the reference's
     raise Exception(f"Invalid dataset name. ({cfg.dataset.name})")
 
 
+def make_resident(db: GeneralDataset, device, max_bytes=None, indices=None):
+    """The same dataset with its tapes cached in HBM (core/datasets/resident.py)."""
+    from .resident import ResidentDataset
+    return ResidentDataset(db, device, max_bytes=max_bytes, indices=indices)
+
+
 def write_synthetic_breakfast(root, n_train=8, n_test=4, num_classes=48, feat_dim=2048, t_range=(130, 1200),
                               n_range=(2, 8), seed=0, splits=(1,)):
     """Write a Breakfast-I3D-shaped tree under <root>/breakfast_i3d with random tapes whose class signal is

@@ -1,13 +1,16 @@
 """Evaluation glue of the hot path (reference src/mucon/evaluators.py:121-180, 225-228): the per-video
 grammar and Poisson length model built from the s-head's prediction, the Viterbi decode on the
 y-head's log-probs (which stay on the device), nearest-neighbour resizing to the ground-truth length
-(src/core/utils.py:34-47) and MoF (src/core/metrics/segmentation.py:16-44).  The other 20-odd
-metrics of the reference's evaluator are CPU post-processing outside this round's scope."""
+(src/core/utils.py:34-47) and the reference's full metric set (y-head, s-head and Viterbi variants of MoF / IoD /
+IoU / edit / F1, transcript matching score and length difference: evaluators.py:84-111, 197-244, 268-296), computed
+by mucon_amd/core/metrics."""
 from typing import Iterable, List
 
 import numpy as np
 import torch
 
+from ..core.metrics import (AbsLenDiffMetric, Edit, F1Score, IoDMetric, IoUMetric, MatchingScoreMetric,  # noqa: F401
+                            MoFAccuracyMetric)
 from ..core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
 
 
@@ -34,26 +37,17 @@ def make_same_size_interpolate(prediction: np.ndarray, target_len: int) -> np.nd
     return torch.nn.functional.interpolate(p, size=target_len, mode="nearest")[0, 0].long().numpy()
 
 
-class MoFAccuracyMetric:
-    def __init__(self, ignore_ids: Iterable[int] = ()):
-        self.ignore_ids = list(ignore_ids)
-        self.reset()
+def create_segmentation_from_segments(actions: np.ndarray, lengths: np.ndarray, n_frames: int) -> np.ndarray:
+    """The s-head's own segmentation: action n repeated round(length_n * n_frames) times (reference evaluators.py:28-35)."""
+    counts = np.around(lengths * n_frames).astype(int)
+    counts[counts < 0] = 0
+    return np.repeat(actions, counts)
 
-    def reset(self):
-        self.total, self.correct = 0, 0
 
-    def add(self, targets, predictions) -> float:
-        targets, predictions = np.array(targets), np.array(predictions)
-        assert len(targets) == len(predictions)
-        mask = np.logical_not(np.isin(targets, self.ignore_ids))
-        targets, predictions = targets[mask], predictions[mask]
-        cur_total, cur_correct = len(targets), int((targets == predictions).sum())
-        self.correct += cur_correct
-        self.total += cur_total
-        return cur_correct / cur_total if cur_total else 0.0
-
-    def summary(self) -> float:
-        return self.correct / self.total if self.total else 0.0
+# result fields of the reference's MuConEvaluatorResult (evaluators.py:38-68), in its order
+RESULT_FIELDS = ("y_mof", "y_mof_nbg", "y_iod", "y_iou", "s_mof", "s_mof_nbg", "s_iod", "s_iou", "s_iod_nbg", "s_iou_nbg",
+                 "s_mat_score", "s_len_diff", "vit_mof", "vit_mof_nbg", "vit_iod", "vit_iou", "vit_iod_nbg", "vit_iou_nbg",
+                 "vit_edit_score", "vit_f1_score", "y_edit_score", "y_f1_score", "s_edit_score", "s_f1_score")
 
 
 class MuConEvaluator:
@@ -65,8 +59,23 @@ class MuConEvaluator:
                                       "(MultiPoissonModel.score raises); not supported")
         self.vi_decoder = Viterbi(None, None, frame_sampling=30)
         bg = getattr(test_db, "background_class_ids", [0])
-        self.y_mof_metric, self.vit_mof_metric = MoFAccuracyMetric(), MoFAccuracyMetric()
-        self.vit_mof_nbg_metric = MoFAccuracyMetric(ignore_ids=bg)
+        m = self.metrics = {}
+        for head in ("y", "s", "vit"):
+            m[f"{head}_mof"], m[f"{head}_mof_nbg"] = MoFAccuracyMetric(), MoFAccuracyMetric(ignore_ids=bg)
+            m[f"{head}_iod"], m[f"{head}_iou"] = IoDMetric(), IoUMetric()
+            if head != "y":
+                m[f"{head}_iod_nbg"], m[f"{head}_iou_nbg"] = IoDMetric(ignore_ids=bg), IoUMetric(ignore_ids=bg)
+            m[f"{head}_edit_score"], m[f"{head}_f1_score"] = Edit(), F1Score()
+        m["s_mat_score"], m["s_len_diff"] = MatchingScoreMetric(), AbsLenDiffMetric()
+        # the attribute names of the reference's evaluator (y_mof_metric, vit_f1_score_metric, ...)
+        for k, v in m.items():
+            setattr(self, f"{k}_metric", v)
+        self.s_abs_len_diff_metric = m["s_len_diff"]
+        self._reset_lists()
+
+    def _reset_lists(self):
+        self.y_segs, self.s_segs, self.vit_segs, self.s_lens = [], [], [], []
+        self.s_transcript, self.target_segs, self.target_transcripts = [], [], []
 
     def viterbi_mode(self, mode=True):
         self.enable_viterbi = mode
@@ -79,12 +88,23 @@ class MuConEvaluator:
         with np.errstate(all="ignore"):
             return transcript, PoissonModel(lengths)
 
+    def _add(self, head: str, target, prediction, with_nbg_overlap: bool):
+        names = ["mof", "mof_nbg", "iod", "iou", "edit_score", "f1_score"] + (["iod_nbg", "iou_nbg"] if with_nbg_overlap else [])
+        with np.errstate(all="ignore"):
+            for n in names:
+                self.metrics[f"{head}_{n}"](targets=target, predictions=prediction)
+
     def batch_eval_calculation(self, batch, forward_out):
+        """One test video (reference evaluators.py:121-257)."""
         pred = self.model.predict(batch, forward_out)
         Tf = batch.feats.shape[1]
         target = batch.gt_label.detach().cpu().numpy()
+        target_transcript = batch.transcript.detach().cpu().numpy().tolist()
+        s_transcript = pred.transcript[:-1]                       # the last word should be EOS
+        rel_lengths = pred.lengths.detach().cpu().numpy()
         y_pred = pred.segmentation_logits.argmax(dim=1).cpu().numpy()
-        self.y_mof_metric.add(target, make_same_size_interpolate(y_pred, len(target)))
+        self.metrics["s_mat_score"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
+        self.metrics["s_len_diff"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
         result = {"y_prediction": y_pred}
         if self.enable_viterbi:
             transcript, lm = self.viterbi_inputs(pred, Tf)
@@ -92,28 +112,54 @@ class MuConEvaluator:
             self.vi_decoder.length_model = lm
             self.vi_decoder.set_multi_length(False)
             score, labels, segments = self.vi_decoder.decode(pred.segmentation_logits)  # device tensor: no D2H of emissions
-            vit = make_same_size_interpolate(np.array(labels), len(target))
-            self.vit_mof_metric.add(target, vit)
-            self.vit_mof_nbg_metric.add(target, vit)
             result.update(viterbi_score=score, viterbi_labels=labels, viterbi_segments=segments)
+        s_pred = create_segmentation_from_segments(np.array(s_transcript), rel_lengths, Tf)
+        s_same = make_same_size_interpolate(s_pred, len(target))
+        y_same = make_same_size_interpolate(y_pred, len(target))
+        self._add("s", target, s_same, True)
+        self._add("y", target, y_same, False)
+        if self.enable_viterbi:
+            vit_same = make_same_size_interpolate(np.array(result["viterbi_labels"]), len(target))
+            self._add("vit", target, vit_same, True)
+        self.vit_segs.append(vit_same if self.enable_viterbi else s_same)
+        self.y_segs.append(y_same)
+        self.s_segs.append(s_same)
+        self.s_lens.append(rel_lengths)
+        self.s_transcript.append(s_transcript)
+        self.target_segs.append(target)
+        self.target_transcripts.append(target_transcript)
         return result
+
+    def on_finish_eval(self):
+        """The reference's result record (evaluators.py:268-296) as a dict, plus `to_save` (evaluators.py:259-267)."""
+        self.to_save = {"y_segs": self.y_segs, "s_segs": self.s_segs, "vit_segs": self.vit_segs, "s_lens": self.s_lens,
+                        "s_transcript": self.s_transcript, "target_segs": self.target_segs,
+                        "target_transcripts": self.target_transcripts}
+        import warnings
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")       # the mean of an empty list (no video evaluated) is nan, as upstream
+            return {k: self.metrics[k].summary() for k in RESULT_FIELDS}
 
     @torch.no_grad()
     def evaluate(self, rank: int = 0, world_size: int = 1):
-        """Test videos sharded over ranks; MoF counters are all-reduced (a few scalars)."""
+        """Test videos sharded over ranks; every metric's accumulator is a few scalars, all-reduced as one vector."""
         self.model.eval()
-        self.model.set_teacher_forcing(False)
-        for m in (self.y_mof_metric, self.vit_mof_metric, self.vit_mof_nbg_metric):
+        self.model.set_teacher_forcing(False)          # reference evaluators.py:316-318
+        for m in self.metrics.values():
             m.reset()
+        self._reset_lists()
         for i in range(rank, len(self.test_db), world_size):
             batch = self.test_db[i].to(self.device)
             self.batch_eval_calculation(batch, self.model.forward(batch))
-        counts = torch.tensor([self.y_mof_metric.correct, self.y_mof_metric.total, self.vit_mof_metric.correct,
-                               self.vit_mof_metric.total, self.vit_mof_nbg_metric.correct, self.vit_mof_nbg_metric.total],
-                              dtype=torch.float64, device=self.device)
         if world_size > 1:
             import torch.distributed as dist
-            dist.all_reduce(counts)
-        c = counts.cpu().numpy()
-        div = lambda a, b: float(a / b) if b else 0.0  # noqa: E731
-        return {"y_mof": div(c[0], c[1]), "vit_mof": div(c[2], c[3]), "vit_mof_nbg": div(c[4], c[5])}
+            keys = sorted(self.metrics)
+            sizes = [len(self.metrics[k].state()) for k in keys]
+            flat = torch.tensor([x for k in keys for x in np.nan_to_num(np.asarray(self.metrics[k].state(), dtype=np.float64))],
+                                dtype=torch.float64, device=self.device)
+            dist.all_reduce(flat)
+            vals, off = flat.cpu().numpy(), 0
+            for k, n in zip(keys, sizes):
+                self.metrics[k].load_state(list(vals[off:off + n]))
+                off += n
+        return self.on_finish_eval()

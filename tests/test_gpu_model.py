@@ -118,4 +118,6 @@ def test_train_steps_and_viterbi_eval_on_synthetic_breakfast(tmp_path):
             assert r["viterbi_labels"] == want[1].tolist()
     if decoded == len(test_db):
         res = ev.evaluate()
-        assert set(res) == {"y_mof", "vit_mof", "vit_mof_nbg"} and 0.0 <= res["vit_mof"] <= 1.0
+        from mucon_amd.mucon.evaluators import RESULT_FIELDS
+        assert set(res) == set(RESULT_FIELDS) and 0.0 <= res["vit_mof"] <= 1.0 and len(res["vit_f1_score"]) == 3
+        assert len(ev.to_save["vit_segs"]) == len(test_db) and 0.0 <= res["s_mat_score"] <= 1.0
