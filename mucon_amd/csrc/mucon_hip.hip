@@ -16,7 +16,8 @@
 
 int g_nt_force_bm = 0;
 int g_fused_bm = 0;
-int g_no_fuse = 1;  // the fused two-stage layer kernels (gemm_fused.hpp) are opt-in: MUCON_FUSE=1
+int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
+long g_fuse_max_rows = 1L << 40;  // ... and only for levels with at most this many rows in the batch (MUCON_FUSE_MAXROWS)
 
 namespace {
 
@@ -329,6 +330,8 @@ int mucon_abi_version(void) {
         if (e) g_fused_bm = atoi(e);
         e = getenv("MUCON_FUSE");
         if (e) g_no_fuse = atoi(e) ? 0 : 1;
+        e = getenv("MUCON_FUSE_MAXROWS");
+        if (e) g_fuse_max_rows = atol(e);
         e = getenv("MUCON_TN_TARGET");
         if (e && atoi(e) > 0) g_tn_target = atoi(e);
         once = true;
@@ -433,7 +436,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         const bool centre_only = cfg->dilation[l] >= Tl;
         const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
         const int pool = !cfg->pool_after[l] ? 0 : (cfg->pool_type == 0 ? 1 : 2);
-        if (!g_no_fuse) {
+        if (!g_no_fuse && (long)B * Tl <= g_fuse_max_rows) {
             // one launch per residual layer: dilated_conv + non-linearity (temporal.py:48-49), then conv_1x1,
             // dropout, residual (:50-52) and the pooling of WaveNetBlock (:137-142); h crosses through LDS
             FusedParams f;
@@ -581,7 +584,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.drop = nodrop;
         rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw);
         if (rc != MUCON_OK) return rc;
-        if (!g_no_fuse && !cfg->pool_after[L - 1]) {
+        if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
             FusedParams f;
             memset(&f, 0, sizeof(f));
             f.Trows = Tz;
@@ -652,7 +655,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             const bool centre_only = cfg->dilation[l] >= Tl;
             const float *W1b = ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0);
             have_dpre = false;
-            if (!g_no_fuse && l >= 1 && !cfg->pool_after[l - 1]) {
+            if (!g_no_fuse && l >= 1 && !cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= g_fuse_max_rows) {
                 FusedParams f;
                 memset(&f, 0, sizeof(f));
                 f.Trows = Tl;

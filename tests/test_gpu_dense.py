@@ -334,3 +334,16 @@ def test_full_size_batch_properties():
     enc_o, _, logp_o = od.hot_path(tape[2:3].cpu().numpy(), params_np, ocfg, torch.float64)
     np.testing.assert_allclose(enc_a[2:3].cpu().numpy(), enc_o, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(logp_a[2:3].cpu().numpy(), logp_o, rtol=1e-4, atol=1e-4)
+
+
+def test_unfused_layer_path_still_green():
+    """The default runs one fused launch per residual layer (gemm_fused.hpp); MUCON_FUSE=0 (read once at library load)
+    selects the two-launch path.  Re-run the golden forward and the gradient checks under it in a fresh interpreter."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MUCON_FUSE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "forward or backward or dropout", "--deselect", f"{os.path.abspath(__file__)}::test_unfused_layer_path_still_green"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
