@@ -9,8 +9,19 @@
 //                 multiplied by layer l's dropout mask, LDS.  With taps = 1 stage 1 is last_conv's data gradient.
 //        stage 2: dpre_l = (g*drop . W2^T) * act'(h_l)                  -> out2
 //
-// Why: the coarse levels (T/8, T/16: <= 64 workgroups) are latency-bound -- every launch costs its own
+// Why: the coarse levels (T/8, T/16: <= 128 workgroups) are latency-bound -- every launch costs its own
 // prologue, k-loop ramp and epilogue, and the K = 128 GEMMs alone reach < 25 % MFMA utilisation.
+//
+// Pipeline: the k-tiles of both stages form ONE sequence v = 0 .. nkt1+3 (stage-1 tiles of W1 with their A rows,
+// then the four k-tiles of W2), staged exactly like gemm_nt.hpp: two register sets, tile v+2 requested while v
+// multiplies, the three phases load / MFMA / LDS-store pinned with sched_barrier, no guards around loads.  The first
+// two W2 tiles are therefore already in flight while stage 1 finishes and its epilogue runs.
+//
+// KS = 2 (opt-in for the BM = 32 variant, MUCON_FUSED_KS=2): 512 threads = 8 waves; waves 4-7 take the second half
+// of every 32-deep k-tile (same output tiles) and the two partial accumulators meet through the intermediate-tile LDS
+// buffer before each epilogue.  Measured on MI355X: no gain at B=8 x T=4096 (1.386 vs 1.381 ms per step) and a loss at
+// batch 1 (2.65 vs 2.29 ms per video), and it changes the summation order (a video alone is no longer bitwise equal
+// to the same video inside a batch) -- so KS = 1 is the default.
 #pragma once
 #include <type_traits>
 
@@ -42,12 +53,15 @@ struct FusedParams {
     DropCfg drop;       // element index (b*Trows + t)*128 + c
 };
 
-template <int WM, int WAVES_M, bool BWD, int POOL>
-__global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
+template <int WM, int WAVES_M, int KS, bool BWD, int POOL>
+__global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p) {
+    constexpr int NTHR = 256 * KS;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WN = 4 / WAVES_N;
     constexpr int BM = WAVES_M * WM * 32;
-    constexpr int NQA = BM / 32;
+    constexpr int LROWS = NTHR / 8;                       // rows one pass of the cooperative loader covers
+    constexpr int NQA = BM > LROWS ? BM / LROWS : 1;      // A float4 loads per thread (BM < LROWS: rows wrap, duplicates)
+    constexpr int NQW = 128 / LROWS;                      // W float4 loads per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
     float *Bs = smem + 2 * BM * NT_LDS;
@@ -55,7 +69,9 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kgrp = wave_all >> 2;      // k-half this wave multiplies (KS = 2), 0 otherwise
+    const int wave = wave_all & 3;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * BM;
@@ -63,9 +79,11 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
     const int lc4 = (tid & 7) * 4;
     const float *Ab = p.A + (long)b * p.Trows * 128;
     const long vbase = (long)b * p.Trows;
+    const int nkt1 = p.taps * 4;         // stage-1 k-tiles (4 per 128-channel tap)
+    const int vlast = nkt1 + 3;
 
-    f32x4 ra[NQA], rb[4];
-    bool ra_ok[NQA];  // padding rows are zeroed at the LDS store, so that the loads stay in flight (see gemm_nt.hpp)
+    f32x4 ra[2][NQA], rb[2][NQW];
+    bool ra_ok[2][NQA];  // padding rows are zeroed at the LDS store, so that the loads stay in flight (see gemm_nt.hpp)
     f32x16 acc[WM][WN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -75,43 +93,52 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     };
-    auto loadW = [&](const float *W, int ldw, int kt) {
+    // tile v of the unified sequence: only ISSUES loads (W1 / W2 chosen by select, A rows clamped)
+    auto gload = [&](int v, auto SET, auto WITH_A) {
+        constexpr int S = decltype(SET)::value;
+        const bool s2 = v >= nkt1;
+        const float *Wp = s2 ? p.W2 : p.W1;
+        const int ldw = s2 ? 128 : p.ldw1;
+        const int kcol = (s2 ? v - nkt1 : v) * 32 + lc4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            rb[q] = *reinterpret_cast<const f32x4 *>(W + (long)(lrow + 32 * q) * ldw + kt * 32 + lc4);
+        for (int q = 0; q < NQW; ++q) rb[S][q] = *reinterpret_cast<const f32x4 *>(Wp + (long)(lrow + LROWS * q) * ldw + kcol);
+        if (decltype(WITH_A)::value) {
+            const int kt = min(v, nkt1 - 1);
+            const int tap = kt >> 2;
+            const int kk = (kt & 3) * 32;
+            const int off = (tap - (p.taps >> 1)) * p.tap_step;
+#pragma unroll
+            for (int q = 0; q < NQA; ++q) {
+                const int t = t0 + ((lrow + LROWS * q) & (BM - 1));
+                const int ts = t + off;
+                ra_ok[S][q] = (t < p.Trows) && (ts >= 0) && (ts < p.Trows);
+                const int tc = ts < 0 ? 0 : (ts >= p.Trows ? p.Trows - 1 : ts);
+                ra[S][q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tc * 128 + kk + lc4);
+            }
+        }
     };
-    auto storeW = [&](int buf) {
+    auto sstore = [&](int buf, auto SET, auto WITH_A) {
+        constexpr int S = decltype(SET)::value;
         float *w = Bs + buf * 128 * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[q];
-    };
-    auto loadA = [&](int kt) {
-        const int tap = kt >> 2;  // 4 k-tiles of 32 per 128-channel tap
-        const int kk = (kt & 3) * 32;
-        const int off = (tap - (p.taps >> 1)) * p.tap_step;
+        for (int q = 0; q < NQW; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + LROWS * q) * NT_LDS + lc4) = rb[S][q];
+        if (decltype(WITH_A)::value) {
+            float *a = As + buf * BM * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < NQA; ++q) {
-            const int t = t0 + lrow + 32 * q;
-            const int ts = t + off;
-            ra_ok[q] = (t < p.Trows) && (ts >= 0) && (ts < p.Trows);   // branch-free load from a clamped row
-            const int tc = ts < 0 ? 0 : (ts >= p.Trows ? p.Trows - 1 : ts);
-            ra[q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tc * 128 + kk + lc4);
+            for (int q = 0; q < NQA; ++q) {
+                f32x4 v = ra[S][q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ra_ok[S][q] ? v[e] : 0.f;
+                *reinterpret_cast<f32x4 *>(a + ((lrow + LROWS * q) & (BM - 1)) * NT_LDS + lc4) = v;   // duplicates store equal values
+            }
         }
     };
-    auto storeA = [&](int buf) {
-        float *a = As + buf * BM * NT_LDS;
-#pragma unroll
-        for (int q = 0; q < NQA; ++q) {
-            f32x4 v = ra[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ra_ok[q] ? v[e] : 0.f;
-            *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = v;
-        }
-    };
-    // 32-deep k-tile of MFMAs: A fragments from `Aw` (row stride lda floats), W fragments from the staging buffer
+    // 32-deep k-tile of MFMAs (this wave's half of it when KS = 2): A fragments from `Aw` (row stride lda floats),
+    // W fragments from the staging buffer
     auto mfma_tile = [&](const float *Aw, int lda, const float *Bw) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int kq = 0; kq < 2 / KS; ++kq) {
+            const int ks = KS == 2 ? kgrp : kq;
             f32x4 av[WM][2], bv[WN][2];
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
@@ -133,32 +160,64 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
                                                                          acc[m][n], 0, 0, 0);
         }
     };
+    // KS = 2: the second k-half's partial sums cross to the first through Hs (each element is written and read by
+    // the same lane position of the wave pair, so no barrier is needed between this read and the epilogue's write)
+    auto merge_halves = [&]() {
+        if (KS == 2) {
+            if (kgrp == 1) {
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int row = (wr * WM + mt) * 32 + 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
+                            Hs[row * FUSED_HS + (wc * WN + nt) * 32 + (lane & 31)] = acc[mt][nt][reg];
+                        }
+            }
+            __syncthreads();
+            if (kgrp == 0) {
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int row = (wr * WM + mt) * 32 + 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
+                            acc[mt][nt][reg] += Hs[row * FUSED_HS + (wc * WN + nt) * 32 + (lane & 31)];
+                        }
+            }
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using YES = std::true_type;
+    using NO = std::false_type;
     const int a_row = wr * WM * 32 + (lane & 31);
     const int k_half = (lane >> 5) * 16;
     const int b_off = (wc * WN * 32 + (lane & 31)) * NT_LDS + k_half;
 
     // ---------------------------------------------------------------- stage 1
     zero_acc();
-    const int nkt1 = p.taps * 4;
-    loadA(0);
-    loadW(p.W1, p.ldw1, 0);
-    storeA(0);
-    storeW(0);
+    gload(0, S0{}, YES{});
+    gload(1, S1{}, YES{});
+    sstore(0, S0{}, YES{});
     __syncthreads();
-    for (int kt = 0; kt < nkt1; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt1) {
-            loadA(kt + 1);
-            loadW(p.W1, p.ldw1, kt + 1);
-        } else {
-            loadW(p.W2, 128, 0);  // first W2 tile rides under the last stage-1 k-tile
-        }
-        mfma_tile(As + cur * BM * NT_LDS + a_row * NT_LDS + k_half, NT_LDS, Bs + cur * 128 * NT_LDS + b_off);
-        if (kt + 1 < nkt1) storeA(cur ^ 1);
-        storeW(cur ^ 1);
+    for (int kt = 0; kt < nkt1; kt += 2) {   // nkt1 is 4 or 12; tiles >= nkt1 are W2's
+        gload(kt + 2, S0{}, YES{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(As + a_row * NT_LDS + k_half, NT_LDS, Bs + b_off);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(1, S1{}, YES{});
+        __syncthreads();
+        gload(kt + 3, S1{}, YES{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(As + BM * NT_LDS + a_row * NT_LDS + k_half, NT_LDS, Bs + 128 * NT_LDS + b_off);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(0, S0{}, YES{});
         __syncthreads();
     }
-    const int w2buf0 = nkt1 & 1;  // staging buffer that now holds W2 k-tile 0
+    // now: staging buffer 0 holds W2 k-tile 0, register set 1 holds W2 k-tile 1 (in flight)
 
     // stage-1 epilogue: global copy (saved / consumed later) + LDS copy (stage-2 A operand).  FULL tiles run
     // straight-line code (loads, math, stores batched per 32x32 tile; see gemm_nt.hpp).
@@ -202,17 +261,27 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
                 }
             }
     };
-    if (full_tile) epilogue1(std::true_type{});
-    else epilogue1(std::false_type{});
+    merge_halves();
+    if (kgrp == 0) {
+        if (full_tile) epilogue1(std::true_type{});
+        else epilogue1(std::false_type{});
+    }
     __syncthreads();
 
     // ---------------------------------------------------------------- stage 2 (K = 128: 4 k-tiles, A from Hs)
     zero_acc();
-    for (int kt = 0; kt < 4; ++kt) {
-        const int cur = (w2buf0 + kt) & 1;
-        if (kt + 1 < 4) loadW(p.W2, 128, kt + 1);
-        mfma_tile(Hs + a_row * FUSED_HS + kt * 32 + k_half, FUSED_HS, Bs + cur * 128 * NT_LDS + b_off);
-        if (kt + 1 < 4) storeW(cur ^ 1);
+    for (int kt = 0; kt < 4; kt += 2) {
+        gload(min(nkt1 + kt + 2, vlast), S0{}, NO{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(Hs + a_row * FUSED_HS + kt * 32 + k_half, FUSED_HS, Bs + b_off);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(1, S1{}, NO{});
+        __syncthreads();
+        gload(min(nkt1 + kt + 3, vlast), S1{}, NO{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(Hs + a_row * FUSED_HS + (kt + 1) * 32 + k_half, FUSED_HS, Bs + 128 * NT_LDS + b_off);
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(0, S0{}, NO{});
         __syncthreads();
     }
 
@@ -268,14 +337,17 @@ __global__ __launch_bounds__(256) void nt_fused_kernel(const FusedParams p) {
                 }
             }
     };
-    if (full_tile) epilogue2(std::true_type{});
-    else epilogue2(std::false_type{});
+    merge_halves();
+    if (kgrp == 0) {
+        if (full_tile) epilogue2(std::true_type{});
+        else epilogue2(std::false_type{});
+    }
 }
 
-template <int WM, int WAVES_M, bool BWD, int POOL>
+template <int WM, int WAVES_M, int KS, bool BWD, int POOL>
 static hipError_t launch_fused_cfg(const FusedParams &p, int B, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32;
-    auto k = nt_fused_kernel<WM, WAVES_M, BWD, POOL>;
+    auto k = nt_fused_kernel<WM, WAVES_M, KS, BWD, POOL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -284,14 +356,16 @@ static hipError_t launch_fused_cfg(const FusedParams &p, int B, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((p.Trows + BM - 1) / BM, B);
-    hipLaunchKernelGGL(k, grid, dim3(256), fused_smem_bytes(BM), s, p);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KS), fused_smem_bytes(BM), s, p);
     return hipGetLastError();
 }
 
 extern int g_fused_bm;  // 0 = automatic (tuning hook: MUCON_FUSED_BM = 32 / 64)
+extern int g_fused_ks;  // k-split of the BM = 32 variant: 1 (default) or 2 (tuning hook: MUCON_FUSED_KS)
 template <bool BWD, int POOL>
 static hipError_t launch_fused(const FusedParams &p, int B, hipStream_t s) {
     int bm = g_fused_bm ? g_fused_bm : (((long)B * p.Trows >= 512L * 64) ? 64 : 32);
-    if (bm == 64) return launch_fused_cfg<1, 2, BWD, POOL>(p, B, s);
-    return launch_fused_cfg<1, 1, BWD, POOL>(p, B, s);
+    if (bm == 64) return launch_fused_cfg<1, 2, 1, BWD, POOL>(p, B, s);
+    if (g_fused_ks == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
+    return launch_fused_cfg<1, 1, 1, BWD, POOL>(p, B, s);
 }

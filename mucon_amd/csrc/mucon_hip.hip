@@ -16,6 +16,7 @@
 
 int g_nt_force_bm = 0;
 int g_fused_bm = 0;
+int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
 long g_fuse_max_rows = 1L << 40;  // ... and only for levels with at most this many rows in the batch (MUCON_FUSE_MAXROWS)
 
@@ -328,6 +329,8 @@ int mucon_abi_version(void) {
         if (e) g_nt_force_bm = atoi(e);
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
+        e = getenv("MUCON_FUSED_KS");
+        if (e) g_fused_ks = atoi(e) == 2 ? 2 : 1;
         e = getenv("MUCON_FUSE");
         if (e) g_no_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_FUSE_MAXROWS");
