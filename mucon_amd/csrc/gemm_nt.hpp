@@ -43,6 +43,8 @@ struct NtParams {
     const float *bias;  // [128] or null
     float *out;         // [B][Tout][128]; Tout = Trows (POOL 0) or Trows/2 (POOL 1,2)
     float *out_pre;     // POOL 1: un-pooled rows [B][Trows][128], kept for the max-pool backward
+    const float *ypre;  // POOL 3: the forward's un-pooled rows [B][Tfine][128] (arg-max routing of the max-pool backward)
+    int Tfine;          // POOL 3 / 4: rows per video of the un-pooled level; out is [B][Tfine][128]
     const float *res;   // EPI_RES : [B][Trows][128] added after bias/act/dropout
     const float *mask;  // EPI_MASK: [B][Trows][128]; result *= act'(mask) (skipped when null)
     float slope;        // 0 = ReLU, 0.01 = leaky ReLU
@@ -223,6 +225,17 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                     if (EPI_RES) rres[reg] = p.res[g];
                     if (EPI_MASK) rmask[reg] = use_mask ? p.mask[g] : 1.f;
                 }
+                // POOL 3: the un-pooled pair of every output row, for the max-pool un-routing below
+                float y0[POOL == 3 ? 16 : 1], y1[POOL == 3 ? 16 : 1];
+                if (POOL == 3) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                        const long gf = ((long)b * p.Tfine + 2 * (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                        y0[reg] = p.ypre[gf];
+                        y1[reg] = p.ypre[gf + 128];
+                    }
+                }
                 float v[16];
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
@@ -248,7 +261,22 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                         if (POOL == 1) p.out_pre[g] = v[reg];
                     }
                 }
-                if (POOL != 0) {
+                if (POOL == 3 || POOL == 4) {
+                    // backward of max_pool1d(2) / the x2 sum pooling, fused into the producer of the pooled level's
+                    // gradient: row t of this (coarse) level goes to rows 2t, 2t+1 of the fine level -- to the arg-max
+                    // of the forward pair (first wins ties, as torch) or to both; an odd trailing fine row gets 0
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                        if (FULL || t < p.Trows) {
+                            const long gf = ((long)b * p.Tfine + 2 * t) * 128 + col;
+                            const bool second = POOL == 3 ? (y1[reg] > y0[reg]) : false;
+                            p.out[gf] = (POOL == 4 || !second) ? v[reg] : 0.f;
+                            p.out[gf + 128] = (POOL == 4 || second) ? v[reg] : 0.f;
+                            if (t == p.Trows - 1 && 2 * p.Trows < p.Tfine) p.out[gf + 256] = 0.f;
+                        }
+                    }
+                } else if (POOL != 0) {
 #pragma unroll
                     for (int rp = 0; rp < 8; ++rp) {
                         const int te = t0 + rbase + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);   // even time step of the pair

@@ -15,6 +15,7 @@
 #include "small_kernels.hpp"
 
 int g_nt_force_bm = 0;
+int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 int g_fused_bm = 0;
 int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
@@ -329,6 +330,8 @@ int mucon_abi_version(void) {
         if (e) g_nt_force_bm = atoi(e);
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
+        e = getenv("MUCON_UNPOOL_FUSE");
+        if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_FUSED_KS");
         if (e) g_fused_ks = atoi(e) == 2 ? 2 : 1;
         e = getenv("MUCON_FUSE");
@@ -570,6 +573,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         f.drop = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
     };
     bool have_dpre = false;  // dpre[l] already produced by the previous (fused) launch
+    bool unpooled_by_producer = false;  // dyd[l] (un-pooled gradient) already written by the launch that produced g[l+1]
     {   // last_conv backward: weight gradient on the side stream, data gradient on the chain
         if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
         WgradArgs a;
@@ -614,13 +618,16 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         if (!have_dpre) {
             if (cfg->pool_after[l]) {
                 float *u = ws + pl.dyd[l];
-                const long n4 = (long)B * Tl * 32;
-                const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
-                hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, ws + pl.g[l + 1],
-                                   cfg->pool_type == 0 ? ws + pl.ypre[l] : nullptr, u, B, Tl, cfg->pool_type);
-                HIPCHK(hipGetLastError());
+                if (!unpooled_by_producer) {
+                    const long n4 = (long)B * Tl * 32;
+                    const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+                    hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, ws + pl.g[l + 1],
+                                       cfg->pool_type == 0 ? ws + pl.ypre[l] : nullptr, u, B, Tl, cfg->pool_type);
+                    HIPCHK(hipGetLastError());
+                }
                 dyd = u;
             }
+            unpooled_by_producer = false;
             // gradient at the dilated conv's pre-activation: through conv_1x1 (dropout replayed) and the non-linearity
             NtParams p = nt_base(dyd, (long)Tl * 128, 128, Tl, Tl, 1, 0, 128, ws + pl.W2t + (size_t)l * 16384, nullptr,
                                  dpre, slope);
@@ -678,7 +685,18 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                 p.ldw = 384;
                 p.res = dyd;
                 p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
-                HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
+                if (l >= 1 && cfg->pool_after[l - 1] && !g_no_unpool_fuse) {
+                    // layer l-1 was pooled: this launch's epilogue scatters the gradient straight onto the un-pooled
+                    // rows of level l-1 (the max-pool backward), instead of a separate pass over that level
+                    p.out = ws + pl.dyd[l - 1];
+                    p.Tfine = pl.Tl[l - 1];
+                    p.ypre = cfg->pool_type == 0 ? ws + pl.ypre[l - 1] : nullptr;
+                    if (cfg->pool_type == 0) HIPCHK((launch_nt<false, false, false, false, true, true, 3>(p, B, s)));
+                    else HIPCHK((launch_nt<false, false, false, false, true, true, 4>(p, B, s)));
+                    unpooled_by_producer = true;
+                } else {
+                    HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
+                }
             }
         }
     }
