@@ -41,15 +41,24 @@ struct TnParams {
     DropCfg drop;     // set 1: Y1 element index (b*Trows + t)*128 + n
 };
 
-template <bool X0_ACT, bool DUAL>
-__global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
+// KS = 2: 512 threads = 8 waves; waves 4-7 multiply the second half (time steps 8-15 of each lane's 16) of every
+// 32-step m-tile into their own accumulators, which are added to those of waves 0-3 through LDS before the slab is
+// written.  A weight-gradient launch of a layer has one workgroup per CU (more workgroups = more slab traffic), i.e.
+// ONE wave per SIMD with KS = 1: every LDS-read latency and barrier is exposed (MFMA pipe 38 % busy at B=8 x T=4096);
+// the second wave per SIMD fills those gaps without adding slabs.
+template <bool X0_ACT, bool DUAL, int KS>
+__global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
+    constexpr int NTHR = 256 * KS;
+    constexpr int NQ = 4 / KS;           // float4 loads per thread and operand per m-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ys = smem;
     float *Xs = smem + 2 * 32 * 128;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kgrp = wave_all >> 2;
+    const int wave = wave_all & 3;
     const int wr = wave >> 1, wc = wave & 1;
     const int kc = blockIdx.x;
     const int mc = blockIdx.y;
@@ -65,15 +74,15 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     const int ldx = second ? 128 : p.ldx;
     const int Tx = second ? p.Trows : p.Tx;
 
-    f32x4 ry[4], rx[4];
-    int rty[4];      // time step of the staged Y row, -1 = padding
-    bool rokx[4];
+    f32x4 ry[NQ], rx[NQ];
+    int rty[NQ];      // time step of the staged Y row, -1 = padding
+    bool rokx[NQ];
     // loads are only ISSUED here (always, from clamped rows); zeroing, dropout replay and the ReLU prologue are
     // applied at the LDS store one m-tile later, so the loads stay in flight under the MFMAs
     auto gload = [&](int mtile) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int f = tid + 256 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int f = tid + NTHR * q;
             const int row = f >> 5, c4 = (f & 31) * 4;
             const int t = tbeg + mtile * 32 + row;
             const int ts = t + xoff;
@@ -88,8 +97,8 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int f = tid + 256 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int f = tid + NTHR * q;
             const int c4 = (f & 31) * 4;
             f32x4 y = ry[q], x = rx[q];
             if (DUAL) {
@@ -140,7 +149,8 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
         const float *Yw = Ys + cur * 4096 + y_off;
         const float *Xw = Xs + cur * 4096 + x_off;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s0 = 0; s0 < 16 / KS; ++s0) {
+            const int s = KS == 2 ? kgrp * 8 + s0 : s0;
             const float a0 = Yw[s * 128], a1 = Yw[s * 128 + 32];
             const float b0 = Xw[s * 128], b1 = Xw[s * 128 + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -158,6 +168,25 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
         __syncthreads();
     }
 
+    if (KS == 2) {   // the tiles are dead after the loop's last barrier: 64 KiB of LDS carry the second half's sums
+        float *xch = smem + ((wave * 4) * 16) * 64 + lane;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) xch[((mt * 2 + nt) * 16 + reg) * 64] = acc[mt][nt][reg];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] += xch[((mt * 2 + nt) * 16 + reg) * 64];
+    }
     float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc * 128;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -173,9 +202,9 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnParams p) {
     if (do_bias) p.bias_slabs[(long)mc * 256 + (second ? 128 : 0) + tid] = bsum;
 }
 
-template <bool X0_ACT, bool DUAL>
+template <bool X0_ACT, bool DUAL, int KS>
 static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
-    auto k = tn_gemm_kernel<X0_ACT, DUAL>;
+    auto k = tn_gemm_kernel<X0_ACT, DUAL, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -184,7 +213,7 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(p.Ktot / 128, B * p.chunks_per_video);
-    hipLaunchKernelGGL(k, grid, dim3(256), TN_SMEM_BYTES, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KS), TN_SMEM_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 #include "small_kernels.hpp"
 
 int g_nt_force_bm = 0;
+int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
 int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 int g_fused_bm = 0;
 int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
@@ -260,9 +261,18 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     arena += need;
     barena += bneed;
     if (prof_slot >= 0) prof_mark(prof_slot, false, s);
-    if (dual) HIPCHK((launch_tn<false, true>(t, pl.B, s)));
-    else if (a.x0_act) HIPCHK((launch_tn<true, false>(t, pl.B, s)));
-    else HIPCHK((launch_tn<false, false>(t, pl.B, s)));
+    // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
+    const bool ks2 = g_tn_ks == 2 || (g_tn_ks == 0 && dual);
+    if (dual) {
+        if (ks2) HIPCHK((launch_tn<false, true, 2>(t, pl.B, s)));
+        else HIPCHK((launch_tn<false, true, 1>(t, pl.B, s)));
+    } else if (a.x0_act) {
+        if (ks2) HIPCHK((launch_tn<true, false, 2>(t, pl.B, s)));
+        else HIPCHK((launch_tn<true, false, 1>(t, pl.B, s)));
+    } else {
+        if (ks2) HIPCHK((launch_tn<false, false, 2>(t, pl.B, s)));
+        else HIPCHK((launch_tn<false, false, 1>(t, pl.B, s)));
+    }
     if (prof_slot >= 0) prof_mark(prof_slot, true, s);
     const long ss = (long)128 * t.Ktot;
     bool ok = red.add(t.slabs, nmc, ss, t.Ktot, 0, 128, a.nk0 * 128, a.out_w0, a.mode0);
@@ -330,6 +340,8 @@ int mucon_abi_version(void) {
         if (e) g_nt_force_bm = atoi(e);
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
+        e = getenv("MUCON_TN_KS");
+        if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_UNPOOL_FUSE");
         if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_FUSED_KS");
