@@ -117,8 +117,11 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
                 y[e] = rty[q] >= 0 ? y[e] : 0.f;
                 x[e] = rokx[q] ? x[e] : 0.f;
             }
-            *reinterpret_cast<f32x4 *>(Ys + buf * 4096 + f * 4) = y;
-            *reinterpret_cast<f32x4 *>(Xs + buf * 4096 + f * 4) = x;
+            // rows 16..31 are rotated by 32 columns: the two lane halves of an MFMA operand read (rows s and 16 + s)
+            // then hit disjoint bank halves instead of colliding 2-way
+            const int sw = (f >> 5) * 128 + ((c4 + ((f >> 9) & 1) * 32) & 127);
+            *reinterpret_cast<f32x4 *>(Ys + buf * 4096 + sw) = y;
+            *reinterpret_cast<f32x4 *>(Xs + buf * 4096 + sw) = x;
         }
     };
 
@@ -133,8 +136,9 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
     const bool do_bias = (p.bias_slabs != nullptr) && (kc == 0 || (DUAL && kc == p.nk0)) && (tid < 128);
 
     // lane (i = lane&31, h = lane>>5): MFMA step s consumes time step 16h + s of the tile.
-    const int y_off = (lane >> 5) * 16 * 128 + wr * 64 + (lane & 31);
-    const int x_off = (lane >> 5) * 16 * 128 + wc * 64 + (lane & 31);
+    const int hrow = (lane >> 5) * 16 * 128, hrot = (lane >> 5) * 32;
+    const int y_off0 = hrow + ((wr * 64 + (lane & 31) + hrot) & 127), y_off1 = hrow + ((wr * 64 + 32 + (lane & 31) + hrot) & 127);
+    const int x_off0 = hrow + ((wc * 64 + (lane & 31) + hrot) & 127), x_off1 = hrow + ((wc * 64 + 32 + (lane & 31) + hrot) & 127);
 
     // ntiles >= 1.  Guard-free loop body (the tail re-loads the last tile into the buffer nobody reads) with the
     // phases pinned: loads issued first, MFMAs, then the first use of the loaded data at the LDS store -- so the
@@ -146,22 +150,22 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
         const int cur = mt & 1;
         gload(min(mt + 1, ntiles - 1));
         __builtin_amdgcn_sched_barrier(0);
-        const float *Yw = Ys + cur * 4096 + y_off;
-        const float *Xw = Xs + cur * 4096 + x_off;
+        const float *Yw0 = Ys + cur * 4096 + y_off0, *Yw1 = Ys + cur * 4096 + y_off1;
+        const float *Xw0 = Xs + cur * 4096 + x_off0, *Xw1 = Xs + cur * 4096 + x_off1;
 #pragma unroll
         for (int s0 = 0; s0 < 16 / KS; ++s0) {
             const int s = KS == 2 ? kgrp * 8 + s0 : s0;
-            const float a0 = Yw[s * 128], a1 = Yw[s * 128 + 32];
-            const float b0 = Xw[s * 128], b1 = Xw[s * 128 + 32];
+            const float a0 = Yw0[s * 128], a1 = Yw1[s * 128];
+            const float b0 = Xw0[s * 128], b1 = Xw1[s * 128];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (do_bias) {
-            const float *Yc = Ys + cur * 4096 + tid;
+            const float *Yc = Ys + cur * 4096;
 #pragma unroll 8
-            for (int m = 0; m < 32; ++m) bsum += Yc[m * 128];
+            for (int m = 0; m < 32; ++m) bsum += Yc[m * 128 + ((tid + (m >> 4) * 32) & 127)];
         }
         __builtin_amdgcn_sched_barrier(0);
         sstore(cur ^ 1);
