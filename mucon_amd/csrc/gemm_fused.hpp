@@ -29,7 +29,11 @@
 #include "gemm_nt.hpp"
 
 constexpr int FUSED_HS = 132;  // padded row length of the intermediate tile (floats): 132 mod 64 = 4 -> conflict-free b128 reads
-constexpr int fused_smem_bytes(int BM) { return nt_smem_bytes(BM) + BM * FUSED_HS * 4; }
+// LDS: [intermediate tile Hs, BM x 132] [W staging, 2 x 128 x 36].  The A staging buffers (2 x BM x 36) OVERLAY the
+// start of Hs: they are dead once stage 1's k-loop has passed its last barrier, which is before the stage-1 epilogue
+// writes Hs.  BM = 64: 70.7 KB instead of 89 KB, i.e. TWO workgroups per CU instead of one (160 KB LDS).
+constexpr int fused_smem_bytes(int BM) { return (BM * FUSED_HS + 2 * 128 * NT_LDS) * 4; }
+static_assert(FUSED_HS >= 2 * NT_LDS, "the A staging buffers must fit inside the intermediate tile");
 
 struct FusedParams {
     int Trows;          // rows per video (same for both stages)
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     constexpr int NQA = BM > LROWS ? BM / LROWS : 1;      // A float4 loads per thread (BM < LROWS: rows wrap, duplicates)
     constexpr int NQW = 128 / LROWS;                      // W float4 loads per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;
-    float *Bs = smem + 2 * BM * NT_LDS;
-    float *Hs = Bs + 2 * 128 * NT_LDS;   // [BM][FUSED_HS]
+    float *Hs = smem;                    // [BM][FUSED_HS]
+    float *As = smem;                    // [2][BM][NT_LDS], dead before Hs is written
+    float *Bs = smem + BM * FUSED_HS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
