@@ -308,13 +308,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
             Ls[zi * HEAD_MAXC + c] = s;
         }
         __syncthreads();
-        if (tid < nz) {
-            float m = -INFINITY;
-            for (int c = 0; c < C; ++c) m = fmaxf(m, Ls[tid * HEAD_MAXC + c]);
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) s += expf(Ls[tid * HEAD_MAXC + c] - m);
-            const float lse = m + logf(s);
-            for (int c = 0; c < C; ++c) Ps[tid * HEAD_MAXC + c] = Ls[tid * HEAD_MAXC + c] - lse;
+        // log-softmax over the classes: a wave per z row, lane = class (C <= 64); the sum runs up a fixed shuffle tree
+        for (int zi = tid >> 6; zi < nz; zi += 4) {
+            const int c = tid & 63;
+            const float x = c < C ? Ls[zi * HEAD_MAXC + c] : -INFINITY;
+            float m = x;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float s = c < C ? expf(x - m) : 0.f;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+            if (c < C) Ps[zi * HEAD_MAXC + c] = x - (m + logf(s));
         }
         __syncthreads();
         for (int e = tid; e < (i1 - i0) * C; e += 256) {
@@ -362,11 +366,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs a) {
         const int zi = o / C, c = o - zi * C;
         const int fa = first_frame(z0 + zi, a.scale, a.Tz, a.Tf);
         const int fb = first_frame(z0 + zi + 1, a.scale, a.Tz, a.Tf);
+        // frames of the bin in order (same sums as a plain loop), eight loads in flight at a time: a bin has ~Tf/Tz = 16
+        // frames and a dependent-looking loop made this kernel a chain of 16 x 3 memory round trips
         float g1 = 0.f, g2 = 0.f;
-        for (int i = fa; i < fb; ++i) {
-            const long g = ((long)b * a.Tf + i) * C + c;
-            if (a.dlogits) g1 += a.dlogits[g];
-            if (a.dlogp) g2 += a.dlogp[g];
+        const int nfr = fb - fa;
+        for (int base = 0; base < nfr; base += 8) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long g = ((long)b * a.Tf + fa + min(base + j, nfr - 1)) * C + c;
+                v1[j] = a.dlogits ? a.dlogits[g] : 0.f;
+                v2[j] = a.dlogp ? a.dlogp[g] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (base + j < nfr) {
+                    g1 += v1[j];
+                    g2 += v2[j];
+                }
+            }
         }
         G1[zi * HEAD_MAXC + c] = g1;
         G2[zi * HEAD_MAXC + c] = g2;
