@@ -220,6 +220,9 @@ def main():
     tape = torch.randn(B, T, spec.in_dim, device=dev, generator=g)      # resident in HBM
     dlogp = torch.randn(B, T, C, device=dev, generator=g) / (B * T)     # dL/dlogp handed to the backward
     lr, wd = 0.01, 0.005                                                # reference default.py:21-24
+    import types
+    sgd = ops.FusedClipSGD([flat_params], None,                         # SGD(lr, weight_decay) in one launch (csrc/optim.hpp)
+                           types.SimpleNamespace(param_groups=[{"lr": lr, "weight_decay": wd, "momentum": 0.0}]))
 
     def step(i):
         for p in flat_params:
@@ -227,15 +230,12 @@ def main():
         enc = ops.encoder_forward(tape, enc_params, spec, training=True, seed=i)
         _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
         logp.backward(dlogp)
-        grads = [p.grad for p in flat_params]
         if dist is not None:
             # the one exchange step: sum the gradients over ranks (the encoder's gradients are views of one flat
             # buffer, the two head tensors ride in a second tiny call), then average
             for buf in ops.flat_grad_buffers(flat_params):
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG)
-        with torch.no_grad():
-            torch._foreach_add_(grads, flat_params, alpha=wd)
-            torch._foreach_add_(flat_params, grads, alpha=-lr)
+        sgd.step()
 
     def sync():
         torch.cuda.synchronize()

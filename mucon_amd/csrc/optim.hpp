@@ -56,6 +56,7 @@ struct SgdHyper {
     float max_norm[SGD_MAXGROUPS];   // <= 0: no clipping for the group
     float lr, weight_decay, momentum;
     int ngroups, nblocks;
+    int any_clip;                    // 0: no group clips -- the norm pass is skipped altogether
 };
 
 __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, int nt, const float *partial, SgdHyper h,
@@ -64,12 +65,12 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
     const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
     // squared norm of this block's group: partials of every tensor of the group, strided over the threads
     float acc = 0.f;
-    for (int i = 0; i < nt; ++i) {
+    for (int i = 0; i < nt && h.any_clip; ++i) {
         if (tab[i].group != t.group) continue;
         const int e0 = tab[i].block0, e1 = i + 1 < nt ? tab[i + 1].block0 : h.nblocks;
         for (int b = e0 + threadIdx.x; b < e1; b += 256) acc += partial[b];
     }
-    const float norm = sqrtf(sgd_block_sum(acc, red));
+    const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];
     const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
     if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {

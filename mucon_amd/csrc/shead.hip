@@ -406,7 +406,9 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     h.momentum = momentum;
     h.ngroups = n_groups;
     h.nblocks = blocks;
-    hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
+    h.any_clip = 0;
+    for (int g = 0; g < n_groups; ++g) h.any_clip |= max_norm[g] > 0.f;
+    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
     hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial, h, group_norms);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
