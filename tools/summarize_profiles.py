@@ -49,7 +49,7 @@ def pmc(pattern, counter):
         k = r["Kernel_Name"]
         if "nt_gemm_kernel" in k and "pack_weights" in prev:
             fwd.append(float(r["Counter_Value"]))
-        if "tn_gemm_kernel<false, false>" in k:
+        if "tn_gemm_kernel<false, false" in k:
             wg.append(float(r["Counter_Value"]))
         prev = k
     return {"first_conv_fwd": fwd, "first_conv_wgrad": wg}
