@@ -224,6 +224,13 @@ def main():
     sgd = ops.FusedClipSGD([flat_params], None,                         # SGD(lr, weight_decay) in one launch (csrc/optim.hpp)
                            types.SimpleNamespace(param_groups=[{"lr": lr, "weight_decay": wd, "momentum": 0.0}]))
 
+    pending = []
+    if dist is not None:
+        def send_early(p):
+            pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True))
+        wc.register_post_accumulate_grad_hook(send_early)
+        bc.register_post_accumulate_grad_hook(send_early)
+
     def step(i):
         for p in flat_params:
             p.grad = None
@@ -231,10 +238,18 @@ def main():
         _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
         logp.backward(dlogp)
         if dist is not None:
-            # the one exchange step: sum the gradients over ranks (the encoder's gradients are views of one flat
-            # buffer, the two head tensors ride in a second tiny call), then average
+            # the one exchange step: average the gradients over ranks.  The two y-head tensors were sent off by their
+            # post-accumulate hooks as soon as the head's backward had produced them (they ride under the encoder's
+            # backward); the encoder's gradients are views of ONE flat buffer: a single all-reduce on the critical path.
+            # (Splitting that one so that all but first_conv's part overlaps first_conv's weight gradient was tried:
+            # +35 us of extra launches and stream hand-offs at world size 1, not measurable here at N > 1 -- left out.)
+            head_bufs = {wc.grad.untyped_storage().data_ptr(), bc.grad.untyped_storage().data_ptr()}
             for buf in ops.flat_grad_buffers(flat_params):
-                dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+                if buf.untyped_storage().data_ptr() not in head_bufs:
+                    dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+            for w in pending:
+                w.wait()
+            pending.clear()
         sgd.step()
 
     def sync():
