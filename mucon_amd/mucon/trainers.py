@@ -32,22 +32,36 @@ def create_scheduler(cfg, optimizer):
 
 
 def all_reduce_gradients(model, world_size: int):
-    """Average the gradients over ranks with one flat all-reduce (1,643,298 floats = 6.57 MB for the
-    default model).  Parameters without a gradient on this rank contribute zeros."""
+    """Average the gradients over ranks (1,643,298 floats = 6.57 MB for the default model) in two collectives:
+    gradients that are views of one flat buffer (the HIP encoder's backward writes all of its 50 gradients into one,
+    ops._EncoderFn.backward) are all-reduced in place; the remaining, individually allocated ones (s-head, y-head) are
+    packed into one buffer, all-reduced, and scattered back with one multi-tensor copy.  Parameters without a gradient on
+    this rank contribute zeros."""
     import torch.distributed as dist
 
     params = [p for p in model.parameters() if p.requires_grad]
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat)
-    flat /= world_size
-    off = 0
+    by_storage = {}
     for p in params:
-        n = p.numel()
+        if p.grad is not None:
+            by_storage.setdefault(p.grad.untyped_storage().data_ptr(), []).append(p)
+    loose = []
+    for p in params:
         if p.grad is None:
-            p.grad = flat[off: off + n].view_as(p).clone()
-        else:
-            p.grad.copy_(flat[off: off + n].view_as(p))
-        off += n
+            p.grad = torch.zeros_like(p)
+            loose.append(p)
+        elif len(by_storage[p.grad.untyped_storage().data_ptr()]) == 1:
+            loose.append(p)
+    for group in by_storage.values():
+        if len(group) > 1:   # one flat buffer behind several gradients: reduce it where it lies
+            g = group[0].grad
+            flat = torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage())
+            dist.all_reduce(flat)
+            flat /= world_size
+    if loose:
+        flat = torch.cat([p.grad.reshape(-1) for p in loose])
+        dist.all_reduce(flat)
+        flat /= world_size
+        torch._foreach_copy_([p.grad for p in loose], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in loose]), loose)])
 
 
 class SimpleTrainer:

@@ -36,7 +36,15 @@ def _worker(rank, world, port, out_dir):
     y = model[3](model[2](h)) if rank == 0 else h[:, :2] * 1.0
     y.sum().backward()
     local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    # like the HIP encoder's backward, the first layer's gradients are views of ONE flat buffer (reduced in place)
+    ps = list(model[0].parameters())
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    off = 0
+    for p in ps:
+        p.grad = flat[off: off + p.numel()].view_as(p)
+        off += p.numel()
     all_reduce_gradients(model, world)
+    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in ps)
     torch.save({"local": local, "avg": [p.grad.clone() for p in model.parameters()]}, os.path.join(out_dir, f"r{rank}.pt"))
 
     # shard arithmetic of SimpleTrainer.train_epoch: disjoint, same count on every rank
