@@ -47,10 +47,9 @@ struct TnParams {
 // ONE wave per SIMD with KS = 1: every LDS-read latency and barrier is exposed (MFMA pipe 38 % busy at B=8 x T=4096);
 // the second wave per SIMD fills those gaps without adding slabs.
 template <bool X0_ACT, bool DUAL, int KS>
-__global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
+__device__ __forceinline__ void tn_body(const TnParams &p, const int kc, const int mc, float *smem) {
     constexpr int NTHR = 256 * KS;
     constexpr int NQ = 4 / KS;           // float4 loads per thread and operand per m-tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ys = smem;
     float *Xs = smem + 2 * 32 * 128;
 
@@ -60,8 +59,6 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
     const int kgrp = wave_all >> 2;
     const int wave = wave_all & 3;
     const int wr = wave >> 1, wc = wave & 1;
-    const int kc = blockIdx.x;
-    const int mc = blockIdx.y;
     const int b = mc / p.chunks_per_video;
     const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
     const int tend = min(tbeg + p.MC, p.Trows);
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
                     for (int reg = 0; reg < 16; ++reg) xch[((mt * 2 + nt) * 16 + reg) * 64] = acc[mt][nt][reg];
         }
         __syncthreads();
-        if (kgrp == 1) return;
+        if (kgrp == 1) return;   // (KS = 2 exists only in the one-job kernel: nothing follows the body there)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -204,6 +201,60 @@ __global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
             }
         }
     if (do_bias) p.bias_slabs[(long)mc * 256 + (second ? 128 : 0) + tid] = bsum;
+}
+
+template <bool X0_ACT, bool DUAL, int KS>
+__global__ __launch_bounds__(256 * KS) void tn_gemm_kernel(const TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    tn_body<X0_ACT, DUAL, KS>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// Every weight gradient of the residual layers (and last_conv's) in ONE launch at the end of the data-gradient chain:
+// a launch per layer costs ~13 us of ramp, prologue and slab write-out each, and on the coarse levels has too few
+// workgroups to fill the chip.  Jobs are laid out longest-first; a workgroup finds its job by its block index.
+constexpr int TN_MAX_BATCH = 16;
+struct TnJob {
+    TnParams p;
+    int block0, nkc;      // first block of the job, k-chunks per time chunk
+    int x0_act, dual;
+};
+struct TnBatch {
+    TnJob j[TN_MAX_BATCH];
+    int njobs, nblocks;
+};
+__global__ __launch_bounds__(256) void tn_batched_kernel(const TnBatch tb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int ji = 0;
+    while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
+    const TnJob &job = tb.j[ji];
+    const int local = blockIdx.x - job.block0;
+    const int mc = local / job.nkc, kc = local - mc * job.nkc;
+    if (job.dual) tn_body<false, true, 1>(job.p, kc, mc, smem);
+    else if (job.x0_act) tn_body<true, false, 1>(job.p, kc, mc, smem);
+    else tn_body<false, false, 1>(job.p, kc, mc, smem);
+}
+static hipError_t launch_tn_batch(TnBatch &tb, hipStream_t s) {
+    if (tb.njobs == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tn_batched_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
+    TnBatch lb;
+    lb.njobs = tb.njobs;
+    int blocks = 0;
+    for (int i = 0; i < tb.njobs; ++i) {
+        lb.j[i] = tb.j[tb.njobs - 1 - i];
+        lb.j[i].block0 = blocks;
+        blocks += lb.j[i].nkc * (tb.j[tb.njobs - 1 - i].block0);   // block0 carried the time-chunk count while queued
+    }
+    lb.nblocks = blocks;
+    hipLaunchKernelGGL(tn_batched_kernel, dim3(blocks), dim3(256), TN_SMEM_BYTES, s, lb);
+    tb.njobs = 0;
+    return hipGetLastError();
 }
 
 template <bool X0_ACT, bool DUAL, int KS>

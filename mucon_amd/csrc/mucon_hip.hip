@@ -15,6 +15,7 @@
 #include "small_kernels.hpp"
 
 int g_nt_force_bm = 0;
+int g_tn_batch = 1;  // all layer weight gradients in one launch after the data-gradient chain (MUCON_TN_BATCH=0: one launch per layer)
 int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
 int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 int g_fused_bm = 0;
@@ -44,8 +45,10 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
-inline int pick_mc(int B, int Trows, int kchunks) {
-    long want = ((long)B * Trows * kchunks + g_tn_target - 1) / g_tn_target;
+int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
+inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {
+    const int target = batched ? g_tn_batch_target : g_tn_target;
+    long want = ((long)B * Trows * kchunks + target - 1) / target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
     if (mc > 1024) mc = 1024;
@@ -232,7 +235,7 @@ struct WgradArgs {
     DropCfg drop;
 };
 int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, const WgradArgs &a, float slope,
-          Reducer &red, hipStream_t s, int prof_slot = -1) {
+          Reducer &red, hipStream_t s, int prof_slot = -1, TnBatch *batch = nullptr) {
     const bool dual = a.Y1 != nullptr;
     TnParams t;
     memset(&t, 0, sizeof(t));
@@ -248,7 +251,7 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     t.Y1 = a.Y1;
     t.X1 = a.X1;
     t.Ktot = 128 * (a.nk0 + (dual ? 1 : 0));
-    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128);
+    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr);
     t.chunks_per_video = (Trows + t.MC - 1) / t.MC;
     t.slope = slope;
     t.drop = a.drop;
@@ -260,6 +263,15 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     t.bias_slabs = ws + pl.bslabs + barena;
     arena += need;
     barena += bneed;
+    if (batch) {
+        if (batch->njobs >= TN_MAX_BATCH) HIPCHK(launch_tn_batch(*batch, s));
+        TnJob &jb = batch->j[batch->njobs++];
+        jb.p = t;
+        jb.nkc = t.Ktot / 128;
+        jb.block0 = nmc;   // time-chunk count while queued; launch_tn_batch turns it into the block offset
+        jb.x0_act = a.x0_act ? 1 : 0;
+        jb.dual = dual ? 1 : 0;
+    } else {
     if (prof_slot >= 0) prof_mark(prof_slot, false, s);
     // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
     const bool ks2 = g_tn_ks == 2 || (g_tn_ks == 0 && dual);
@@ -274,6 +286,7 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
         else HIPCHK((launch_tn<false, false, 1>(t, pl.B, s)));
     }
     if (prof_slot >= 0) prof_mark(prof_slot, true, s);
+    }
     const long ss = (long)128 * t.Ktot;
     bool ok = red.add(t.slabs, nmc, ss, t.Ktot, 0, 128, a.nk0 * 128, a.out_w0, a.mode0);
     if (a.out_b0) ok = ok && red.add(t.bias_slabs, nmc, 256, 256, 0, 1, 128, a.out_b0, 0);
@@ -340,6 +353,10 @@ int mucon_abi_version(void) {
         if (e) g_nt_force_bm = atoi(e);
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
+        e = getenv("MUCON_TN_BATCH");
+        if (e) g_tn_batch = atoi(e) ? 1 : 0;
+        e = getenv("MUCON_TN_BATCH_TARGET");
+        if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
         if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_UNPOOL_FUSE");
@@ -549,6 +566,9 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     Reducer red(s);
     size_t arena = 0, barena = 0;
     float *gz = ws + pl.gz;
+    TnBatch tnb;
+    tnb.njobs = 0;
+    TnBatch *batch = g_tn_batch ? &tnb : nullptr;   // queue the layer weight gradients for one launch after the chain
 
     {   // GroupNorm / ReLU / Dropout backward -> dz
         GnBwdArgs g;
@@ -586,8 +606,8 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     };
     bool have_dpre = false;  // dpre[l] already produced by the previous (fused) launch
     bool unpooled_by_producer = false;  // dyd[l] (un-pooled gradient) already written by the launch that produced g[l+1]
-    {   // last_conv backward: weight gradient on the side stream, data gradient on the chain
-        if (overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
+    {   // last_conv backward: weight gradient queued (or on the side stream), data gradient on the chain
+        if (!batch && overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
         WgradArgs a;
         memset(&a, 0, sizeof(a));
         a.Y0 = gz;
@@ -601,7 +621,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.out_w0 = gr->last_w;
         a.out_b0 = gr->last_b;
         a.drop = nodrop;
-        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw);
+        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw, -1, batch);
         if (rc != MUCON_OK) return rc;
         if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
             FusedParams f;
@@ -650,7 +670,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         {   // all four parameter gradients of the layer in one launch -- off the critical path (second stream) at the
             // coarse levels, where neither this launch nor the data-gradient chain fills the chip; at the fine
             // levels both do, and running them side by side only makes them thrash
-            const bool side = overlap && (long)B * Tl < 512L * 64;
+            const bool side = !batch && overlap && (long)B * Tl < 512L * 64;
             if (side && (rc = g_side.fork(s)) != MUCON_OK) return rc;
             WgradArgs a;
             memset(&a, 0, sizeof(a));
@@ -670,7 +690,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             a.out_w1 = gr->pw_w[l];
             a.out_b1 = gr->pw_b[l];
             a.drop = dl;
-            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, side ? sw : s);
+            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, side ? sw : s, -1, batch);
             if (rc != MUCON_OK) return rc;
         }
         {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
@@ -712,6 +732,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
+    if (batch) HIPCHK(launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
