@@ -167,7 +167,8 @@ int mucon_bench_first_conv(const float *tape, const float *w, const float *b, fl
 
 /* Per-launch timing of the two kernels that stream the tape, taken with HIP events on the stream
  * the kernels run on, while the normal fwd/bwd calls execute (bench.py's roofline leg):
- * slot 0 = first_conv forward, slot 1 = first_conv weight gradient.  begin() arms up to
+ * slot 0 = first_conv forward, slot 1 = the weight-gradient launch (the one batched launch of every layer's and
+ * first_conv's weight gradients; first_conv's alone with MUCON_TN_BATCH<2).  begin() arms up to
  * max_records launches per slot; end() synchronises on the recorded events and returns the
  * summed milliseconds and the launch count per slot (arrays of 2). */
 int mucon_profile_begin(int32_t max_records);

@@ -15,7 +15,9 @@
 #include "small_kernels.hpp"
 
 int g_nt_force_bm = 0;
-int g_tn_batch = 1;  // all layer weight gradients in one launch after the data-gradient chain (MUCON_TN_BATCH=0: one launch per layer)
+// weight gradients: 2 = ONE launch for every layer's and first_conv's after the data-gradient chain; 1 = the layers' in one
+// launch, first_conv's in its own; 0 = one launch per layer (coarse levels on the side stream)  (MUCON_TN_BATCH)
+int g_tn_batch = 2;
 int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
 int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 int g_fused_bm = 0;
@@ -354,7 +356,7 @@ int mucon_abi_version(void) {
         e = getenv("MUCON_FUSED_BM");
         if (e) g_fused_bm = atoi(e);
         e = getenv("MUCON_TN_BATCH");
-        if (e) g_tn_batch = atoi(e) ? 1 : 0;
+        if (e) g_tn_batch = atoi(e);
         e = getenv("MUCON_TN_BATCH_TARGET");
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
@@ -732,7 +734,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
-    if (batch) HIPCHK(launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
+    if (batch && g_tn_batch < 2) HIPCHK(launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
@@ -746,10 +748,15 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.out_w0 = gr->first_w;
         a.out_b0 = gr->first_b;
         a.drop = nodrop;
-        rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1);
+        rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1, g_tn_batch >= 2 ? batch : nullptr);
         if (rc != MUCON_OK) return rc;
     }
-    if (overlap && (rc = g_side.join(s)) != MUCON_OK) return rc;
+    if (batch && g_tn_batch >= 2) {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
+        prof_mark(1, false, s);
+        HIPCHK(launch_tn_batch(tnb, s));
+        prof_mark(1, true, s);
+    }
+    if (!batch && overlap && (rc = g_side.join(s)) != MUCON_OK) return rc;
     HIPCHK(red.run());
     return MUCON_OK;
 }
