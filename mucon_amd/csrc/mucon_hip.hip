@@ -47,13 +47,14 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
+int g_tn_mc_cap = 1024;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {
     const int target = batched ? g_tn_batch_target : g_tn_target;
     long want = ((long)B * Trows * kchunks + target - 1) / target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
-    if (mc > 1024) mc = 1024;
+    if (mc > g_tn_mc_cap) mc = g_tn_mc_cap;
     return (int)mc;
 }
 
@@ -357,6 +358,8 @@ int mucon_abi_version(void) {
         if (e) g_fused_bm = atoi(e);
         e = getenv("MUCON_TN_BATCH");
         if (e) g_tn_batch = atoi(e);
+        e = getenv("MUCON_TN_MC_CAP");
+        if (e && atoi(e) >= 128) g_tn_mc_cap = atoi(e) / 32 * 32;
         e = getenv("MUCON_TN_BATCH_TARGET");
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
