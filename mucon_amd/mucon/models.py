@@ -171,7 +171,7 @@ class MuCon(nn.Module):
         if self.teacher_forcing:
             transcript = batch.transcript_tf_target.detach().cpu().numpy().tolist()
         else:
-            transcript = [w.argmax().item() for w in forward_out.transcript]
+            transcript = forward_out.transcript.argmax(dim=1).tolist()   # one host sync, not one per word
         logp = getattr(forward_out, "_logp", None)
         if logp is None:
             logp = F.log_softmax(forward_out.segmentation, dim=1)
@@ -334,9 +334,8 @@ class MuCon(nn.Module):
         if self.teacher_forcing:
             target = batch.transcript
         else:
-            target = torch.tensor([w.argmax().item() for w in forward_out.transcript[:-1]], dtype=torch.long,
-                                  device=batch.transcript.device)
-            target[target >= self.num_classes] = 0
+            target = forward_out.transcript[:-1].argmax(dim=1)           # stays on the device
+            target = torch.where(target >= self.num_classes, torch.zeros_like(target), target)
         T = forward_out.segmentation.shape[0]
         absolute_lengths = project_lengths_softmax(T=T, L=forward_out.lengths)
         mc = self.cfg.model.loss.mucon
