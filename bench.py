@@ -188,6 +188,58 @@ def end_to_end_bench(dev, steps=40):
             "reference_readme_it_per_s": [14.67, 16.23]}
 
 
+def eval_bench(dev, n_videos=16):
+    """Evaluation scope: MuConEvaluator.evaluate() per test video = eval-mode forward (greedy s-head decode, at most 8
+    words here), predict, Viterbi decode on the device-resident log-probs, and the reference's full metric set on the host
+    (reference src/mucon/evaluators.py:121-257).  Random-init weights; the EOS logit is biased down so that the greedy
+    decode emits a transcript (an untrained s-head emits EOS first, on which the reference's evaluator fails as well)."""
+    from mucon_amd import synth
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.core.datasets import Batch
+    from mucon_amd.mucon.evaluators import MuConEvaluator
+    from mucon_amd.mucon.models import create_model
+
+    T, N, C = 2000, 6, 48
+    cfg = update_config(get_cfg_defaults(), [], [])
+    torch.manual_seed(0)
+    model = create_model(cfg, C, 8, 2048).to(dev)
+    with torch.no_grad():
+        model.fs_decoder_transcript[2].bias[C] = -20.0
+
+    class Videos:
+        background_class_ids = [0]
+
+        def __init__(self):
+            self.items = []
+            for v in range(n_videos):
+                tr = synth.transcript(100 + v, N, C, allow_repeats=False)
+                self.items.append(Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(200 + v, T, tr)),
+                                        transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
+                                        transcript_tf_target=torch.tensor(tr.tolist() + [C]), video_name=f"v{v}").to(dev))
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            return self.items[i]
+
+        def get_num_classes(self):
+            return C
+
+    db = Videos()
+    ev = MuConEvaluator(cfg, db, model, dev)
+    ev.viterbi_mode(True)
+    ev.evaluate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev.evaluate()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / len(db)
+    return {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3),
+            "config": f"MuConEvaluator.evaluate(): {n_videos} videos, T={T}: eval forward + greedy decode (8 words) + predict + "
+                      f"Viterbi (fs=30) + MoF/IoD/IoU/edit/F1 for y-, s- and Viterbi segmentations; tapes resident in HBM"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -316,6 +368,7 @@ def main():
         if not args.no_viterbi:
             out["viterbi"] = viterbi_bench(dev, C)
             out["end_to_end"] = end_to_end_bench(dev)
+            out["evaluation"] = eval_bench(dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

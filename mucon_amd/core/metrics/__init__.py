@@ -162,27 +162,36 @@ def edit_score(recognized, ground_truth, norm: bool = True, bg_class=()) -> floa
         return float((1 - np.float64(d) / max(len(P), len(Y))) * 100)
 
 
-def f_score(recognized, ground_truth, overlap: float, bg_class=()):
-    """(tp, fp, fn) of the segmental F1 at an IoU threshold: predicted segments claim, in order, the ground-truth
-    segment of the same label they overlap most (first one on ties); a segment can be claimed once."""
+def f_scores(recognized, ground_truth, overlaps: Sequence[float], bg_class=()):
+    """[(tp, fp, fn)] of the segmental F1 at each IoU threshold: predicted segments claim, in order, the ground-truth
+    segment of the same label they overlap most (first one on ties); a segment can be claimed once.  The segment-pair IoU
+    matrix is built once for all thresholds."""
     pv, ps, pe = runs(recognized, bg_class)
     yv, ys, ye = runs(ground_truth, bg_class)
-    hits = np.zeros(yv.shape[0], dtype=bool)
-    tp = fp = 0
-    for j in range(pv.shape[0]):
-        if yv.shape[0] == 0:   # the reference's argmax over an empty array raises here; count a false positive instead
-            fp += 1
-            continue
-        inter = np.minimum(pe[j], ye) - np.maximum(ps[j], ys)
-        union = np.maximum(pe[j], ye) - np.minimum(ps[j], ys)
-        iou = (1.0 * inter / union) * (yv == pv[j])
-        k = int(iou.argmax())
-        if iou[k] >= overlap and not hits[k]:
-            tp += 1
-            hits[k] = True
-        else:
-            fp += 1
-    return float(tp), float(fp), float(yv.shape[0] - hits.sum())
+    P, Y = pv.shape[0], yv.shape[0]
+    if Y == 0:   # the reference's argmax over an empty array raises here; count false positives instead
+        return [(0.0, float(P), 0.0) for _ in overlaps]
+    if P == 0:
+        return [(0.0, 0.0, float(Y)) for _ in overlaps]
+    inter = np.minimum(pe[:, None], ye[None, :]) - np.maximum(ps[:, None], ys[None, :])
+    union = np.maximum(pe[:, None], ye[None, :]) - np.minimum(ps[:, None], ys[None, :])
+    iou = (1.0 * inter / union) * (pv[:, None] == yv[None, :])
+    best = iou.argmax(axis=1)
+    best_val = iou[np.arange(P), best].tolist()
+    best = best.tolist()
+    out = []
+    for ov in overlaps:
+        hits, tp = set(), 0
+        for k, v in zip(best, best_val):
+            if v >= ov and k not in hits:
+                tp += 1
+                hits.add(k)
+        out.append((float(tp), float(P - tp), float(Y - len(hits))))
+    return out
+
+
+def f_score(recognized, ground_truth, overlap: float, bg_class=()):
+    return f_scores(recognized, ground_truth, [overlap], bg_class)[0]
 
 
 class Edit(Metric):
@@ -219,8 +228,7 @@ class F1Score(Metric):
 
     def add(self, targets: List[int], predictions: List[int]) -> List[float]:
         out = []
-        for s, ov in enumerate(self.overlaps):
-            tp, fp, fn = f_score(predictions, targets, ov, bg_class=self.ignore_ids)
+        for s, (tp, fp, fn) in enumerate(f_scores(predictions, targets, self.overlaps, bg_class=self.ignore_ids)):
             self.tp[s] += tp
             self.fp[s] += fp
             self.fn[s] += fn

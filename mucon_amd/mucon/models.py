@@ -175,8 +175,9 @@ class MuCon(nn.Module):
         logp = getattr(forward_out, "_logp", None)
         if logp is None:
             logp = F.log_softmax(forward_out.segmentation, dim=1)
-        return MuConPredictOut(transcript=transcript, lengths=F.softmax(forward_out.lengths, dim=0),
-                               segmentation_logits=logp)
+        # softmax over a handful of length logits, written out: F.softmax goes through MIOpen on ROCm (~1 ms of host time)
+        e = torch.exp(forward_out.lengths - forward_out.lengths.max())
+        return MuConPredictOut(transcript=transcript, lengths=e / e.sum(), segmentation_logits=logp)
 
     # ------------------------------------------------------------------------------ s-head
     def sequence_generation_forward(self, temporal_encoded: Tensor, tf_transcript_target_length: int,
