@@ -21,7 +21,7 @@ from torch.nn import functional as F
 
 from .. import ops
 from ..core.datasets import Batch
-from ..core.modules.temporal import WaveNetBlock
+from ..core.modules.temporal import MSTCNPPFirstStage, NoFt, WaveNetBlock
 from .masks import create_masks, project_lengths_softmax
 
 
@@ -78,12 +78,18 @@ class MuCon(nn.Module):
         self.loss_mul_mucon, self.loss_mul_transcript = m.loss.mul_mucon, m.loss.mul_transcript
         self.loss_mul_smoothing, self.loss_mul_length = m.loss.mul_smoothing, m.loss.mul_length
 
-        if m.ft.type != "wavenet":
-            raise NotImplementedError(f"ft type {m.ft.type!r}: only the default 'wavenet' encoder has HIP kernels")
         H = m.ft.hidden_size
-        self.ft = WaveNetBlock(in_channels=input_feature_size, stages=m.ft.stages, out_dims=H, pooling=m.ft.pooling,
-                               pooling_type=m.ft.pooling_type, pooling_layers=m.ft.pooling_layers,
-                               leaky=m.ft.leaky_relu, dropout_rate=m.ft.dropout_rate)
+        if m.ft.type == "wavenet":
+            self.ft = WaveNetBlock(in_channels=input_feature_size, stages=m.ft.stages, out_dims=H, pooling=m.ft.pooling,
+                                   pooling_type=m.ft.pooling_type, pooling_layers=m.ft.pooling_layers,
+                                   leaky=m.ft.leaky_relu, dropout_rate=m.ft.dropout_rate)
+        elif m.ft.type == "mstcnpp":   # reference models.py:172-179
+            self.ft = MSTCNPPFirstStage(input_dim=input_feature_size, num_layers=len(m.ft.stages), output_dim=H, num_f_maps=H,
+                                        pooling_layers=m.ft.pooling_layers)
+        elif m.ft.type == "noft":      # reference models.py:180-184
+            self.ft = NoFt(in_chnnels=input_feature_size, out_dims=H)
+        else:
+            raise Exception(f"Invalid ft type ({m.ft.type})")
         self.ft_last_gn = nn.GroupNorm(num_groups=m.ft.last_gn_num_groups, num_channels=H)
         self.ft_last_dropout = nn.Dropout(p=m.ft.last_dropout_rate)
 
@@ -137,6 +143,18 @@ class MuCon(nn.Module):
     def temporal_modeling_forward(self, input: Tensor) -> Tensor:
         """[B x T x D] -> [B x T' x D'] (reference models.py:746-773): one fused HIP pipeline --
         no permute, no transposed copy of the tape."""
+        if not isinstance(self.ft, WaveNetBlock):
+            # non-default encoders (NoFt, MSTCNPPFirstStage): library ops, then the wrapper of models.py:759-768
+            ft = self.cfg.model.ft
+            z = (self.ft.forward_time_major(input).permute(0, 2, 1) if isinstance(self.ft, NoFt)
+                 else self.ft(input.permute(0, 2, 1)))                      # [B x D' x T']
+            if ft.last_gn:
+                z = self.ft_last_gn(z)
+            if ft.last_relu:
+                z = F.relu(z)
+            if ft.last_dropout:
+                z = self.ft_last_dropout(z)
+            return z.permute(0, 2, 1).contiguous()
         self._step += 1
         seed = (int(self.cfg.system.seed) << 32) ^ self._step if self.training else 0
         return self.ft.forward_time_major(input, self.ft_last_gn.weight, self.ft_last_gn.bias, self._encoder_spec(), seed)

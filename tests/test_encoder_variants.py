@@ -1,0 +1,66 @@
+"""cfg.model.ft.type = "noft" / "mstcnpp" (SURVEY 8f row 4): the non-default encoders of the reference
+(src/core/modules/temporal.py:56-74, :150-204) behind MuCon.temporal_modeling_forward, against outputs of the reference's
+own model on the same seeded parameters and tape (tests/golden/variant_cases.npz, tools/make_golden_variants.py).
+They run on library ops (torch), so the comparison runs on the CPU here; the gpu-marked test repeats it on the device and
+takes a full training step.  Tolerance 1e-5 (same float32 ops, different blocking)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import seeded_model_value
+from mucon_amd import synth
+from mucon_amd.config import get_cfg_defaults, update_config
+from mucon_amd.mucon.models import create_model
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "variant_cases.npz"))
+
+
+def _model(kind):
+    cfg = update_config(get_cfg_defaults(), [], [["model.ft.type", kind]])
+    model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(seeded_model_value(name, p.shape).astype(np.float32)))
+    return cfg, model
+
+
+@pytest.mark.parametrize("kind", ["noft", "mstcnpp"])
+def test_variant_matches_reference(kind):
+    _, model = _model(kind)
+    model.eval()
+    assert [k for k in model.state_dict() if k.startswith("ft.")] == [str(k) for k in GOLD[f"{kind}__keys"]]
+    T, Tz = [int(v) for v in GOLD[f"{kind}__meta"]]
+    tape = torch.from_numpy(synth.uniform_pm1(55, (1, T, 2048)))
+    with torch.no_grad():
+        enc = model.temporal_modeling_forward(tape)
+    assert tuple(enc.shape) == (1, Tz, 128)
+    np.testing.assert_allclose(enc.numpy(), GOLD[f"{kind}__enc"], rtol=1e-5, atol=1e-5)
+
+
+def test_invalid_type_raises_like_the_reference():
+    cfg = update_config(get_cfg_defaults(), [], [["model.ft.type", "transformer"]])
+    with pytest.raises(Exception, match="Invalid ft type"):
+        create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["noft", "mstcnpp"])
+def test_variant_on_gpu_and_training_step(kind):
+    from test_gpu_model import make_batch
+    from mucon_amd.mucon.trainers import SimpleTrainer
+    cfg, model = _model(kind)
+    model = model.cuda().eval()
+    T, Tz = [int(v) for v in GOLD[f"{kind}__meta"]]
+    tape = torch.from_numpy(synth.uniform_pm1(55, (1, T, 2048))).cuda()
+    with torch.no_grad():
+        enc = model.temporal_modeling_forward(tape)
+    np.testing.assert_allclose(enc.cpu().numpy(), GOLD[f"{kind}__enc"], rtol=1e-4, atol=1e-4)
+    tr = SimpleTrainer(cfg, model, "cuda")
+    tr.on_start_epoch(0)
+    model.train()
+    batch = make_batch(640, 5).to("cuda")
+    before = model.conv_classifier.weight.detach().clone()
+    loss, _ = tr._train_1_batch(0, batch)
+    assert torch.isfinite(loss.main) and not torch.equal(before, model.conv_classifier.weight)
