@@ -38,6 +38,17 @@ class Batch:
         return self
 
 
+@dataclass(repr=False)
+class FullySupervisedBatch(Batch):
+    """+ the ground-truth segment lengths (reference general_dataset.py:36-39)."""
+    absolute_lengths: Tensor = None   # [N] float
+
+
+@dataclass(repr=False)
+class MixedSupervisionBatch(FullySupervisedBatch):
+    fully_supervised: bool = False    # whether full supervision should be used for this video (general_dataset.py:42-43)
+
+
 def create_tf_input(transcript, sos_i: int) -> np.ndarray:
     return np.array([sos_i] + list(transcript))
 
@@ -85,6 +96,73 @@ class GeneralDataset(torch.utils.data.Dataset):
         return items[0]
 
 
+class GeneralFullySupervisedDataset(GeneralDataset):
+    """+ <root>/lengths/<NAME>.npy: the segment lengths of the ground truth (reference general_dataset.py:176-208)."""
+
+    def __getitem__(self, item: int) -> FullySupervisedBatch:
+        b = super().__getitem__(item)
+        lengths = torch.tensor(np.load(str(self.root / "lengths" / f"{self.file_names[item]}.npy")), dtype=torch.float32)
+        return FullySupervisedBatch(**{f.name: getattr(b, f.name) for f in dataclasses.fields(Batch)}, absolute_lengths=lengths)
+
+
+class GeneralMixedSupervisionDataset(GeneralFullySupervisedDataset):
+    """A fixed, seeded subset of the videos is marked fully supervised (reference general_dataset.py:211-263): the
+    same `random.seed(f"{seed}-{n}")` + `random.shuffle` draw, so the subset is the reference's."""
+
+    def __init__(self, cfg, root, full_supervision_percentage: float, relative_path_to_list="split1.train",
+                 relative_path_to_mapping="mapping.txt", feat_dim: int = -1):
+        super().__init__(cfg, root, relative_path_to_list, relative_path_to_mapping, feat_dim)
+        assert 0.0 < full_supervision_percentage < 100.0
+        self.full_supervision_percentage = full_supervision_percentage
+        n = len(self.file_names)
+        self.number_of_full_supervision_examples = min(n, max(1, int(round(n * full_supervision_percentage / 100.0))))
+        flags = [i < self.number_of_full_supervision_examples for i in range(n)]
+        import random
+        random.seed(f"{self.cfg.system.seed}-{self.number_of_full_supervision_examples}")
+        random.shuffle(flags)
+        self.is_it_supervised = flags
+
+    def __getitem__(self, item: int) -> MixedSupervisionBatch:
+        b = super().__getitem__(item)
+        return MixedSupervisionBatch(**{f.name: getattr(b, f.name) for f in dataclasses.fields(FullySupervisedBatch)},
+                                     fully_supervised=self.is_it_supervised[item])
+
+
+def _breakfast(cfg, train: bool, cls, name_fmt: str, **extra):
+    split, feat_name = cfg.dataset.split, cfg.dataset.feat_name
+    assert split in POSSIBLE_SPLITS
+    db_path = Path(cfg.dataset.root) / f"breakfast_{feat_name}"
+    set_name = "train" if train else "test"
+    db = cls(cfg, db_path, relative_path_to_list=f"split{split}.{set_name}", relative_path_to_mapping=cfg.dataset.mapping_file_name,
+             feat_dim=FEAT_DIM_MAPPING[feat_name], **extra)
+    db.convenient_name = name_fmt.format(split=split, set_name=set_name)
+    db.split, db.max_transcript_length = split, MAX_TRANSCRIPT_LENGTH
+    return db
+
+
+def create_fully_supervised_breakfast_dataset(cfg, train: bool = True) -> GeneralFullySupervisedDataset:
+    return _breakfast(cfg, train, GeneralFullySupervisedDataset, "fully_supervised_breakfast_split{split}_{set_name}")
+
+
+def create_mixed_supervision_breakfast_dataset(cfg, train: bool = True) -> GeneralMixedSupervisionDataset:
+    pct = cfg.dataset.mixed.full_supervision_percentage
+    return _breakfast(cfg, train, GeneralMixedSupervisionDataset,
+                      "mixed_supervision_percentage_" + str(pct) + "_breakfast_split{split}_{set_name}",
+                      full_supervision_percentage=pct)
+
+
+def handel_fully_supervised_dataset(cfg, train: bool) -> GeneralFullySupervisedDataset:
+    if cfg.dataset.name == "breakfast":
+        return create_fully_supervised_breakfast_dataset(cfg, train)
+    raise Exception("Invalid dataset name.")
+
+
+def handel_mixed_supervision_dataset(cfg, train: bool) -> GeneralMixedSupervisionDataset:
+    if cfg.dataset.name == "breakfast":
+        return create_mixed_supervision_breakfast_dataset(cfg, train)
+    raise Exception("Invalid dataset name.")
+
+
 def create_breakfast_dataset(cfg, train: bool = True) -> GeneralDataset:
     split, feat_name = cfg.dataset.split, cfg.dataset.feat_name
     assert split in POSSIBLE_SPLITS
@@ -116,7 +194,7 @@ def write_synthetic_breakfast(root, n_train=8, n_test=4, num_classes=48, feat_di
     from ... import synth
 
     base = Path(root) / "breakfast_i3d"
-    for d in ("features", "labels", "transcripts"):
+    for d in ("features", "labels", "transcripts", "lengths"):
         os.makedirs(base / d, exist_ok=True)
     with open(base / "mapping.txt", "w") as f:
         for c in range(num_classes):
@@ -136,6 +214,8 @@ def write_synthetic_breakfast(root, n_train=8, n_test=4, num_classes=48, feat_di
             np.save(base / "features" / f"{name}.npy", feats.astype(np.float32))
             np.save(base / "labels" / f"{name}.npy", labels.astype(np.int64))
             np.save(base / "transcripts" / f"{name}.npy", tr.astype(np.int64))
+            cuts = np.flatnonzero(np.diff(labels)) + 1
+            np.save(base / "lengths" / f"{name}.npy", np.diff(np.concatenate(([0], cuts, [T]))).astype(np.int64))
             names[part].append(name)
             k += 1
     for s in splits:

@@ -60,6 +60,22 @@ def rand_p(*sz):
     return nn.Parameter(rand_t(*sz), requires_grad=True)
 
 
+def create_fully_supervised_model(cfg, num_classes: int, max_decoding_steps: int, input_feature_size: int) -> "MuConFullySupervised":
+    """reference models.py:49-64"""
+    if cfg.model.name != "mucon":
+        raise Exception("Invalid model name")
+    return MuConFullySupervised(cfg, input_feature_size=input_feature_size, num_classes=num_classes,
+                                max_decoding_steps=max_decoding_steps)
+
+
+def create_mixed_supervision_model(cfg, num_classes: int, max_decoding_steps: int, input_feature_size: int) -> "MuConMixedSupervision":
+    """reference models.py:67-82"""
+    if cfg.model.name != "mucon":
+        raise Exception("Invalid model name")
+    return MuConMixedSupervision(cfg, input_feature_size=input_feature_size, num_classes=num_classes,
+                                 max_decoding_steps=max_decoding_steps)
+
+
 def create_model(cfg, num_classes: int, max_decoding_steps: int, input_feature_size: int) -> "MuCon":
     if cfg.model.name == "mucon":
         return MuCon(cfg=cfg, input_feature_size=input_feature_size, num_classes=num_classes,
@@ -399,3 +415,54 @@ class MuCon(nn.Module):
 
     def set_teacher_forcing(self, teacher_forcing: bool = True):
         self.teacher_forcing = teacher_forcing
+
+
+@dataclass(repr=False)
+class MuConFullySupervisedLoss(MuConLoss):
+    classification_loss: Tensor = None
+    supervised_length_loss: Tensor = None
+
+
+class MuConFullySupervised(MuCon):
+    """+ frame classification and length regression against the ground truth (reference models.py:781-868)."""
+
+    def __init__(self, cfg, input_feature_size: int, num_classes: int, max_decoding_steps: int):
+        super().__init__(cfg, input_feature_size=input_feature_size, num_classes=num_classes, max_decoding_steps=max_decoding_steps)
+        fs = self.cfg.model.loss.fully_supervised
+        self.loss_mul_classification, self.loss_mul_supervised_length = fs.mul_classification, fs.mul_supervised_length
+
+    def classification_loss(self, batch, forward_out: MuConForwardOut) -> Tensor:
+        return self.calculate_classification_loss_for_logit(forward_out.segmentation, batch.gt_label, batch.gt_label.shape[0],
+                                                            logp=getattr(forward_out, "_logp", None))
+
+    def calculate_classification_loss_for_logit(self, segmentation, target_labels, target_length, logp=None):
+        if segmentation.shape[0] != target_length:
+            segmentation = F.interpolate(segmentation.transpose(0, 1).unsqueeze(0), size=target_length).squeeze(0).transpose(0, 1)
+            logp = None
+        if logp is not None:      # the y-head kernel's own log-softmax: cross-entropy = nll of it
+            return F.nll_loss(logp, target_labels, reduction="mean")
+        return F.cross_entropy(segmentation, target_labels, reduction="mean")
+
+    def supervised_length_loss(self, batch, forward_out: MuConForwardOut) -> Tensor:
+        relative = batch.absolute_lengths / batch.absolute_lengths.sum()
+        return F.mse_loss(relative, torch.softmax(forward_out.lengths, dim=0), reduction="mean")
+
+    def _with_supervision(self, batch, forward_out: MuConForwardOut, supervised: bool) -> MuConFullySupervisedLoss:
+        base = super().loss(batch, forward_out)          # the four weakly supervised losses (fused HIP kernels on the GPU)
+        cls, sl = self.classification_loss(batch, forward_out), self.supervised_length_loss(batch, forward_out)
+        main = base.main
+        if supervised:
+            main = main + self.loss_mul_classification * cls + self.loss_mul_supervised_length * sl
+        return MuConFullySupervisedLoss(main=main, transcript_loss=base.transcript_loss, length_loss=base.length_loss,
+                                        mucon_loss=base.mucon_loss, smoothing_loss=base.smoothing_loss,
+                                        classification_loss=cls, supervised_length_loss=sl)
+
+    def loss(self, batch, forward_out: MuConForwardOut) -> MuConFullySupervisedLoss:
+        return self._with_supervision(batch, forward_out, True)
+
+
+class MuConMixedSupervision(MuConFullySupervised):
+    """Full supervision only on the videos the dataset marks (reference models.py:871-911)."""
+
+    def loss(self, batch, forward_out: MuConForwardOut) -> MuConFullySupervisedLoss:
+        return self._with_supervision(batch, forward_out, bool(batch.fully_supervised))
