@@ -503,6 +503,9 @@ class FusedClipSGD:
         _lib.check(lib.mucon_sgd_clip_step(n, tab, len(self.groups), mx, lr, wd, mom, _lib.ptr(self.last_norms),
                                            _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream_ptr()),
                    "mucon_sgd_clip_step")
+        # this call stands in for optimizer.step(): tell torch's schedulers so (they warn about the call order otherwise)
+        if hasattr(self.optimizer, "_opt_called"):
+            self.optimizer._opt_called = True
 
 
 # --------------------------------------------------------------------------------------- viterbi
