@@ -10,7 +10,7 @@
 //   decoder_fwd_kernel   the step loop; saves every activation the backward needs
 //   decoder_bwd_kernel   back-propagation through the steps; per-step "delta" vectors go to the workspace
 //   dec_outer_kernel     every weight gradient = sum over steps of delta (x) input: one batched launch
-//   dec_memgrad_kernel   d_memory += d_mp @ W1^T
+//   dec_attn_grad_kernel d_mp and d_memory for all encoder states, from the per-step d_score / d_ctx the backward saved
 // Vector width D = 128 (embedding = hidden = attention size: the reference's only configuration).
 #pragma once
 #include "common.hpp"
@@ -59,6 +59,8 @@ struct DecSaved {   // forward activations (workspace)
     int *toks;      // [S]           the token each step consumed
 };
 struct DecDeltas {  // backward: gradients at the pre-activations (workspace)
+    float *ctx;     // [S][ME]   d context, per step   } consumed by dec_attn_grad_kernel, which turns them into
+    float *score;   // [S][Tz]   d attention score     } d_memory and d_mp for all encoder states in parallel
     float *mp;      // [Tz][D]
     float *q, *mixed, *gates, *t1, *logits, *l1, *len;  // [S][...]
     float *h0, *c0; // [D]
@@ -205,29 +207,49 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int row
     }
 }
 
-// Two transposed mat-vecs with the same d in one pass over the rows (128 columns each):
-// out_a += Wa^T d,  out_b = Wb^T d.   scratch: 2 * DEC_THREADS floats.
-__device__ __forceinline__ void matvec_cols_pair(const float *__restrict__ Wa, const float *__restrict__ Wb, int rows,
-                                                 const float *d, float *out_a, float *out_b, float *scratch) {
-    constexpr int ng = DEC_THREADS / DEC_D;
-    const int g = threadIdx.x / DEC_D, j = threadIdx.x - g * DEC_D;
-    float a = 0.f, b = 0.f;
-#pragma unroll 8
-    for (int i = g; i < rows; i += ng) {
-        const float dv = d[i];
-        a += Wa[(long)i * DEC_D + j] * dv;
-        b += Wb[(long)i * DEC_D + j] * dv;
+// The same for a column count that is a multiple of 4: a thread owns FOUR adjacent columns (one 16-byte load per row), so
+// cols/4 threads cover a row and the 1024 threads form up to 32 row groups -- 512 x 128 weights are 16 dependent steps per
+// thread instead of 64.  PAIR: two matrices with the same d in one pass (out_a += Wa^T d, out_b = Wb^T d).
+// scratch: groups * cols (* 2) floats -- DEC_SCR floats cover every use below.
+constexpr int DEC_SCR = 2 * 32 * DEC_D;
+template <bool ACC, bool PAIR>
+__device__ __forceinline__ void matvec_cols4(const float *__restrict__ Wa, const float *__restrict__ Wb, int rows, int cols,
+                                             const float *d, float *out_a, float *out_b, float *scratch) {
+    const int tpg = cols >> 2;                 // threads per row group
+    const int ng = DEC_THREADS / tpg;          // row groups
+    const int g = threadIdx.x / tpg, j4 = threadIdx.x - g * tpg;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (g < ng) {
+#pragma unroll 4
+        for (int i = g; i < rows; i += ng) {
+            const float dv = d[i];
+            const f32x4 wa = *reinterpret_cast<const f32x4 *>(Wa + (long)i * cols + 4 * j4);
+            a[0] += wa[0] * dv;
+            a[1] += wa[1] * dv;
+            a[2] += wa[2] * dv;
+            a[3] += wa[3] * dv;
+            if (PAIR) {
+                const f32x4 wb = *reinterpret_cast<const f32x4 *>(Wb + (long)i * cols + 4 * j4);
+                b[0] += wb[0] * dv;
+                b[1] += wb[1] * dv;
+                b[2] += wb[2] * dv;
+                b[3] += wb[3] * dv;
+            }
+        }
+    }
+    __syncthreads();  // scratch may still be read by the previous user
+    if (g < ng) {
+        *reinterpret_cast<f32x4 *>(scratch + g * cols + 4 * j4) = a;
+        if (PAIR) *reinterpret_cast<f32x4 *>(scratch + ng * cols + g * cols + 4 * j4) = b;
     }
     __syncthreads();
-    scratch[threadIdx.x] = a;
-    scratch[DEC_THREADS + threadIdx.x] = b;
-    __syncthreads();
-    if (threadIdx.x < 2 * DEC_D) {
-        const int which = threadIdx.x >> 7, jj = threadIdx.x & 127;
-        float s = 0.f;
-        for (int gg = 0; gg < ng; ++gg) s += scratch[which * DEC_THREADS + gg * DEC_D + jj];
-        if (which == 0) out_a[jj] += s;
-        else out_b[jj] = s;
+    const int nout = PAIR ? 2 * cols : cols;
+    if ((int)threadIdx.x < nout) {
+        const int which = threadIdx.x >= cols, jj = threadIdx.x - which * cols;
+        float sum = 0.f;
+        for (int gg = 0; gg < ng; ++gg) sum += scratch[which * ng * cols + gg * cols + jj];
+        if (which == 0) out_a[jj] = ACC ? out_a[jj] + sum : sum;
+        else out_b[jj] = sum;
     }
 }
 
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
 }
 
 // dynamic LDS: Tz floats.  dm.S = the number of steps the forward ran.  d_logp [S][NC] / d_len [S] may be null.
-// d_memory [Tz][ME] and d_emb [n_emb][D] are zeroed here; d_v [D]; d_hn / d_cn [ME].
+// d_emb [n_emb][D] is zeroed here; d_v [D]; d_hn / d_cn [ME]; d_memory and dl.mp are written by dec_attn_grad_kernel.
 __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl,
                                                                   const float *memory, const float *logp, const float *d_logp,
                                                                   const float *d_len, const float *dropmask, float *d_memory,
@@ -421,12 +443,11 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
     extern __shared__ float s_ds[];  // d_attn, then d_score
     __shared__ float s_dh[DEC_D], s_dc[DEC_D], s_dlogits[DEC_MAXNC], s_dl1[DEC_NL], s_dlencat[DEC_D + DEC_MAXNC];
     __shared__ float s_dt1[DEC_D], s_dgates[4 * DEC_D], s_dmixed[DEC_D], s_dcat[DEC_D + DEC_MAXME], s_dq[DEC_D];
-    __shared__ float s_scr[2 * DEC_THREADS], s_red[DEC_WAVES + 1], s_out[DEC_MAXME];
+    __shared__ __attribute__((aligned(16))) float s_scr[DEC_SCR];
+    __shared__ float s_red[DEC_WAVES + 1], s_out[DEC_MAXME];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tz = dm.Tz, ME = dm.ME, NC = dm.NC, CW = DEC_D + ME, LW = DEC_D + NC;
 
-    for (long e = tid; e < (long)Tz * DEC_D; e += DEC_THREADS) dl.mp[e] = 0.f;
-    for (long e = tid; e < (long)Tz * ME; e += DEC_THREADS) d_memory[e] = 0.f;
     for (long e = tid; e < (long)dm.n_emb * DEC_D; e += DEC_THREADS) d_emb[e] = 0.f;
     if (tid < DEC_D) {
         s_dh[tid] = 0.f;
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
         }
         __syncthreads();
         // transcript MLP backward -> d dec_out (added to the recurrent dh)
-        matvec_cols<false>(p.t2_w, NC, DEC_D, s_dlogits, s_dt1, s_scr);
+        matvec_cols4<false, false>(p.t2_w, nullptr, NC, DEC_D, s_dlogits, s_dt1, nullptr, s_scr);
         __syncthreads();
         if (tid < DEC_D) {
             const float v = sv.t1[s * DEC_D + tid] > 0.f ? s_dt1[tid] : 0.f;
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             dl.t1[s * DEC_D + tid] = v;
         }
         __syncthreads();
-        matvec_cols<true>(p.t1_w, DEC_D, DEC_D, s_dt1, s_dh, s_scr);
+        matvec_cols4<true, false>(p.t1_w, nullptr, DEC_D, DEC_D, s_dt1, s_dh, nullptr, s_scr);
         __syncthreads();
         // LSTM cell backward
         if (tid < DEC_D) {
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
         }
         __syncthreads();
         // d mixed += W_ih^T dgates;  dh w.r.t. the previous hidden state = W_hh^T dgates
-        matvec_cols_pair(p.w_ih, p.w_hh, 4 * DEC_D, s_dgates, s_dmixed, s_dh, s_scr);
+        matvec_cols4<true, true>(p.w_ih, p.w_hh, 4 * DEC_D, DEC_D, s_dgates, s_dmixed, s_dh, s_scr);
         __syncthreads();
         if (tid < DEC_D) {
             const float v = sv.mixed[s * DEC_D + tid] > 0.f ? s_dmixed[tid] : 0.f;
@@ -501,7 +522,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             dl.mixed[s * DEC_D + tid] = v;
         }
         __syncthreads();
-        matvec_cols<false>(p.cmb_w, DEC_D, CW, s_dmixed, s_dcat, s_scr);
+        if ((CW & 3) == 0) matvec_cols4<false, false>(p.cmb_w, nullptr, DEC_D, CW, s_dmixed, s_dcat, nullptr, s_scr);
+        else matvec_cols<false>(p.cmb_w, DEC_D, CW, s_dmixed, s_dcat, s_scr);
         __syncthreads();
         // embedding row gradient (this workgroup is the only writer; thread tid owns column tid)
         if (tid < DEC_D) {
@@ -510,19 +532,23 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             if (dropmask) g *= dropmask[s * DEC_D + tid];
             d_emb[(long)tok * DEC_D + tid] += g;
         }
-        // context backward: d_attn[t] = memory[t] . d_ctx;  d_memory[t] += attn[t] d_ctx
+        // context backward: d_attn[t] = memory[t] . d_ctx   (d_memory += attn (x) d_ctx is summed over the steps later, in
+        // dec_attn_grad_kernel: a read-modify-write of [Tz][ME] per step does not belong in this serial loop)
+        if (tid < ME) dl.ctx[(long)s * ME + tid] = s_dcat[DEC_D + tid];
         {
             const float *dctx = s_dcat + DEC_D;
-            for (int t = wave; t < Tz; t += DEC_WAVES) {
-                const float a = sv.attn[(long)s * Tz + t];
-                float acc = 0.f;
-                for (int j = lane; j < ME; j += 64) {
-                    const float dc = dctx[j];
-                    acc += memory[(long)t * ME + j] * dc;
-                    d_memory[(long)t * ME + j] += a * dc;
+            for (int t0 = wave * 4; t0 < Tz; t0 += DEC_WAVES * 4) {   // 4 encoder states per wave at a time
+                float acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float *m = memory + (long)min(t0 + i, Tz - 1) * ME;
+                    float v = 0.f;
+                    for (int j = lane; j < ME; j += 64) v += m[j] * dctx[j];
+                    acc[i] = v;
                 }
-                acc = wave_sum(acc);
-                if (lane == 0) s_ds[t] = acc;
+                const float sum = wave_sum_rows<4>(acc);
+                const int t = t0 + ((lane >> 4) & 3);
+                if ((lane & 15) == 0 && t < Tz) s_ds[t] = sum;
             }
         }
         __syncthreads();
@@ -530,21 +556,24 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             float part = 0.f;
             for (int t = tid; t < Tz; t += DEC_THREADS) part += sv.attn[(long)s * Tz + t] * s_ds[t];
             const float dot = block_sum(part, s_red);
-            for (int t = tid; t < Tz; t += DEC_THREADS) s_ds[t] = sv.attn[(long)s * Tz + t] * (s_ds[t] - dot);
+            for (int t = tid; t < Tz; t += DEC_THREADS) {
+                const float v = sv.attn[(long)s * Tz + t] * (s_ds[t] - dot);
+                s_ds[t] = v;
+                dl.score[(long)s * Tz + t] = v;
+            }
         }
         __syncthreads();
-        // score backward through tanh: d_mp, d_q, dV
+        // score backward through tanh: d_q, dV   (d_mp is rebuilt from the saved d_score in dec_attn_grad_kernel)
         {
             const int g = tid >> 7, k = tid & 127;
             const float qk = sv.q[s * DEC_D + k], vk = p.v[k];
             float dq = 0.f;
+#pragma unroll 4
             for (int t = g; t < Tz; t += DEC_THREADS / DEC_D) {
                 const float u = tanhf(sv.mp[(long)t * DEC_D + k] + qk);
                 const float ds = s_ds[t];
                 dv_acc += ds * u;
-                const float dp = ds * vk * (1.f - u * u);
-                dl.mp[(long)t * DEC_D + k] += dp;
-                dq += dp;
+                dq += ds * vk * (1.f - u * u);
             }
             s_scr[tid] = dq;
             __syncthreads();
@@ -556,7 +585,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             }
         }
         __syncthreads();
-        matvec_cols<true>(p.l2_w, DEC_D, DEC_D, s_dq, s_dh, s_scr);
+        matvec_cols4<true, false>(p.l2_w, nullptr, DEC_D, DEC_D, s_dq, s_dh, nullptr, s_scr);
         __syncthreads();
     }
     // initial state -> h_n / c_n through hidden_out / cn_out
@@ -611,14 +640,27 @@ __global__ __launch_bounds__(256) void dec_outer_kernel(OuterBatch ob) {
     }
 }
 
-// d_memory[t][j] += sum_k d_mp[t][k] W1[j][k]; grid (Tz), 256 threads
-__global__ __launch_bounds__(256) void dec_memgrad_kernel(const float *dmp, const float *w1, float *d_memory, int ME) {
+// Per encoder state t (grid (Tz), 256 threads), summed over the S decoding steps in step order:
+//   d_mp[t][k]     = sum_s d_score[s][t] v[k] (1 - tanh^2(mp[t][k] + q[s][k]))        -> dl.mp (input of dW1's outer product)
+//   d_memory[t][j] = sum_s attn[s][t] d_ctx[s][j]  +  sum_k d_mp[t][k] W1[j][k]
+__global__ __launch_bounds__(256) void dec_attn_grad_kernel(DecSaved sv, DecDeltas dl, const float *w1, const float *v,
+                                                            float *d_memory, int S, int Tz, int ME) {
     __shared__ __attribute__((aligned(16))) float ds[DEC_D];
     const int t = blockIdx.x, j = threadIdx.x;
-    if (j < DEC_D) ds[j] = dmp[(long)t * DEC_D + j];
+    if (j < DEC_D) {
+        const float m = sv.mp[(long)t * DEC_D + j], vk = v[j];
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float u = tanhf(m + sv.q[s * DEC_D + j]);
+            acc += dl.score[(long)s * Tz + t] * vk * (1.f - u * u);
+        }
+        ds[j] = acc;
+        dl.mp[(long)t * DEC_D + j] = acc;
+    }
     __syncthreads();
     if (j >= ME) return;
     float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += sv.attn[(long)s * Tz + t] * dl.ctx[(long)s * ME + j];
     const f32x4 *w = reinterpret_cast<const f32x4 *>(w1 + (long)j * DEC_D);
 #pragma unroll 8
     for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
@@ -626,5 +668,5 @@ __global__ __launch_bounds__(256) void dec_memgrad_kernel(const float *dmp, cons
         const f32x4 dv = *reinterpret_cast<const f32x4 *>(&ds[k4 * 4]);
         acc += wv[0] * dv[0] + wv[1] * dv[1] + wv[2] * dv[2] + wv[3] * dv[3];
     }
-    d_memory[(long)t * ME + j] += acc;
+    d_memory[(long)t * ME + j] = acc;
 }

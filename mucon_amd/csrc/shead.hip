@@ -152,6 +152,8 @@ static DecLayout dec_layout(const mucon_decoder_cfg *c, float *base) {
     L.sv.lencat = take(S * LW);
     L.sv.l1 = take(S * DEC_NL);
     L.sv.toks = reinterpret_cast<int *>(take(S));
+    L.dl.ctx = take(S * c->ME);
+    L.dl.score = take(S * Tz);
     L.dl.mp = take(Tz * DEC_D);
     L.dl.q = take(S * DEC_D);
     L.dl.mixed = take(S * DEC_D);
@@ -265,8 +267,8 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     job(L.dl.c0, DEC_D, DEC_D, cn, ME, ME, 1, g.co_w, g.co_b, nullptr);
     job(memory, ME, ME, L.dl.mp, DEC_D, DEC_D, Tz, g.w1, nullptr, nullptr);
     ob.njobs = nj;
+    hipLaunchKernelGGL(dec_attn_grad_kernel, dim3(Tz), dim3(256), 0, s, L.sv, L.dl, p.w1, p.v, d_memory, S, Tz, ME);   // before dW1's job
     hipLaunchKernelGGL(dec_outer_kernel, dim3(blocks), dim3(256), 0, s, ob);
-    hipLaunchKernelGGL(dec_memgrad_kernel, dim3(Tz), dim3(256), 0, s, L.dl.mp, p.w1, d_memory, ME);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

@@ -196,8 +196,14 @@ class MuCon(nn.Module):
             temporal_encoded=temporal_encoded, tf_transcript_target_length=batch.transcript_tf_target.shape[0],
             transcript_tf_input=batch.transcript_tf_input, transcript_tf_target=batch.transcript_tf_target)
         segmentation, logp = self._segmentation_and_logp(temporal_encoded, Tf)  # [Tf x M] each
-        out = MuConForwardOut(transcript=torch.cat(transcripts, dim=0), lengths=torch.stack(lengths[:-1]),
-                              segmentation=segmentation)
+        fused = self.__dict__.pop("_decoder_tensors", None)
+        if fused is not None:      # the persistent decoder kernel's outputs, without the list round trip
+            if fused[1].shape[0] < 2:
+                raise RuntimeError("stack expects a non-empty TensorList")   # EOS first: what torch.stack([]) raises (models.py:351)
+            out = MuConForwardOut(transcript=fused[0], lengths=fused[1][:-1], segmentation=segmentation)
+        else:
+            out = MuConForwardOut(transcript=torch.cat(transcripts, dim=0), lengths=torch.stack(lengths[:-1]),
+                                  segmentation=segmentation)
         out._logp = logp  # the kernel's log-softmax, reused by predict() and the smoothing loss
         return out
 
@@ -275,6 +281,9 @@ class MuCon(nn.Module):
         logp, lengths = ops.decoder_forward(memory, h_n, c_n, transcript_tf_input, self._decoder_param_list(), steps,
                                             self.teacher_forcing, stop, self.EOS_token_id, mask)
         n = logp.shape[0]
+        # forward() takes the two tensors as they are; the per-step lists below only serve callers of the reference's
+        # list interface (each slice is an autograd node: ~4 tiny launches apiece in the backward)
+        self._decoder_tensors = (logp, lengths)
         return [logp[i:i + 1] for i in range(n)], [lengths[i] for i in range(n)]
 
     def _sequence_encoder(self, temporal_encoded: Tensor):
