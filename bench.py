@@ -184,7 +184,7 @@ def end_to_end_bench(dev, steps=40):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"videos_per_s": round(1.0 / dt, 1), "frames_per_s": round(T / dt, 1), "ms_per_video": round(dt * 1e3, 3),
-            "config": f"full MuCon train step, batch 1, T={T}, N={N}: all-HIP: hot path, s-head (persistent LSTM / decoder), fused losses, fused clip+SGD; torch = autograd glue only",
+            "config": f"full MuCon train step, batch 1, T={T}, N={N}: all-HIP, graph-free: encoder, s-head (persistent LSTM / decoder), y-head, fused losses, backward, fused clip+SGD as one straight line of launches (MuCon.fused_train_step)",
             "reference_readme_it_per_s": [14.67, 16.23]}
 
 

@@ -207,6 +207,76 @@ class MuCon(nn.Module):
         out._logp = logp  # the kernel's log-softmax, reused by predict() and the smoothing loss
         return out
 
+    # ------------------------------------------------------------------------------ the training step without autograd
+    def can_fuse_step(self, batch: Batch) -> bool:
+        lc = self.cfg.model.loss
+        return (type(self).loss is MuCon.loss and self.training and isinstance(self.ft, WaveNetBlock) and batch.feats.is_cuda
+                and batch.feats.shape[0] == 1 and self.native_lstm and self.native_decoder and self.native_loss
+                and self.fs_encoder_lstm.input_size == 128 and self.fs_encoder_lstm.hidden_size == 128
+                and self.fs_encoder_lstm.num_layers == 1 and lc.mucon.type in ("flint", "arithmetic")
+                and batch.feats.shape[1] >= 2 and self.num_classes <= 64 and 1 <= batch.transcript_tf_target.shape[0] - 1 <= 64
+                and batch.feats.shape[1] // 16 <= 8192)
+
+    @torch.no_grad()
+    def fused_train_step(self, batch: Batch) -> MuConLoss:
+        """forward + loss + backward of one video as a straight line of kernel launches: the same autograd Functions
+        (same C entry points, same arithmetic) called directly in dependency order, gradients assigned to `.grad`.
+        Equivalent to `loss = self.loss(batch, self.forward(batch)); loss.main.backward()` (tests/test_gpu_fused_step.py);
+        what it saves is the autograd graph walk: ~40 nodes with a Python round trip each -- half of the step's host time,
+        and the step is host-bound."""
+        F_ = ops
+        lc = self.cfg.model.loss
+        feats = batch.feats
+        Tf = feats.shape[1]
+        self._step += 1
+        seed = (int(self.cfg.system.seed) << 32) ^ self._step
+        enc_params = self.ft.ordered_parameters() + [self.ft_last_gn.weight, self.ft_last_gn.bias]
+        enc, c_enc = F_.run_forward(F_._EncoderFn, feats, self._encoder_spec(), True, int(seed), *enc_params)
+        lstm = self.fs_encoder_lstm
+        lstm_w = list(lstm.parameters())
+        ndir = 2 if lstm.bidirectional else 1
+        (memory, h_n, c_n), c_lstm = F_.run_forward(F_._LstmFn, enc[0], ndir, *lstm_w)
+        steps = batch.transcript_tf_target.shape[0]
+        p = self.fs_decoder_embedding_drop.p
+        mask = (torch.rand((steps, 128), device=feats.device) >= p).to(torch.float32) / (1.0 - p) if p > 0 else None
+        dec_params = self._decoder_param_list()
+        (tlogp, lens), c_dec = F_.run_forward(F_._DecoderFn, memory, h_n.reshape(-1), c_n.reshape(-1), batch.transcript_tf_input,
+                                               mask, (int(steps), bool(self.teacher_forcing), False, int(self.EOS_token_id)),
+                                               *dec_params)
+        wc = self.conv_classifier.weight
+        (logits, logp), c_head = F_.run_forward(F_._HeadFn, enc, wc.reshape(wc.shape[0], wc.shape[1]), self.conv_classifier.bias,
+                                                 int(Tf), True, True)
+        seg = logits[0]
+        sx = logp[0] if lc.smoothing.log_softmax_before else seg
+        fo = MuConForwardOut(transcript=tlogp, lengths=lens[:-1], segmentation=seg)
+        if self.teacher_forcing:
+            target = batch.transcript
+        else:
+            target = tlogp[:-1].argmax(dim=1)
+            target = torch.where(target >= self.num_classes, torch.zeros_like(target), target)
+        self._loss_constants(seg.device)
+        (main, parts), c_loss = F_.run_forward(F_._LossFn, seg, sx, tlogp, lens[:-1].contiguous(), self._loss_spec(), target.to(torch.int64),
+                                                batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw, self._loss_tw)
+        d_seg, d_sx, d_tlogp, d_len = c_loss.saved_tensors            # d main / d input, computed with the loss itself
+        if lc.smoothing.log_softmax_before:
+            d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
+        else:
+            d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, (d_seg + d_sx).unsqueeze(0), None)[:3]
+        d_lens = torch.cat((d_len, d_len.new_zeros(1)))                # the last step's length is not used by the losses
+        d_mem, d_hn, d_cn, _, _, _, *g_dec = F_.run_backward(F_._DecoderFn, c_dec, d_tlogp, d_lens)
+        d_x, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
+        d_enc[0] += d_x
+        g_enc = F_.run_backward(F_._EncoderFn, c_enc, d_enc)[4:]
+        for prm, g in zip(enc_params, g_enc):
+            prm.grad = g
+        for prm, g in zip(lstm_w, g_lstm):
+            prm.grad = g
+        for prm, g in zip(dec_params, g_dec):
+            prm.grad = g
+        wc.grad, self.conv_classifier.bias.grad = d_wc.view_as(wc), d_bc
+        loss = MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2], smoothing_loss=parts[3])
+        return loss, fo
+
     def predict(self, batch: Batch, forward_out: MuConForwardOut) -> MuConPredictOut:
         if self.teacher_forcing:
             transcript = batch.transcript_tf_target.detach().cpu().numpy().tolist()
@@ -334,6 +404,17 @@ class MuCon(nn.Module):
             sx = logp if logp is not None else F.log_softmax(seg, dim=1)
         else:
             sx = seg
+        self._loss_constants(dev)
+        spec = self._loss_spec()
+        main, parts = ops.losses_forward(seg, sx, forward_out.transcript, forward_out.lengths, spec, target.to(torch.int64),
+                                         batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw,
+                                         self._loss_tw)
+        return MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2],
+                         smoothing_loss=parts[3])
+
+    def _loss_constants(self, dev):
+        """Mask template and class-weight vectors on the device (built once per template / device)."""
+        lc = self.cfg.model.loss
         key = (lc.mucon.template, str(dev))
         if getattr(self, "_loss_consts_key", None) != key:
             from .masks import _template
@@ -344,16 +425,14 @@ class MuCon(nn.Module):
                                              lc.transcript_weight_background_value, dev)
                              if lc.transcript_weight_background else None)
             self._loss_consts_key = key
-        spec = ops.LossSpec(mucon_type=lc.mucon.type, overlap=float(lc.mucon.overlap), smoothing_clamp=bool(lc.smoothing.clamp),
+
+    def _loss_spec(self) -> ops.LossSpec:
+        lc = self.cfg.model.loss
+        return ops.LossSpec(mucon_type=lc.mucon.type, overlap=float(lc.mucon.overlap), smoothing_clamp=bool(lc.smoothing.clamp),
                             clamp_min=float(lc.smoothing.clamp_min), clamp_max=float(lc.smoothing.clamp_max),
                             length_width=float(lc.length_width), transcript_average=bool(lc.transcript_average),
                             mul_transcript=float(self.loss_mul_transcript), mul_length=float(self.loss_mul_length),
                             mul_mucon=float(self.loss_mul_mucon), mul_smoothing=float(self.loss_mul_smoothing))
-        main, parts = ops.losses_forward(seg, sx, forward_out.transcript, forward_out.lengths, spec, target.to(torch.int64),
-                                         batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw,
-                                         self._loss_tw)
-        return MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2],
-                         smoothing_loss=parts[3])
 
     def smoothing_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
         sm = self.cfg.model.loss.smoothing

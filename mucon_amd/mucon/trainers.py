@@ -73,6 +73,7 @@ class SimpleTrainer:
         self.clip_grad_norm: Optional[float] = cfg.trainer.clip_grad_norm_value if cfg.trainer.clip_grad_norm else None
         self.iter_num = 0
         self.fused_step = self._make_fused_step()
+        self.fuse_step = True   # False: always go through torch.autograd
 
     def _make_fused_step(self):
         """The two clip_grad_norm_ calls + SGD.step() as ops.FusedClipSGD (two launches) when the configuration is the
@@ -108,9 +109,13 @@ class SimpleTrainer:
         if iter_num % acc == 0:
             self.optimizer.zero_grad()
         batch.to(self.device)
-        forward_out = self.model.forward(batch)
-        loss = self.model.loss(batch, forward_out)
-        (loss.main / acc).backward()
+        if acc == 1 and self.fuse_step and hasattr(self.model, "can_fuse_step") and self.model.can_fuse_step(batch):
+            # forward + loss + backward as one straight line of launches, no autograd graph (MuCon.fused_train_step)
+            loss, forward_out = self.model.fused_train_step(batch)
+        else:
+            forward_out = self.model.forward(batch)
+            loss = self.model.loss(batch, forward_out)
+            (loss.main / acc).backward()
         last_of_group = iter_num % acc == (acc - 1)
         if last_of_group and self.world_size > 1:
             all_reduce_gradients(self.model, self.world_size)

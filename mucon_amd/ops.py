@@ -508,6 +508,35 @@ class FusedClipSGD:
             self.optimizer._opt_called = True
 
 
+# --------------------------------------------------------------------------------------- graph-free execution
+class PlainCtx:
+    """Stand-in for torch.autograd's context object: lets the Functions above run their forward / backward as plain
+    calls, without building an autograd graph (MuCon.fused_train_step: the training step as one straight line of
+    launches -- the graph walk and its per-node Python round trips cost as much host time as the GPU needs for the step)."""
+    saved_tensors = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def set_materialize_grads(self, flag):
+        pass
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+
+def run_forward(fn, *args):
+    """(outputs, ctx) of an autograd Function's forward, called directly."""
+    ctx = PlainCtx()
+    with torch.no_grad():
+        return fn.forward(ctx, *args), ctx
+
+
+def run_backward(fn, ctx, *grads):
+    with torch.no_grad():
+        return fn.backward(ctx, *grads)
+
+
 # --------------------------------------------------------------------------------------- viterbi
 @dataclass
 class ViterbiResult:
