@@ -6,8 +6,8 @@
 //
 // MIOpen needs 5.9 ms for this forward and 11.9 ms with the backward (Tz = 125): the work is a chain of Tz
 // dependent 512x128 mat-vecs, i.e. pure latency.  Here ONE workgroup per direction stays resident for the
-// whole sequence: 512 threads, thread r keeps row r of W_hh (128 floats) in registers, h_{t-1} is broadcast
-// from LDS, the four gates of a hidden unit meet through LDS; two barriers per time step.
+// whole sequence: 512 threads, each keeps one row of W_hh (128 floats) in registers, h_{t-1} is broadcast
+// from LDS, the four gates of a hidden unit sit in one wave and meet through shuffles; one barrier per time step.
 //   lstm_inproj_kernel      Gx[d][t][r] = W_ih[d][r] . x[t] + b_ih[d][r] + b_hh[d][r]     (all t at once)
 //   lstm_recur_fwd_kernel   the recurrence; saves gate activations and cell states for the backward
 //   lstm_recur_bwd_kernel   BPTT: thread (q, j) keeps column j of gate block q of W_hh, dh_{t-1} = W_hh^T dgates_t
@@ -62,11 +62,17 @@ __global__ __launch_bounds__(512) void lstm_inproj_kernel(const float *x, LstmWe
 
 // grid (ndir), 512 threads.  out [T][ndir*128]; saves: gates [ndir][T][4][128] (post-activation i,f,g,o),
 // cells [ndir][T][128]; hn / cn [ndir][128].
+// Thread layout: wave w owns hidden units 16w .. 16w+15; lane (u = lane & 15, q = lane >> 4) holds row q*128 + 16w + u of
+// W_hh, i.e. the four gates of a unit sit in ONE wave: they meet through three wave shuffles instead of an LDS round trip
+// and a barrier, every lane applies its own gate's non-linearity (tanh x = 2 sigmoid(2x) - 1: branch-free), lanes 0-15
+// update the cell.  One barrier per time step (the new h for everybody).
 __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, LstmWeights w, float *out, float *gates,
                                                              float *cells, float *hn, float *cn, int T, int ndir) {
     __shared__ __attribute__((aligned(16))) float hs[2][LSTM_H];
-    __shared__ float pre[LSTM_G];
-    const int d = blockIdx.x, r = threadIdx.x;
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, unit = wave * 16 + (lane & 15);
+    const int r = q * LSTM_H + unit;
     float wr[LSTM_H];
 #pragma unroll
     for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
@@ -76,10 +82,11 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
         wr[c4 * 4 + 2] = v[2];
         wr[c4 * 4 + 3] = v[3];
     }
-    if (r < LSTM_H) hs[0][r] = 0.f;
-    float c = 0.f;  // cell state of hidden unit r (threads r < 128)
+    if (tid < LSTM_H) hs[0][tid] = 0.f;
+    float c = 0.f;  // cell state of `unit` (lanes with q == 0)
     const float *gx = Gx + (long)d * T * LSTM_G + r;
     float gnext = gx[(long)(d == 0 ? 0 : T - 1) * LSTM_G];
+    const float asc = q == 2 ? 2.f : 1.f;   // gate g: tanh through the sigmoid
     __syncthreads();
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
@@ -91,85 +98,97 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
             const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][c4 * 4]);  // broadcast read
             acc += wr[c4 * 4 + 0] * hv[0] + wr[c4 * 4 + 1] * hv[1] + wr[c4 * 4 + 2] * hv[2] + wr[c4 * 4 + 3] * hv[3];
         }
-        pre[r] = acc;
-        __syncthreads();
-        if (r < LSTM_H) {
-            const float gi = sigmoid_f(pre[r]), gf = sigmoid_f(pre[LSTM_H + r]);
-            const float gg = tanhf(pre[2 * LSTM_H + r]), go = sigmoid_f(pre[3 * LSTM_H + r]);
-            c = gf * c + gi * gg;
+        const float sg = sigmoid_f(asc * acc);
+        const float act = q == 2 ? 2.f * sg - 1.f : sg;
+        gates[((long)d * T + t) * LSTM_G + r] = act;
+        const float gf = __shfl(act, (lane & 15) + 16), gg = __shfl(act, (lane & 15) + 32), go = __shfl(act, (lane & 15) + 48);
+        if (q == 0) {
+            c = gf * c + act * gg;
             const float h = go * tanhf(c);
-            float *gs = gates + ((long)d * T + t) * LSTM_G;
-            gs[r] = gi;
-            gs[LSTM_H + r] = gf;
-            gs[2 * LSTM_H + r] = gg;
-            gs[3 * LSTM_H + r] = go;
-            cells[((long)d * T + t) * LSTM_H + r] = c;
-            out[(long)t * (ndir * LSTM_H) + d * LSTM_H + r] = h;
-            hs[cur ^ 1][r] = h;
+            cells[((long)d * T + t) * LSTM_H + unit] = c;
+            out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] = h;
+            hs[cur ^ 1][unit] = h;
             if (s == T - 1) {
-                hn[d * LSTM_H + r] = h;
-                cn[d * LSTM_H + r] = c;
+                hn[d * LSTM_H + unit] = h;
+                cn[d * LSTM_H + unit] = c;
             }
         }
         __syncthreads();
     }
 }
 
-// grid (ndir), 512 threads: thread (q = tid >> 7, j = tid & 127) keeps W_hh[d][q*128 + r'][j], r' = 0..127.
+// grid (ndir), 512 threads.  Same ownership as the forward for the gate gradients (lane (u, q) -> gate q of unit 16w + u:
+// every lane derives its own pre-activation gradient, the four lanes of a unit carry identical copies of dc); for
+// dh_{t-1} = W_hh^T dgates thread (qq = tid >> 7, j = tid & 127) keeps W_hh[qq*128 + r'][j], r' = 0..127, and the four
+// partial sums of a unit are added by the lanes that need them: two barriers per time step.
 // dG [ndir][T][512]: gradient at the gate pre-activations (input of the weight / input gradients).
 __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, const float *out, const float *gates,
                                                              const float *cells, const float *d_out, const float *d_hn,
                                                              const float *d_cn, float *dG, int T, int ndir) {
     __shared__ __attribute__((aligned(16))) float dgs[LSTM_G];
     __shared__ float part[4][LSTM_H];
-    __shared__ float dhrec[LSTM_H];
     const int d = blockIdx.x, tid = threadIdx.x;
-    const int q = tid >> 7, j = tid & 127;
+    const int qq = tid >> 7, j = tid & 127;                 // mat-vec role
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, unit = wave * 16 + (lane & 15);   // gate role
     float wt[LSTM_H];
 #pragma unroll
-    for (int rr = 0; rr < LSTM_H; ++rr) wt[rr] = w.w_hh[d][(long)(q * LSTM_H + rr) * LSTM_H + j];
-    float dc = 0.f;
-    if (tid < LSTM_H) {
-        dhrec[tid] = d_hn ? d_hn[d * LSTM_H + tid] : 0.f;
-        dc = d_cn ? d_cn[d * LSTM_H + tid] : 0.f;
+    for (int rr = 0; rr < LSTM_H; ++rr) wt[rr] = w.w_hh[d][(long)(qq * LSTM_H + rr) * LSTM_H + j];
+    float dc = d_cn ? d_cn[d * LSTM_H + unit] : 0.f;
+    if (tid < LSTM_H) {   // the recurrent dh of the first processed step = d_hn: park it in part[0], zeros in part[1..3]
+        part[0][tid] = d_hn ? d_hn[d * LSTM_H + tid] : 0.f;
+        part[1][tid] = 0.f;
+        part[2][tid] = 0.f;
+        part[3][tid] = 0.f;
     }
     __syncthreads();
-    for (int s = T - 1; s >= 0; --s) {           // reverse of the processing order
+    // the saved activations / upstream gradient of a step do not depend on the recurrence: step s-1's are requested while
+    // step s is processed (one L2 round trip per step would otherwise sit on the critical path)
+    struct StepIn {
+        float gi, gf, gg, go, ct, cp, dout;
+    };
+    auto load_step = [&](int s) {
+        StepIn v;
         const int t = d == 0 ? s : T - 1 - s;
         const int tp = d == 0 ? t - 1 : t + 1;   // previous step in processing order (s - 1)
-        if (tid < LSTM_H) {
-            const float *gs = gates + ((long)d * T + t) * LSTM_G;
-            const float gi = gs[tid], gf = gs[LSTM_H + tid], gg = gs[2 * LSTM_H + tid], go = gs[3 * LSTM_H + tid];
-            const float ct = cells[((long)d * T + t) * LSTM_H + tid];
-            const float cp = s > 0 ? cells[((long)d * T + tp) * LSTM_H + tid] : 0.f;
-            const float dh = (d_out ? d_out[(long)t * (ndir * LSTM_H) + d * LSTM_H + tid] : 0.f) + dhrec[tid];
+        const float *gs = gates + ((long)d * T + t) * LSTM_G;
+        v.gi = gs[unit];
+        v.gf = gs[LSTM_H + unit];
+        v.gg = gs[2 * LSTM_H + unit];
+        v.go = gs[3 * LSTM_H + unit];
+        v.ct = cells[((long)d * T + t) * LSTM_H + unit];
+        v.cp = s > 0 ? cells[((long)d * T + tp) * LSTM_H + unit] : 0.f;
+        v.dout = d_out ? d_out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] : 0.f;
+        return v;
+    };
+    StepIn nx = load_step(T - 1);
+    for (int s = T - 1; s >= 0; --s) {           // reverse of the processing order
+        const int t = d == 0 ? s : T - 1 - s;
+        const StepIn in = nx;
+        if (s > 0) nx = load_step(s - 1);
+        {
+            const float gi = in.gi, gf = in.gf, gg = in.gg, go = in.go, ct = in.ct, cp = in.cp;
+            const float dh = in.dout + ((part[0][unit] + part[1][unit]) + (part[2][unit] + part[3][unit]));
             const float th = tanhf(ct);
             const float dct = dc + dh * go * (1.f - th * th);
-            const float dpi = dct * gg * gi * (1.f - gi);
-            const float dpf = dct * cp * gf * (1.f - gf);
-            const float dpg = dct * gi * (1.f - gg * gg);
-            const float dpo = dh * th * go * (1.f - go);
             dc = dct * gf;
-            dgs[tid] = dpi;
-            dgs[LSTM_H + tid] = dpf;
-            dgs[2 * LSTM_H + tid] = dpg;
-            dgs[3 * LSTM_H + tid] = dpo;
-            float *o = dG + ((long)d * T + t) * LSTM_G;
-            o[tid] = dpi;
-            o[LSTM_H + tid] = dpf;
-            o[2 * LSTM_H + tid] = dpg;
-            o[3 * LSTM_H + tid] = dpo;
+            float dp;
+            if (q == 0) dp = dct * gg * gi * (1.f - gi);
+            else if (q == 1) dp = dct * cp * gf * (1.f - gf);
+            else if (q == 2) dp = dct * gi * (1.f - gg * gg);
+            else dp = dh * th * go * (1.f - go);
+            // (dgs was last read before the barrier that ended the previous step; part[] is rewritten only after the next one)
+            dgs[q * LSTM_H + unit] = dp;
+            dG[((long)d * T + t) * LSTM_G + q * LSTM_H + unit] = dp;
         }
         __syncthreads();
         float acc = 0.f;
 #pragma unroll
         for (int r4 = 0; r4 < LSTM_H / 4; ++r4) {
-            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[q * LSTM_H + r4 * 4]);  // broadcast within a wave pair
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[qq * LSTM_H + r4 * 4]);  // broadcast within a wave pair
             acc += wt[r4 * 4 + 0] * gv[0] + wt[r4 * 4 + 1] * gv[1] + wt[r4 * 4 + 2] * gv[2] + wt[r4 * 4 + 3] * gv[3];
         }
-        part[q][j] = acc;
-        __syncthreads();
-        if (tid < LSTM_H) dhrec[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        part[qq][j] = acc;
         __syncthreads();
     }
 }
