@@ -57,12 +57,15 @@ struct FusedParams {
     DropCfg drop;       // element index (b*Trows + t)*128 + c
 };
 
-template <int WM, int WAVES_M, int KS, bool BWD, int POOL>
+template <int WM, int WAVES_M, int KS, bool BWD, int POOL, int MT = 32>
 __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p) {
+    using TL = NtTile<MT>;
+    constexpr int NREG = TL::NREG;
+    static_assert(MT == 32 || KS == 1, "the k-split variant exists for 32x32 tiles only");
     constexpr int NTHR = 256 * KS;
     constexpr int WAVES_N = 4 / WAVES_M;
-    constexpr int WN = 4 / WAVES_N;
-    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int WN = (128 / WAVES_N) / MT;
+    constexpr int BM = WAVES_M * WM * MT;
     constexpr int LROWS = NTHR / 8;                       // rows one pass of the cooperative loader covers
     constexpr int NQA = BM > LROWS ? BM / LROWS : 1;      // A float4 loads per thread (BM < LROWS: rows wrap, duplicates)
     constexpr int NQW = 128 / LROWS;                      // W float4 loads per thread
@@ -88,14 +91,14 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 
     f32x4 ra[2][NQA], rb[2][NQW];
     bool ra_ok[2][NQA];  // padding rows are zeroed at the LDS store, so that the loads stay in flight (see gemm_nt.hpp)
-    f32x16 acc[WM][WN];
+    typename TL::Acc acc[WM][WN];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < NREG; ++e) acc[i][j][e] = 0.f;
     };
     // tile v of the unified sequence: only ISSUES loads (W1 / W2 chosen by select, A rows clamped)
     auto gload = [&](int v, auto SET, auto WITH_A) {
@@ -140,28 +143,46 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     // 32-deep k-tile of MFMAs (this wave's half of it when KS = 2): A fragments from `Aw` (row stride lda floats),
     // W fragments from the staging buffer
     auto mfma_tile = [&](const float *Aw, int lda, const float *Bw) {
+        if (MT == 32) {
 #pragma unroll
-        for (int kq = 0; kq < 2 / KS; ++kq) {
-            const int ks = KS == 2 ? kgrp : kq;
+            for (int kq = 0; kq < 2 / KS; ++kq) {
+                const int ks = KS == 2 ? kgrp : kq;
+                f32x4 av[WM][2], bv[WN][2];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + ks * 8);
+                    av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + ks * 8 + 4);
+                }
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + ks * 8);
+                    bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + ks * 8 + 4);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
+            }
+        } else {   // 16x16x4 tiles: the lane's eight k of the 32-deep tile in two 16-byte reads
             f32x4 av[WM][2], bv[WN][2];
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
-                av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * lda + ks * 8);
-                av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * lda + ks * 8 + 4);
+                av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda);
+                av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + 4);
             }
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
-                bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8);
-                bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8 + 4);
+                bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS);
+                bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + 4);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3],
-                                                                         acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < WN; ++n) nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
         }
     };
     // KS = 2: the second k-half's partial sums cross to the first through Hs (each element is written and read by
@@ -174,9 +195,9 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 #pragma unroll
                     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int row = (wr * WM + mt) * 32 + 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
-                            Hs[row * FUSED_HS + (wc * WN + nt) * 32 + (lane & 31)] = acc[mt][nt][reg];
+                        for (int reg = 0; reg < NREG; ++reg) {
+                            const int row = (wr * WM + mt) * MT + TL::row0(lane) + TL::rowr(reg);
+                            Hs[row * FUSED_HS + (wc * WN + nt) * MT + (lane & (MT - 1))] = acc[mt][nt][reg];
                         }
             }
             __syncthreads();
@@ -186,9 +207,9 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 #pragma unroll
                     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int row = (wr * WM + mt) * 32 + 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
-                            acc[mt][nt][reg] += Hs[row * FUSED_HS + (wc * WN + nt) * 32 + (lane & 31)];
+                        for (int reg = 0; reg < NREG; ++reg) {
+                            const int row = (wr * WM + mt) * MT + TL::row0(lane) + TL::rowr(reg);
+                            acc[mt][nt][reg] += Hs[row * FUSED_HS + (wc * WN + nt) * MT + (lane & (MT - 1))];
                         }
             }
         }
@@ -197,9 +218,9 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     using S1 = std::integral_constant<int, 1>;
     using YES = std::true_type;
     using NO = std::false_type;
-    const int a_row = wr * WM * 32 + (lane & 31);
-    const int k_half = (lane >> 5) * 16;
-    const int b_off = (wc * WN * 32 + (lane & 31)) * NT_LDS + k_half;
+    const int a_row = wr * WM * MT + (lane & (MT - 1));
+    const int k_half = TL::koff(lane);
+    const int b_off = (wc * WN * MT + (lane & (MT - 1))) * NT_LDS + k_half;
 
     // ---------------------------------------------------------------- stage 1
     zero_acc();
@@ -232,22 +253,22 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
-                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const int col = (wc * WN + nt) * MT + (lane & (MT - 1));
                 const float bias = (!BWD && p.bias1) ? p.bias1[col] : 0.f;
-                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
-                float rres[16], rmask[16];
+                const int rbase = (wr * WM + mt) * MT + TL::row0(lane);
+                float rres[NREG], rmask[NREG];
                 if (BWD) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    for (int reg = 0; reg < NREG; ++reg) {
+                        const int t = t0 + rbase + TL::rowr(reg);
                         const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
                         rres[reg] = p.res1 ? p.res1[g] : 0.f;
                         rmask[reg] = p.mask1 ? p.mask1[g] : 1.f;
                     }
                 }
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int row = rbase + TL::rowr(reg);
                     const int t = t0 + row;
                     const long g = (vbase + t) * 128 + col;
                     float x = acc[mt][nt][reg] + bias;
@@ -296,20 +317,20 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
-                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const int col = (wc * WN + nt) * MT + (lane & (MT - 1));
                 const float bias = (!BWD && p.bias2) ? p.bias2[col] : 0.f;
-                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
-                float raux[16];   // FWD: residual x; BWD: h (mask)
+                const int rbase = (wr * WM + mt) * MT + TL::row0(lane);
+                float raux[NREG];   // FWD: residual x; BWD: h (mask)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
                     raux[reg] = BWD ? p.mask2[g] : p.res2[g];
                 }
-                float v[16];
+                float v[NREG];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + t) * 128 + col;
                     float x = acc[mt][nt][reg] + bias;
                     if (!BWD) {
@@ -321,8 +342,8 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
                     v[reg] = x;
                 }
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + t) * 128 + col;
                     if (FULL || t < p.Trows) {
                         if (BWD || POOL == 0) p.out2[g] = v[reg];
@@ -331,8 +352,8 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
                 }
                 if (!BWD && POOL != 0) {
 #pragma unroll
-                    for (int rp = 0; rp < 8; ++rp) {
-                        const int te = t0 + rbase + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);
+                    for (int rp = 0; rp < NREG / 2; ++rp) {
+                        const int te = t0 + rbase + TL::rowr(2 * rp);
                         if (FULL || te + 1 < p.Trows) {
                             const long g = ((long)b * (p.Trows >> 1) + (te >> 1)) * 128 + col;
                             p.out2[g] = (POOL == 1) ? fmaxf(v[2 * rp], v[2 * rp + 1]) : (v[2 * rp] + v[2 * rp + 1]);
@@ -348,10 +369,10 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     }
 }
 
-template <int WM, int WAVES_M, int KS, bool BWD, int POOL>
+template <int WM, int WAVES_M, int KS, bool BWD, int POOL, int MT = 32>
 static hipError_t launch_fused_cfg(const FusedParams &p, int B, hipStream_t s) {
-    constexpr int BM = WAVES_M * WM * 32;
-    auto k = nt_fused_kernel<WM, WAVES_M, KS, BWD, POOL>;
+    constexpr int BM = WAVES_M * WM * MT;
+    auto k = nt_fused_kernel<WM, WAVES_M, KS, BWD, POOL, MT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -368,8 +389,9 @@ extern int g_fused_bm;  // 0 = automatic (tuning hook: MUCON_FUSED_BM = 32 / 64)
 extern int g_fused_ks;  // k-split of the BM = 32 variant: 1 (default) or 2 (tuning hook: MUCON_FUSED_KS)
 template <bool BWD, int POOL>
 static hipError_t launch_fused(const FusedParams &p, int B, hipStream_t s) {
-    int bm = g_fused_bm ? g_fused_bm : (((long)B * p.Trows >= 512L * 64) ? 64 : 32);
+    int bm = g_fused_bm ? g_fused_bm : (((long)B * p.Trows >= 512L * 64) ? 64 : ((long)B * p.Trows < g_nt_bm16_rows ? 16 : 32));
     if (bm == 64) return launch_fused_cfg<1, 2, 1, BWD, POOL>(p, B, s);
+    if (bm == 16) return launch_fused_cfg<1, 1, 1, BWD, POOL, 16>(p, B, s);
     if (g_fused_ks == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
     return launch_fused_cfg<1, 1, 1, BWD, POOL>(p, B, s);
 }

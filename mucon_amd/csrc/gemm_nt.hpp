@@ -52,12 +52,36 @@ struct NtParams {
 };
 
 // TAG only names the instantiation (TAG 1 = first_conv forward, so that profilers list it separately)
-template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG>
+template <int MT, typename ACC>
+__device__ __forceinline__ void nt_mfma(ACC &c, float a, float b) {
+    if constexpr (MT == 32) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// MT = MFMA tile edge: 32 (v_mfma_f32_32x32x2_f32, 16 accumulator registers per tile) or 16 (v_mfma_f32_16x16x4_f32, 4
+// registers; same 64 FLOP/clk/SIMD).  MT = 16 exists for BM = 16: the latency-bound coarse levels get twice the workgroups
+// with half the MFMA chain each.
+template <int MT>
+struct NtTile {
+    using Acc = typename std::conditional<MT == 32, f32x16, f32x4>::type;
+    static constexpr int NREG = MT == 32 ? 16 : 4;
+    // C/D layout: column = lane & (MT-1); row of register `reg`:
+    //   32x32: (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)        16x16: reg + 4 * (lane >> 4)
+    __device__ static __forceinline__ int row0(int lane) { return MT == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4); }
+    __device__ static __forceinline__ int rowr(int reg) { return MT == 32 ? (reg & 3) + 8 * (reg >> 2) : reg; }
+    // operand lane (i = lane & (MT-1), kg = lane / MT) reads k = kg * (32 / groups) + s of the 32-deep k-tile at step s
+    __device__ static __forceinline__ int koff(int lane) { return MT == 32 ? (lane >> 5) * 16 : (lane >> 4) * 8; }
+};
+
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG,
+          int MT = 32>
 __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
+    using TL = NtTile<MT>;
+    constexpr int NREG = TL::NREG;
     constexpr int WAVES_N = 4 / WAVES_M;
-    constexpr int WN = 4 / WAVES_N;            // 32-wide column tiles per wave (128 columns in all)
-    constexpr int BM = WAVES_M * WM * 32;
-    constexpr int NQA = BM / 32;               // A-tile float4 loads per thread
+    constexpr int WN = (128 / WAVES_N) / MT;   // MT-wide column tiles per wave (128 columns in all)
+    constexpr int BM = WAVES_M * WM * MT;
+    constexpr int NQA = BM >= 32 ? BM / 32 : 1;   // A-tile float4 loads per thread (BM = 16: rows wrap, duplicate loads)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
     float *Bs = smem + 2 * BM * NT_LDS;
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
             rb[S][q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + 32 * q) * Ktot + kt * 32 + lc4);
 #pragma unroll
         for (int q = 0; q < NQA; ++q) {
-            const int t = t0 + lrow + 32 * q;
+            const int t = t0 + ((lrow + 32 * q) & (BM - 1));
             const int ts = t + off;
             const bool ok = (t < p.Trows) && (ts >= 0) && (ts < p.Ta);
             const int tc = ts < 0 ? 0 : (ts >= p.Ta ? p.Ta - 1 : ts);
@@ -127,40 +151,62 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t >= 0 ? v[e] : 0.f;
-            *reinterpret_cast<f32x4 *>(a + (lrow + 32 * q) * NT_LDS + lc4) = v;
+            *reinterpret_cast<f32x4 *>(a + ((lrow + 32 * q) & (BM - 1)) * NT_LDS + lc4) = v;   // duplicates store equal values
         }
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    f32x16 acc[WM][WN];
+    typename TL::Acc acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < NREG; ++e) acc[i][j][e] = 0.f;
 
-    // lane (i = lane&31, h = lane>>5) feeds row i of its tile and k = 16h + s at MFMA step s:
-    // both operands use the same k permutation inside the 32-wide tile, so the sum is unchanged.
-    const int a_off = (wr * WM * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
-    const int b_off = (wc * WN * 32 + (lane & 31)) * NT_LDS + (lane >> 5) * 16;
+    // lane (i = lane & (MT-1), group = lane / MT) feeds row i of its tile and a fixed k sub-range of the 32-deep tile
+    // (k = 16h + s for 32x32x2, k = 8g + s for 16x16x4): both operands use the same k permutation, so the sum is unchanged.
+    const int a_off = (wr * WM * MT + (lane & (MT - 1))) * NT_LDS + TL::koff(lane);
+    const int b_off = (wc * WN * MT + (lane & (MT - 1))) * NT_LDS + TL::koff(lane);
 
     auto compute = [&](int cur) {
         const float *Aw = As + cur * BM * NT_LDS + a_off;
         const float *Bw = Bs + cur * 128 * NT_LDS + b_off;
+        if (MT == 32) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 av[WM][2], bv[WN][2];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * NT_LDS + ks * 8);
+                    av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * NT_LDS + ks * 8 + 4);
+                }
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + ks * 8);
+                    bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + ks * 8 + 4);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n)
+                            nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
+                }
+            }
+        } else {   // 16x16x4: four k per MFMA, the lane's eight k of the tile in two 16-byte reads
             f32x4 av[WM][2], bv[WN][2];
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
-                av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * NT_LDS + ks * 8);
-                av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * 32 * NT_LDS + ks * 8 + 4);
+                av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * NT_LDS);
+                av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * NT_LDS + 4);
             }
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
-                bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8);
-                bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * 32 * NT_LDS + ks * 8 + 4);
+                bv[n][0] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS);
+                bv[n][1] = *reinterpret_cast<const f32x4 *>(Bw + n * MT * NT_LDS + 4);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -168,8 +214,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
                     for (int n = 0; n < WN; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3],
-                                                                         acc[m][n], 0, 0, 0);
+                        nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
             }
         }
     };
@@ -200,10 +245,9 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
         __syncthreads();
     }
 
-    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
-    // registers (4q, 4q+1) and (4q+2, 4q+3) hold time steps (2i, 2i+1): max_pool1d(2) pairs.
+    // Epilogue.  C/D layout (NtTile): col = lane & (MT-1); registers (2i, 2i+1) hold adjacent time steps: max_pool1d(2) pairs.
     // Two instantiations, chosen by a workgroup-uniform branch: FULL tiles (every row inside the video, the
-    // common case) run straight-line code -- all residual / mask loads of a 32x32 tile first, then the math,
+    // common case) run straight-line code -- all residual / mask loads of a tile first, then the math,
     // then the stores -- because per-element bounds checks put every load and store under a divergent branch
     // and hipcc then separates them with vmcnt(0) waits, which serialises the whole epilogue.
     const long vbase = (long)b * p.Trows;
@@ -213,33 +257,33 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
         for (int mt = 0; mt < WM; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
-                const int col = (wc * WN + nt) * 32 + (lane & 31);
+                const int col = (wc * WN + nt) * MT + (lane & (MT - 1));
                 const float bias = p.bias ? p.bias[col] : 0.f;
-                const int rbase = (wr * WM + mt) * 32 + 4 * (lane >> 5);
-                float rres[16], rmask[16];
+                const int rbase = (wr * WM + mt) * MT + TL::row0(lane);
+                float rres[NREG], rmask[NREG];
                 const bool use_mask = EPI_MASK && (p.mask != nullptr);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
                     if (EPI_RES) rres[reg] = p.res[g];
                     if (EPI_MASK) rmask[reg] = use_mask ? p.mask[g] : 1.f;
                 }
                 // POOL 3: the un-pooled pair of every output row, for the max-pool un-routing below
-                float y0[POOL == 3 ? 16 : 1], y1[POOL == 3 ? 16 : 1];
+                float y0[POOL == 3 ? NREG : 1], y1[POOL == 3 ? NREG : 1];
                 if (POOL == 3) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    for (int reg = 0; reg < NREG; ++reg) {
+                        const int t = t0 + rbase + TL::rowr(reg);
                         const long gf = ((long)b * p.Tfine + 2 * (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
                         y0[reg] = p.ypre[gf];
                         y1[reg] = p.ypre[gf + 128];
                     }
                 }
-                float v[16];
+                float v[NREG];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + t) * 128 + col;
                     float x = acc[mt][nt][reg] + bias;
                     if (EPI_ACT) x = act_f(x, p.slope);
@@ -253,8 +297,8 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                     v[reg] = x;
                 }
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                for (int reg = 0; reg < NREG; ++reg) {
+                    const int t = t0 + rbase + TL::rowr(reg);
                     const long g = (vbase + t) * 128 + col;
                     if (FULL || t < p.Trows) {
                         if (POOL == 0) p.out[g] = v[reg];
@@ -266,8 +310,8 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                     // gradient: row t of this (coarse) level goes to rows 2t, 2t+1 of the fine level -- to the arg-max
                     // of the forward pair (first wins ties, as torch) or to both; an odd trailing fine row gets 0
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int t = t0 + rbase + (reg & 3) + 8 * (reg >> 2);
+                    for (int reg = 0; reg < NREG; ++reg) {
+                        const int t = t0 + rbase + TL::rowr(reg);
                         if (FULL || t < p.Trows) {
                             const long gf = ((long)b * p.Tfine + 2 * t) * 128 + col;
                             const bool second = POOL == 3 ? (y1[reg] > y0[reg]) : false;
@@ -278,8 +322,8 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
                     }
                 } else if (POOL != 0) {
 #pragma unroll
-                    for (int rp = 0; rp < 8; ++rp) {
-                        const int te = t0 + rbase + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2);   // even time step of the pair
+                    for (int rp = 0; rp < NREG / 2; ++rp) {
+                        const int te = t0 + rbase + TL::rowr(2 * rp);   // even time step of the pair
                         if (FULL || te + 1 < p.Trows) {  // floor pooling drops an odd last step
                             const long g = ((long)b * (p.Trows >> 1) + (te >> 1)) * 128 + col;
                             p.out[g] = (POOL == 1) ? fmaxf(v[2 * rp], v[2 * rp + 1]) : (v[2 * rp] + v[2 * rp + 1]);
@@ -293,10 +337,11 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     else epilogue(std::false_type{});
 }
 
-template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG>
+template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG,
+          int MT = 32>
 static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
-    constexpr int BM = WAVES_M * WM * 32;
-    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>;
+    constexpr int BM = WAVES_M * WM * MT;
+    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, MT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -309,13 +354,16 @@ static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it.
+// Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it; below ~one workgroup
+// per CU at BM = 32 the launch is latency-bound and 16-row tiles (twice the workgroups, half the MFMA chain) are faster.
 extern int g_nt_force_bm;  // 0 = automatic (tuning hook: MUCON_NT_BM)
+extern long g_nt_bm16_rows;  // levels with fewer rows in the batch than this use BM = 16 (MUCON_NT_BM16_ROWS; 0 = never)
 static inline int nt_pick_bm(int B, int Trows) {
     if (g_nt_force_bm) return g_nt_force_bm;
     const long rows = (long)B * Trows;
     if (rows >= 512L * 128) return 128;
     if (rows >= 512L * 64) return 64;
+    if (rows < g_nt_bm16_rows) return 16;
     return 32;
 }
 
@@ -324,6 +372,7 @@ static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
     switch (nt_pick_bm(B, p.Trows)) {
         case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
         case 64: return launch_nt_cfg<1, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
+        case 16: return launch_nt_cfg<1, 1, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, 16>(p, B, s);
         default: return launch_nt_cfg<1, 1, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
     }
 }

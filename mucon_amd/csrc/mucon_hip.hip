@@ -20,6 +20,7 @@ int g_nt_force_bm = 0;
 int g_tn_batch = 2;
 int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
 int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
+long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
 int g_fused_bm = 0;
 int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
@@ -364,6 +365,8 @@ int mucon_abi_version(void) {
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
         if (e) g_tn_ks = atoi(e);
+        e = getenv("MUCON_NT_BM16_ROWS");
+        if (e) g_nt_bm16_rows = atol(e);
         e = getenv("MUCON_UNPOOL_FUSE");
         if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_FUSED_KS");

@@ -504,7 +504,7 @@ class FusedClipSGD:
                                            _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream_ptr()),
                    "mucon_sgd_clip_step")
         # this call stands in for optimizer.step(): tell torch's schedulers so (they warn about the call order otherwise)
-        if hasattr(self.optimizer, "_opt_called"):
+        if isinstance(self.optimizer, torch.optim.Optimizer):
             self.optimizer._opt_called = True
 
 

@@ -292,7 +292,9 @@ def test_training_mode_dropout_replay():
 def test_full_size_batch_properties():
     """BASELINE config 3 shape (B=8, T=4096, D=2048): size-independent properties.
     (1) determinism: two runs are bitwise identical (no float atomics anywhere);
-    (2) batch independence: video b of the batch == the same video run alone, bitwise;
+    (2) batch independence: video b of the batch == the same video run alone, to rounding (a video alone has so few
+        rows per level that it takes the 16-row tiles / 16x16x4 MFMA, whose k-order of summation differs from the
+        32x32x2 tiles the batch of 8 uses: 1e-5 relative; bitwise with MUCON_NT_BM16_ROWS=0);
     (3) gradient additivity: batch gradient == sum of per-video gradients (to rounding)."""
     from mucon_amd import ops
     from oracle import dense as od
@@ -319,21 +321,43 @@ def test_full_size_batch_properties():
     assert torch.equal(enc_a, enc_b) and torch.equal(logp_a, logp_b)
     for x, y in zip(g_a, g_b):
         assert torch.equal(x, y)
+    # With the default tile policy a video alone takes the 16x16x4 MFMA tiles at the levels where the batch of 8 takes
+    # 32x32x2 (different k-order of summation): the forwards agree to rounding, and -- as between fp32 and fp64 -- the few
+    # ReLU inputs within rounding of zero flip, which re-routes single gradient entries (~1e-2 of a gradient's max).
+    # MUCON_NT_BM16_ROWS=0 (same tiles at every batch size) makes (2) bitwise and (3) exact to 1e-4:
+    # test_full_size_properties_with_one_tile_shape runs this test under it.
+    one_shape = os.environ.get("MUCON_NT_BM16_ROWS") == "0"
     gsum = [torch.zeros_like(g, dtype=torch.float64) for g in g_a]
     for b in (0, 3, 7):
         enc_1, logp_1, _ = run(tape[b:b + 1], w[b:b + 1])
-        assert torch.equal(enc_1[0], enc_a[b]) and torch.equal(logp_1[0], logp_a[b])
+        if one_shape:
+            assert torch.equal(enc_1[0], enc_a[b]) and torch.equal(logp_1[0], logp_a[b])
+        assert float((enc_1[0] - enc_a[b]).abs().max()) <= 1e-5 * float(enc_a[b].abs().max())
+        assert float((logp_1[0] - logp_a[b]).abs().max()) <= 1e-5 * float(logp_a[b].abs().max())
     for b in range(B):
         _, _, g_1 = run(tape[b:b + 1], w[b:b + 1])
         for acc, g in zip(gsum, g_1):
             acc += g.double()
     for k, acc, g in zip(names + ["wc", "bc"], gsum, g_a):
         scale = acc.abs().max().item() + 1e-12
-        assert (acc - g.double()).abs().max().item() / scale < 1e-4, k
+        assert (acc - g.double()).abs().max().item() / scale < (1e-4 if one_shape else 5e-2), k
     # and the sampled oracle check of the forward on one video of the batch
     enc_o, _, logp_o = od.hot_path(tape[2:3].cpu().numpy(), params_np, ocfg, torch.float64)
     np.testing.assert_allclose(enc_a[2:3].cpu().numpy(), enc_o, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(logp_a[2:3].cpu().numpy(), logp_o, rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_properties_with_one_tile_shape():
+    """Bitwise batch independence and 1e-4 gradient additivity at B=8 x T=4096 when every batch size uses the same MFMA
+    tile shape (MUCON_NT_BM16_ROWS=0, read once at library load: fresh interpreter)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MUCON_NT_BM16_ROWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::test_full_size_batch_properties", "-q", "-x",
+                        "-m", "gpu"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout
 
 
 def test_unfused_layer_path_still_green():
