@@ -276,32 +276,30 @@ def main():
     sgd = ops.FusedClipSGD([flat_params], None,                         # SGD(lr, weight_decay) in one launch (csrc/optim.hpp)
                            types.SimpleNamespace(param_groups=[{"lr": lr, "weight_decay": wd, "momentum": 0.0}]))
 
-    pending = []
-    if dist is not None:
-        def send_early(p):
-            pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True))
-        wc.register_post_accumulate_grad_hook(send_early)
-        bc.register_post_accumulate_grad_hook(send_early)
+    wc2 = wc.reshape(wc.shape[0], wc.shape[1]) if wc.dim() == 3 else wc
 
     def step(i):
-        for p in flat_params:
-            p.grad = None
-        enc = ops.encoder_forward(tape, enc_params, spec, training=True, seed=i)
-        _, logp = ops.head_forward(enc, wc, bc, T, want_logits=False)
-        logp.backward(dlogp)
+        # forward and backward of the hot path as direct calls of the autograd Functions (the same C entry points in the
+        # same order as logp.backward() would issue them; ops.run_forward / run_backward) -- no graph walk on the host, so
+        # the step stays GPU-bound also on a busy host (the autograd route needs ~1.0 ms of host time per 1.2 ms step)
+        enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, int(i), *enc_params)
+        (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
+        d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
+        wc.grad, bc.grad = d_w.view_as(wc), d_b
+        pending = []
+        if dist is not None:   # the two y-head tensors ride under the encoder's backward
+            pending = [dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True) for t in (d_w, d_b)]
+        g_enc = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
+        for p_, g_ in zip(enc_params, g_enc):
+            p_.grad = g_
         if dist is not None:
-            # the one exchange step: average the gradients over ranks.  The two y-head tensors were sent off by their
-            # post-accumulate hooks as soon as the head's backward had produced them (they ride under the encoder's
-            # backward); the encoder's gradients are views of ONE flat buffer: a single all-reduce on the critical path.
-            # (Splitting that one so that all but first_conv's part overlaps first_conv's weight gradient was tried:
-            # +35 us of extra launches and stream hand-offs at world size 1, not measurable here at N > 1 -- left out.)
-            head_bufs = {wc.grad.untyped_storage().data_ptr(), bc.grad.untyped_storage().data_ptr()}
-            for buf in ops.flat_grad_buffers(flat_params):
-                if buf.untyped_storage().data_ptr() not in head_bufs:
-                    dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+            # the one exchange step on the critical path: the encoder's gradients are views of ONE flat buffer.
+            # (Splitting it so that all but first_conv's part overlaps the last launch was tried: +35 us of extra launches
+            # and stream hand-offs at world size 1, not measurable here at N > 1 -- left out.)
+            for buf in ops.flat_grad_buffers(enc_params):
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG)
             for w in pending:
                 w.wait()
-            pending.clear()
         sgd.step()
 
     def sync():
