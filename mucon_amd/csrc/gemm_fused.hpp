@@ -8,6 +8,10 @@
 //        stage 1: g = (dgrad_dilated_conv(dpre_{l+1}) + res1) * act'(mask1) -> out1 (gradient at layer l's output) and,
 //                 multiplied by layer l's dropout mask, LDS.  With taps = 1 stage 1 is last_conv's data gradient.
 //        stage 2: dpre_l = (g*drop . W2^T) * act'(h_l)                  -> out2
+//        With POOL = 3 / 4 the boundary is a pooled one: stage 1 works on the coarse level's rows, its epilogue routes every
+//        value onto the arg-max row of the forward pair (or both rows, sum pooling) of the finer level -- in global memory
+//        (out1: the un-pooled gradient, needed by the weight gradients and as the next residual) and in LDS -- and stage 2
+//        multiplies twice as many rows.
 //
 // Why: the coarse levels (T/8, T/16: <= 128 workgroups) are latency-bound -- every launch costs its own
 // prologue, k-loop ramp and epilogue, and the K = 128 GEMMs alone reach < 25 % MFMA utilisation.
@@ -32,7 +36,7 @@ constexpr int FUSED_HS = 132;  // padded row length of the intermediate tile (fl
 // LDS: [intermediate tile Hs, BM x 132] [W staging, 2 x 128 x 36].  The A staging buffers (2 x BM x 36) OVERLAY the
 // start of Hs: they are dead once stage 1's k-loop has passed its last barrier, which is before the stage-1 epilogue
 // writes Hs.  BM = 64: 70.7 KB instead of 89 KB, i.e. TWO workgroups per CU instead of one (160 KB LDS).
-constexpr int fused_smem_bytes(int BM) { return (BM * FUSED_HS + 2 * 128 * NT_LDS) * 4; }
+constexpr int fused_smem_bytes(int BM, int R2 = 1) { return (R2 * BM * FUSED_HS + 2 * 128 * NT_LDS) * 4; }
 static_assert(FUSED_HS >= 2 * NT_LDS, "the A staging buffers must fit inside the intermediate tile");
 
 struct FusedParams {
@@ -53,6 +57,10 @@ struct FusedParams {
     const float *mask2; // BWD: h
     float *out2;        // FWD: [B][Tout][128]; BWD: [B][Trows][128]
     float *out_pre;     // FWD POOL 1
+    // BWD across a pooled boundary (POOL 3 max / 4 sum): stage 1 runs on the Trows rows of the coarse level, its epilogue
+    // un-pools onto the 2 x rows of the fine level (out1, mask2, out2 are [B][Tfine][128]), stage 2 runs on those
+    const float *ypre;  // POOL 3: the forward's un-pooled rows [B][Tfine][128]
+    int Tfine;
     float slope;
     DropCfg drop;       // element index (b*Trows + t)*128 + c
 };
@@ -69,10 +77,13 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     constexpr int LROWS = NTHR / 8;                       // rows one pass of the cooperative loader covers
     constexpr int NQA = BM > LROWS ? BM / LROWS : 1;      // A float4 loads per thread (BM < LROWS: rows wrap, duplicates)
     constexpr int NQW = 128 / LROWS;                      // W float4 loads per thread
+    constexpr bool UNPOOL = BWD && POOL >= 3;             // pooled boundary: stage 2 on 2 x BM rows of the finer level
+    constexpr int R2 = UNPOOL ? 2 : 1;
+    static_assert(!UNPOOL || KS == 1, "no k-split across a pooled boundary");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Hs = smem;                    // [BM][FUSED_HS]
+    float *Hs = smem;                    // [R2 * BM][FUSED_HS]
     float *As = smem;                    // [2][BM][NT_LDS], dead before Hs is written
-    float *Bs = smem + BM * FUSED_HS;
+    float *Bs = smem + R2 * BM * FUSED_HS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,14 +153,16 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     };
     // 32-deep k-tile of MFMAs (this wave's half of it when KS = 2): A fragments from `Aw` (row stride lda floats),
     // W fragments from the staging buffer
-    auto mfma_tile = [&](const float *Aw, int lda, const float *Bw) {
+    typename TL::Acc acc2[R2 * WM][WN];   // stage-2 accumulators (aliases nothing: stage 1's are dead by then)
+    auto mfma_tile_n = [&](auto &accs, auto MC, const float *Aw, int lda, const float *Bw) {
+        constexpr int NM = decltype(MC)::value;
         if (MT == 32) {
 #pragma unroll
             for (int kq = 0; kq < 2 / KS; ++kq) {
                 const int ks = KS == 2 ? kgrp : kq;
-                f32x4 av[WM][2], bv[WN][2];
+                f32x4 av[NM][2], bv[WN][2];
 #pragma unroll
-                for (int m = 0; m < WM; ++m) {
+                for (int m = 0; m < NM; ++m) {
                     av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + ks * 8);
                     av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + ks * 8 + 4);
                 }
@@ -161,14 +174,14 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
-                    for (int m = 0; m < WM; ++m)
+                    for (int m = 0; m < NM; ++m)
 #pragma unroll
-                        for (int n = 0; n < WN; ++n) nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
+                        for (int n = 0; n < WN; ++n) nt_mfma<MT>(accs[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
             }
         } else {   // 16x16x4 tiles: the lane's eight k of the 32-deep tile in two 16-byte reads
-            f32x4 av[WM][2], bv[WN][2];
+            f32x4 av[NM][2], bv[WN][2];
 #pragma unroll
-            for (int m = 0; m < WM; ++m) {
+            for (int m = 0; m < NM; ++m) {
                 av[m][0] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda);
                 av[m][1] = *reinterpret_cast<const f32x4 *>(Aw + m * MT * lda + 4);
             }
@@ -180,10 +193,13 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int m = 0; m < WM; ++m)
+                for (int m = 0; m < NM; ++m)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) nt_mfma<MT>(acc[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
+                    for (int n = 0; n < WN; ++n) nt_mfma<MT>(accs[m][n], av[m][s >> 2][s & 3], bv[n][s >> 2][s & 3]);
         }
+    };
+    auto mfma_tile = [&](const float *Aw, int lda, const float *Bw) {
+        mfma_tile_n(acc, std::integral_constant<int, WM>{}, Aw, lda, Bw);
     };
     // KS = 2: the second k-half's partial sums cross to the first through Hs (each element is written and read by
     // the same lane position of the wave pair, so no barrier is needed between this read and the epilogue's write)
@@ -281,8 +297,32 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
                         if (p.mask1) x *= act_grad(rmask[reg], p.slope);
                         xl = p.drop.thresh ? x * drop_mul(p.drop, (uint32_t)g) : x;
                     }
-                    if (FULL || t < p.Trows) p.out1[g] = x;
-                    Hs[row * FUSED_HS + col] = (FULL || t < p.Trows) ? xl : 0.f;
+                    if (!UNPOOL) {
+                        if (FULL || t < p.Trows) p.out1[g] = x;
+                        Hs[row * FUSED_HS + col] = (FULL || t < p.Trows) ? xl : 0.f;
+                    } else {
+                        // max-pool backward (first wins ties, as torch) / sum-pool backward: rows 2t, 2t+1 of the fine level
+                        const bool valid = FULL || t < p.Trows;
+                        const long gf = ((long)b * p.Tfine + 2 * (valid ? t : 0)) * 128 + col;
+                        bool second = false;
+                        if (POOL == 3) second = p.ypre[gf + 128] > p.ypre[gf];
+                        const float u0 = (POOL == 4 || !second) ? x : 0.f, u1 = (POOL == 4 || second) ? x : 0.f;
+                        float h0 = u0, h1 = u1;
+                        if (p.drop.thresh) {
+                            h0 *= drop_mul(p.drop, (uint32_t)gf);
+                            h1 *= drop_mul(p.drop, (uint32_t)(gf + 128));
+                        }
+                        if (valid) {
+                            p.out1[gf] = u0;
+                            p.out1[gf + 128] = u1;
+                            if (t == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
+                                p.out1[gf + 256] = 0.f;
+                                p.out2[gf + 256] = 0.f;
+                            }
+                        }
+                        Hs[(2 * row) * FUSED_HS + col] = valid ? h0 : 0.f;
+                        Hs[(2 * row + 1) * FUSED_HS + col] = valid ? h1 : 0.f;
+                    }
                 }
             }
     };
@@ -294,45 +334,56 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
     __syncthreads();
 
     // ---------------------------------------------------------------- stage 2 (K = 128: 4 k-tiles, A from Hs)
-    zero_acc();
+    constexpr int WM2 = R2 * WM;
+    using M2 = std::integral_constant<int, WM2>;
+    const int a_row2 = wr * WM2 * MT + (lane & (MT - 1));
+#pragma unroll
+    for (int i = 0; i < WM2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < NREG; ++e) acc2[i][j][e] = 0.f;
     for (int kt = 0; kt < 4; kt += 2) {
         gload(min(nkt1 + kt + 2, vlast), S0{}, NO{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(Hs + a_row * FUSED_HS + kt * 32 + k_half, FUSED_HS, Bs + b_off);
+        mfma_tile_n(acc2, M2{}, Hs + a_row2 * FUSED_HS + kt * 32 + k_half, FUSED_HS, Bs + b_off);
         __builtin_amdgcn_sched_barrier(0);
         sstore(1, S1{}, NO{});
         __syncthreads();
         gload(min(nkt1 + kt + 3, vlast), S1{}, NO{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(Hs + a_row * FUSED_HS + (kt + 1) * 32 + k_half, FUSED_HS, Bs + 128 * NT_LDS + b_off);
+        mfma_tile_n(acc2, M2{}, Hs + a_row2 * FUSED_HS + (kt + 1) * 32 + k_half, FUSED_HS, Bs + 128 * NT_LDS + b_off);
         __builtin_amdgcn_sched_barrier(0);
         sstore(0, S0{}, NO{});
         __syncthreads();
     }
 
-    // stage-2 epilogue
+    // stage-2 epilogue (rows of the stage-2 level: the finer one across a pooled boundary)
+    const int rows2 = UNPOOL ? min(2 * p.Trows, p.Tfine) : p.Trows;   // rows with a gradient
+    const long vbase2 = UNPOOL ? (long)b * p.Tfine : vbase;
+    const int t02 = R2 * t0;
     auto epilogue2 = [&](auto FULLT) {
         constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
-        for (int mt = 0; mt < WM; ++mt)
+        for (int mt = 0; mt < WM2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
                 const int col = (wc * WN + nt) * MT + (lane & (MT - 1));
                 const float bias = (!BWD && p.bias2) ? p.bias2[col] : 0.f;
-                const int rbase = (wr * WM + mt) * MT + TL::row0(lane);
+                const int rbase = (wr * WM2 + mt) * MT + TL::row0(lane);
                 float raux[NREG];   // FWD: residual x; BWD: h (mask)
 #pragma unroll
                 for (int reg = 0; reg < NREG; ++reg) {
-                    const int t = t0 + rbase + TL::rowr(reg);
-                    const long g = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                    const int t = t02 + rbase + TL::rowr(reg);
+                    const long g = (vbase2 + (FULL ? t : min(t, rows2 - 1))) * 128 + col;
                     raux[reg] = BWD ? p.mask2[g] : p.res2[g];
                 }
                 float v[NREG];
 #pragma unroll
                 for (int reg = 0; reg < NREG; ++reg) {
-                    const int t = t0 + rbase + TL::rowr(reg);
-                    const long g = (vbase + t) * 128 + col;
-                    float x = acc[mt][nt][reg] + bias;
+                    const int t = t02 + rbase + TL::rowr(reg);
+                    const long g = (vbase2 + t) * 128 + col;
+                    float x = acc2[mt][nt][reg] + bias;
                     if (!BWD) {
                         if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
                         x += raux[reg];
@@ -343,9 +394,9 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
                 }
 #pragma unroll
                 for (int reg = 0; reg < NREG; ++reg) {
-                    const int t = t0 + rbase + TL::rowr(reg);
-                    const long g = (vbase + t) * 128 + col;
-                    if (FULL || t < p.Trows) {
+                    const int t = t02 + rbase + TL::rowr(reg);
+                    const long g = (vbase2 + t) * 128 + col;
+                    if (FULL || t < rows2) {
                         if (BWD || POOL == 0) p.out2[g] = v[reg];
                         if (!BWD && POOL == 1) p.out_pre[g] = v[reg];
                     }
@@ -362,7 +413,17 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
                 }
             }
     };
-    merge_halves();
+    if (KS == 2) {   // (never with UNPOOL) hand the second k-half's stage-2 sums over
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = acc2[i][j];
+        merge_halves();
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc2[i][j] = acc[i][j];
+    }
     if (kgrp == 0) {
         if (full_tile) epilogue2(std::true_type{});
         else epilogue2(std::false_type{});
@@ -372,16 +433,17 @@ __global__ __launch_bounds__(256 * KS) void nt_fused_kernel(const FusedParams p)
 template <int WM, int WAVES_M, int KS, bool BWD, int POOL, int MT = 32>
 static hipError_t launch_fused_cfg(const FusedParams &p, int B, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * MT;
+    constexpr int R2 = (BWD && POOL >= 3) ? 2 : 1;
     auto k = nt_fused_kernel<WM, WAVES_M, KS, BWD, POOL, MT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(BM));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(BM, R2));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((p.Trows + BM - 1) / BM, B);
-    hipLaunchKernelGGL(k, grid, dim3(256 * KS), fused_smem_bytes(BM), s, p);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KS), fused_smem_bytes(BM, R2), s, p);
     return hipGetLastError();
 }
 
@@ -392,6 +454,7 @@ static hipError_t launch_fused(const FusedParams &p, int B, hipStream_t s) {
     int bm = g_fused_bm ? g_fused_bm : (((long)B * p.Trows >= 512L * 64) ? 64 : ((long)B * p.Trows < g_nt_bm16_rows ? 16 : 32));
     if (bm == 64) return launch_fused_cfg<1, 2, 1, BWD, POOL>(p, B, s);
     if (bm == 16) return launch_fused_cfg<1, 1, 1, BWD, POOL, 16>(p, B, s);
-    if (g_fused_ks == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
+    if constexpr (!(BWD && POOL >= 3))
+        if (g_fused_ks == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
     return launch_fused_cfg<1, 1, 1, BWD, POOL>(p, B, s);
 }

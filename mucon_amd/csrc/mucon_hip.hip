@@ -19,6 +19,7 @@ int g_nt_force_bm = 0;
 // launch, first_conv's in its own; 0 = one launch per layer (coarse levels on the side stream)  (MUCON_TN_BATCH)
 int g_tn_batch = 2;
 int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
+int g_pool_fuse = 1;   // fused launch across pooled boundaries in the backward (MUCON_POOL_FUSE=0: NT launch pair)
 int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
 int g_fused_bm = 0;
@@ -367,6 +368,8 @@ int mucon_abi_version(void) {
         if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_NT_BM16_ROWS");
         if (e) g_nt_bm16_rows = atol(e);
+        e = getenv("MUCON_POOL_FUSE");
+        if (e) g_pool_fuse = atoi(e) ? 1 : 0;
         e = getenv("MUCON_UNPOOL_FUSE");
         if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
         e = getenv("MUCON_FUSED_KS");
@@ -655,6 +658,10 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
         const float *dyd = ws + pl.g[l + 1];   // gradient at the layer output
         float *dpre = ws + pl.dpre[l];
+        if (have_dpre && cfg->pool_after[l]) {   // un-pooled by the fused launch that also made dpre[l]
+            dyd = ws + pl.dyd[l];
+            unpooled_by_producer = false;
+        }
         if (!have_dpre) {
             if (cfg->pool_after[l]) {
                 float *u = ws + pl.dyd[l];
@@ -719,6 +726,26 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                 fused_tail(f, l - 1);
                 HIPCHK((launch_fused<true, 0>(f, B, s)));
                 have_dpre = true;
+            } else if (!g_no_fuse && g_pool_fuse && l >= 1 && cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= g_fuse_max_rows) {
+                // pooled boundary: dilated-conv data gradient on this (coarse) level, max-pool backward in its epilogue,
+                // layer l-1's conv_1x1 backward on the 2 x rows of the finer level -- one launch instead of two
+                FusedParams f;
+                memset(&f, 0, sizeof(f));
+                f.Trows = Tl;
+                f.A = dpre;
+                f.taps = centre_only ? 1 : 3;
+                f.tap_step = -cfg->dilation[l];
+                f.W1 = W1b;
+                f.ldw1 = 384;
+                f.res1 = dyd;
+                f.out1 = ws + pl.dyd[l - 1];
+                f.ypre = cfg->pool_type == 0 ? ws + pl.ypre[l - 1] : nullptr;
+                f.Tfine = pl.Tl[l - 1];
+                fused_tail(f, l - 1);
+                if (cfg->pool_type == 0) HIPCHK((launch_fused<true, 3>(f, B, s)));
+                else HIPCHK((launch_fused<true, 4>(f, B, s)));
+                have_dpre = true;
+                unpooled_by_producer = true;
             } else {
                 NtParams p = nt_base(dpre, (long)Tl * 128, 128, Tl, Tl, centre_only ? 1 : 3, -cfg->dilation[l], 128, W1b,
                                      nullptr, ws + pl.g[l], slope);
