@@ -222,23 +222,28 @@ struct TnBatch {
     TnJob j[TN_MAX_BATCH];
     int njobs, nblocks;
 };
-__global__ __launch_bounds__(256) void tn_batched_kernel(const TnBatch tb) {
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void tn_batched_kernel(const TnBatch tb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int ji = 0;
     while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
     const TnJob &job = tb.j[ji];
     const int local = blockIdx.x - job.block0;
     const int mc = local / job.nkc, kc = local - mc * job.nkc;
-    if (job.dual) tn_body<false, true, 1>(job.p, kc, mc, smem);
-    else if (job.x0_act) tn_body<true, false, 1>(job.p, kc, mc, smem);
-    else tn_body<false, false, 1>(job.p, kc, mc, smem);
+    if (job.dual) tn_body<false, true, KS>(job.p, kc, mc, smem);
+    else if (job.x0_act) tn_body<true, false, KS>(job.p, kc, mc, smem);
+    else tn_body<false, false, KS>(job.p, kc, mc, smem);
 }
+extern int g_tn_batch_ks;   // waves per workgroup of the batched launch: 1 -> 4 waves, 2 -> 8 waves (k-split)  (MUCON_TN_BATCH_KS)
 static hipError_t launch_tn_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tn_batched_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tn_batched_kernel<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(tn_batched_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -252,7 +257,8 @@ static hipError_t launch_tn_batch(TnBatch &tb, hipStream_t s) {
         blocks += lb.j[i].nkc * (tb.j[tb.njobs - 1 - i].block0);   // block0 carried the time-chunk count while queued
     }
     lb.nblocks = blocks;
-    hipLaunchKernelGGL(tn_batched_kernel, dim3(blocks), dim3(256), TN_SMEM_BYTES, s, lb);
+    if (g_tn_batch_ks == 2) hipLaunchKernelGGL(tn_batched_kernel<2>, dim3(blocks), dim3(512), TN_SMEM_BYTES, s, lb);
+    else hipLaunchKernelGGL(tn_batched_kernel<1>, dim3(blocks), dim3(256), TN_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();
 }

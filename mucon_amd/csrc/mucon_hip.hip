@@ -14,6 +14,7 @@
 #include "gemm_tn.hpp"
 #include "small_kernels.hpp"
 
+int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
 int g_nt_force_bm = 0;
 // weight gradients: 2 = ONE launch for every layer's and first_conv's after the data-gradient chain; 1 = the layers' in one
 // launch, first_conv's in its own; 0 = one launch per layer (coarse levels on the side stream)  (MUCON_TN_BATCH)
@@ -360,6 +361,8 @@ int mucon_abi_version(void) {
         if (e) g_fused_bm = atoi(e);
         e = getenv("MUCON_TN_BATCH");
         if (e) g_tn_batch = atoi(e);
+        e = getenv("MUCON_TN_BATCH_KS");
+        if (e) g_tn_batch_ks = atoi(e) == 2 ? 2 : 1;
         e = getenv("MUCON_TN_MC_CAP");
         if (e && atoi(e) >= 128) g_tn_mc_cap = atoi(e) / 32 * 32;
         e = getenv("MUCON_TN_BATCH_TARGET");
