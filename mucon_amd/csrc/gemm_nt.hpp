@@ -73,15 +73,19 @@ struct NtTile {
     __device__ static __forceinline__ int koff(int lane) { return MT == 32 ? (lane >> 5) * 16 : (lane >> 4) * 8; }
 };
 
+// NW = waves per workgroup: 4, or 8 for the 128-row first_conv tile (two such workgroups per CU = 4 waves per SIMD, and
+// the W tile is fetched once per 128 rows instead of once per 64).
 template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG,
-          int MT = 32>
-__global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
+          int MT = 32, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
     using TL = NtTile<MT>;
     constexpr int NREG = TL::NREG;
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WN = (128 / WAVES_N) / MT;   // MT-wide column tiles per wave (128 columns in all)
     constexpr int BM = WAVES_M * WM * MT;
-    constexpr int NQA = BM >= 32 ? BM / 32 : 1;   // A-tile float4 loads per thread (BM = 16: rows wrap, duplicate loads)
+    constexpr int LROWS = NW * 8;                 // rows one pass of the cooperative loader covers
+    constexpr int NQA = BM >= LROWS ? BM / LROWS : 1;   // A-tile float4 loads per thread (BM < LROWS: rows wrap, duplicate loads)
+    constexpr int NQW = 128 / LROWS;              // W-tile float4 loads per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
     float *Bs = smem + 2 * BM * NT_LDS;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
     // two register sets: tile kt+2 is requested while tile kt is being multiplied and tile kt+1 (requested one
     // iteration earlier) waits in the other set -- with 32-row tiles one k-tile of MFMAs (1024 cycles) is
     // shorter than an L2 round trip, so a single tile of look-ahead leaves the loop latency-bound
-    f32x4 ra[2][NQA], rb[2][4];
+    f32x4 ra[2][NQA], rb[2][NQW];
     int rt[2][NQA];   // time step of each staged A row, or -1 when the row is padding (zeroed at the LDS store)
     int rkk[2];       // channel offset of the staged k-tile (dropout replay)
 
@@ -116,11 +120,11 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
         const int off = (tap - (p.taps >> 1)) * p.tap_step;
         rkk[S] = kk;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            rb[S][q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + 32 * q) * Ktot + kt * 32 + lc4);
+        for (int q = 0; q < NQW; ++q)
+            rb[S][q] = *reinterpret_cast<const f32x4 *>(p.W + (long)(lrow + LROWS * q) * Ktot + kt * 32 + lc4);
 #pragma unroll
         for (int q = 0; q < NQA; ++q) {
-            const int t = t0 + ((lrow + 32 * q) & (BM - 1));
+            const int t = t0 + ((lrow + LROWS * q) & (BM - 1));
             const int ts = t + off;
             const bool ok = (t < p.Trows) && (ts >= 0) && (ts < p.Ta);
             const int tc = ts < 0 ? 0 : (ts >= p.Ta ? p.Ta - 1 : ts);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
         float *a = As + buf * BM * NT_LDS;
         float *w = Bs + buf * 128 * NT_LDS;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + 32 * q) * NT_LDS + lc4) = rb[S][q];
+        for (int q = 0; q < NQW; ++q) *reinterpret_cast<f32x4 *>(w + (lrow + LROWS * q) * NT_LDS + lc4) = rb[S][q];
 #pragma unroll
         for (int q = 0; q < NQA; ++q) {
             f32x4 v = ra[S][q];
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t >= 0 ? v[e] : 0.f;
-            *reinterpret_cast<f32x4 *>(a + ((lrow + 32 * q) & (BM - 1)) * NT_LDS + lc4) = v;   // duplicates store equal values
+            *reinterpret_cast<f32x4 *>(a + ((lrow + LROWS * q) & (BM - 1)) * NT_LDS + lc4) = v;   // duplicates store equal values
         }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -338,10 +342,10 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtParams p) {
 }
 
 template <int WM, int WAVES_M, bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG,
-          int MT = 32>
+          int MT = 32, int NW = 4>
 static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * MT;
-    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, MT>;
+    auto k = nt_gemm_kernel<WM, WAVES_M, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, MT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -350,13 +354,14 @@ static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((p.Trows + BM - 1) / BM, B);
-    hipLaunchKernelGGL(k, grid, dim3(256), nt_smem_bytes(BM), s, p);
+    hipLaunchKernelGGL(k, grid, dim3(64 * NW), nt_smem_bytes(BM), s, p);
     return hipGetLastError();
 }
 
 // Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it; below ~one workgroup
 // per CU at BM = 32 the launch is latency-bound and 16-row tiles (twice the workgroups, half the MFMA chain) are faster.
 extern int g_nt_force_bm;  // 0 = automatic (tuning hook: MUCON_NT_BM)
+extern int g_first_conv_8w;   // first_conv forward as 128-row, 8-wave workgroups (MUCON_FIRST_CONV_8W)
 extern long g_nt_bm16_rows;  // levels with fewer rows in the batch than this use BM = 16 (MUCON_NT_BM16_ROWS; 0 = never)
 static inline int nt_pick_bm(int B, int Trows) {
     if (g_nt_force_bm) return g_nt_force_bm;
@@ -369,6 +374,8 @@ static inline int nt_pick_bm(int B, int Trows) {
 
 template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG = 0>
 static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
+    if ((TAG == 1 || g_first_conv_8w == 2) && g_first_conv_8w && POOL < 3 && (long)B * p.Trows >= 512L * 64)   // 128 rows x 8 waves
+        return launch_nt_cfg<1, 4, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, 32, 8>(p, B, s);
     switch (nt_pick_bm(B, p.Trows)) {
         case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);
         case 64: return launch_nt_cfg<1, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);

@@ -15,6 +15,7 @@
 #include "small_kernels.hpp"
 
 int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
+int g_first_conv_8w = 1;   // 1: first_conv forward as 128-row 8-wave workgroups; 2: every full-resolution NT launch; 0: off
 int g_nt_force_bm = 0;
 // weight gradients: 2 = ONE launch for every layer's and first_conv's after the data-gradient chain; 1 = the layers' in one
 // launch, first_conv's in its own; 0 = one launch per layer (coarse levels on the side stream)  (MUCON_TN_BATCH)
@@ -369,6 +370,8 @@ int mucon_abi_version(void) {
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
         if (e) g_tn_ks = atoi(e);
+        e = getenv("MUCON_FIRST_CONV_8W");
+        if (e) g_first_conv_8w = atoi(e);
         e = getenv("MUCON_NT_BM16_ROWS");
         if (e) g_nt_bm16_rows = atol(e);
         e = getenv("MUCON_POOL_FUSE");
