@@ -280,9 +280,9 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // Batched slab reduction: ONE launch sums every gradient's partial slabs of a backward pass, in a
-// fixed order (bitwise reproducible -- no float atomics).  1024 threads = 16 slab lanes x 64
-// elements: lane group g sums slabs g, g+16, ... (eight independent loads in flight per thread),
-// then the 16 partials are combined through LDS in lane-group order.
+// fixed order (bitwise reproducible -- no float atomics).  64*G threads = G slab lanes x 64
+// float4 elements: lane group g sums slabs g, g+G, ... (four independent loads in flight per thread),
+// then the G partials are combined through LDS in lane-group order.
 //   element (row, col) of a job reads slabs[s*slab_stride + row*ld + coff + col]
 //   mode 0: out[row*ncols + col]      mode 1 (conv k=3 weight, ncols = 384): col = tap*128 + i ->
 //   out[(row*128 + i)*3 + tap], the reference's [out][in][k] layout
@@ -301,9 +301,10 @@ struct ReduceBatch {
     int njobs, nblocks;
 };
 
-__global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb) {
-    // a workgroup owns 256 consecutive elements of one job: 64 lanes x float4, 16 slab lanes
-    __shared__ f32x4 part[16][64];
+template <int G>
+__global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch rb) {
+    // a workgroup owns 256 consecutive elements of one job: 64 lanes x float4, G slab lanes
+    __shared__ f32x4 part[G][64];
     int ji = 0;
     while (ji + 1 < rb.njobs && (int)blockIdx.x >= rb.j[ji + 1].block0) ++ji;
     const ReduceJob &J = rb.j[ji];
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb
                 const int r = ek / J.ncols, c = ek - r * J.ncols;
                 const float *p = J.slabs + (long)r * J.ld + J.coff + c;
                 float a = 0.f;
-                for (int i = g; i < J.nslabs; i += 16) a += p[(long)i * J.slab_stride];
+                for (int i = g; i < J.nslabs; i += G) a += p[(long)i * J.slab_stride];
                 s[k] = a;
             }
         }
@@ -328,21 +329,23 @@ __global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb
         col = e - row * J.ncols;
         const float *p = J.slabs + (long)row * J.ld + J.coff + col;
         int i = g;
-        for (; i + 3 * 16 < J.nslabs; i += 4 * 16) {
+        for (; i + 3 * G < J.nslabs; i += 4 * G) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + 16 * u) * J.slab_stride);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * J.slab_stride);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += v[u];
         }
-        for (; i < J.nslabs; i += 16) s += *reinterpret_cast<const f32x4 *>(p + (long)i * J.slab_stride);
+        for (; i < J.nslabs; i += G) s += *reinterpret_cast<const f32x4 *>(p + (long)i * J.slab_stride);
     }
-    part[g][lane] = s;
-    __syncthreads();
+    if (G > 1) {
+        part[g][lane] = s;
+        __syncthreads();
+    }
     if (g == 0 && e < J.n_elems) {
-        f32x4 t = part[0][lane];
+        f32x4 t = s;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t += part[k][lane];
+        for (int k = 1; k < G; ++k) t += part[k][lane];
         if (!J.vec) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)

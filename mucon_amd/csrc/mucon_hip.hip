@@ -51,7 +51,8 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
-int g_tn_mc_cap = 1024;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
+int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
+int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {
     const int target = batched ? g_tn_batch_target : g_tn_target;
@@ -220,7 +221,14 @@ struct Reducer {
     }
     hipError_t run() {
         if (rb.njobs == 0) return hipSuccess;
-        hipLaunchKernelGGL(reduce_batch_kernel, dim3(rb.nblocks), dim3(1024), 0, stream, rb);
+        switch (g_reduce_lanes) {
+            case 1: hipLaunchKernelGGL(reduce_batch_kernel<1>, dim3(rb.nblocks), dim3(64), 0, stream, rb); break;
+            case 2: hipLaunchKernelGGL(reduce_batch_kernel<2>, dim3(rb.nblocks), dim3(128), 0, stream, rb); break;
+            case 4: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
+            case 8: hipLaunchKernelGGL(reduce_batch_kernel<8>, dim3(rb.nblocks), dim3(512), 0, stream, rb); break;
+            case 16: hipLaunchKernelGGL(reduce_batch_kernel<16>, dim3(rb.nblocks), dim3(1024), 0, stream, rb); break;
+            default: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
+        }
         rb.njobs = 0;
         rb.nblocks = 0;
         return hipGetLastError();
@@ -370,6 +378,8 @@ int mucon_abi_version(void) {
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
         if (e) g_tn_ks = atoi(e);
+        e = getenv("MUCON_REDUCE_LANES");
+        if (e) g_reduce_lanes = atoi(e);
         e = getenv("MUCON_FIRST_CONV_8W");
         if (e) g_first_conv_8w = atoi(e);
         e = getenv("MUCON_NT_BM16_ROWS");
