@@ -165,6 +165,14 @@ int mucon_test_dropout_mask(uint8_t *mask, int64_t n, uint64_t seed, int32_t sit
 int mucon_bench_first_conv(const float *tape, const float *w, const float *b, float *out, int32_t B,
                            int32_t T, int32_t D, int32_t iters, float *ms_host, void *stream);
 
+/* first_conv forward on the bf16 MFMA with exactly split operands (csrc/gemm_split.hpp), whatever the size
+ * threshold of mucon_encoder_fwd says: out[B][T][128] = act(tape[B][T][D] * w[128][D]^T + b).  `planes` receives
+ * the three bf16 planes of w (3*128*D*2 bytes).  Runs 1 + iters launches; *ms_host (may be null) = average
+ * milliseconds of the timed ones (HIP events on `stream`; synchronises). */
+int mucon_test_first_conv_split(const float *tape, const float *w, const float *b, float *out, int32_t B,
+                                int32_t T, int32_t D, int32_t relu, void *planes, size_t planes_bytes,
+                                int32_t iters, float *ms_host, void *stream);
+
 /* Per-launch timing of the two kernels that stream the tape, taken with HIP events on the stream
  * the kernels run on, while the normal fwd/bwd calls execute (bench.py's roofline leg):
  * slot 0 = first_conv forward, slot 1 = the weight-gradient launch (the one batched launch of every layer's and

@@ -104,6 +104,8 @@ SYMBOLS = {
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
+    "mucon_test_first_conv_split": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32,
+                                                  ctypes.POINTER(ctypes.c_float), _vp]),
     "mucon_bench_first_conv": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_float), _vp]),
     "mucon_lstm_workspace_bytes": (_sz, [_i32, _i32]),
     "mucon_lstm_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _sz, _vp]),

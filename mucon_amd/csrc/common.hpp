@@ -6,6 +6,45 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- exact three-way bf16 split of fp32 (gemm_split.hpp explains the arithmetic) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> two bf16 (round to nearest even), packed low = a, high = b: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t sp_pack(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// exact split of two fp32 values into packed (hi, mid, lo) bf16 pairs
+__device__ __forceinline__ void sp_split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = sp_pack(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = sp_pack(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = sp_pack(s0, s1);
+}
+
+// W [128][D] fp32 -> bf16 planes in k-tile order [D/32][3][128][32]: the (hi, mid, lo) image of one 32-deep k-tile is
+// 24 KB of consecutive bytes, so the workgroups of gemm_split.hpp fetch it in whole cache lines
+// (pack_weights launches this once per forward pass)
+__device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *planes, int D, long first, long stride) {
+    uint32_t *P = reinterpret_cast<uint32_t *>(planes);
+    const long n_pairs = 64L * D;
+    for (long e = first; e < n_pairs; e += stride) {
+        const int n = (int)(e / (D / 2)), k = (int)(e - (long)n * (D / 2)) * 2;
+        uint32_t h, m, l;
+        sp_split2(W[2 * e], W[2 * e + 1], h, m, l);
+        const long base = (((long)(k >> 5) * 3) * 128 + n) * 16 + ((k & 31) >> 1);   // in pairs: plane stride 128 * 16
+        P[base] = h;
+        P[base + 2048] = m;
+        P[base + 4096] = l;
+    }
+}
+
 #define MUCON_H 128  // hidden width the MFMA kernels are specialised for (cfg.model.ft.hidden_size)
 
 // activation of the reference's apply_non_lin (temporal.py:40-41): relu or leaky_relu(0.01);

@@ -12,6 +12,7 @@
 #include "gemm_nt.hpp"
 #include "gemm_fused.hpp"
 #include "gemm_tn.hpp"
+#include "gemm_split.hpp"
 #include "small_kernels.hpp"
 
 int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
@@ -28,6 +29,8 @@ int g_fused_bm = 0;
 int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
 long g_fuse_max_rows = 1L << 40;  // ... and only for levels with at most this many rows in the batch (MUCON_FUSE_MAXROWS)
+
+int g_split_rot = 0;   // gemm_split.hpp: k-tile rotation stride between neighbouring workgroups (MUCON_SPLIT_ROT)
 
 namespace {
 
@@ -52,6 +55,8 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
+int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
+long g_first_conv_split_rows = 16384;  // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {
@@ -67,6 +72,7 @@ struct Plan {
     int L, B, T, D, Tz;
     int Tl[MUCON_MAX_LAYERS + 1];
     size_t W1f, W1b, W2t, Wlt;
+    size_t W0s;  // first_conv.weight as three bf16 planes [3][128][D] (gemm_split.hpp)
     size_t x[MUCON_MAX_LAYERS + 1], h[MUCON_MAX_LAYERS], ypre[MUCON_MAX_LAYERS];
     size_t z, gnstat, gnpart;
     size_t gz, g[MUCON_MAX_LAYERS + 1], dpre[MUCON_MAX_LAYERS], dyd[MUCON_MAX_LAYERS];
@@ -117,6 +123,7 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.W1b = take((size_t)p.L * 49152);
     p.W2t = take((size_t)p.L * 16384);
     p.Wlt = take(16384);
+    p.W0s = take((size_t)3 * 128 * p.D / 2);
     for (int l = 0; l <= p.L; ++l) p.x[l] = take((size_t)p.B * p.Tl[l] * 128);
     for (int l = 0; l < p.L; ++l) {
         p.h[l] = take((size_t)p.B * p.Tl[l] * 128);
@@ -378,6 +385,12 @@ int mucon_abi_version(void) {
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         e = getenv("MUCON_TN_KS");
         if (e) g_tn_ks = atoi(e);
+        e = getenv("MUCON_FIRST_CONV_SPLIT");
+        if (e) g_first_conv_split = atoi(e) ? 1 : 0;
+        e = getenv("MUCON_SPLIT_ROT");
+        if (e) g_split_rot = atoi(e);
+        e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
+        if (e) g_first_conv_split_rows = atol(e);
         e = getenv("MUCON_REDUCE_LANES");
         if (e) g_reduce_lanes = atoi(e);
         e = getenv("MUCON_FIRST_CONV_8W");
@@ -480,7 +493,12 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     pa.W2t = ws + pl.W2t;
     pa.Wlt = ws + pl.Wlt;
     pa.L = L;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(192, L + 1), dim3(256), 0, s, pa);
+    pa.D = pl.D;
+    // first_conv on the bf16 MFMA with exactly split operands: worth it once the launch fills the chip
+    const bool split_first = g_first_conv_split && (long)B * pl.T >= g_first_conv_split_rows;
+    pa.first_w = prm->first_w;
+    pa.first_planes = split_first ? reinterpret_cast<uint16_t *>(ws + pl.W0s) : nullptr;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(192, L + (split_first ? 2 : 1)), dim3(256), 0, s, pa);
     HIPCHK(hipGetLastError());
 
     // first_conv + non-linearity (temporal.py:133); the tape is consumed row-major, no permute
@@ -488,7 +506,8 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         NtParams p = nt_base(tape, (long)pl.T * pl.D, pl.D, pl.T, pl.T, 1, 0, pl.D, prm->first_w, prm->first_b,
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
-        HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
+        if (split_first) HIPCHK((launch_first_conv_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+        else HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
         prof_mark(0, true, s);
     }
     for (int l = 0; l < L; ++l) {
@@ -977,6 +996,44 @@ int mucon_profile_end(float *total_ms_host, int32_t *count_host) {
         delete[] g_prof.ev[k];
         g_prof.ev[k] = nullptr;
     }
+    return MUCON_OK;
+}
+
+__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D) {
+    sp_split_weights(W, planes, D, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+int mucon_test_first_conv_split(const float *tape, const float *w, const float *b, float *out, int32_t B, int32_t T,
+                                int32_t D, int32_t relu, void *planes, size_t planes_bytes, int32_t iters, float *ms_host,
+                                void *stream) {
+    if (B < 1 || T < 1 || D < 128 || D % 128 != 0 || iters < 1) return fail(MUCON_E_ARG, "test_first_conv_split: B=%d T=%d D=%d", B, T, D);
+    if (!planes || planes_bytes < (size_t)3 * 128 * D * 2) return fail(MUCON_E_WORKSPACE, "test_first_conv_split: planes buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint16_t *P = static_cast<uint16_t *>(planes);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
+    HIPCHK(hipGetLastError());
+    NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
+    const char *ae = getenv("MUCON_SPLIT_ABL");
+    const int abl = ae ? atoi(ae) : 0;
+    auto go = [&]() {
+#define ABLCASE(V) if (abl == (V)) return launch_first_conv_split<true, (V)>(p, P, B, s);
+        ABLCASE(8) ABLCASE(0x1008) ABLCASE(0x208) ABLCASE(0x108) ABLCASE(0x308) ABLCASE(0x408) ABLCASE(0x4008) ABLCASE(0x1308)
+        ABLCASE(0x4408) ABLCASE(0x5708) ABLCASE(0x4708) ABLCASE(0x2008) ABLCASE(0x1000) ABLCASE(0x5300)
+#undef ABLCASE
+        return relu ? launch_first_conv_split<true>(p, P, B, s) : launch_first_conv_split<false>(p, P, B, s);
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(go());  // warm-up
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(go());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_host) *ms_host = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return MUCON_OK;
 }
 

@@ -16,7 +16,9 @@ struct PackArgs {
     const float *pw_w[16];
     const float *last_w;
     float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]
-    int L;
+    const float *first_w;          // [128][D]; split into first_planes when that is non-null (grid row L + 1)
+    uint16_t *first_planes;        // [D/32][3][128][32] bf16: hi / mid / lo of first_conv.weight by k-tile (gemm_split.hpp)
+    int L, D;
 };
 __global__ void pack_weights_kernel(const PackArgs a) {
     const int l = blockIdx.y;
@@ -33,9 +35,13 @@ __global__ void pack_weights_kernel(const PackArgs a) {
             const int o = e >> 7, i = e & 127;
             a.W2t[(long)l * 16384 + i * 128 + o] = a.pw_w[l][e];
         }
-    } else if (e < 128 * 128) {
-        const int o = e >> 7, i = e & 127;
-        a.Wlt[i * 128 + o] = a.last_w[e];
+    } else if (l == a.L) {
+        if (e < 128 * 128) {
+            const int o = e >> 7, i = e & 127;
+            a.Wlt[i * 128 + o] = a.last_w[e];
+        }
+    } else if (a.first_planes) {
+        sp_split_weights(a.first_w, a.first_planes, a.D, e, (long)gridDim.x * blockDim.x);
     }
 }
 

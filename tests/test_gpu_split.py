@@ -1,0 +1,82 @@
+"""first_conv forward on the bf16 MFMA with exactly split operands (csrc/gemm_split.hpp) against float64, next to the
+f32-MFMA kernel it replaces for chip-filling launches.
+
+Claim under test: x = hi + mid + lo is exact, six of the nine partial products are kept, and the result is fp32-grade:
+its distance to the float64 product is of the size of the f32-MFMA kernel's own (both are dominated by the fp32
+accumulation over K = 2048), far inside the 1e-4 tolerance of the dense path (test_gpu_dense.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from mucon_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run_split(tape, W, bias, relu):
+    from mucon_amd import _lib
+    lib = _lib.load()
+    B, T, D = tape.shape
+    out = torch.full((B, T, 128), float("nan"), device=DEV)
+    planes = torch.empty(3 * 128 * D * 2, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.mucon_test_first_conv_split(_lib.ptr(tape), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), B, T, D, relu,
+                                               _lib.ptr(planes), planes.numel(), 1, None, _lib.current_stream_ptr()),
+               "first_conv_split")
+    return out, planes
+
+
+@pytest.mark.parametrize("B,T,D", [(1, 128, 2048), (1, 257, 2048), (3, 1000, 2048), (2, 130, 128), (1, 77, 1024)])
+def test_split_first_conv_matches_float64(B, T, D):
+    from mucon_amd import _lib
+    lib = _lib.load()
+    tape = torch.tensor(synth.uniform_pm1(11, (B, T, D)), device=DEV)
+    W = torch.tensor(synth.uniform_pm1(12, (128, D)), device=DEV) * 0.05
+    bias = torch.tensor(synth.uniform_pm1(13, (128,)), device=DEV)
+    ref = tape.double() @ W.double().T + bias.double()
+    out, _ = _run_split(tape, W, bias, 0)
+    assert torch.isfinite(out).all()
+    err_split = (out.double() - ref).abs().max().item()
+    # the f32-MFMA kernel on the same operands
+    out32 = torch.full((B * T, 128), float("nan"), device=DEV)
+    _lib.check(lib.mucon_test_gemm_nt(_lib.ptr(tape), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out32), B * T, D, 1,
+                                      _lib.current_stream_ptr()), "gemm_nt")
+    err_f32 = (out32.double() - torch.relu(ref).reshape(B * T, 128)).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"B={B} T={T} D={D}: max|err| split {err_split:.3e}  f32-MFMA {err_f32:.3e}  (|out| up to {scale:.2f})")
+    assert err_split <= 2e-6 * scale + 4 * err_f32   # fp32-grade: same size as the f32 kernel's own error
+    out_relu, _ = _run_split(tape, W, bias, 1)
+    torch.testing.assert_close(out_relu, torch.relu(out), rtol=0, atol=0)
+
+
+def test_split_is_exact():
+    """hi + mid + lo == x bit for bit (the planes pack_weights writes), for values across the exponent range."""
+    D = 256
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(128, D, generator=g) * torch.exp2(torch.randint(-40, 40, (128, D), generator=g).float())
+    # exact for 0 and for 2^-100 < |x| < the bf16 maximum (3.39e38); below that the low parts are denormal
+    w[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0 + 2 ** -23, 1.0e38, 1.0e-30, -2.5])
+    W = w.to(DEV)
+    tape = torch.zeros(1, 128, D, device=DEV)
+    _, planes = _run_split(tape, W, torch.zeros(128, device=DEV), 0)
+    p = planes.view(torch.bfloat16).reshape(D // 32, 3, 128, 32).permute(1, 2, 0, 3).reshape(3, 128, D).double()   # k-tile order
+    np.testing.assert_array_equal((p[0] + p[1] + p[2]).cpu().numpy(), W.double().cpu().numpy())
+
+
+def test_encoder_uses_split_kernel_and_agrees_with_f32_path():
+    """Above the size threshold mucon_encoder_fwd takes the split kernel: x[0] agrees with float64 as above."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T = 4, 4096
+    spec, ocfg = ops.EncoderSpec(), od.EncoderConfig()
+    params_np = od.seeded_params(ocfg, 31)
+    P = [torch.tensor(params_np[k], device=DEV) for k in ops.param_names(spec)]
+    tape = torch.tensor(synth.tape(32, B, T, 2048), device=DEV)
+    with torch.no_grad():
+        enc = ops.encoder_forward(tape, P, spec, training=False)
+    x0 = torch.relu(tape.double() @ P[0][:, :, 0].double().T + P[1].double())
+    out, _ = _run_split(tape, P[0][:, :, 0].contiguous(), P[1], 1)
+    assert (out.double() - x0).abs().max().item() <= 2e-6 * x0.abs().max().item() + 1e-6
+    assert torch.isfinite(enc).all()
