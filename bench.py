@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32-input MFMA peak (= f32 vector peak), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (first_conv forward issues six bf16 MFMAs per fp32 product block)
 BYTES_PER_FRAME_FWD_BWD = 16768  # tape read twice (fwd + first-conv dW) + log-probs written + their grad read
 
 
@@ -344,16 +345,29 @@ def main():
         value = frames / elapsed
         k_fwd_ms = tot_ms[0] / max(cnt[0], 1)
         k_wg_ms = tot_ms[1] / max(cnt[1], 1)
-        flops = 2.0 * B * T * spec.in_dim * spec.hidden            # per launch, either kernel
-        # slot 1 times the ONE batched weight-gradient launch (every layer's + first_conv's): not a single-GEMM figure
-        dom = ("first_conv_fwd nt_gemm_kernel", k_fwd_ms)
-        achieved = flops / (dom[1] * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch from the rocprofv3 --pmc passes of tools/profile_round.sh (profiles/)
+        flops_first = 2.0 * B * T * spec.in_dim * spec.hidden      # first_conv: forward, and again inside the weight-gradient launch
+        # the ONE batched weight-gradient launch: every residual layer (dilated conv taps + conv_1x1), last_conv, first_conv
+        rows, flops_wg, bytes_wg = T, flops_first, B * T * (spec.in_dim + spec.hidden) * 4.0
+        for l, d in enumerate(spec.stages):
+            taps = 1 if d >= rows else 3          # dilation past the sequence: centre tap only
+            flops_wg += 2.0 * B * rows * spec.hidden * spec.hidden * (taps + 1)
+            bytes_wg += 4.0 * B * rows * spec.hidden * 4   # two gradient and two activation operands, each read once
+            if spec.pooling and l in spec.pooling_layers:
+                rows //= 2
+        flops_wg += 2.0 * B * rows * spec.hidden * spec.hidden
+        bytes_wg += 2.0 * B * rows * spec.hidden * 4
+        # dominant kernel = the longest launch of the step: the batched weight gradients (f32-input MFMA, exact fp32)
+        dom = ("tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)", k_wg_ms)
+        achieved = flops_wg / (dom[1] * 1e-3) / 1e12
+        traffic = traffic_fwd = None   # HBM bytes per launch from the rocprofv3 --pmc passes of tools/profile_round.sh (profiles/)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)["first_conv_fwd"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+                tj = json.load(f)
+            traffic = tj.get("weight_gradients", {}).get("hbm_bytes_per_launch")
+            traffic_fwd = tj.get("first_conv_fwd", {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
             pass
+        bytes_fwd = B * T * (spec.in_dim + spec.hidden) * 4.0
         out = {
             "metric": "frames/sec fwd+bwd (Breakfast I3D Tx2048)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,9 +379,17 @@ def main():
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": B * T * (spec.in_dim + spec.hidden) * 4,
-                         "avg_launch_ms": round(dom[1], 4), "flops_per_launch": flops,
-                         "first_conv_fwd_ms": round(k_fwd_ms, 4), "all_weight_gradients_launch_ms": round(k_wg_ms, 4)},
+                         "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
+                         "flops_per_launch": flops_wg, "all_weight_gradients_launch_ms": round(k_wg_ms, 4)},
+            # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
+            # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
+            "roofline_first_conv_fwd": {"bound": "hbm", "kernel": "first_conv_split_kernel",
+                                        "achieved": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                        "unit": "GB/s", "frac": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                        "traffic": traffic_fwd, "algorithmic_bytes_per_launch": bytes_fwd,
+                                        "avg_launch_ms": round(k_fwd_ms, 4), "flops_per_launch": flops_first,
+                                        "fp32_equivalent_tflops": round(flops_first / (k_fwd_ms * 1e-3) / 1e12, 1),
+                                        "bf16_mfma_frac": round(6 * flops_first / (k_fwd_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)},
             "roofline_hbm_whole_path": {"bound": "hbm", "achieved": round(value / world * BYTES_PER_FRAME_FWD_BWD / 1e9, 1),
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(value / world * BYTES_PER_FRAME_FWD_BWD / 1e9 / PEAK_HBM_GBS, 4),

@@ -28,20 +28,22 @@ __device__ __forceinline__ void sp_split2(float x0, float x1, uint32_t &h, uint3
     l = sp_pack(s0, s1);
 }
 
-// W [128][D] fp32 -> bf16 planes in k-tile order [D/32][3][128][32]: the (hi, mid, lo) image of one 32-deep k-tile is
-// 24 KB of consecutive bytes, so the workgroups of gemm_split.hpp fetch it in whole cache lines
-// (pack_weights launches this once per forward pass)
-__device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *planes, int D, long first, long stride) {
-    uint32_t *P = reinterpret_cast<uint32_t *>(planes);
+// W [128][D] fp32 -> the fragment-ordered bf16 image gemm_split.hpp stages (pack_weights writes it once per forward pass): per 64-deep k-tile
+// [k-step 4][plane 3][lane half 2][channel 128][slot 8] bf16, with k16 = k mod 16 at half (k16 >> 2) & 1, slot (k16 & 3) + 4 (k16 >> 3)
+__device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *img, int D, long first, long stride) {
+    uint32_t *P = reinterpret_cast<uint32_t *>(img);
     const long n_pairs = 64L * D;
     for (long e = first; e < n_pairs; e += stride) {
         const int n = (int)(e / (D / 2)), k = (int)(e - (long)n * (D / 2)) * 2;
         uint32_t h, m, l;
         sp_split2(W[2 * e], W[2 * e + 1], h, m, l);
-        const long base = (((long)(k >> 5) * 3) * 128 + n) * 16 + ((k & 31) >> 1);   // in pairs: plane stride 128 * 16
+        const int S = k >> 6, s = (k >> 4) & 3, k16 = k & 15;
+        const int half = (k16 >> 2) & 1, slot = (k16 & 3) + 4 * (k16 >> 3);
+        // element offset (((s*3 + pl)*2 + half)*128 + n)*8 + slot, in pairs; plane stride 2*128*8/2 = 1024 pairs
+        const long base = (long)S * (24576 / 2) + ((long)((s * 3) * 2 + half) * 128 + n) * 4 + (slot >> 1);
         P[base] = h;
-        P[base + 2048] = m;
-        P[base + 4096] = l;
+        P[base + 1024] = m;
+        P[base + 2048] = l;
     }
 }
 

@@ -30,7 +30,6 @@ int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measur
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
 long g_fuse_max_rows = 1L << 40;  // ... and only for levels with at most this many rows in the batch (MUCON_FUSE_MAXROWS)
 
-int g_split_rot = 0;   // gemm_split.hpp: k-tile rotation stride between neighbouring workgroups (MUCON_SPLIT_ROT)
 
 namespace {
 
@@ -387,8 +386,6 @@ int mucon_abi_version(void) {
         if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_FIRST_CONV_SPLIT");
         if (e) g_first_conv_split = atoi(e) ? 1 : 0;
-        e = getenv("MUCON_SPLIT_ROT");
-        if (e) g_split_rot = atoi(e);
         e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
         if (e) g_first_conv_split_rows = atol(e);
         e = getenv("MUCON_REDUCE_LANES");
@@ -1012,15 +1009,7 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
     hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
     HIPCHK(hipGetLastError());
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
-    const char *ae = getenv("MUCON_SPLIT_ABL");
-    const int abl = ae ? atoi(ae) : 0;
-    auto go = [&]() {
-#define ABLCASE(V) if (abl == (V)) return launch_first_conv_split<true, (V)>(p, P, B, s);
-        ABLCASE(8) ABLCASE(0x1008) ABLCASE(0x208) ABLCASE(0x108) ABLCASE(0x308) ABLCASE(0x408) ABLCASE(0x4008) ABLCASE(0x1308)
-        ABLCASE(0x4408) ABLCASE(0x5708) ABLCASE(0x4708) ABLCASE(0x2008) ABLCASE(0x1000) ABLCASE(0x5300)
-#undef ABLCASE
-        return relu ? launch_first_conv_split<true>(p, P, B, s) : launch_first_conv_split<false>(p, P, B, s);
-    };
+    auto go = [&]() { return relu ? launch_first_conv_split<true>(p, P, B, s) : launch_first_conv_split<false>(p, P, B, s); };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

@@ -17,7 +17,7 @@ struct PackArgs {
     const float *last_w;
     float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]
     const float *first_w;          // [128][D]; split into first_planes when that is non-null (grid row L + 1)
-    uint16_t *first_planes;        // [D/32][3][128][32] bf16: hi / mid / lo of first_conv.weight by k-tile (gemm_split.hpp)
+    uint16_t *first_planes;        // hi / mid / lo bf16 of first_conv.weight in the fragment order of gemm_split.hpp (3*128*D values)
     int L, D;
 };
 __global__ void pack_weights_kernel(const PackArgs a) {

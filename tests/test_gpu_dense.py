@@ -294,7 +294,8 @@ def test_full_size_batch_properties():
     (1) determinism: two runs are bitwise identical (no float atomics anywhere);
     (2) batch independence: video b of the batch == the same video run alone, to rounding (a video alone has so few
         rows per level that it takes the 16-row tiles / 16x16x4 MFMA, whose k-order of summation differs from the
-        32x32x2 tiles the batch of 8 uses: 1e-5 relative; bitwise with MUCON_NT_BM16_ROWS=0);
+        32x32x2 tiles the batch of 8 uses, and first_conv runs on the f32 MFMA instead of the split-bf16 kernel of
+        chip-filling launches: 1e-5 relative; bitwise with MUCON_NT_BM16_ROWS=0 MUCON_FIRST_CONV_SPLIT_ROWS=0);
     (3) gradient additivity: batch gradient == sum of per-video gradients (to rounding)."""
     from mucon_amd import ops
     from oracle import dense as od
@@ -349,10 +350,12 @@ def test_full_size_batch_properties():
 
 def test_full_size_properties_with_one_tile_shape():
     """Bitwise batch independence and 1e-4 gradient additivity at B=8 x T=4096 when every batch size uses the same MFMA
-    tile shape (MUCON_NT_BM16_ROWS=0, read once at library load: fresh interpreter)."""
+    tile shape and the same first_conv kernel (MUCON_NT_BM16_ROWS=0, MUCON_FIRST_CONV_SPLIT_ROWS=0, read once at library
+    load: fresh interpreter)."""
     import subprocess
     import sys
-    env = dict(os.environ, MUCON_NT_BM16_ROWS="0")
+    # ... and the same first_conv kernel: by default only chip-filling launches (>= 16384 frames) take the split-bf16 one
+    env = dict(os.environ, MUCON_NT_BM16_ROWS="0", MUCON_FIRST_CONV_SPLIT_ROWS="0")
     r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::test_full_size_batch_properties", "-q", "-x",
                         "-m", "gpu"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

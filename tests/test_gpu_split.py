@@ -61,7 +61,10 @@ def test_split_is_exact():
     W = w.to(DEV)
     tape = torch.zeros(1, 128, D, device=DEV)
     _, planes = _run_split(tape, W, torch.zeros(128, device=DEV), 0)
-    p = planes.view(torch.bfloat16).reshape(D // 32, 3, 128, 32).permute(1, 2, 0, 3).reshape(3, 128, D).double()   # k-tile order
+    # fragment order: [k-tile D/64][k-step 4][plane 3][lane half 2][channel 128][slot 8], k16 = 4*half + slot (slot < 4) or 8 + 4*half + slot - 4
+    img = planes.view(torch.bfloat16).reshape(D // 64, 4, 3, 2, 128, 2, 4).double()   # slot = 4*hi + lo4
+    # k = 64*S + 16*s + 8*hi + 4*half + lo4  ->  order the axes as (plane, n, S, s, hi, half, lo4)
+    p = img.permute(2, 4, 0, 1, 5, 3, 6).reshape(3, 128, D)
     np.testing.assert_array_equal((p[0] + p[1] + p[2]).cpu().numpy(), W.double().cpu().numpy())
 
 

@@ -40,23 +40,23 @@ def pmc(pattern, counter):
     if not f:
         return res
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
-    # first_conv forward = the NT launch right after pack_weights; first_conv wgrad = the last tn_gemm of a step
+    # first_conv forward = the launch right after pack_weights; weight_gradients = the one batched TN launch of a step
     prev, fwd, wg = "", [], []
     step_tn = None
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if "nt_gemm_kernel" in k and "pack_weights" in prev:
+        if ("first_conv_split_kernel" in k or "nt_gemm_kernel" in k) and "pack_weights" in prev:
             fwd.append(float(r["Counter_Value"]))
-        if "tn_gemm_kernel<false, false" in k:
+        if "tn_batched_kernel" in k:
             wg.append(float(r["Counter_Value"]))
         prev = k
-    return {"first_conv_fwd": fwd, "first_conv_wgrad": wg}
+    return {"first_conv_fwd": fwd, "weight_gradients": wg}
 
 fetch, write = pmc("pmc_fetch/*/*_counter_collection.csv", "FETCH_SIZE"), pmc("pmc_write/*/*_counter_collection.csv", "WRITE_SIZE")
 traffic = {}
-for k in ("first_conv_fwd", "first_conv_wgrad"):
+for k in ("first_conv_fwd", "weight_gradients"):
     if fetch.get(k) and write.get(k):
         fk = sum(fetch[k]) / len(fetch[k]) * 1024          # counter unit: KiB
         wk = sum(write[k]) / len(write[k]) * 1024
