@@ -25,12 +25,14 @@
 // MFMAs of the step before it (sched_group_barrier).  The two k-groups' accumulators meet through LDS at the end,
 // always summed as group 0 + group 1 (bitwise reproducible, batch independent).
 //
-// Measured at B=8, T=4096 (tools/split_bench.py): 93-96 us against 153-160 us for the f32-MFMA kernel.
+// Measured (tools/split_bench.py): 93 us at B=8, T=4096 (one workgroup on every CU) against 153-160 us for the
+// f32-MFMA kernel; 60 us when only a quarter of the CUs are busy (B=2) -- a workgroup alone runs its MFMA pipe 68 % busy
+// at 2.4 GHz, and with all 256 CUs issuing bf16 MFMAs the clock settles near 2.0 GHz (GRBM cycles / time) and the pipe at
+// 52 %.  With the tape served from cache the full launch still takes 89 us: bound by MFMA issue, LDS-read latency and
+// power, not yet by HBM (3.1 TB/s).  It wins from 8,192 frames per launch (mucon_hip.hip: g_first_conv_split_rows).
 // A first structure that staged both operands as bf16 planes in LDS (tape split by the staging threads, 18 fragment
-// reads + 9 VGPR-path stores per wave and 32-deep k-tile) reached 99-108 us: its MFMAs alone took 52 us and its LDS
-// work alone 63 us, and the two overlapped badly.  Here the MFMA pipe is 52 % busy at ~2.0 GHz (the bf16 MFMAs pull
-// the clock down from 2.4); with the tape served from cache the kernel still takes 89 us, so it is bound by MFMA issue
-// and LDS-read latency inside the workgroup, not yet by HBM (2.9-3.1 TB/s).
+// reads + 9 VGPR-path stores per wave and 32-deep k-tile) reached 99-108 us: its MFMAs alone took 52 us, its LDS work
+// alone 63 us, and the two overlapped badly.
 #pragma once
 #include <type_traits>
 

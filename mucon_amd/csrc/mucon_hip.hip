@@ -55,7 +55,7 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
-long g_first_conv_split_rows = 16384;  // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
+long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {

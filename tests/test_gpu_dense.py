@@ -354,7 +354,7 @@ def test_full_size_properties_with_one_tile_shape():
     load: fresh interpreter)."""
     import subprocess
     import sys
-    # ... and the same first_conv kernel: by default only chip-filling launches (>= 16384 frames) take the split-bf16 one
+    # ... and the same first_conv kernel: by default only launches of >= 8192 frames take the split-bf16 one
     env = dict(os.environ, MUCON_NT_BM16_ROWS="0", MUCON_FIRST_CONV_SPLIT_ROWS="0")
     r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::test_full_size_batch_properties", "-q", "-x",
                         "-m", "gpu"], env=env, capture_output=True, text=True,
