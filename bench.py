@@ -380,7 +380,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
-                         "flops_per_launch": flops_wg, "all_weight_gradients_launch_ms": round(k_wg_ms, 4)},
+                         "flops_per_launch": flops_wg, "all_weight_gradients_launch_ms": round(k_wg_ms, 4),
+                         "rocprof_summary": "profiles/r01_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
+                                            "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
             "roofline_first_conv_fwd": {"bound": "hbm", "kernel": "first_conv_split_kernel",

@@ -28,11 +28,15 @@ def _run_split(tape, W, bias, relu):
     return out, planes
 
 
-@pytest.mark.parametrize("B,T,D", [(1, 128, 2048), (1, 257, 2048), (3, 1000, 2048), (2, 130, 128), (1, 77, 1024)])
-def test_split_first_conv_matches_float64(B, T, D):
+@pytest.mark.parametrize("B,T,D,kind", [(1, 128, 2048, "pm1"), (1, 257, 2048, "pm1"), (3, 1000, 2048, "pm1"), (2, 130, 128, "pm1"),
+                                         (1, 77, 1024, "pm1"), (2, 515, 2048, "abs_normal")])
+def test_split_first_conv_matches_float64(B, T, D, kind):
+    """kind abs_normal: non-negative features, as real post-ReLU I3D tapes -- sums that do not cancel."""
     from mucon_amd import _lib
     lib = _lib.load()
     tape = torch.tensor(synth.uniform_pm1(11, (B, T, D)), device=DEV)
+    if kind == "abs_normal":
+        tape = torch.randn(B, T, D, generator=torch.Generator().manual_seed(14)).abs().to(DEV)
     W = torch.tensor(synth.uniform_pm1(12, (128, D)), device=DEV) * 0.05
     bias = torch.tensor(synth.uniform_pm1(13, (128,)), device=DEV)
     ref = tape.double() @ W.double().T + bias.double()

@@ -1,5 +1,6 @@
 """Condense one tools/profile_round.sh output directory into the files profiles/ keeps:
   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (as written by rocprofv3)
+  <tag>_kernel_stats_hotpath.csv  the same for `bench.py --no-viterbi --no-cpu-baseline` (hot-path leg only)
   <tag>_step_timeline.txt     per-launch timeline of the last benchmark step
   <tag>_traffic.json          per-launch HBM traffic of the two tape-streaming kernels from the PMC passes
                               (FETCH_SIZE doubled for wide coalesced reads on gfx950 as MI355X_MICROARCH.md
@@ -24,6 +25,14 @@ if stats:
         w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
     print("kernel stats (top 12):")
     for r in rows[:12]:
+        print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} {float(r['Percentage']):6.2f}%")
+hot = one("trace_hot/*/*_kernel_stats.csv")
+if hot:
+    rows = list(csv.DictReader(open(hot)))
+    with open(os.path.join(dst, f"{tag}_kernel_stats_hotpath.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
+    print("hot-path leg only (top 6):")
+    for r in rows[:6]:
         print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} {float(r['Percentage']):6.2f}%")
 trace = one("trace/*/*_kernel_trace.csv")
 if trace:

@@ -6,14 +6,10 @@ cd $R
 run() {
   env "$@" python3 bench.py --steps 200 --warmup 30 2>/dev/null | tail -1 | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$*', 'ms/step %.4f'%d['ms_per_step'], 'e2e', d.get('end_to_end',{}).get('ms_per_video'))"
+d=json.loads(sys.stdin.readline()); print('$*', 'ms/step %.4f'%d['ms_per_step'], 'wg %.4f' % d['roofline']['all_weight_gradients_launch_ms'], 'e2e', d.get('end_to_end',{}).get('ms_per_video'))"
 }
-run MUCON_REDUCE_LANES=4
-run MUCON_REDUCE_LANES=4 MUCON_TN_BATCH_TARGET=96
-run MUCON_REDUCE_LANES=4 MUCON_TN_BATCH_TARGET=160
-run MUCON_REDUCE_LANES=4 MUCON_TN_BATCH_TARGET=192
-run MUCON_REDUCE_LANES=4 MUCON_TN_BATCH_TARGET=256
-run MUCON_REDUCE_LANES=4 MUCON_TN_MC_CAP=2048
-run MUCON_REDUCE_LANES=4 MUCON_TN_MC_CAP=512
-run MUCON_REDUCE_LANES=16
-run MUCON_REDUCE_LANES=4
+run MUCON_TN_MC_CAP=2048
+run MUCON_TN_MC_CAP=4096
+run MUCON_TN_MC_CAP=2048 MUCON_TN_BATCH_TARGET=96
+run MUCON_TN_MC_CAP=4096 MUCON_TN_BATCH_TARGET=96
+run MUCON_TN_MC_CAP=2048
