@@ -94,7 +94,8 @@ def test_forward_matches_reference_golden(name, over):
     np.testing.assert_allclose(logp.cpu().numpy(), GOLD[f"{name}__logp_z"][:, idx], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,T,over", [(1, 353, {}), (3, 1201, {}), (2, 640, {"pooling_type": "sum", "leaky_relu": True}),
+@pytest.mark.parametrize("B,T,over", [(2, 16, {}), (1, 33, {}),   # the shortest tapes four poolings allow (Tz = 1, 2)
+                                      (1, 353, {}), (3, 1201, {}), (2, 640, {"pooling_type": "sum", "leaky_relu": True}),
                                       (1, 1500, {"last_relu": False}), (2, 333, {"last_gn_num_groups": 8})])
 def test_forward_matches_oracle_f64(B, T, over):
     from mucon_amd import ops
@@ -164,7 +165,8 @@ def _pattern_agrees(hip, oracle_masks, only=None, tol=2e-5):
     return flips
 
 
-@pytest.mark.parametrize("B,T,over", [(1, 600, {}), (2, 777, {}), (1, 2097, {}), (3, 1201, {}),
+@pytest.mark.parametrize("B,T,over", [(2, 16, {}), (1, 33, {}),   # the shortest tapes four poolings allow
+                                      (1, 600, {}), (2, 777, {}), (1, 2097, {}), (3, 1201, {}),
                                       (2, 500, {"pooling_type": "sum"}),
                                       (1, 900, {"leaky_relu": True}), (1, 640, {"last_gn": False}),
                                       (1, 512, {"last_relu": False, "last_gn_num_groups": 16})])
