@@ -385,7 +385,7 @@ def main():
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
-            "roofline_first_conv_fwd": {"bound": "hbm", "kernel": "first_conv_split_kernel",
+            "roofline_first_conv_fwd": {"bound": "hbm", "kernel": "nt_split_kernel<true, false, false, false>",
                                         "achieved": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                         "unit": "GB/s", "frac": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                         "traffic": traffic_fwd, "algorithmic_bytes_per_launch": bytes_fwd,

@@ -30,13 +30,14 @@ __device__ __forceinline__ void sp_split2(float x0, float x1, uint32_t &h, uint3
 
 // W [128][D] fp32 -> the fragment-ordered bf16 image gemm_split.hpp stages (pack_weights writes it once per forward pass): per 64-deep k-tile
 // [k-step 4][plane 3][lane half 2][channel 128][slot 8] bf16, with k16 = k mod 16 at half (k16 >> 2) & 1, slot (k16 & 3) + 4 (k16 >> 3)
-__device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *img, int D, long first, long stride) {
+template <class SRC>   // src(n, k): element k of output channel n's weight row
+__device__ __forceinline__ void sp_split_weights_fn(SRC src, uint16_t *img, int D, long first, long stride) {
     uint32_t *P = reinterpret_cast<uint32_t *>(img);
     const long n_pairs = 64L * D;
     for (long e = first; e < n_pairs; e += stride) {
         const int n = (int)(e / (D / 2)), k = (int)(e - (long)n * (D / 2)) * 2;
         uint32_t h, m, l;
-        sp_split2(W[2 * e], W[2 * e + 1], h, m, l);
+        sp_split2(src(n, k), src(n, k + 1), h, m, l);
         const int S = k >> 6, s = (k >> 4) & 3, k16 = k & 15;
         const int half = (k16 >> 2) & 1, slot = (k16 & 3) + 4 * (k16 >> 3);
         // element offset (((s*3 + pl)*2 + half)*128 + n)*8 + slot, in pairs; plane stride 2*128*8/2 = 1024 pairs
@@ -45,6 +46,9 @@ __device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *img, 
         P[base + 1024] = m;
         P[base + 2048] = l;
     }
+}
+__device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *img, int D, long first, long stride) {
+    sp_split_weights_fn([=](int n, int k) { return W[(long)n * D + k]; }, img, D, first, stride);
 }
 
 #define MUCON_H 128  // hidden width the MFMA kernels are specialised for (cfg.model.ft.hidden_size)

@@ -42,8 +42,10 @@
 constexpr int S2_WIMG = 4 * 3 * 2 * 128 * 8;          // bf16 elements of one k-tile's W image (49,152 B)
 constexpr int S2_SMEM_BYTES = 2 * S2_WIMG * 2;        // double buffered: 98,304 B (the final exchange reuses it: 64 KB)
 
-template <bool EPI_ACT>
-__global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p, const uint16_t *__restrict__ Wimg) {
+// TAPS: the k-tiles walk taps x Kc channels, A rows shifted by (tap - taps/2) * tap_step with zero padding (the dilated
+// convolutions and their data gradients); without it the one tap needs no bounds logic (first_conv).  EPI_* as in gemm_nt.hpp.
+template <bool EPI_ACT, bool EPI_RES, bool EPI_MASK, bool TAPS>
+__global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const uint16_t *__restrict__ Wimg) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s2_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -52,17 +54,30 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * 128;
-    const int nS = p.Kc >> 6;                 // 64-deep k-tiles; even (D is a multiple of 128)
-    const int trow = min(t0 + wr * 32 + r, p.Trows - 1);   // padding rows re-read a valid row
-    const float *a_src = p.A + (long)b * p.a_bstride + (long)trow * p.lda + 32 * g + 4 * h;
+    const int ktt = p.Kc >> 6;                // 64-deep k-tiles per tap
+    const int nS = (TAPS ? p.taps : 1) * ktt; // even (Kc is a multiple of 128)
+    const int trow_raw = t0 + wr * 32 + r;
+    const int trow = min(trow_raw, p.Trows - 1);   // padding rows re-read a valid row
+    const float *a_vid = p.A + (long)b * p.a_bstride + 32 * g + 4 * h;
+    const float *a_src = a_vid + (long)trow * p.lda;
     const uint16_t *w_src = Wimg + tid * 8;
 
-    f32x4 ra[2][4];   // two k-tiles of this lane's tape values in flight
+    f32x4 ra[2][4];   // two k-tiles of this lane's A values in flight
+    bool rok[2] = {true, true};   // TAPS: the staged row exists (else it is zero padding; the load re-read a clamped row)
     u32x4 rws[6];     // this thread's share of the next W image
     auto gloadA = [&](int S, auto SET) {
         constexpr int Q = decltype(SET)::value;
+        if (TAPS) {
+            const int tap = S / ktt;
+            const int ts = trow_raw + (tap - (p.taps >> 1)) * p.tap_step;
+            rok[Q] = trow_raw < p.Trows && ts >= 0 && ts < p.Ta;
+            const float *src = a_vid + (long)min(max(ts, 0), p.Ta - 1) * p.lda + 64 * (S - tap * ktt);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[Q][i] = *reinterpret_cast<const f32x4 *>(a_src + 64 * S + 8 * i);
+            for (int i = 0; i < 4; ++i) ra[Q][i] = *reinterpret_cast<const f32x4 *>(src + 8 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[Q][i] = *reinterpret_cast<const f32x4 *>(a_src + 64 * S + 8 * i);
+        }
     };
     auto gloadW = [&](int S) {
 #pragma unroll
@@ -74,9 +89,16 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
     };
     struct Planes { bf16x8 pl[3]; };
     // the lane's 8 k of one MFMA step -> (hi, mid, lo) operands
-    auto convert = [&](const f32x4 &v0, const f32x4 &v1) {
+    auto convert = [&](f32x4 v0, f32x4 v1, bool ok) {
         u32x4 hh, mm, ll;
         uint32_t a, bb, c;
+        if (TAPS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = ok ? v0[e] : 0.f;
+                v1[e] = ok ? v1[e] : 0.f;
+            }
+        }
         sp_split2(v0[0], v0[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
         sp_split2(v0[2], v0[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
         sp_split2(v1[0], v1[1], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
@@ -120,7 +142,7 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
     gloadA(0, I0{});
     gloadA(1, I1{});
     storeW(0);
-    Planes cur = convert(ra[0][0], ra[0][1]);
+    Planes cur = convert(ra[0][0], ra[0][1], rok[0]);
     __syncthreads();
 
     // One k-tile: { MFMAs of this group's first step | split of the second step } then { MFMAs of the second step |
@@ -131,7 +153,7 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
         gloadW(min(S + 1, nS - 1));
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 2 * g, cur);
-        Planes nxt = convert(ra[Q][2], ra[Q][3]);
+        Planes nxt = convert(ra[Q][2], ra[Q][3], rok[Q]);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the first two column blocks' fragments, the rest under their MFMAs
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
         gloadA(min(S + 2, nS - 1), SET);   // the tail re-loads the last tile; nobody uses it
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 2 * g + 1, nxt);
-        cur = convert(ra[O][0], ra[O][1]);
+        cur = convert(ra[O][0], ra[O][1], rok[O]);
         storeW(buf ^ 1);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
@@ -179,12 +201,27 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
             const int nb = g == 0 ? j : 2 + j;   // the blocks this wave keeps
             const int col = nb * 32 + r;
             const float bias = p.bias ? p.bias[col] : 0.f;
+            const bool use_mask = EPI_MASK && (p.mask != nullptr);
+            float rres[16], rmask[16];
+            if (EPI_RES || EPI_MASK) {   // all loads of the block first, then the math, then the stores
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int t = t0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const long gi = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
+                    if (EPI_RES) rres[e] = p.res[gi];
+                    if (EPI_MASK) rmask[e] = use_mask ? p.mask[gi] : 1.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float other = xch[((partner * 2 + j) * 16 + e) * 64 + lane];
                 const float mine = g == 0 ? acc[j][e] : acc[2 + j][e];
                 float x = (g == 0 ? mine + other : other + mine) + bias;
                 if (EPI_ACT) x = act_f(x, p.slope);
+                if (EPI_RES) x += rres[e];
+                if (EPI_MASK) {
+                    if (use_mask) x *= act_grad(rmask[e], p.slope);
+                }
                 const int t = t0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (FULL || t < p.Trows) p.out[(vbase + t) * 128 + col] = x;
             }
@@ -194,9 +231,9 @@ __global__ __launch_bounds__(512) void first_conv_split_kernel(const NtParams p,
     else epilogue(std::false_type{});
 }
 
-template <bool EPI_ACT>
-static hipError_t launch_first_conv_split(const NtParams &p, const uint16_t *Wimg, int B, hipStream_t s) {
-    auto k = first_conv_split_kernel<EPI_ACT>;
+template <bool EPI_ACT, bool EPI_RES = false, bool EPI_MASK = false, bool TAPS = false>
+static hipError_t launch_nt_split(const NtParams &p, const uint16_t *Wimg, int B, hipStream_t s) {
+    auto k = nt_split_kernel<EPI_ACT, EPI_RES, EPI_MASK, TAPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -54,6 +54,7 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
+int g_nt_split = 1;                    // ... and layer 0's dilated-conv data gradient (MUCON_NT_SPLIT)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
@@ -71,7 +72,8 @@ struct Plan {
     int L, B, T, D, Tz;
     int Tl[MUCON_MAX_LAYERS + 1];
     size_t W1f, W1b, W2t, Wlt;
-    size_t W0s;  // first_conv.weight as three bf16 planes [3][128][D] (gemm_split.hpp)
+    size_t W0s;  // first_conv.weight as pre-split bf16 fragment images (gemm_split.hpp)
+    size_t Wd0s; // layer 0's data-gradient operand (W1b) likewise: 3*128*384 bf16
     size_t x[MUCON_MAX_LAYERS + 1], h[MUCON_MAX_LAYERS], ypre[MUCON_MAX_LAYERS];
     size_t z, gnstat, gnpart;
     size_t gz, g[MUCON_MAX_LAYERS + 1], dpre[MUCON_MAX_LAYERS], dyd[MUCON_MAX_LAYERS];
@@ -123,6 +125,7 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.W2t = take((size_t)p.L * 16384);
     p.Wlt = take(16384);
     p.W0s = take((size_t)3 * 128 * p.D / 2);
+    p.Wd0s = take((size_t)3 * 128 * 384 / 2);
     for (int l = 0; l <= p.L; ++l) p.x[l] = take((size_t)p.B * p.Tl[l] * 128);
     for (int l = 0; l < p.L; ++l) {
         p.h[l] = take((size_t)p.B * p.Tl[l] * 128);
@@ -386,6 +389,8 @@ int mucon_abi_version(void) {
         if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_FIRST_CONV_SPLIT");
         if (e) g_first_conv_split = atoi(e) ? 1 : 0;
+        e = getenv("MUCON_NT_SPLIT");
+        if (e) g_nt_split = atoi(e) ? 1 : 0;
         e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
         if (e) g_first_conv_split_rows = atol(e);
         e = getenv("MUCON_REDUCE_LANES");
@@ -495,7 +500,10 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     const bool split_first = g_first_conv_split && (long)B * pl.T >= g_first_conv_split_rows;
     pa.first_w = prm->first_w;
     pa.first_planes = split_first ? reinterpret_cast<uint16_t *>(ws + pl.W0s) : nullptr;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(192, L + (split_first ? 2 : 1)), dim3(256), 0, s, pa);
+    // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
+    const bool split_dgrad0 = g_nt_split && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
+    pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(192, L + (split_dgrad0 ? 3 : (split_first ? 2 : 1))), dim3(256), 0, s, pa);
     HIPCHK(hipGetLastError());
 
     // first_conv + non-linearity (temporal.py:133); the tape is consumed row-major, no permute
@@ -503,7 +511,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         NtParams p = nt_base(tape, (long)pl.T * pl.D, pl.D, pl.T, pl.T, 1, 0, pl.D, prm->first_w, prm->first_b,
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
-        if (split_first) HIPCHK((launch_first_conv_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+        if (split_first) HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
         else HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
         prof_mark(0, true, s);
     }
@@ -793,6 +801,9 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                     if (cfg->pool_type == 0) HIPCHK((launch_nt<false, false, false, false, true, true, 3>(p, B, s)));
                     else HIPCHK((launch_nt<false, false, false, false, true, true, 4>(p, B, s)));
                     unpooled_by_producer = true;
+                } else if (l == 0 && !centre_only && g_nt_split && (long)B * Tl >= g_first_conv_split_rows) {
+                    // bf16 MFMA on exactly split operands (gemm_split.hpp); the W1b image was written by the forward's pack_weights
+                    HIPCHK((launch_nt_split<false, true, true, true>(p, reinterpret_cast<const uint16_t *>(ws + pl.Wd0s), B, s)));
                 } else {
                     HIPCHK((launch_nt<false, false, false, false, true, true, 0>(p, B, s)));
                 }
@@ -1009,7 +1020,7 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
     hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
     HIPCHK(hipGetLastError());
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
-    auto go = [&]() { return relu ? launch_first_conv_split<true>(p, P, B, s) : launch_first_conv_split<false>(p, P, B, s); };
+    auto go = [&]() { return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s); };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

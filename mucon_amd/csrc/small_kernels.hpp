@@ -18,6 +18,7 @@ struct PackArgs {
     float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]
     const float *first_w;          // [128][D]; split into first_planes when that is non-null (grid row L + 1)
     uint16_t *first_planes;        // hi / mid / lo bf16 of first_conv.weight in the fragment order of gemm_split.hpp (3*128*D values)
+    uint16_t *dgrad0_planes;       // same for layer 0's data-gradient operand W1b[i][tap*128 + o] (3*128*384 values), or null
     int L, D;
 };
 __global__ void pack_weights_kernel(const PackArgs a) {
@@ -40,8 +41,12 @@ __global__ void pack_weights_kernel(const PackArgs a) {
             const int o = e >> 7, i = e & 127;
             a.Wlt[i * 128 + o] = a.last_w[e];
         }
-    } else if (a.first_planes) {
-        sp_split_weights(a.first_w, a.first_planes, a.D, e, (long)gridDim.x * blockDim.x);
+    } else if (l == a.L + 1) {
+        if (a.first_planes) sp_split_weights(a.first_w, a.first_planes, a.D, e, (long)gridDim.x * blockDim.x);
+    } else if (a.dgrad0_planes) {
+        const float *w0 = a.dil_w[0];
+        sp_split_weights_fn([=](int i, int k) { return w0[((k & 127) * 128 + i) * 3 + (k >> 7)]; }, a.dgrad0_planes, 384, e,
+                            (long)gridDim.x * blockDim.x);
     }
 }
 

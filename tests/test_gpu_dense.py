@@ -357,7 +357,7 @@ def test_full_size_properties_with_one_tile_shape():
     import subprocess
     import sys
     # ... and the same first_conv kernel: by default only launches of >= 8192 frames take the split-bf16 one
-    env = dict(os.environ, MUCON_NT_BM16_ROWS="0", MUCON_FIRST_CONV_SPLIT_ROWS="0")
+    env = dict(os.environ, MUCON_NT_BM16_ROWS="0", MUCON_FIRST_CONV_SPLIT_ROWS="0")   # the row threshold covers both split-bf16 launches
     r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::test_full_size_batch_properties", "-q", "-x",
                         "-m", "gpu"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -374,5 +374,19 @@ def test_unfused_layer_path_still_green():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "forward or backward or dropout", "--deselect", f"{os.path.abspath(__file__)}::test_unfused_layer_path_still_green"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_split_kernels_at_every_size():
+    """The split-bf16 launches (first_conv forward, layer 0's dilated-conv data gradient) normally start at 8,192 frames per launch;
+    MUCON_FIRST_CONV_SPLIT_ROWS=0 (read once at library load: fresh interpreter) sends every size through them: the reference
+    goldens and the float64-oracle forward / backward checks of this file under that setting."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MUCON_FIRST_CONV_SPLIT_ROWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or oracle_f64 or dropout"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

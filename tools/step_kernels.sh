@@ -11,7 +11,7 @@ import csv, sys
 tot = 0
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Name'].replace('void ', '').split('(')[0]
-    if any(k in n for k in ('gemm', 'fused', 'batched', 'head', 'reduce', 'gn_', 'pack', 'unpool', 'sgd_')):
+    if any(k in n for k in ('gemm', 'fused', 'batched', 'head', 'reduce', 'gn_', 'pack', 'unpool', 'sgd_', 'split')):
         print(f"  {n[:66]:66s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us total/step {float(r['TotalDurationNs'])/12e3:8.1f}")
         tot += float(r['TotalDurationNs']) / 12e3
 print("  kernel time per step: %.1f us" % tot)

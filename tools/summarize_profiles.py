@@ -56,7 +56,7 @@ def pmc(pattern, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if ("first_conv_split_kernel" in k or "nt_gemm_kernel" in k) and "pack_weights" in prev:
+        if ("nt_split_kernel" in k or "nt_gemm_kernel" in k) and "pack_weights" in prev:
             fwd.append(float(r["Counter_Value"]))
         if "tn_batched_kernel" in k:
             wg.append(float(r["Counter_Value"]))

@@ -8,6 +8,6 @@ import json,sys
 d=json.loads(sys.stdin.readline()); print('$*', 'ms/step %.4f'%d['ms_per_step'], 'wg %.4f' % d['roofline']['all_weight_gradients_launch_ms'])"
 }
 for i in 1 2; do
-run MUCON_TN_XCD=0
-run MUCON_TN_XCD=1
+run MUCON_NT_SPLIT=0
+run MUCON_NT_SPLIT=1
 done
