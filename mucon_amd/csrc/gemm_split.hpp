@@ -186,14 +186,30 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
     // The k-groups exchange halves: group 0 finishes column blocks 0, 1 and group 1 blocks 2, 3 of their 32 rows;
     // each hands the other two blocks over as [wave][block][reg][lane] floats.  Sum order: group 0 + group 1.
     float *xch = reinterpret_cast<float *>(s2_smem);
+    const int partner = wave ^ 4;
+    const long vbase = (long)b * p.Trows;
+    const bool use_mask = EPI_MASK && (p.mask != nullptr);
+    // residual / mask values of the blocks this wave keeps: requested before the exchange, so that their latency runs under it
+    float rres[EPI_RES ? 2 : 1][16], rmask[EPI_MASK ? 2 : 1][16];
+    if (EPI_RES || EPI_MASK) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = (g == 0 ? j : 2 + j) * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = t0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long gi = (vbase + min(t, p.Trows - 1)) * 128 + col;
+                if (EPI_RES) rres[j][e] = p.res[gi];
+                if (EPI_MASK) rmask[j][e] = use_mask ? p.mask[gi] : 1.f;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) xch[((wave * 2 + j) * 16 + e) * 64 + lane] = g == 0 ? acc[2 + j][e] : acc[j][e];   // the blocks given away
     }
     __syncthreads();
-    const int partner = wave ^ 4;
-    const long vbase = (long)b * p.Trows;
     auto epilogue = [&](auto FULLT) {
         constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
@@ -201,26 +217,15 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
             const int nb = g == 0 ? j : 2 + j;   // the blocks this wave keeps
             const int col = nb * 32 + r;
             const float bias = p.bias ? p.bias[col] : 0.f;
-            const bool use_mask = EPI_MASK && (p.mask != nullptr);
-            float rres[16], rmask[16];
-            if (EPI_RES || EPI_MASK) {   // all loads of the block first, then the math, then the stores
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int t = t0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const long gi = (vbase + (FULL ? t : min(t, p.Trows - 1))) * 128 + col;
-                    if (EPI_RES) rres[e] = p.res[gi];
-                    if (EPI_MASK) rmask[e] = use_mask ? p.mask[gi] : 1.f;
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float other = xch[((partner * 2 + j) * 16 + e) * 64 + lane];
                 const float mine = g == 0 ? acc[j][e] : acc[2 + j][e];
                 float x = (g == 0 ? mine + other : other + mine) + bias;
                 if (EPI_ACT) x = act_f(x, p.slope);
-                if (EPI_RES) x += rres[e];
+                if (EPI_RES) x += rres[EPI_RES ? j : 0][e];
                 if (EPI_MASK) {
-                    if (use_mask) x *= act_grad(rmask[e], p.slope);
+                    if (use_mask) x *= act_grad(rmask[EPI_MASK ? j : 0][e], p.slope);
                 }
                 const int t = t0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (FULL || t < p.Trows) p.out[(vbase + t) * 128 + col] = x;
