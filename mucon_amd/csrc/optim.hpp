@@ -81,15 +81,54 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
     }
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
-    for (long e = b0 + threadIdx.x; e < b1; e += 256) {
-        const float g = t.g[e] * coef;
-        t.g[e] = g;
-        const float p = t.p[e];
+    auto update = [&](float g, float p, float m, float &g_out, float &p_out, float &m_out) {
+        g *= coef;
+        g_out = g;
         float u = g + h.weight_decay * p;
         if (t.mom) {
-            u = h.momentum * t.mom[e] + u;
-            t.mom[e] = u;
+            u = h.momentum * m + u;
+            m_out = u;
         }
-        t.p[e] = p - h.lr * u;
+        p_out = p - h.lr * u;
+    };
+    // a chunk is 4096 floats = 4 float4 per thread: all loads of the chunk first, then the arithmetic, then the stores (the
+    // element-at-a-time loop was a chain of 16 dependent memory round trips per thread: 20 us for 1 M parameters)
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
+                       reinterpret_cast<uintptr_t>(t.mom ? t.mom : t.p)) & 15) == 0;
+    const long nvec = vec ? (b1 - b0) >> 2 : 0;   // whole float4 of the chunk (b0 is a multiple of 4096)
+    if (nvec > 0) {
+        f32x4 vg[4], vp[4], vm[4];
+        long q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q[j] = b0 + 4 * min((long)threadIdx.x + 256 * j, nvec - 1);   // clamped: loads are never under a branch
+            vg[j] = *reinterpret_cast<const f32x4 *>(t.g + q[j]);
+            vp[j] = *reinterpret_cast<const f32x4 *>(t.p + q[j]);
+            vm[j] = t.mom ? *reinterpret_cast<const f32x4 *>(t.mom + q[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 og, op, om = vm[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a, b, c = vm[j][e];
+                update(vg[j][e], vp[j][e], vm[j][e], a, b, c);
+                og[e] = a;
+                op[e] = b;
+                om[e] = c;
+            }
+            if ((long)threadIdx.x + 256 * j < nvec) {
+                *reinterpret_cast<f32x4 *>(t.g + q[j]) = og;
+                *reinterpret_cast<f32x4 *>(t.p + q[j]) = op;
+                if (t.mom) *reinterpret_cast<f32x4 *>(t.mom + q[j]) = om;
+            }
+        }
+    }
+    for (long e = b0 + 4 * nvec + threadIdx.x; e < b1; e += 256) {   // the tail, or everything when a pointer is unaligned
+        float og, op, om = 0.f;
+        update(t.g[e], t.p[e], t.mom ? t.mom[e] : 0.f, og, op, om);
+        t.g[e] = og;
+        t.p[e] = op;
+        if (t.mom) t.mom[e] = om;
     }
 }
