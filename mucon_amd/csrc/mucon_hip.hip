@@ -588,7 +588,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
-        hipLaunchKernelGGL(gn_fwd_kernel, dim3(B), dim3(GN_THREADS), 0, s, g);
+        hipLaunchKernelGGL(gn_fwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g);
         HIPCHK(hipGetLastError());
     }
     return MUCON_OK;
@@ -635,7 +635,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
-        hipLaunchKernelGGL(gn_bwd_kernel, dim3(B), dim3(GN_THREADS), 0, s, g);
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
             red.add(ws + pl.gnpart, B, 256, 256, 0, 1, 128, gr->gn_w, 0);

@@ -101,65 +101,66 @@ struct GnArgs {
     DropCfg drop;
 };
 
-constexpr int GN_ROWS = 32;               // row slots per workgroup
-constexpr int GN_THREADS = 32 * GN_ROWS;   // x 32 float4 columns
+// One workgroup per (video, group): 256 threads walk the Tz x (channels of the group) elements as float4; sums run up a
+// fixed shuffle tree per wave and a fixed 4-wave order (bitwise reproducible, independent of the batch).  (One 1024-thread
+// workgroup per video -- 8 workgroups on 256 CUs at B = 8 -- took 12 / 15 us forward / backward: three dependent passes.)
+constexpr int GN_THREADS = 256;
 
-__device__ __forceinline__ float block_group_sum(float v, float *red, int c4, int trow, int lanes_per_group) {
-    // sum over the float4 columns of one group (adjacent c4) and over the row slots
-    for (int o = 1; o < lanes_per_group; o <<= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    red[trow * 32 + c4] = v;
-    __syncthreads();
-    float s = 0.f;
+__device__ __forceinline__ float gn_block_sum(float v, float *red) {
 #pragma unroll
-    for (int r = 0; r < GN_ROWS; ++r) s += red[r * 32 + c4];
-    return s;
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const GnArgs a) {
-    __shared__ float red[GN_THREADS];
-    const int b = blockIdx.x;
-    const int c4 = threadIdx.x & 31, trow = threadIdx.x >> 5;
-    const int cpg = 128 / a.G;           // channels per group (>= 4)
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = 128 / a.G;           // channels per group (a multiple of 4)
     const int lpg = cpg >> 2;            // float4 columns per group
-    const int g = (c4 * 4) / cpg;
-    const float *zb = a.z + (long)b * a.Tz * 128 + c4 * 4;
+    const int nel = a.Tz * lpg;
+    const float *zb = a.z + (long)b * a.Tz * 128 + g * cpg;
     float mean = 0.f, rstd = 1.f;
     if (a.use_gn) {
         const float n = (float)a.Tz * (float)cpg;
         float s = 0.f;
-        for (int t = trow; t < a.Tz; t += GN_ROWS) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
+        for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
+            const int t = e / lpg, c = e - t * lpg;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
-        mean = block_group_sum(s, red, c4, trow, lpg) / n;
+        mean = gn_block_sum(s, red) / n;
         float q = 0.f;
-        for (int t = trow; t < a.Tz; t += GN_ROWS) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
+        for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
+            const int t = e / lpg, c = e - t * lpg;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = v[k] - mean;
                 q += d * d;
             }
         }
-        const float var = block_group_sum(q, red, c4, trow, lpg) / n;
+        const float var = gn_block_sum(q, red) / n;
         rstd = rsqrtf(var + a.eps);
         // rsqrtf is approximate on AMD (1 ulp); refine once so rstd matches 1/sqrt to rounding
         rstd = rstd * (1.5f - 0.5f * (var + a.eps) * rstd * rstd);
-        if (trow == 0 && (c4 % lpg) == 0) {
+        if (threadIdx.x == 0) {
             a.stats[((long)b * a.G + g) * 2 + 0] = mean;
             a.stats[((long)b * a.G + g) * 2 + 1] = rstd;
         }
     }
-    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-    if (a.use_gn) {
-        ga = *reinterpret_cast<const f32x4 *>(a.gamma + c4 * 4);
-        be = *reinterpret_cast<const f32x4 *>(a.beta + c4 * 4);
-    }
-    float *eb = a.enc + (long)b * a.Tz * 128 + c4 * 4;
-    for (int t = trow; t < a.Tz; t += GN_ROWS) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
-        const uint32_t idx = (uint32_t)(b * a.Tz + t) * 128u + (uint32_t)(c4 * 4);
+    float *eb = a.enc + (long)b * a.Tz * 128 + g * cpg;
+    for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
+        const int t = e / lpg, c = e - t * lpg;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+        if (a.use_gn) {
+            ga = *reinterpret_cast<const f32x4 *>(a.gamma + g * cpg + c * 4);
+            be = *reinterpret_cast<const f32x4 *>(a.beta + g * cpg + c * 4);
+        }
+        const uint32_t idx = (uint32_t)(b * a.Tz + t) * 128u + (uint32_t)(g * cpg + c * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float y = a.use_gn ? (v[k] - mean) * rstd * ga[k] + be[k] : v[k];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const GnArgs a) {
             if (a.drop.thresh) y *= drop_mul(a.drop, idx + k);
             v[k] = y;
         }
-        *reinterpret_cast<f32x4 *>(eb + (long)t * 128) = v;
+        *reinterpret_cast<f32x4 *>(eb + (long)t * 128 + c * 4) = v;
     }
 }
 
@@ -182,28 +183,30 @@ struct GnBwdArgs {
 };
 
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
-    __shared__ float red[GN_THREADS];
-    __shared__ float cred[2][GN_ROWS][128];
-    const int b = blockIdx.x;
-    const int c4 = threadIdx.x & 31, trow = threadIdx.x >> 5;
+    __shared__ float red[4];
+    __shared__ float cred[2][4][128];   // per-channel partials [d_gamma | d_beta][wave][channel of the group]
+    const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = 128 / a.G, lpg = cpg >> 2;
-    const int g = (c4 * 4) / cpg;
-    const float *zb = a.z + (long)b * a.Tz * 128 + c4 * 4;
-    const float *db = a.denc + (long)b * a.Tz * 128 + c4 * 4;
-    float *ob = a.dz + (long)b * a.Tz * 128 + c4 * 4;
+    const int nel = a.Tz * lpg;
+    const float *zb = a.z + (long)b * a.Tz * 128 + g * cpg;
+    const float *db = a.denc + (long)b * a.Tz * 128 + g * cpg;
+    float *ob = a.dz + (long)b * a.Tz * 128 + g * cpg;
     float mean = 0.f, rstd = 1.f;
-    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
     if (a.use_gn) {
         mean = a.stats[((long)b * a.G + g) * 2 + 0];
         rstd = a.stats[((long)b * a.G + g) * 2 + 1];
-        ga = *reinterpret_cast<const f32x4 *>(a.gamma + c4 * 4);
-        be = *reinterpret_cast<const f32x4 *>(a.beta + c4 * 4);
     }
     // gradient at the GroupNorm output: through dropout and ReLU
-    auto dgn_at = [&](int t, f32x4 &xh, f32x4 &dg) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(db + (long)t * 128);
-        const uint32_t idx = (uint32_t)(b * a.Tz + t) * 128u + (uint32_t)(c4 * 4);
+    auto dgn_at = [&](int t, int c, f32x4 &xh, f32x4 &dg, f32x4 &ga) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(db + (long)t * 128 + c * 4);
+        f32x4 be = {0.f, 0.f, 0.f, 0.f};
+        ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (a.use_gn) {
+            ga = *reinterpret_cast<const f32x4 *>(a.gamma + g * cpg + c * 4);
+            be = *reinterpret_cast<const f32x4 *>(a.beta + g * cpg + c * 4);
+        }
+        const uint32_t idx = (uint32_t)(b * a.Tz + t) * 128u + (uint32_t)(g * cpg + c * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             xh[k] = (v[k] - mean) * rstd;
@@ -215,18 +218,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
         }
     };
     if (!a.use_gn) {
-        for (int t = trow; t < a.Tz; t += GN_ROWS) {
-            f32x4 xh, dg;
-            dgn_at(t, xh, dg);
-            *reinterpret_cast<f32x4 *>(ob + (long)t * 128) = dg;
+        for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
+            const int t = e / lpg, c = e - t * lpg;
+            f32x4 xh, dg, ga;
+            dgn_at(t, c, xh, dg, ga);
+            *reinterpret_cast<f32x4 *>(ob + (long)t * 128 + c * 4) = dg;
         }
         return;
     }
+    // a thread keeps ONE float4 column (threads per column = 256 / lpg row slots): its d_gamma / d_beta partials are per channel
+    const int col = threadIdx.x % lpg, slot = threadIdx.x / lpg, nslots = GN_THREADS / lpg;
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
-    for (int t = trow; t < a.Tz; t += GN_ROWS) {
-        f32x4 xh, dg;
-        dgn_at(t, xh, dg);
+    for (int t = slot; t < a.Tz; t += nslots) {
+        f32x4 xh, dg, ga;
+        dgn_at(t, col, xh, dg, ga);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             sg[k] += dg[k] * xh[k];
@@ -237,27 +243,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
         }
     }
     const float n = (float)a.Tz * (float)cpg;
-    const float m1 = block_group_sum(s1, red, c4, trow, lpg) / n;
-    const float m2 = block_group_sum(s2, red, c4, trow, lpg) / n;
+    const float m1 = gn_block_sum(s1, red) / n;
+    const float m2 = gn_block_sum(s2, red) / n;
+    // per-channel sums: up a fixed shuffle tree over the lanes that hold the same float4 column (lane offsets >= lpg keep the
+    // column), then the four waves in order
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        cred[0][trow][c4 * 4 + k] = sg[k];
-        cred[1][trow][c4 * 4 + k] = sb[k];
+        for (int o = 32; o >= lpg; o >>= 1) {
+            sg[k] += __shfl_xor(sg[k], o);
+            sb[k] += __shfl_xor(sb[k], o);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < lpg) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cred[0][wave][lane * 4 + k] = sg[k];   // lane < lpg: lane == its column (64 % lpg == 0)
+            cred[1][wave][lane * 4 + k] = sb[k];
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < GN_ROWS; ++r) s += cred[which][r][c];
-        a.part[((long)b * 2 + which) * 128 + c] = s;
+    if (threadIdx.x < 2 * cpg) {
+        const int which = threadIdx.x / cpg, c = threadIdx.x - which * cpg;
+        a.part[((long)b * 2 + which) * 128 + g * cpg + c] =
+            (cred[which][0][c] + cred[which][1][c]) + (cred[which][2][c] + cred[which][3][c]);
     }
-    for (int t = trow; t < a.Tz; t += GN_ROWS) {
-        f32x4 xh, dg, o;
-        dgn_at(t, xh, dg);
+    for (int t = slot; t < a.Tz; t += nslots) {
+        f32x4 xh, dg, ga, o;
+        dgn_at(t, col, xh, dg, ga);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = rstd * (dg[k] * ga[k] - m1 - xh[k] * m2);
-        *reinterpret_cast<f32x4 *>(ob + (long)t * 128) = o;
+        *reinterpret_cast<f32x4 *>(ob + (long)t * 128 + col * 4) = o;
     }
 }
 
