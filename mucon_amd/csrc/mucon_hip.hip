@@ -879,7 +879,8 @@ int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((Tf + HEAD_FB - 1) / HEAD_FB, B), dim3(256), smem, s, a);
+    if (H % 16 == 0) hipLaunchKernelGGL(head_fwd_z_kernel, dim3((Tz + HF_Z - 1) / HF_Z, B), dim3(256), head_fwd_z_smem_bytes(H), s, a);
+    else hipLaunchKernelGGL(head_fwd_kernel, dim3((Tf + HEAD_FB - 1) / HEAD_FB, B), dim3(256), smem, s, a);
     HIPCHK(hipGetLastError());
     return MUCON_OK;
 }

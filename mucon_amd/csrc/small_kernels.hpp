@@ -364,6 +364,82 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
     }
 }
 
+// Forward organised by z rows (H a multiple of 16): a workgroup owns HF_Z rows of the encoding and the frames that map onto
+// them.  Thread (class c = tid >> 2, k-quarter q = tid & 3) keeps its share of W[c] in registers straight from global (the four
+// lanes of a class read 64 contiguous bytes per step) and multiplies it with all HF_Z rows from LDS; the quarters meet by two
+// shuffles.  No W staging pass, no divisions: 22 -> ~8 us at B=8, T=4096 against the frame-organised kernel above.
+constexpr int HF_Z = 8;
+__global__ __launch_bounds__(256) void head_fwd_z_kernel(const HeadFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, C = a.C;
+    float *Es = smem;                      // [HF_Z][H]
+    float *Ls = Es + HF_Z * H;             // [HF_Z][MAXC] logits
+    float *Ps = Ls + HF_Z * HEAD_MAXC;     // [HF_Z][MAXC] log-probs
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int z0 = blockIdx.x * HF_Z;
+    const int nz = min(HF_Z, a.Tz - z0);
+    const int c = tid >> 2, q = tid & 3;
+    for (int e = tid * 4; e < nz * H; e += 1024)
+        *reinterpret_cast<f32x4 *>(Es + e) = *reinterpret_cast<const f32x4 *>(a.enc + ((long)b * a.Tz + z0) * H + e);
+    for (int e = nz * H + tid; e < HF_Z * H; e += 256) Es[e] = 0.f;
+    __syncthreads();
+    float acc[HF_Z];
+#pragma unroll
+    for (int zi = 0; zi < HF_Z; ++zi) acc[zi] = 0.f;
+    if (c < C) {
+        const float *wr = a.w + (long)c * H;
+        for (int k = q * 4; k < H; k += 16) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k);
+#pragma unroll
+            for (int zi = 0; zi < HF_Z; ++zi) {
+                const f32x4 ev = *reinterpret_cast<const f32x4 *>(Es + zi * H + k);
+                acc[zi] += (wv[0] * ev[0] + wv[1] * ev[1]) + (wv[2] * ev[2] + wv[3] * ev[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int zi = 0; zi < HF_Z; ++zi) {
+        acc[zi] += __shfl_xor(acc[zi], 1);
+        acc[zi] += __shfl_xor(acc[zi], 2);
+    }
+    if (c < C && q == 0) {
+        const float bias = a.b[c];
+#pragma unroll
+        for (int zi = 0; zi < HF_Z; ++zi) Ls[zi * HEAD_MAXC + c] = acc[zi] + bias;
+    }
+    __syncthreads();
+    // log-softmax over the classes: a wave per z row, lane = class (C <= 64); the sum runs up a fixed shuffle tree
+    for (int zi = tid >> 6; zi < nz; zi += 4) {
+        const int cc = tid & 63;
+        const float x = cc < C ? Ls[zi * HEAD_MAXC + cc] : -INFINITY;
+        float m = x;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = cc < C ? expf(x - m) : 0.f;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        if (cc < C) {
+            const float lp = x - (m + logf(s));
+            Ps[zi * HEAD_MAXC + cc] = lp;
+            a.logp_z[((long)b * a.Tz + z0 + zi) * C + cc] = lp;
+        }
+    }
+    __syncthreads();
+    // the frames of these rows are contiguous: [first frame of z0, first frame of z0 + nz)
+    const int fa = first_frame(z0, a.scale, a.Tz, a.Tf), fb = first_frame(z0 + nz, a.scale, a.Tz, a.Tf);
+    for (int i = fa + (tid >> 6); i < fb; i += 4) {   // a wave per frame, lane = class
+        const int cc = tid & 63;
+        const int zi = zmap(i, a.scale, a.Tz) - z0;
+        if (cc < C) {
+            const long gi = ((long)b * a.Tf + i) * C + cc;
+            if (a.logits) a.logits[gi] = Ls[zi * HEAD_MAXC + cc];
+            if (a.logp) a.logp[gi] = Ps[zi * HEAD_MAXC + cc];
+        }
+    }
+}
+static inline size_t head_fwd_z_smem_bytes(int H) { return sizeof(float) * ((size_t)HF_Z * H + 2 * HF_Z * HEAD_MAXC); }
+
 struct HeadBwdArgs {
     const float *enc, *w;          // [B][Tz][H], [C][H]
     const float *dlogits, *dlogp;  // [B][Tf][C] or null
