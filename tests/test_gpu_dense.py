@@ -390,3 +390,31 @@ def test_split_kernels_at_every_size():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("B,Tz,Tf,H,C", [(2, 37, 600, 128, 48), (1, 9, 100, 48, 7), (3, 21, 333, 40, 64), (1, 5, 5, 20, 3)])
+def test_head_kernels_against_torch(B, Tz, Tf, H, C):
+    """y-head alone, forward and backward, for hidden sizes on both kernels (H % 16 == 0: z-organised forward; otherwise the
+    frame-organised one) against the reference's formulation in float64: nearest interpolate (torch's float32 index rule),
+    1x1 conv, log-softmax (models.py:567-582, :368)."""
+    from mucon_amd import ops
+    g = torch.Generator().manual_seed(40 + H)
+    enc = torch.randn(B, Tz, H, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(C, H, generator=g) * 0.2).to(DEV).requires_grad_()
+    bias = torch.randn(C, generator=g).to(DEV).requires_grad_()
+    u = torch.randn(B, Tf, C, generator=g).to(DEV)
+    v = torch.randn(B, Tf, C, generator=g).to(DEV)
+    logits, logp = ops.head_forward(enc, w, bias, Tf)
+    ((u * logits).sum() + (v * logp).sum()).backward()
+    got = [logits.detach(), logp.detach(), enc.grad.clone(), w.grad.clone(), bias.grad.clone()]
+    idx = torch.clamp(torch.floor(torch.arange(Tf, dtype=torch.float32) * (torch.tensor(Tz, dtype=torch.float32) /
+                                                                          torch.tensor(Tf, dtype=torch.float32))), max=Tz - 1).long().to(DEV)
+    e64, w64, b64 = (t.detach().double().requires_grad_() for t in (enc, w, bias))
+    lz = e64 @ w64.T + b64
+    lo = lz[:, idx]
+    lp = torch.log_softmax(lo, dim=2)
+    ((u.double() * lo).sum() + (v.double() * lp).sum()).backward()
+    want = [lo.detach(), lp.detach(), e64.grad, w64.grad, b64.grad]
+    for name, a_, b_ in zip(("logits", "logp", "d_enc", "d_w", "d_b"), got, want):
+        scale = b_.abs().max().item() + 1e-12
+        assert (a_.double() - b_).abs().max().item() <= 1e-5 * scale + 1e-6, name
