@@ -839,7 +839,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
 
 // ------------------------------------------------------------------------------------------ head
 size_t mucon_head_workspace_bytes(int32_t B, int32_t Tz, int32_t H, int32_t C) {
-    const size_t nblk = (size_t)B * ((Tz + HEAD_ZC - 1) / HEAD_ZC);
+    const size_t nblk = (size_t)B * ((Tz + HB_Z - 1) / HB_Z);   // HB_Z <= HEAD_ZC: the larger block count of the two backward kernels
     return sizeof(float) * (align64((size_t)B * Tz * C) + align64(nblk * C * H) + align64(nblk * C));
 }
 
@@ -894,7 +894,7 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     if (workspace_bytes < mucon_head_workspace_bytes(B, Tz, H, C)) return fail(MUCON_E_WORKSPACE, "head workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *ws = static_cast<float *>(workspace);
-    const int zblocks = (Tz + HEAD_ZC - 1) / HEAD_ZC;
+    const int zblocks = H == 128 ? (Tz + HB_Z - 1) / HB_Z : (Tz + HEAD_ZC - 1) / HEAD_ZC;
     const size_t nblk = (size_t)B * zblocks;
     HeadBwdArgs a;
     a.enc = enc;
@@ -916,7 +916,8 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
+    if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
     HIPCHK(hipGetLastError());
     Reducer red(s);
     red.add(a.w_slabs, (int)nblk, (long)C * H, C * H, 0, 1, C * H, d_w, 0);

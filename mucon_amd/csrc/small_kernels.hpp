@@ -527,6 +527,97 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs a) {
     }
 }
 
+// Backward for H = 128 with HB_Z rows per workgroup (twice the workgroups of the kernel above), nothing staged but the rows
+// themselves: thread (k = tid & 127, half = tid >> 7) reads its column of W straight from global (coalesced over k) for
+// d_enc, keeps its column of the encoding rows in registers for the weight-gradient partials, and the per-row class sums run
+// up shuffle trees.  30 -> ~14 us at B=8, T=4096.
+constexpr int HB_Z = 8;
+__global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float Es[HB_Z][128];
+    __shared__ float G1[HB_Z][HEAD_MAXC], G2[HB_Z][HEAD_MAXC], S2[HB_Z];
+    const int C = a.C;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int z0 = blockIdx.x * HB_Z;
+    const int nz = min(HB_Z, a.Tz - z0);
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int zi = tid >> 5, k4 = (tid & 31) * 4;   // 8 rows x 32 float4
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (zi < nz) v = *reinterpret_cast<const f32x4 *>(a.enc + ((long)b * a.Tz + z0 + zi) * 128 + k4);
+        *reinterpret_cast<f32x4 *>(&Es[zi][k4]) = v;
+    }
+    for (int o = tid; o < HB_Z * HEAD_MAXC; o += 256) {
+        const int zi = o >> 6, c = o & 63;
+        float g1 = 0.f, g2 = 0.f;
+        if (zi < nz && c < C) {
+            const int fa = first_frame(z0 + zi, a.scale, a.Tz, a.Tf);
+            const int fb = first_frame(z0 + zi + 1, a.scale, a.Tz, a.Tf);
+            // frames of the bin in order, eight loads in flight at a time (a bin has ~Tf/Tz frames)
+            const int nfr = fb - fa;
+            for (int base = 0; base < nfr; base += 8) {
+                float v1[8], v2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long gi = ((long)b * a.Tf + fa + min(base + j, nfr - 1)) * C + c;
+                    v1[j] = a.dlogits ? a.dlogits[gi] : 0.f;
+                    v2[j] = a.dlogp ? a.dlogp[gi] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (base + j < nfr) {
+                        g1 += v1[j];
+                        g2 += v2[j];
+                    }
+                }
+            }
+        }
+        G1[zi][c] = g1;
+        G2[zi][c] = g2;
+    }
+    __syncthreads();
+    for (int zi = tid >> 6; zi < HB_Z; zi += 4) {   // a wave per row: S2 = sum_c G2, then the log-softmax backward
+        const int c = tid & 63;
+        float s = G2[zi][c];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        float d = G1[zi][c] + G2[zi][c];
+        if (zi < nz && c < C && s != 0.f) d -= expf(a.logp_z[((long)b * a.Tz + z0 + zi) * C + c]) * s;
+        G1[zi][c] = d;
+        if (c == 0) S2[zi] = s;
+    }
+    __syncthreads();
+    const int k = tid & 127, half = tid >> 7;
+    {   // d_enc[z][k] = sum_c dlogit[z][c] * W[c][k] for rows 4 half .. 4 half + 3
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float w = a.w[(long)c * 128 + k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += G1[half * 4 + j][c] * w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (half * 4 + j < nz) a.denc[((long)b * a.Tz + z0 + half * 4 + j) * 128 + k] = acc[j];
+    }
+    {   // partial dW[c][k] = sum_z dlogit[z][c] * enc[z][k] for classes c = half, half + 2, ...
+        float e[HB_Z];
+#pragma unroll
+        for (int zi = 0; zi < HB_Z; ++zi) e[zi] = Es[zi][k];
+        for (int c = half; c < C; c += 2) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int zi = 0; zi < HB_Z; ++zi) sacc += G1[zi][c] * e[zi];
+            a.w_slabs[(long)blk * C * 128 + c * 128 + k] = sacc;
+        }
+    }
+    if (tid < C) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int zi = 0; zi < HB_Z; ++zi) sacc += G1[zi][tid];
+        a.b_slabs[(long)blk * C + tid] = sacc;
+    }
+}
+
 static inline size_t head_smem_bytes(int H, int C) {
     return sizeof(float) * ((size_t)C * (H + 1) + (size_t)HEAD_ZC * H + 2 * HEAD_ZC * HEAD_MAXC + HEAD_ZC);
 }
