@@ -503,7 +503,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
     const bool split_dgrad0 = g_nt_split && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(192, L + (split_dgrad0 ? 3 : (split_first ? 2 : 1))), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(32, L + (split_dgrad0 ? 3 : (split_first ? 2 : 1))), dim3(PACK_THREADS), 0, s, pa);
     HIPCHK(hipGetLastError());
 
     // first_conv + non-linearity (temporal.py:133); the tape is consumed row-major, no permute

@@ -8,45 +8,100 @@
 // Weight packing (per forward call; ~2 MB total, L2 resident afterwards).
 //   dilated_conv.weight [o][i][tap]  ->  W1f [o][tap*128 + i]   (forward NT operand)
 //                                    ->  W1b [i][tap*128 + o]   (data-gradient NT operand)
-//   conv_1x1.weight     [o][i]       ->  W2t [i][o]
-// grid = (ceil(49152/256), n_mats)
+//   conv_1x1.weight     [o][i]       ->  W2t [i][o]           last_conv.weight -> Wlt likewise
+//   first_conv.weight   [o][D]       ->  pre-split bf16 fragment image of gemm_split.hpp (and layer 0's W1b likewise)
+// Every transposition goes through LDS, so that both the reads and the writes of a workgroup are whole contiguous runs
+// (the element-per-thread version issued 1.1 M scattered 4-byte stores: 13 us in front of every forward pass).
+// grid = (32, L + 3), 1024 threads:
+//   y <  L      x < 4: layer y, output channels 32x .. 32x+31 (W1f, W1b, W2t)
+//   y == L      x < 4: last_conv
+//   y == L + 1  first_conv image, 64-deep k-tiles x, x + 32, ...      y == L + 2  x < 6: layer 0's W1b image, k-tile x
 // ------------------------------------------------------------------------------------------
 struct PackArgs {
     const float *dil_w[16];
     const float *pw_w[16];
     const float *last_w;
     float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]
-    const float *first_w;          // [128][D]; split into first_planes when that is non-null (grid row L + 1)
+    const float *first_w;          // [128][D]; split into first_planes when that is non-null
     uint16_t *first_planes;        // hi / mid / lo bf16 of first_conv.weight in the fragment order of gemm_split.hpp (3*128*D values)
     uint16_t *dgrad0_planes;       // same for layer 0's data-gradient operand W1b[i][tap*128 + o] (3*128*384 values), or null
     int L, D;
 };
-__global__ void pack_weights_kernel(const PackArgs a) {
-    const int l = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < a.L) {
-        if (e < 128 * 384) {
-            const int o = e / 384, r = e - o * 384;
-            const int tap = r >> 7, i = r & 127;
-            const float w = a.dil_w[l][(o * 128 + i) * 3 + tap];
-            a.W1f[(long)l * 49152 + e] = w;
-            a.W1b[(long)l * 49152 + i * 384 + tap * 128 + o] = w;
+constexpr int PACK_LDS_FLOATS = 32 * 385;   // 32 rows of dilated_conv.weight, padded; also 128 x 65 for an image k-tile
+
+constexpr int PACK_THREADS = 1024;   // few workgroups (86 at L = 11), so each gets many threads: its loops are 12 steps, not 48
+// one 64-deep k-tile of a [128][ld] fp32 matrix held in LDS as tile[n][65] -> the 48 KB fragment image (common.hpp order)
+__device__ __forceinline__ void pack_image_tile(const float *tile, uint16_t *img_tile) {
+    uint32_t *P = reinterpret_cast<uint32_t *>(img_tile);
+    // image pair index p = ((s*3 + pl)*2 + half)*512 + n*4 + sp; consecutive threads -> consecutive p of one plane
+    for (int q = threadIdx.x; q < 4 * 2 * 512; q += PACK_THREADS) {
+        const int sp = q & 3, n = (q >> 2) & 127, half = (q >> 9) & 1, s = q >> 10;
+        const int k = 16 * s + (sp < 2 ? 4 * half + 2 * sp : 8 + 4 * half + 2 * (sp - 2));
+        uint32_t h, m, l;
+        sp_split2(tile[n * 65 + k], tile[n * 65 + k + 1], h, m, l);
+        const int base = ((s * 3) * 2 + half) * 512 + n * 4 + sp;
+        P[base] = h;
+        P[base + 1024] = m;
+        P[base + 2048] = l;
+    }
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void pack_weights_kernel(const PackArgs a) {
+    __shared__ float lds[PACK_LDS_FLOATS];
+    const int y = blockIdx.y, x = blockIdx.x, tid = threadIdx.x;
+    if (y <= a.L) {
+        if (x >= 4) return;
+        const int o0 = 32 * x;
+        if (y < a.L) {
+            // 32 output channels of dilated_conv.weight: 32 x 384 contiguous floats -> lds[o][385]
+            const float *src = a.dil_w[y] + (long)o0 * 384;
+            const int ro = tid >> 5, rc = tid & 31;   // 32 rows x 32 lanes: division-free index math, 12 independent steps per loop
+#pragma unroll
+            for (int r = rc; r < 384; r += 32) lds[ro * 385 + r] = src[ro * 384 + r];
+            __syncthreads();
+            float *f = a.W1f + (long)y * 49152 + (long)o0 * 384;
+#pragma unroll
+            for (int r = rc; r < 384; r += 32)   // W1f[o][tap*128 + i] = w[o][i][tap]: contiguous per o
+                f[ro * 384 + r] = lds[ro * 385 + (r & 127) * 3 + (r >> 7)];
+            float *bk = a.W1b + (long)y * 49152;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {         // W1b[i][tap*128 + o]: runs of 32 consecutive o (lane = o)
+                const int i = ro + 32 * j;
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) bk[i * 384 + tap * 128 + o0 + rc] = lds[rc * 385 + i * 3 + tap];
+            }
+            __syncthreads();
         }
-        if (e < 128 * 128) {
-            const int o = e >> 7, i = e & 127;
-            a.W2t[(long)l * 16384 + i * 128 + o] = a.pw_w[l][e];
+        // conv_1x1 / last_conv: 32 rows [o][128] -> [i][o]
+        const float *src = (y < a.L ? a.pw_w[y] : a.last_w) + (long)o0 * 128;
+        float *dst = y < a.L ? a.W2t + (long)y * 16384 : a.Wlt;
+#pragma unroll
+        for (int e = tid; e < 32 * 128; e += PACK_THREADS) lds[(e >> 7) * 129 + (e & 127)] = src[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = tid; e < 32 * 128; e += PACK_THREADS) {
+            const int o = e & 31, i = e >> 5;
+            dst[i * 128 + o0 + o] = lds[o * 129 + i];
         }
-    } else if (l == a.L) {
-        if (e < 128 * 128) {
-            const int o = e >> 7, i = e & 127;
-            a.Wlt[i * 128 + o] = a.last_w[e];
+    } else if (y == a.L + 1) {
+        if (!a.first_planes) return;
+        for (int S = x; S < (a.D >> 6); S += gridDim.x) {
+            __syncthreads();
+            for (int e = tid; e < 128 * 64; e += PACK_THREADS) lds[(e >> 6) * 65 + (e & 63)] = a.first_w[(long)(e >> 6) * a.D + 64 * S + (e & 63)];
+            __syncthreads();
+            pack_image_tile(lds, a.first_planes + (long)S * 24576);
         }
-    } else if (l == a.L + 1) {
-        if (a.first_planes) sp_split_weights(a.first_w, a.first_planes, a.D, e, (long)gridDim.x * blockDim.x);
-    } else if (a.dgrad0_planes) {
+    } else {
+        if (!a.dgrad0_planes || x >= 6) return;
+        // k-tile x of W1b(layer 0)[i][tap*128 + o]: tap = x / 2, o = 64 (x & 1) + kk;  source w[o][i][tap]
         const float *w0 = a.dil_w[0];
-        sp_split_weights_fn([=](int i, int k) { return w0[((k & 127) * 128 + i) * 3 + (k >> 7)]; }, a.dgrad0_planes, 384, e,
-                            (long)gridDim.x * blockDim.x);
+        const int tap = x >> 1, ob = 64 * (x & 1);
+        for (int e = tid; e < 128 * 64; e += PACK_THREADS) {
+            const int i = e & 127, kk = e >> 7;   // consecutive threads: consecutive i (stride 3 floats in the source)
+            lds[i * 65 + kk] = w0[((long)(ob + kk) * 128 + i) * 3 + tap];
+        }
+        __syncthreads();
+        pack_image_tile(lds, a.dgrad0_planes + (long)x * 24576);
     }
 }
 
