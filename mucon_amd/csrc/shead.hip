@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/mucon_hip.h"
 #include "lstm.hpp"
@@ -400,7 +401,35 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     hipStream_t s = static_cast<hipStream_t>(stream);
     SgdTensor *dtab = static_cast<SgdTensor *>(workspace);
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + al64(sizeof(SgdTensor) * n_tensors));
-    SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+    // The table is the same step after step (torch's caching allocator hands the same gradient buffers back).  Uploading it
+    // puts a 5 us copy on the stream in front of every optimizer step, so a copy is kept in a buffer the LIBRARY owns (the
+    // caller cannot overwrite it) and reused while table, device and stream are the ones it was filled for.  Another stream
+    // or device never touches that buffer: it takes the upload into the caller's workspace, as every call did before.
+    static std::vector<SgdTensor> shadow;
+    static SgdTensor *cache_dev = nullptr;
+    static hipStream_t cache_stream = nullptr;
+    static int cache_device = -1;
+    static bool cache_owned = false;
+    constexpr size_t CACHE_TENSORS = 1024;
+    int device = -1;
+    SHIPCHK(hipGetDevice(&device));
+    const SgdTensor *use_tab = dtab;
+    const bool cacheable = (size_t)n_tensors <= CACHE_TENSORS && (!cache_owned || (cache_device == device && cache_stream == s));
+    if (cacheable) {
+        if (!cache_dev) SHIPCHK(hipMalloc(&cache_dev, sizeof(SgdTensor) * CACHE_TENSORS));
+        const bool same = cache_owned && shadow.size() == tab.size() &&
+                          memcmp(shadow.data(), tab.data(), sizeof(SgdTensor) * n_tensors) == 0;
+        if (!same) {
+            shadow = tab;   // the source of the async copy must outlive it: the shadow does
+            SHIPCHK(hipMemcpyAsync(cache_dev, shadow.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+            cache_owned = true;
+            cache_device = device;
+            cache_stream = s;
+        }
+        use_tab = cache_dev;
+    } else {
+        SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+    }
     SgdHyper h;
     for (int g = 0; g < SGD_MAXGROUPS; ++g) h.max_norm[g] = g < n_groups ? max_norm[g] : 0.f;
     h.lr = lr;
@@ -410,8 +439,8 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     h.nblocks = blocks;
     h.any_clip = 0;
     for (int g = 0; g < n_groups; ++g) h.any_clip |= max_norm[g] > 0.f;
-    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
-    hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial, h, group_norms);
+    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, use_tab, n_tensors, partial);
+    hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, use_tab, n_tensors, partial, h, group_norms);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }
