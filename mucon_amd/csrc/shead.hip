@@ -405,28 +405,34 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     // puts a 5 us copy on the stream in front of every optimizer step, so a copy is kept in a buffer the LIBRARY owns (the
     // caller cannot overwrite it) and reused while table, device and stream are the ones it was filled for.  Another stream
     // or device never touches that buffer: it takes the upload into the caller's workspace, as every call did before.
-    static std::vector<SgdTensor> shadow;
-    static SgdTensor *cache_dev = nullptr;
-    static hipStream_t cache_stream = nullptr;
-    static int cache_device = -1;
-    static bool cache_owned = false;
+    // Two slots: a training loop that still holds step i-1's gradients while step i's are allocated alternates between two
+    // sets of buffers, i.e. between two tables.
     constexpr size_t CACHE_TENSORS = 1024;
+    constexpr int SLOTS = 2;
+    static std::vector<SgdTensor> shadow[SLOTS];
+    static SgdTensor *cache_dev[SLOTS] = {nullptr, nullptr};
+    static hipStream_t cache_stream = nullptr;
+    static int cache_device = -1, next_slot = 0;
+    static bool cache_owned = false;
     int device = -1;
     SHIPCHK(hipGetDevice(&device));
     const SgdTensor *use_tab = dtab;
     const bool cacheable = (size_t)n_tensors <= CACHE_TENSORS && (!cache_owned || (cache_device == device && cache_stream == s));
     if (cacheable) {
-        if (!cache_dev) SHIPCHK(hipMalloc(&cache_dev, sizeof(SgdTensor) * CACHE_TENSORS));
-        const bool same = cache_owned && shadow.size() == tab.size() &&
-                          memcmp(shadow.data(), tab.data(), sizeof(SgdTensor) * n_tensors) == 0;
-        if (!same) {
-            shadow = tab;   // the source of the async copy must outlive it: the shadow does
-            SHIPCHK(hipMemcpyAsync(cache_dev, shadow.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+        int hit = -1;
+        for (int k = 0; k < SLOTS && cache_owned; ++k)
+            if (shadow[k].size() == tab.size() && memcmp(shadow[k].data(), tab.data(), sizeof(SgdTensor) * n_tensors) == 0) hit = k;
+        if (hit < 0) {
+            hit = next_slot;
+            next_slot = (next_slot + 1) % SLOTS;
+            if (!cache_dev[hit]) SHIPCHK(hipMalloc(&cache_dev[hit], sizeof(SgdTensor) * CACHE_TENSORS));
+            shadow[hit] = tab;   // the source of the async copy must outlive it: the shadow does
+            SHIPCHK(hipMemcpyAsync(cache_dev[hit], shadow[hit].data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
             cache_owned = true;
             cache_device = device;
             cache_stream = s;
         }
-        use_tab = cache_dev;
+        use_tab = cache_dev[hit];
     } else {
         SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
     }
