@@ -230,7 +230,9 @@ struct Reducer {
     }
     hipError_t run() {
         if (rb.njobs == 0) return hipSuccess;
-        switch (g_reduce_lanes) {
+        // few, deep jobs (the y-head's 256 slabs of 6 K elements: 25 workgroups) want many slab lanes: the chain of dependent
+        // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
+        switch (rb.nblocks <= 128 ? 16 : g_reduce_lanes) {
             case 1: hipLaunchKernelGGL(reduce_batch_kernel<1>, dim3(rb.nblocks), dim3(64), 0, stream, rb); break;
             case 2: hipLaunchKernelGGL(reduce_batch_kernel<2>, dim3(rb.nblocks), dim3(128), 0, stream, rb); break;
             case 4: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
