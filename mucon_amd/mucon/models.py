@@ -237,8 +237,7 @@ class MuCon(nn.Module):
         ndir = 2 if lstm.bidirectional else 1
         (memory, h_n, c_n), c_lstm = F_.run_forward(F_._LstmFn, enc[0], ndir, *lstm_w)
         steps = batch.transcript_tf_target.shape[0]
-        p = self.fs_decoder_embedding_drop.p
-        mask = (torch.rand((steps, 128), device=feats.device) >= p).to(torch.float32) / (1.0 - p) if p > 0 else None
+        mask = self._embedding_drop_mask(steps, feats.device)
         dec_params = self._decoder_param_list()
         (tlogp, lens), c_dec = F_.run_forward(F_._DecoderFn, memory, h_n.reshape(-1), c_n.reshape(-1), batch.transcript_tf_input,
                                                mask, (int(steps), bool(self.teacher_forcing), False, int(self.EOS_token_id)),
@@ -262,7 +261,7 @@ class MuCon(nn.Module):
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
         else:
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, (d_seg + d_sx).unsqueeze(0), None)[:3]
-        d_lens = torch.cat((d_len, d_len.new_zeros(1)))                # the last step's length is not used by the losses
+        d_lens = torch.nn.functional.pad(d_len, (0, 1))                # the last step's length is not used by the losses
         d_mem, d_hn, d_cn, _, _, _, *g_dec = F_.run_backward(F_._DecoderFn, c_dec, d_tlogp, d_lens)
         d_x, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
         d_enc[0] += d_x
@@ -340,13 +339,21 @@ class MuCon(nn.Module):
                 and d.num_layers == 1 and enc_out.shape[2] <= 256 and self.num_classes + 1 <= 128
                 and self.fs_decoder_embedding.embedding_dim == 128 and enc_out.shape[1] <= 8192)
 
+    def _embedding_drop_mask(self, steps: int, device):
+        """[steps x 128] keep-mask / (1 - p) of the decoder's embedding dropout (None for p = 0), in ONE launch: dropout of a
+        cached tensor of ones (rand, compare, cast and divide were four).  Drawn with torch's generator."""
+        p = self.fs_decoder_embedding_drop.p
+        if p <= 0:
+            return None
+        ones = getattr(self, "_drop_ones", None)
+        if ones is None or ones.shape[0] < steps or ones.device != device:
+            ones = self._drop_ones = torch.ones((max(steps, 64), 128), device=device)
+        return torch.nn.functional.dropout(ones[:steps], p, training=True)
+
     def _native_decoder(self, memory: Tensor, h_n: Tensor, c_n: Tensor, steps: int, transcript_tf_input: Tensor):
         """The decoding loop below as one persistent HIP kernel (ops.decoder_forward, csrc/decoder.hpp); returns
         the same per-step lists.  The embedding dropout mask is drawn with torch's generator."""
-        p = self.fs_decoder_embedding_drop.p
-        mask = None
-        if self.training and p > 0:
-            mask = (torch.rand((steps, 128), device=memory.device) >= p).to(torch.float32) / (1.0 - p)
+        mask = self._embedding_drop_mask(steps, memory.device) if self.training else None
         stop = not self.teacher_forcing and not self.training
         logp, lengths = ops.decoder_forward(memory, h_n, c_n, transcript_tf_input, self._decoder_param_list(), steps,
                                             self.teacher_forcing, stop, self.EOS_token_id, mask)
