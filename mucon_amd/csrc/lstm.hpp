@@ -201,13 +201,26 @@ __global__ __launch_bounds__(512) void lstm_wgrad_kernel(const float *dG, const 
     const int r = blockIdx.x * 4 + (threadIdx.x >> 7), c = threadIdx.x & 127;
     const float *dg = dG + (long)d * T * LSTM_G + r;
     float ai = 0.f, ah = 0.f, ab = 0.f;
-    for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? s : T - 1 - s;
-        const int tp = d == 0 ? t - 1 : t + 1;
-        const float gv = dg[(long)t * LSTM_G];
-        ai += gv * x[(long)t * LSTM_H + c];
-        if (s > 0) ah += gv * out[(long)tp * (ndir * LSTM_H) + d * LSTM_H + c];
-        ab += gv;
+    // eight time steps' loads in flight at a time, summed in time order (a step-at-a-time loop is a chain of T memory round trips)
+    for (int s0 = 0; s0 < T; s0 += 8) {
+        float gv[8], xv[8], hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = min(s0 + j, T - 1);
+            const int t = d == 0 ? s : T - 1 - s;
+            const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, T - 1);
+            gv[j] = dg[(long)t * LSTM_G];
+            xv[j] = x[(long)t * LSTM_H + c];
+            hv[j] = out[(long)tp * (ndir * LSTM_H) + d * LSTM_H + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (s0 + j < T) {
+                ai += gv[j] * xv[j];
+                if (s0 + j > 0) ah += gv[j] * hv[j];
+                ab += gv[j];
+            }
+        }
     }
     g.w_ih[d][(long)r * LSTM_H + c] = ai;
     g.w_hh[d][(long)r * LSTM_H + c] = ah;
@@ -224,7 +237,15 @@ __global__ __launch_bounds__(128) void lstm_dx_kernel(const float *dG, LstmWeigh
     for (int e = c; e < ndir * LSTM_G; e += 128) gsm[e] = dG[((long)(e / LSTM_G) * T + t) * LSTM_G + e % LSTM_G];
     __syncthreads();
     float acc = 0.f;
-    for (int d = 0; d < ndir; ++d)
-        for (int r = 0; r < LSTM_G; ++r) acc += gsm[d * LSTM_G + r] * w.w_ih[d][(long)r * LSTM_H + c];
+    for (int d = 0; d < ndir; ++d) {
+        const float *wd = w.w_ih[d] + c;
+        for (int r0 = 0; r0 < LSTM_G; r0 += 16) {   // sixteen rows' loads in flight at a time, summed in row order
+            float wv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wv[j] = wd[(long)(r0 + j) * LSTM_H];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += gsm[d * LSTM_G + r0 + j] * wv[j];
+        }
+    }
     dx[(long)t * LSTM_H + c] = acc;
 }
