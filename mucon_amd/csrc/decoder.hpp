@@ -628,10 +628,23 @@ __global__ __launch_bounds__(256) void dec_outer_kernel(OuterBatch ob) {
     if (e >= (long)jb.ra * jb.cb) return;
     const int i = (int)(e / jb.cb), j = (int)(e - (long)i * jb.cb);
     float acc = 0.f, accb = 0.f;
-    for (int n = 0; n < jb.n; ++n) {
-        const float a = jb.A[(long)n * jb.lda + i];
-        acc += a * jb.B[(long)n * jb.ldb + j];
-        accb += a;
+    // eight terms' loads in flight at a time, summed in order (dW1 sums over the Tz encoder states: a term-at-a-time loop is a
+    // chain of Tz memory round trips)
+    for (int n0 = 0; n0 < jb.n; n0 += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = min(n0 + q, jb.n - 1);
+            av[q] = jb.A[(long)n * jb.lda + i];
+            bv[q] = jb.B[(long)n * jb.ldb + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (n0 + q < jb.n) {
+                acc += av[q] * bv[q];
+                accb += av[q];
+            }
+        }
     }
     jb.out[e] = acc;
     if (j == 0) {

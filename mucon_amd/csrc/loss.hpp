@@ -67,6 +67,21 @@ __device__ __forceinline__ float loss_wave_sum(float v) {
     return v;
 }
 
+// sum of p[c * stride] over c = 0 .. n-1 in order, eight loads in flight at a time (a term-at-a-time loop over the T/32 slab
+// chunks is a chain of dependent memory round trips: 25 us of the 29 us loss_mid_kernel took)
+__device__ __forceinline__ float loss_ordered_sum(const float *p, long stride, int n) {
+    float acc = 0.f;
+    for (int c0 = 0; c0 < n; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(long)min(c0 + q, n - 1) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (c0 + q < n) acc += v[q];
+    }
+    return acc;
+}
+
 // mask value and its derivative w.r.t. the pixel coordinate ix
 __device__ __forceinline__ void mask_sample(const float *tmpl, float scale, float shift, int t, int T, float &val, float &dval,
                                             float &xb) {
@@ -228,16 +243,13 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(LossDims d, LossBufs b, i
     const int N = d.N, M = d.M, stride = N * M + 2;
     if (d.mucon_type == 0) {
         for (int e = tid; e < N * M; e += 256) {
-            float acc = 0.f;
-            for (int c = 0; c < chunks; ++c) acc += b.slab[(long)c * stride + e];
+            const float acc = loss_ordered_sum(b.slab + e, stride, chunks);
             const int n = e / M, m = e - n * M;
             s_win[n][m] = acc / b.geo[0 * LOSS_MAXN + n];
         }
     }
     if (tid < 2) {  // arithmetic partials, smoothing partials
-        float acc = 0.f;
-        for (int c = 0; c < chunks; ++c) acc += b.slab[(long)c * stride + N * M + tid];
-        s_scal[tid] = acc;
+        s_scal[tid] = loss_ordered_sum(b.slab + N * M + tid, stride, chunks);
     }
     __syncthreads();
     const float wsum = b.small[2];
@@ -382,11 +394,10 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
 __global__ __launch_bounds__(64) void loss_fin_kernel(LossDims d, LossBufs b, int chunks) {
     const int lane = threadIdx.x, N = d.N;
     float gsc = 0.f, gsh = 0.f;
-    if (lane < N)
-        for (int c = 0; c < chunks; ++c) {
-            gsc += b.gslab[((long)c * N + lane) * 2 + 0];
-            gsh += b.gslab[((long)c * N + lane) * 2 + 1];
-        }
+    if (lane < N) {
+        gsc = loss_ordered_sum(b.gslab + lane * 2 + 0, (long)N * 2, chunks);
+        gsh = loss_ordered_sum(b.gslab + lane * 2 + 1, (long)N * 2, chunks);
+    }
     const float L = lane < N ? b.geo[0 * LOSS_MAXN + lane] : 1.f;
     const float startp = lane < N ? b.geo[3 * LOSS_MAXN + lane] : 0.f;
     const float p = lane < N ? b.geo[4 * LOSS_MAXN + lane] : 0.f;
