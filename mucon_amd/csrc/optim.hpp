@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
     __shared__ float red[4];
     const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
     // squared norm of this block's group: partials of every tensor of the group, strided over the threads
+    // (thread-strided over ALL blocks, each looked up in the table: walking the tensors one after the other made every
+    // block of a 75-tensor model run 75 short dependent loops -- 14 us of the 24 us this kernel took there)
     float acc = 0.f;
-    for (int i = 0; i < nt && h.any_clip; ++i) {
-        if (tab[i].group != t.group) continue;
-        const int e0 = tab[i].block0, e1 = i + 1 < nt ? tab[i + 1].block0 : h.nblocks;
-        for (int b = e0 + threadIdx.x; b < e1; b += 256) acc += partial[b];
+    if (h.any_clip) {
+        for (int b = threadIdx.x; b < h.nblocks; b += 256)
+            if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
     }
     const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];
