@@ -49,6 +49,10 @@ struct NtParams {
     const float *mask;  // EPI_MASK: [B][Trows][128]; result *= act'(mask) (skipped when null)
     float slope;        // 0 = ReLU, 0.01 = leaky ReLU
     DropCfg drop;       // element index (b*Trows + t)*128 + c
+    // TAG 1 (first_conv) on few rows: grid.z k-chunks, chunk z writes its raw partial sums to part[z] ([B][Trows][128]);
+    // first_conv_combine_kernel then adds them in order, with bias and activation (ksplit <= 1: off)
+    int ksplit;
+    float *part[4];
 };
 
 // TAG only names the instantiation (TAG 1 = first_conv forward, so that profilers list it separately)
@@ -97,7 +101,9 @@ __global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * BM;
     const int ktiles_per_tap = p.Kc >> 5;
-    const int nkt = p.taps * ktiles_per_tap;
+    const bool ksplit = TAG == 1 && p.ksplit > 1;
+    const int nkt = ksplit ? (p.taps * ktiles_per_tap) / p.ksplit : p.taps * ktiles_per_tap;   // k-tiles of this workgroup
+    const int kt_base = ksplit ? (int)blockIdx.z * nkt : 0;
     const int Ktot = p.ldw;
     const int lrow = tid >> 3;
     const int lc4 = (tid & 7) * 4;
@@ -113,8 +119,9 @@ __global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
     // gload only ISSUES loads (always, from a clamped valid row: a load under a divergent `if` makes hipcc wait
     // vmcnt(0) around it); every use of the loaded values -- zeroing of padding rows, ReLU / dropout prologues --
     // happens in sstore, one or two k-tiles later, so the loads stay in flight under the MFMAs.
-    auto gload = [&](int kt, auto SET) {
+    auto gload = [&](int kt_local, auto SET) {
         constexpr int S = decltype(SET)::value;
+        const int kt = kt_local + kt_base;
         const int tap = kt / ktiles_per_tap;
         const int kk = (kt - tap * ktiles_per_tap) * 32;
         const int off = (tap - (p.taps >> 1)) * p.tap_step;
@@ -255,6 +262,23 @@ __global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
     // then the stores -- because per-element bounds checks put every load and store under a divergent branch
     // and hipcc then separates them with vmcnt(0) waits, which serialises the whole epilogue.
     const long vbase = (long)b * p.Trows;
+    if (TAG == 1) {
+        if (ksplit) {   // raw partial sums of this k-chunk; bias, activation and the sum over chunks: first_conv_combine_kernel
+            float *dst = p.part[blockIdx.z];
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt) {
+                    const int col = (wc * WN + nt) * MT + (lane & (MT - 1));
+#pragma unroll
+                    for (int reg = 0; reg < NREG; ++reg) {
+                        const int t = t0 + (wr * WM + mt) * MT + TL::row0(lane) + TL::rowr(reg);
+                        if (t < p.Trows) dst[(vbase + t) * 128 + col] = acc[mt][nt][reg];
+                    }
+                }
+            return;
+        }
+    }
     auto epilogue = [&](auto FULLT) {
         constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
@@ -353,9 +377,21 @@ static hipError_t launch_nt_cfg(const NtParams &p, int B, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((p.Trows + BM - 1) / BM, B);
+    dim3 grid((p.Trows + BM - 1) / BM, B, (TAG == 1 && p.ksplit > 1) ? p.ksplit : 1);
     hipLaunchKernelGGL(k, grid, dim3(64 * NW), nt_smem_bytes(BM), s, p);
     return hipGetLastError();
+}
+
+// out = act(part[0] + part[1] + ... + bias): the k-chunks of a split first_conv, summed in chunk order (out may be part[0])
+__global__ __launch_bounds__(256) void first_conv_combine_kernel(const NtParams p, long n4) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p.part[0] + e * 4);
+    for (int z = 1; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4 *>(p.part[z] + e * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + (e & 31) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act_f(v[k] + bv[k], p.slope);
+    *reinterpret_cast<f32x4 *>(p.out + e * 4) = v;
 }
 
 // Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it; below ~one workgroup

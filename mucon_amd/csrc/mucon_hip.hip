@@ -54,6 +54,7 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
+int g_first_conv_ksplit = 1;           // first_conv of launches with <= 4096 frames in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
 int g_nt_split = 1;                    // ... and layer 0's dilated-conv data gradient (MUCON_NT_SPLIT)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
@@ -391,6 +392,8 @@ int mucon_abi_version(void) {
         if (e) g_tn_ks = atoi(e);
         e = getenv("MUCON_FIRST_CONV_SPLIT");
         if (e) g_first_conv_split = atoi(e) ? 1 : 0;
+        e = getenv("MUCON_FIRST_CONV_KSPLIT");
+        if (e) g_first_conv_ksplit = atoi(e) ? 1 : 0;
         e = getenv("MUCON_NT_SPLIT");
         if (e) g_nt_split = atoi(e) ? 1 : 0;
         e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
@@ -513,8 +516,23 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         NtParams p = nt_base(tape, (long)pl.T * pl.D, pl.D, pl.T, pl.T, 1, 0, pl.D, prm->first_w, prm->first_b,
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
-        if (split_first) HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
-        else HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
+        if (split_first) {
+            HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+        } else if (g_first_conv_ksplit && (long)B * pl.T <= 4096 && pl.D % 256 == 0 && prm->first_b) {
+            // few rows: every workgroup would walk all D/32 k-tiles alone (64 dependent steps, 38 us at T = 2000).  Four k-chunks
+            // in grid.z, partial sums in level-0 buffers that are idle during the forward, one ordered combine pass.
+            p.ksplit = 4;
+            p.part[0] = ws + pl.x[0];
+            p.part[1] = ws + pl.h[0];     // written only by layer 0, after this
+            p.part[2] = ws + pl.g[0];     // backward buffers
+            p.part[3] = ws + pl.dpre[0];
+            HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
+            const long n4 = (long)B * pl.T * 32;
+            hipLaunchKernelGGL(first_conv_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, n4);
+            HIPCHK(hipGetLastError());
+        } else {
+            HIPCHK((launch_nt<false, false, true, false, false, false, 0, 1>(p, B, s)));
+        }
         prof_mark(0, true, s);
     }
     for (int l = 0; l < L; ++l) {
