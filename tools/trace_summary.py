@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals (hot-path kernels only) and the
-per-launch timeline of the last benchmark step."""
+per-launch timeline of the MEDIAN benchmark step (by wall time on the GPU timeline: a single step can carry a host
+hiccup of 100 us between two launches, which says nothing about the step)."""
 import csv, sys, collections
 f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
@@ -8,7 +9,11 @@ hp = [r for r in rows if 'viterbi' not in r['Kernel_Name']]
 # a hot-path bench step starts at a pack_weights launch followed by the first conv of a B > 1 batch (grid y = B);
 # bench.py's end-to-end leg (batch 1) is summarised separately by tools/e2e_trace_summary.py
 idx = [i for i, r in enumerate(hp) if 'pack_weights' in r['Kernel_Name'] and i + 1 < len(hp) and int(hp[i + 1]['Grid_Size_Y']) > 1]
-s, e = idx[-2], idx[-1]
+def wall(a, b):
+    return max(int(r['End_Timestamp']) for r in hp[a:b]) - int(hp[a]['Start_Timestamp'])
+cands = sorted(((wall(idx[i], idx[i + 1]), i) for i in range(max(0, len(idx) - 21), len(idx) - 1)))
+s = idx[cands[len(cands) // 2][1]]
+e = idx[cands[len(cands) // 2][1] + 1]
 step = hp[s:e]
 t0 = int(step[0]['Start_Timestamp'])
 agg = collections.OrderedDict()
