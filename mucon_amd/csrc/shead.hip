@@ -77,7 +77,7 @@ extern "C" int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *Gx = static_cast<float *>(workspace);
     float *gates = Gx + al64(per * LSTM_G);
     float *cells = gates + al64(per * LSTM_G);
-    hipLaunchKernelGGL(lstm_inproj_kernel, dim3((T + 7) / 8, ndir), dim3(512), 0, s, x, w, Gx, T);
+    hipLaunchKernelGGL(lstm_inproj_kernel, dim3((T + LSTM_IP_T - 1) / LSTM_IP_T, ndir), dim3(512), 0, s, x, w, Gx, T);
     hipLaunchKernelGGL(lstm_recur_fwd_kernel, dim3(ndir), dim3(512), 0, s, Gx, w, out, gates, cells, hn, cn, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
