@@ -57,12 +57,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_weights_kernel(const PackAr
             const float *src = a.dil_w[y] + (long)o0 * 384;
             const int ro = tid >> 5, rc = tid & 31;   // 32 rows x 32 lanes: division-free index math, 12 independent steps per loop
 #pragma unroll
-            for (int r = rc; r < 384; r += 32) lds[ro * 385 + r] = src[ro * 384 + r];
+            for (int j = 0; j < 12; ++j) lds[ro * 385 + rc + 32 * j] = src[ro * 384 + rc + 32 * j];
             __syncthreads();
             float *f = a.W1f + (long)y * 49152 + (long)o0 * 384;
 #pragma unroll
-            for (int r = rc; r < 384; r += 32)   // W1f[o][tap*128 + i] = w[o][i][tap]: contiguous per o
+            for (int j = 0; j < 12; ++j) {       // W1f[o][tap*128 + i] = w[o][i][tap]: contiguous per o
+                const int r = rc + 32 * j;
                 f[ro * 384 + r] = lds[ro * 385 + (r & 127) * 3 + (r >> 7)];
+            }
             float *bk = a.W1b + (long)y * 49152;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {         // W1b[i][tap*128 + o]: runs of 32 consecutive o (lane = o)
@@ -76,10 +78,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_weights_kernel(const PackAr
         const float *src = (y < a.L ? a.pw_w[y] : a.last_w) + (long)o0 * 128;
         float *dst = y < a.L ? a.W2t + (long)y * 16384 : a.Wlt;
 #pragma unroll
-        for (int e = tid; e < 32 * 128; e += PACK_THREADS) lds[(e >> 7) * 129 + (e & 127)] = src[e];
+        for (int j = 0; j < 32 * 128 / PACK_THREADS; ++j) {
+            const int e = tid + PACK_THREADS * j;
+            lds[(e >> 7) * 129 + (e & 127)] = src[e];
+        }
         __syncthreads();
 #pragma unroll
-        for (int e = tid; e < 32 * 128; e += PACK_THREADS) {
+        for (int j = 0; j < 32 * 128 / PACK_THREADS; ++j) {
+            const int e = tid + PACK_THREADS * j;
             const int o = e & 31, i = e >> 5;
             dst[i * 128 + o0 + o] = lds[o * 129 + i];
         }
