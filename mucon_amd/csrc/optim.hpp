@@ -44,7 +44,17 @@ __global__ __launch_bounds__(256) void sgd_norm_kernel(const SgdTensor *tab, int
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     float acc = 0.f;
-    for (long e = b0 + threadIdx.x; e < b1; e += 256) {
+    const bool vec = (reinterpret_cast<uintptr_t>(t.g) & 15) == 0;
+    const long nvec = vec ? (b1 - b0) >> 2 : 0;   // whole float4 of the chunk: four per thread, all loads first
+    if (nvec > 0) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4 *>(t.g + b0 + 4 * min((long)threadIdx.x + 256 * j, nvec - 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((long)threadIdx.x + 256 * j < nvec) acc += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+    }
+    for (long e = b0 + 4 * nvec + threadIdx.x; e < b1; e += 256) {
         const float g = t.g[e];
         acc += g * g;
     }
