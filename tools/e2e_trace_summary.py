@@ -1,13 +1,18 @@
-"""Summarise a rocprofv3 --kernel-trace CSV of tools/e2e_loop.py: one training step = the launches between two
-consecutive sgd_apply_kernel launches; prints the step's wall time on the GPU timeline, the kernel-time sum, the gaps,
+"""Summarise a rocprofv3 --kernel-trace CSV of tools/e2e_loop.py or bench.py: one training step = the launches between two
+consecutive sgd_apply_kernel launches (the median of the last 20); prints the step's wall time on the GPU timeline, the kernel-time sum, the gaps,
 and the per-kernel totals."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'sgd_apply_kernel' in r['Kernel_Name']]
-s, e = idx[-3] + 1, idx[-2] + 1
+# the median (by wall time on the GPU timeline) of the last 20 steps: a single step can carry a host hiccup between two launches
+def wall(k):
+    return max(int(r['End_Timestamp']) for r in rows[idx[k] + 1: idx[k + 1] + 1]) - int(rows[idx[k]]['End_Timestamp'])
+cands = sorted((wall(k), k) for k in range(max(0, len(idx) - 22), len(idx) - 2))
+k = cands[len(cands) // 2][1]
+s, e = idx[k] + 1, idx[k + 1] + 1
 step = rows[s:e]
-t0 = int(rows[idx[-3]]['End_Timestamp'])
+t0 = int(rows[idx[k]]['End_Timestamp'])
 agg = collections.OrderedDict(); prev_end = t0; gaps = 0.0; busy = 0.0
 for r in step:
     st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
