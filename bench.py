@@ -301,20 +301,27 @@ def main():
         (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
         d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
         wc.grad, bc.grad = d_w.view_as(wc), d_b
-        pending = []
-        if dist is not None:   # the two y-head tensors ride under the encoder's backward
-            pending = [dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True) for t in (d_w, d_b)]
         g_enc = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
         for p_, g_ in zip(enc_params, g_enc):
             p_.grad = g_
         if dist is not None:
-            # the one exchange step on the critical path: the encoder's gradients are views of ONE flat buffer.
-            # (Splitting it so that all but first_conv's part overlaps the last launch was tried: +35 us of extra launches
-            # and stream hand-offs at world size 1, not measurable here at N > 1 -- left out.)
-            for buf in ops.flat_grad_buffers(enc_params):
-                dist.all_reduce(buf, op=dist.ReduceOp.AVG)
-            for w in pending:
-                w.wait()
+            # the one exchange step: ONE all-reduce per optimizer step.  The encoder's gradients are views of one flat buffer;
+            # the two y-head tensors are appended to a copy of it (every RCCL call costs ~25 us of stream hand-offs even at
+            # world size 1: three calls were +75 us per step, one is +30).  (Splitting the buffer so that all but first_conv's
+            # part overlaps the last launch was tried: +35 us of extra launches at world size 1 -- left out.)
+            bufs = ops.flat_grad_buffers(enc_params)
+            if os.environ.get("MUCON_BENCH_COALESCE") == "1":   # one RCCL group call on the three tensors in place (A/B hook)
+                with dist._coalescing_manager(device=dev):
+                    for t_ in bufs + [d_w, d_b]:
+                        dist.all_reduce(t_, op=dist.ReduceOp.AVG)
+            else:
+                parts = [b_.reshape(-1) for b_ in bufs] + [d_w.reshape(-1), d_b.reshape(-1)]
+                packed = torch.cat(parts)
+                dist.all_reduce(packed, op=dist.ReduceOp.AVG)
+                off = 0
+                for t_ in parts:
+                    t_.copy_(packed[off: off + t_.numel()])
+                    off += t_.numel()
         sgd.step()
 
     def sync():
