@@ -54,7 +54,8 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
 int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
-int g_first_conv_ksplit = 1;           // first_conv of launches with <= 4096 frames in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
+int g_first_conv_ksplit = 1;           // first_conv of small launches in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
+long g_first_conv_ksplit_rows = 6144;  // ... up to this many frames per launch (MUCON_FIRST_CONV_KSPLIT_ROWS; measured: 65 -> 47 us at 5,000, even at 8,000)
 int g_nt_split = 1;                    // ... and layer 0's dilated-conv data gradient (MUCON_NT_SPLIT)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
@@ -394,6 +395,8 @@ int mucon_abi_version(void) {
         if (e) g_first_conv_split = atoi(e) ? 1 : 0;
         e = getenv("MUCON_FIRST_CONV_KSPLIT");
         if (e) g_first_conv_ksplit = atoi(e) ? 1 : 0;
+        e = getenv("MUCON_FIRST_CONV_KSPLIT_ROWS");
+        if (e) g_first_conv_ksplit_rows = atol(e);
         e = getenv("MUCON_NT_SPLIT");
         if (e) g_nt_split = atoi(e) ? 1 : 0;
         e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
@@ -518,7 +521,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         prof_mark(0, false, s);
         if (split_first) {
             HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
-        } else if (g_first_conv_ksplit && (long)B * pl.T <= 4096 && pl.D % 256 == 0 && prm->first_b) {
+        } else if (g_first_conv_ksplit && (long)B * pl.T <= g_first_conv_ksplit_rows && pl.D % 256 == 0 && prm->first_b) {
             // few rows: every workgroup would walk all D/32 k-tiles alone (64 dependent steps, 38 us at T = 2000).  Four k-chunks
             // in grid.z, partial sums in level-0 buffers that are idle during the forward, one ordered combine pass.
             p.ksplit = 4;

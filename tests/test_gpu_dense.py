@@ -95,7 +95,7 @@ def test_forward_matches_reference_golden(name, over):
 
 
 @pytest.mark.parametrize("B,T,over", [(2, 16, {}), (1, 33, {}),   # the shortest tapes four poolings allow (Tz = 1, 2)
-                                      (2, 2500, {}),                # 4096 < frames < 8192: first_conv neither in k-chunks nor split-bf16
+                                      (2, 3500, {}),                # 6144 < frames < 8192: first_conv neither in k-chunks nor split-bf16
                                       (1, 353, {}), (3, 1201, {}), (2, 640, {"pooling_type": "sum", "leaky_relu": True}),
                                       (1, 1500, {"last_relu": False}), (2, 333, {"last_gn_num_groups": 8})])
 def test_forward_matches_oracle_f64(B, T, over):
@@ -167,7 +167,7 @@ def _pattern_agrees(hip, oracle_masks, only=None, tol=2e-5):
 
 
 @pytest.mark.parametrize("B,T,over", [(2, 16, {}), (1, 33, {}),   # the shortest tapes four poolings allow
-                                      (2, 2500, {}),                # 4096 < frames < 8192: the plain f32 first_conv and its plain data gradient
+                                      (2, 3500, {}),                # 6144 < frames < 8192: the plain f32 first_conv and its plain data gradient
                                       (1, 600, {}), (2, 777, {}), (1, 2097, {}), (3, 1201, {}),
                                       (2, 500, {"pooling_type": "sum"}),
                                       (1, 900, {"leaky_relu": True}), (1, 640, {"last_gn": False}),
