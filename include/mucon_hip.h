@@ -8,9 +8,10 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / C++ types.
  *   - every data pointer is a DEVICE pointer (HBM) unless the name ends in _host;
- *     the caller owns all buffers; the library allocates no device memory (it creates one auxiliary
- *     HIP stream and a few events on first use: weight-gradient launches overlap the data-gradient chain
- *     and are joined back into `stream` before the call's last kernel; MUCON_NO_OVERLAP=1 disables it).
+ *     the caller owns all buffers; the library allocates no device memory beyond one small table for the
+ *     fused SGD step.  Everything a call launches runs on `stream`, in order (the one exception is the
+ *     regression schedule MUCON_TN_BATCH=0, which runs coarse-level weight gradients on a library-owned
+ *     side stream and joins it back into `stream` before the call's last kernel).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
  *     enqueues work on it and returns (no host synchronisation), except where stated.
  *   - return value: 0 on success, negative MUCON_E_* on error; mucon_last_error() gives the text.
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 1
+#define MUCON_ABI_VERSION 2
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -142,46 +143,6 @@ int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, 
                                int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
                                int32_t *status, void *workspace, void *stream);
 
-/* ------------------------------------------------------------------------------------------
- * Test / bench helpers (not part of the reference surface)
- * ---------------------------------------------------------------------------------------- */
-/* Where mucon_encoder_fwd left an intermediate inside the workspace ([B][rows][128] float32):
- * kind 0 = x[layer] (input of layer `layer`; x[0] = activated first_conv output, x[n_layers] =
- * last_conv input), 1 = h[layer] (activated dilated_conv output), 2 = ypre[layer] (un-pooled output
- * of a max-pooled layer), 3 = z (last_conv output).  Lets the parity tests compare gradients on the
- * activation pattern (ReLU masks, max-pool arg-max) the kernels actually took. */
-int mucon_encoder_saved_view(const mucon_encoder_cfg *cfg, int32_t kind, int32_t layer, size_t *byte_offset,
-                             int32_t *rows_per_video);
-/* Plain GEMM on the same MFMA core the encoder uses: out[M][128] = A[M][K] * W[128][K]^T (+bias, relu) */
-int mucon_test_gemm_nt(const float *A, const float *W, const float *bias, float *out, int32_t M,
-                       int32_t K, int32_t relu, void *stream);
-/* out[128][K] = Y[M][128]^T * X[M][K] through the weight-gradient core (slabs + reduce). */
-int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, int32_t K,
-                       void *workspace, size_t workspace_bytes, void *stream);
-/* The dropout keep-mask (1 = kept) for `site`, written as uint8 [n]. */
-int mucon_test_dropout_mask(uint8_t *mask, int64_t n, uint64_t seed, int32_t site, float p, void *stream);
-/* Times `iters` launches of the first-conv forward kernel with HIP events on `stream`;
- * returns the average milliseconds per launch in *ms (synchronises the stream). */
-int mucon_bench_first_conv(const float *tape, const float *w, const float *b, float *out, int32_t B,
-                           int32_t T, int32_t D, int32_t iters, float *ms_host, void *stream);
-
-/* first_conv forward on the bf16 MFMA with exactly split operands (csrc/gemm_split.hpp), whatever the size
- * threshold of mucon_encoder_fwd says: out[B][T][128] = act(tape[B][T][D] * w[128][D]^T + b).  `planes` receives
- * the three bf16 planes of w (3*128*D*2 bytes).  Runs 1 + iters launches; *ms_host (may be null) = average
- * milliseconds of the timed ones (HIP events on `stream`; synchronises). */
-int mucon_test_first_conv_split(const float *tape, const float *w, const float *b, float *out, int32_t B,
-                                int32_t T, int32_t D, int32_t relu, void *planes, size_t planes_bytes,
-                                int32_t iters, float *ms_host, void *stream);
-
-/* Per-launch timing of the two kernels that stream the tape, taken with HIP events on the stream
- * the kernels run on, while the normal fwd/bwd calls execute (bench.py's roofline leg):
- * slot 0 = first_conv forward, slot 1 = the weight-gradient launch (the one batched launch of every layer's and
- * first_conv's weight gradients; first_conv's alone with MUCON_TN_BATCH<2).  begin() arms up to
- * max_records launches per slot; end() synchronises on the recorded events and returns the
- * summed milliseconds and the launch count per slot (arrays of 2). */
-int mucon_profile_begin(int32_t max_records);
-int mucon_profile_end(float *total_ms_host, int32_t *count_host);
-
 /* ---- s-head sequence encoder: bidirectional LSTM --------------------------------
  * Replaces torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True) as the reference's s-head calls
  * it (reference src/mucon/models.py:195-201 construction, :605-611 call: batch 1, zero initial state).
@@ -270,6 +231,9 @@ typedef struct mucon_loss_cfg {
     float clamp_min, clamp_max; /* cfg.model.loss.smoothing.clamp_min / clamp_max */
     float length_width;         /* cfg.model.loss.length_width */
     float mul_transcript, mul_length, mul_mucon, mul_smoothing; /* cfg.model.loss.mul_* */
+    int32_t align_corners;      /* convention of masks.py's affine_grid / grid_sample calls (masks.py:72-73 pass none):
+                                 * 1 = PyTorch <= 1.2 behaviour, i.e. the 1.1 the reference pins (docker/pytorch1.1/Dockerfile:25);
+                                 * 0 = the default since PyTorch 1.3 (what the same code does under a current torch) */
 } mucon_loss_cfg;
 size_t mucon_loss_workspace_bytes(const mucon_loss_cfg *cfg);
 /* segmentation [T][M] logits; smoothing_input [T][M] = what the smoothing loss runs on (log_softmax(segmentation)

@@ -1,0 +1,61 @@
+/* mucon_hip_test.h -- test, bench and tuning hooks of libmucon_hip.so.
+ *
+ * NOT part of the surface that replaces the reference (that is include/mucon_hip.h): these entry points exist so
+ * that tests/ can drive single kernels through the C ABI, bench.py can time the tape-streaming launches with HIP
+ * events on their own stream, and regression tests can switch code paths inside one process.
+ */
+#ifndef MUCON_HIP_TEST_H
+#define MUCON_HIP_TEST_H
+
+#include "mucon_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Where mucon_encoder_fwd left an intermediate inside the workspace ([B][rows][128] float32):
+ * kind 0 = x[layer] (input of layer `layer`; x[0] = activated first_conv output, x[n_layers] =
+ * last_conv input), 1 = h[layer] (activated dilated_conv output), 2 = ypre[layer] (un-pooled output
+ * of a max-pooled layer), 3 = z (last_conv output).  Lets the parity tests compare gradients on the
+ * activation pattern (ReLU masks, max-pool arg-max) the kernels actually took. */
+int mucon_encoder_saved_view(const mucon_encoder_cfg *cfg, int32_t kind, int32_t layer, size_t *byte_offset,
+                             int32_t *rows_per_video);
+/* Plain GEMM on the same MFMA core the encoder uses: out[M][128] = A[M][K] * W[128][K]^T (+bias, relu) */
+int mucon_test_gemm_nt(const float *A, const float *W, const float *bias, float *out, int32_t M,
+                       int32_t K, int32_t relu, void *stream);
+/* out[128][K] = Y[M][128]^T * X[M][K] through the weight-gradient core (slabs + reduce). */
+int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, int32_t K,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* The dropout keep-mask (1 = kept) for `site`, written as uint8 [n]. */
+int mucon_test_dropout_mask(uint8_t *mask, int64_t n, uint64_t seed, int32_t site, float p, void *stream);
+/* Times `iters` launches of the first-conv forward kernel with HIP events on `stream`;
+ * returns the average milliseconds per launch in *ms (synchronises the stream). */
+int mucon_bench_first_conv(const float *tape, const float *w, const float *b, float *out, int32_t B,
+                           int32_t T, int32_t D, int32_t iters, float *ms_host, void *stream);
+
+/* first_conv forward on the bf16 MFMA with exactly split operands (csrc/gemm_split.hpp), whatever the size
+ * threshold of mucon_encoder_fwd says: out[B][T][128] = act(tape[B][T][D] * w[128][D]^T + b).  `planes` receives
+ * the three bf16 planes of w (3*128*D*2 bytes).  Runs 1 + iters launches; *ms_host (may be null) = average
+ * milliseconds of the timed ones (HIP events on `stream`; synchronises). */
+int mucon_test_first_conv_split(const float *tape, const float *w, const float *b, float *out, int32_t B,
+                                int32_t T, int32_t D, int32_t relu, void *planes, size_t planes_bytes,
+                                int32_t iters, float *ms_host, void *stream);
+
+/* Per-launch timing of the two kernels that stream the tape, taken with HIP events on the stream
+ * the kernels run on, while the normal fwd/bwd calls execute (bench.py's roofline leg):
+ * slot 0 = first_conv forward, slot 1 = the weight-gradient launch (the one batched launch of every layer's and
+ * first_conv's weight gradients; first_conv's alone with MUCON_TN_BATCH<2).  begin() arms up to
+ * max_records launches per slot; end() synchronises on the recorded events and returns the
+ * summed milliseconds and the launch count per slot (arrays of 2). */
+int mucon_profile_begin(int32_t max_records);
+int mucon_profile_end(float *total_ms_host, int32_t *count_host);
+
+/* Sets one tuning / regression knob by its environment name (e.g. "MUCON_TN_SPLIT", "0"), with the parsing the
+ * environment gets when the library is first used.  Affects later calls; workspaces sized before a change that
+ * needs more slab space make those calls fail with MUCON_E_WORKSPACE, never overrun. */
+int mucon_test_set_knob(const char *name, const char *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUCON_HIP_TEST_H */

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
 VIT_OK, VIT_INDEX_ERROR, VIT_NO_HYPOTHESIS, VIT_TRUNCATED = 0, 1, 2, 3
@@ -74,7 +74,8 @@ class DecoderParams(ctypes.Structure):
 class LossCfg(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in ("T", "M", "N", "S", "NC", "mucon_type", "smoothing_clamp", "transcript_average")]
                 + [(n, ctypes.c_float) for n in ("overlap", "clamp_min", "clamp_max", "length_width", "mul_transcript",
-                                                 "mul_length", "mul_mucon", "mul_smoothing")])
+                                                 "mul_length", "mul_mucon", "mul_smoothing")]
+                + [("align_corners", ctypes.c_int32)])
 
 
 class SgdTensor(ctypes.Structure):
@@ -102,6 +103,7 @@ SYMBOLS = {
     "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
+    "mucon_test_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_first_conv_split": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32,
@@ -155,6 +157,11 @@ def load(build_if_missing: bool = True):
         raise MuconHipError(f"ABI version mismatch: library {lib.mucon_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def set_knob(name: str, value) -> None:
+    """Tuning / regression knob by its environment name (include/mucon_hip_test.h); tests switch code paths with it."""
+    check(load().mucon_test_set_knob(name.encode(), str(value).encode()), f"set_knob({name})")
 
 
 def check(rc: int, what: str):

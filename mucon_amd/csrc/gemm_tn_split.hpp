@@ -1,0 +1,381 @@
+// Weight gradients (the TN products of gemm_tn.hpp) on the bf16 MFMA with EXACT three-way operand splitting -- the
+// arithmetic of gemm_split.hpp (x = hi + mid + lo, six of the nine partial products, fp32 accumulate: fp32-grade) applied to
+//
+//     dW[n][c] = sum_t G[t][n] * X[t][c]          (autograd of nn.Conv1d w.r.t. its weight: temporal.py:23-32, :133, :145)
+//
+// Both operands are time-major in HBM and the reduction runs over time, so both MFMA fragments want 8 consecutive TIME steps
+// of one column per lane: lane (r, h) of v_mfma_f32_32x32x16_bf16 holds A[row r][k = 8h + j] / B[k = 8h + j][col r].  With
+// k = time that is eight 4-byte loads whose 32 lanes sit on 32 adjacent columns (whole 128-B lines per row) -- the transpose
+// is done by the load addresses, nothing is shuffled.
+//
+// One workgroup = 8 waves = 256 weight columns x all 128 output channels over one time chunk.
+//   * X (the tape / layer input): wave (half, cg) owns 32 columns.  Every X element belongs to exactly ONE wave, which loads
+//     it straight into the MFMA operand position (two 32-step tiles in flight), splits it in registers, once.  No LDS.
+//   * G (the gradient rows, shared by all column groups): staged by all threads (thread = (channel, 8 time steps)), split once
+//     per workgroup, written to LDS as a fragment-ordered bf16 image [step 2][plane 3][lane half 2][channel 128][8 steps]
+//     (conflict-free ds_read_b128 / ds_write_b64), double buffered, one barrier per 32 time steps.
+//   * the two 128-column halves of a workgroup are two k-chunks of the job (two taps of a dilated conv, two column blocks
+//     of the tape).  Where they need different gradient operands -- the last tap and the conv_1x1 chunk of a residual layer --
+//     each half stages its own image (TWO_G); the conv_1x1 gradient's dropout mask is replayed at staging.
+// Bias gradients are the exact fp32 column sums of the staged G values (they never see bf16).
+//
+// Interior tiles run a mask-free body; tiles that touch a video edge (zero padding of a tap, a partial last tile) or need the
+// non-linearity on X take the general body.  The split arithmetic of a step is woven between the MFMAs of the step before.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+#include "gemm_tn.hpp"
+
+#ifndef TS_ABL
+#define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
+#endif
+constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 32-step G image (24,576 B)
+constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2;       // two buffers x two images: 98,304 B
+
+template <bool TWO_G, bool DROP>
+__device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
+                                        uint16_t *smem) {
+    constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave >> 2, cg = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = mc / p.chunks_per_video;
+    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
+    const int tend = min(tbeg + p.MC, p.Trows);
+    const int ntiles = (tend - tbeg + 31) >> 5;
+    const int last = ntiles - 1;
+    const int nch = p.nk0 + (dual ? 1 : 0);
+    const int kc_raw = 2 * kc2 + hf;
+    const bool active = kc_raw < nch;           // an odd chunk count leaves the last workgroup's second half without columns:
+    const int kc = active ? kc_raw : 2 * kc2;   // it repeats the first half's work and writes nothing
+    const bool second = dual && kc >= p.nk0;
+    const int xoff = (!second && p.taps == 3) ? (kc - 1) * p.tap_step : 0;
+    const int xcol = (second || p.taps == 3) ? 0 : kc * 128;
+    const int ldx = second ? 128 : p.ldx;
+    const int Tx = second ? p.Trows : p.Tx;
+    const float *Xu = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;   // wave-uniform
+    const uint32_t x_lane = (uint32_t)((8 * h) * ldx + cg * 32 + r) * 4u;                             // per-lane byte offset
+
+    // staging role: SAME image -> unit (s, h) = (wave >> 2, (wave >> 1) & 1); TWO_G -> image wave >> 2, s = (wave >> 1) & 1, units h = 0, 1
+    const int sn = tid & 127;
+    const int s_hi = wave >> 2, s_lo = (wave >> 1) & 1;
+    const int s_img = TWO_G ? s_hi : 0;
+    const int s_s = TWO_G ? s_lo : s_hi;
+    const float *Yu = ((TWO_G && s_img) ? p.Y1 : p.Y0) + (long)b * p.Trows * 128;   // wave-uniform
+    const uint32_t y_lane = (uint32_t)sn * 4u;
+    auto unit_h = [&](int u) { return TWO_G ? u : s_lo; };
+    // dropout replay for image 1 only, branch-free (a branch would cut the woven schedule): image 0 keeps every element at scale 1
+    DropCfg dcfg = p.drop;
+    dcfg.thresh = s_img ? dcfg.thresh : 0u;
+    dcfg.scale = s_img ? dcfg.scale : 1.f;
+    // uniform base + 32-bit per-lane byte offset: the scalar-base form of global_load (no 64-bit vector address arithmetic per load)
+    auto ld_su = [](const float *ubase, uint32_t lane_bytes) {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + lane_bytes);
+    };
+
+    float rx[2][2][8];       // X: [set][step][time slot], two tiles in flight
+    float rgA[NU][4], rgB[NU][4];   // G: time slots 0-3 / 4-7 of the next image
+    float bsum[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
+
+    // A tile is interior when none of its 32 rows needs a mask: inside the chunk (G) and, for this wave's tap, inside the video (X).
+    // Interior tiles are loaded with wave-uniform row addresses and enter the MFMA body as they are; the others are loaded
+    // from clamped rows and masked in their registers by the (rare) fix-up branches in front of the woven phases.
+    auto g_int = [&](int tile) { return tbeg + tile * 32 + 32 <= tend; };
+    auto x_int = [&](int tile) {
+        const int t0 = tbeg + tile * 32;
+        return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
+    };
+    auto gloadX = [&](int tile, auto SET) {
+        constexpr int Q = decltype(SET)::value;
+        if (x_int(tile)) {
+            const float *ub = Xu + (long)(tbeg + tile * 32 + xoff) * ldx;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rx[Q][s][j] = ld_su(ub + (long)(16 * s + j) * ldx, x_lane);
+        } else {
+            const int row0 = tbeg + tile * 32 + 8 * h + xoff;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ts = min(max(row0 + 16 * s + j, 0), Tx - 1);
+                    rx[Q][s][j] = Xu[(long)ts * ldx + cg * 32 + r];
+                }
+        }
+    };
+    auto fixX = [&](float (&raw)[8], int tile, int s) {   // non-linearity of the last_conv job, zero padding, chunk end
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = tbeg + tile * 32 + 16 * s + 8 * h + j;
+            const int ts = t + xoff;
+            float x = raw[j];
+            if (x0_act) x = act_f(x, p.slope);
+            raw[j] = (t < tend && ts >= 0 && ts < Tx) ? x : 0.f;
+        }
+    };
+    auto gloadG = [&](int tile, auto HALF) {
+        constexpr int HB = decltype(HALF)::value;
+        const bool inner = g_int(tile);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;   // wave-uniform
+                if (!inner) t = min(t, p.Trows - 1);
+                const float v = ld_su(Yu + (long)t * 128, y_lane);
+                if constexpr (HB) rgB[u][jj] = v;
+                else rgA[u][jj] = v;
+            }
+    };
+    auto fixG = [&](int tile, auto HALF) {   // rows past the chunk end are zero
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                if constexpr (HB) rgB[u][jj] = t < tend ? rgB[u][jj] : 0.f;
+                else rgA[u][jj] = t < tend ? rgA[u][jj] : 0.f;
+            }
+    };
+    // four time slots of every unit: dropout replay, bias sums, exact split, three 8-byte LDS stores
+    // (bw = 0 for the image past the chunk's last tile, which the tail of the pipeline builds from a re-load and nobody reads)
+    auto splitstoreG = [&](int tile, int buf, auto HALF, float bw) {
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                v[jj] = HB ? rgB[u][jj] : rgA[u][jj];
+                if (DROP) {
+                    const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                    v[jj] *= drop_mul(dcfg, (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)sn);
+                }
+                bsum[u] = fmaf(v[jj], bw, bsum[u]);
+            }
+            uint32_t a0, m0, l0, a1, m1, l1;
+            sp_split2(v[0], v[1], a0, m0, l0);
+            sp_split2(v[2], v[3], a1, m1, l1);
+            uint16_t *dst = smem + (buf * 2 + s_img) * TS_IMG + (((s_s * 3) * 2 + unit_h(u)) * 128 + sn) * 8 + 4 * HB;
+            *reinterpret_cast<u32x2 *>(dst) = u32x2{a0, a1};
+            *reinterpret_cast<u32x2 *>(dst + 2 * 128 * 8) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2 *>(dst + 4 * 128 * 8) = u32x2{l0, l1};
+        }
+    };
+    struct Planes { bf16x8 pl[3]; };
+    auto convertX = [&](const float (&x)[8]) {
+        u32x4 hh, mm, ll;
+        uint32_t a, bb, c;
+        if (TS_ABL & 2) {
+            Planes P;
+            hh = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+            mm = u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+            P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+            P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+            P.pl[2] = __builtin_bit_cast(bf16x8, hh);
+            return P;
+        }
+        sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
+        sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
+        sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
+        sp_split2(x[6], x[7], a, bb, c); hh[3] = a; mm[3] = bb; ll[3] = c;
+        Planes P;
+        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
+        return P;
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // G fragment (step s, plane pl, channel block nb): image[s][pl][h][nb*32 + r][8]
+    const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
+    auto mfma_step = [&](int buf, int s, const Planes &X) {
+        const uint16_t *base = smem + buf * 2 * TS_IMG + s * (3 * 2 * 128 * 8) + g_off;
+        bf16x8 w[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
+        if (TS_ABL & 1) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, w[nb][pl])));
+            return;
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[1], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][2], X.pl[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[2], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[1], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[0], acc[nb], 0, 0, 0);
+        }
+    };
+    // 24 MFMAs with the fragment reads of the first column blocks in front, VPM vector instructions behind every MFMA and the
+    // LDS stores (which need the split results) in the second half
+    constexpr int VPM = DROP ? 7 : (TWO_G ? 4 : 3);
+    auto weave = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            if (i >= 12 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+
+    auto pin = [](auto &arr) {
+#pragma unroll
+        for (auto &v : arr) asm volatile("" : "+v"(v));
+    };
+    auto use = [](const Planes &P) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
+    };
+    Planes cur;
+    {   // prologue: image of tile 0, X of tiles 0 and 1, first half of image 1, operand of step (0, 0)
+        gloadG(0, I0{});
+        gloadG(0, I1{});
+        gloadX(0, I0{});
+        gloadX(min(1, last), I1{});
+        if (!g_int(0)) {
+            fixG(0, I0{});
+            fixG(0, I1{});
+        }
+        splitstoreG(0, 0, I0{}, 1.f);
+        splitstoreG(0, 0, I1{}, 1.f);
+        gloadG(min(1, last), I0{});
+        if (!x_int(0)) fixX(rx[0][0], 0, 0);
+        cur = convertX(rx[0][0]);
+        __syncthreads();
+    }
+
+    // tile mt (image in buffer Q, X in set Q):
+    //   { second half of image mt+1 requested } { MFMAs of step 0 | split of X step 1, first half of image mt+1 -> buffer O }
+    //   { first half of image mt+2 and X of tile mt+2 requested } { MFMAs of step 1 | split of X (mt+1, step 0), second half of image mt+1 }
+    auto tile = [&](int mt, auto SET, auto OTHER) {
+        constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
+        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last);
+        const float bw = mt < last ? 1.f : 0.f;
+        if (!(TS_ABL & 8)) gloadG(n1, I1{});
+        if (!x_int(mt)) fixX(rx[Q][1], mt, 1);
+        if (!x_int(n1)) fixX(rx[O][0], n1, 0);
+        if (!g_int(n1)) fixG(n1, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        pin(rx[Q][1]);   // (keeps the splits below in this block: without it they are duplicated into the fix-up branches, outside the weave)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pin(rgA[u]);
+        mfma_step(Q, 0, cur);
+        Planes nxt = convertX(rx[Q][1]);
+        if (!(TS_ABL & 4)) splitstoreG(n1, O, I0{}, bw);
+        weave();
+        use(nxt);   // (a use inside the phase: otherwise the split is sunk behind the branches below, out of the weave)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(TS_ABL & 8)) {
+            gloadG(n2, I0{});
+            gloadX(n2, SET);
+        }
+        if (!g_int(n1)) fixG(n1, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        pin(rx[O][0]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pin(rgB[u]);
+        mfma_step(Q, 1, nxt);
+        cur = convertX(rx[O][0]);
+        if (!(TS_ABL & 4)) splitstoreG(n1, O, I1{}, bw);
+        weave();
+        use(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    for (int mt = 0; mt < ntiles; mt += 2) {
+        tile(mt, I0{}, I1{});
+        if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
+    }
+
+    if (active) {
+        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                slab[(long)row * p.Ktot] = acc[nb][reg];
+            }
+    }
+    // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
+    // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
+    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
+    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
+    if (bias0 || bias1) {   // workgroup-uniform
+        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
+        float own = bsum[0];
+        if (TWO_G) own += bsum[NU - 1];
+        red[(s_hi * 2 + s_lo) * 128 + sn] = own;
+        __syncthreads();
+        if (TWO_G) {
+            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
+            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
+        } else if (tid < 128 && bias0) {
+            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        }
+    }
+}
+
+// All weight gradients of a backward pass in one launch (the job table of gemm_tn.hpp): a job with n 128-column chunks has
+// ceil(n / 2) workgroups per time chunk.
+__global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+    int ji = 0;
+    while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
+    const TnJob &job = tb.j[ji];
+    const int nkc2 = (job.nkc + 1) >> 1;
+    const int local = blockIdx.x - job.block0;
+    const int mc = local / nkc2, kc2 = local - mc * nkc2;
+    const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
+    if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
+    else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
+    else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
+}
+
+static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
+    if (tb.njobs == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, TS_SMEM_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
+    TnBatch lb;
+    lb.njobs = tb.njobs;
+    int blocks = 0;
+    for (int i = 0; i < tb.njobs; ++i) {
+        const TnJob &src = tb.j[tb.njobs - 1 - i];
+        lb.j[i] = src;
+        lb.j[i].block0 = blocks;
+        blocks += ((src.nkc + 1) / 2) * src.block0;   // block0 carried the time-chunk count while queued
+    }
+    lb.nblocks = blocks;
+    hipLaunchKernelGGL(ts_batched_kernel, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
+    tb.njobs = 0;
+    return hipGetLastError();
+}

@@ -7,12 +7,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "../../include/mucon_hip.h"
+#include "../../include/mucon_hip_test.h"
 #include "common.hpp"
 #include "gemm_nt.hpp"
 #include "gemm_fused.hpp"
 #include "gemm_tn.hpp"
 #include "gemm_split.hpp"
+#include "gemm_tn_split.hpp"
 #include "small_kernels.hpp"
 
 int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
@@ -61,12 +65,15 @@ int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, o
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
-inline int pick_mc(int B, int Trows, int kchunks, bool batched = false) {
+int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
+int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
+inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false) {
     const int target = batched ? g_tn_batch_target : g_tn_target;
+    const int cap = split ? g_ts_mc_cap : g_tn_mc_cap;
     long want = ((long)B * Trows * kchunks + target - 1) / target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
-    if (mc > g_tn_mc_cap) mc = g_tn_mc_cap;
+    if (mc > cap) mc = cap;
     return (int)mc;
 }
 
@@ -147,8 +154,9 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     // slab arena: every weight-gradient launch of a backward pass keeps its own slabs until the
     // single batched reduction at the end
     size_t sf = 0, bf = 0;
-    auto consider = [&](int Trows, int Ktot) {
-        const int mc = pick_mc(p.B, Trows, Ktot / 128);
+    auto consider = [&](int Trows, int Ktot) {   // the shortest time chunk any schedule (batched or not, split or f32) would take
+        int mc = pick_mc(p.B, Trows, Ktot / 128);
+        for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(p.B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0));
         const size_t nmc = (size_t)p.B * ((Trows + mc - 1) / mc);
         sf += align64(nmc * 128 * Ktot);
         bf += align64(nmc * 256);
@@ -279,7 +287,10 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     t.Y1 = a.Y1;
     t.X1 = a.X1;
     t.Ktot = 128 * (a.nk0 + (dual ? 1 : 0));
-    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr);
+    const bool split = g_tn_split != 0;
+    if (split && dual && a.nk0 % 2 == 0)   // the split kernel pairs the conv_1x1 chunk with the last tap (gemm_tn_split.hpp)
+        return fail(MUCON_E_ARG, "internal: dual weight-gradient job with an even chunk count");
+    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr, split);
     t.chunks_per_video = (Trows + t.MC - 1) / t.MC;
     t.slope = slope;
     t.drop = a.drop;
@@ -292,13 +303,24 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     arena += need;
     barena += bneed;
     if (batch) {
-        if (batch->njobs >= TN_MAX_BATCH) HIPCHK(launch_tn_batch(*batch, s));
+        if (batch->njobs >= TN_MAX_BATCH) HIPCHK(g_tn_split ? launch_ts_batch(*batch, s) : launch_tn_batch(*batch, s));
         TnJob &jb = batch->j[batch->njobs++];
         jb.p = t;
         jb.nkc = t.Ktot / 128;
         jb.block0 = nmc;   // time-chunk count while queued; launch_tn_batch turns it into the block offset
         jb.x0_act = a.x0_act ? 1 : 0;
         jb.dual = dual ? 1 : 0;
+    } else if (split) {
+        TnBatch one;
+        one.njobs = 1;
+        one.j[0].p = t;
+        one.j[0].nkc = t.Ktot / 128;
+        one.j[0].block0 = nmc;
+        one.j[0].x0_act = a.x0_act ? 1 : 0;
+        one.j[0].dual = dual ? 1 : 0;
+        if (prof_slot >= 0) prof_mark(prof_slot, false, s);
+        HIPCHK(launch_ts_batch(one, s));
+        if (prof_slot >= 0) prof_mark(prof_slot, true, s);
     } else {
     if (prof_slot >= 0) prof_mark(prof_slot, false, s);
     // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
@@ -370,58 +392,124 @@ __global__ void dropout_mask_kernel(uint8_t *mask, long n, DropCfg d) {
 
 }  // namespace
 
+// Tuning / regression knobs: read from the environment once when the library is first used; the test hook
+// mucon_test_set_knob applies the same parsing at run time (tests compare code paths inside one process).
+static bool apply_knob(const char *name, const char *e) {
+    if (!strcmp(name, "MUCON_NT_BM")) {
+        if (e) g_nt_force_bm = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSED_BM")) {
+        if (e) g_fused_bm = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_BATCH")) {
+        if (e) g_tn_batch = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_BATCH_KS")) {
+        if (e) g_tn_batch_ks = atoi(e) == 2 ? 2 : 1;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_MC_CAP")) {
+        if (e && atoi(e) >= 128) g_tn_mc_cap = atoi(e) / 32 * 32;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_BATCH_TARGET")) {
+        if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_SPLIT")) {
+        if (e) g_tn_split = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TS_MC_CAP")) {
+        if (e && atoi(e) >= 128) g_ts_mc_cap = atoi(e) / 32 * 32;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_KS")) {
+        if (e) g_tn_ks = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT")) {
+        if (e) g_first_conv_split = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FIRST_CONV_KSPLIT")) {
+        if (e) g_first_conv_ksplit = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FIRST_CONV_KSPLIT_ROWS")) {
+        if (e) g_first_conv_ksplit_rows = atol(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_NT_SPLIT")) {
+        if (e) g_nt_split = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT_ROWS")) {
+        if (e) g_first_conv_split_rows = atol(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_REDUCE_LANES")) {
+        if (e) g_reduce_lanes = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FIRST_CONV_8W")) {
+        if (e) g_first_conv_8w = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_NT_BM16_ROWS")) {
+        if (e) g_nt_bm16_rows = atol(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_POOL_FUSE")) {
+        if (e) g_pool_fuse = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_UNPOOL_FUSE")) {
+        if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSED_KS")) {
+        if (e) g_fused_ks = atoi(e) == 2 ? 2 : 1;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSE")) {
+        if (e) g_no_fuse = atoi(e) ? 0 : 1;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSE_MAXROWS")) {
+        if (e) g_fuse_max_rows = atol(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TN_TARGET")) {
+        if (e && atoi(e) > 0) g_tn_target = atoi(e);
+        return true;
+    }
+    return false;
+}
+static const char *const kKnobs[] = {"MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
+
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
 extern "C" {
 
 int mucon_abi_version(void) {
     static bool once = false;
-    if (!once) {  // tuning hook: force the NT tile height (32 / 64 / 128)
-        const char *e = getenv("MUCON_NT_BM");
-        if (e) g_nt_force_bm = atoi(e);
-        e = getenv("MUCON_FUSED_BM");
-        if (e) g_fused_bm = atoi(e);
-        e = getenv("MUCON_TN_BATCH");
-        if (e) g_tn_batch = atoi(e);
-        e = getenv("MUCON_TN_BATCH_KS");
-        if (e) g_tn_batch_ks = atoi(e) == 2 ? 2 : 1;
-        e = getenv("MUCON_TN_MC_CAP");
-        if (e && atoi(e) >= 128) g_tn_mc_cap = atoi(e) / 32 * 32;
-        e = getenv("MUCON_TN_BATCH_TARGET");
-        if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
-        e = getenv("MUCON_TN_KS");
-        if (e) g_tn_ks = atoi(e);
-        e = getenv("MUCON_FIRST_CONV_SPLIT");
-        if (e) g_first_conv_split = atoi(e) ? 1 : 0;
-        e = getenv("MUCON_FIRST_CONV_KSPLIT");
-        if (e) g_first_conv_ksplit = atoi(e) ? 1 : 0;
-        e = getenv("MUCON_FIRST_CONV_KSPLIT_ROWS");
-        if (e) g_first_conv_ksplit_rows = atol(e);
-        e = getenv("MUCON_NT_SPLIT");
-        if (e) g_nt_split = atoi(e) ? 1 : 0;
-        e = getenv("MUCON_FIRST_CONV_SPLIT_ROWS");
-        if (e) g_first_conv_split_rows = atol(e);
-        e = getenv("MUCON_REDUCE_LANES");
-        if (e) g_reduce_lanes = atoi(e);
-        e = getenv("MUCON_FIRST_CONV_8W");
-        if (e) g_first_conv_8w = atoi(e);
-        e = getenv("MUCON_NT_BM16_ROWS");
-        if (e) g_nt_bm16_rows = atol(e);
-        e = getenv("MUCON_POOL_FUSE");
-        if (e) g_pool_fuse = atoi(e) ? 1 : 0;
-        e = getenv("MUCON_UNPOOL_FUSE");
-        if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
-        e = getenv("MUCON_FUSED_KS");
-        if (e) g_fused_ks = atoi(e) == 2 ? 2 : 1;
-        e = getenv("MUCON_FUSE");
-        if (e) g_no_fuse = atoi(e) ? 0 : 1;
-        e = getenv("MUCON_FUSE_MAXROWS");
-        if (e) g_fuse_max_rows = atol(e);
-        e = getenv("MUCON_TN_TARGET");
-        if (e && atoi(e) > 0) g_tn_target = atoi(e);
+    if (!once) {
+        for (const char *name : kKnobs) {
+            const char *e = getenv(name);
+            if (e) apply_knob(name, e);
+        }
         once = true;
     }
     return MUCON_ABI_VERSION;
+}
+int mucon_test_set_knob(const char *name, const char *value) {
+    mucon_abi_version();   // the environment first: a later first use must not overwrite this
+    if (!name || !value || !apply_knob(name, value)) return fail(MUCON_E_ARG, "unknown tuning knob %s", name ? name : "(null)");
+    return MUCON_OK;
 }
 const char *mucon_last_error(void) { return g_err; }
 
@@ -833,7 +921,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
-    if (batch && g_tn_batch < 2) HIPCHK(launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
+    if (batch && g_tn_batch < 2) HIPCHK(g_tn_split ? launch_ts_batch(tnb, s) : launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
@@ -852,7 +940,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     if (batch && g_tn_batch >= 2) {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
         prof_mark(1, false, s);
-        HIPCHK(launch_tn_batch(tnb, s));
+        HIPCHK(g_tn_split ? launch_ts_batch(tnb, s) : launch_tn_batch(tnb, s));
         prof_mark(1, true, s);
     }
     if (!batch && overlap && (rc = g_side.join(s)) != MUCON_OK) return rc;
@@ -966,7 +1054,8 @@ int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, in
     Plan pl;
     memset(&pl, 0, sizeof(pl));
     pl.B = 1;
-    const int mc = pick_mc(1, M, K / 128);
+    int mc = pick_mc(1, M, K / 128);
+    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(1, M, K / 128, (v & 1) != 0, (v & 2) != 0));
     const size_t nmc = (M + mc - 1) / mc;
     pl.slabs = 0;
     pl.slab_floats = align64(nmc * 128 * K);

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mucon_hip.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("mucon_hip.h", "mucon_hip_test.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mucon_[a-z0-9_]+)\s*\(", text)))
 
@@ -18,7 +18,7 @@ def declared_symbols():
 def test_header_and_binding_agree():
     from mucon_amd import _lib
 
-    assert declared_symbols() == sorted(_lib.SYMBOLS), "include/mucon_hip.h and mucon_amd/_lib.py list different entry points"
+    assert declared_symbols() == sorted(_lib.SYMBOLS), "include/mucon_hip*.h and mucon_amd/_lib.py list different entry points"
 
 
 def test_library_builds_and_exports_every_symbol():
@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} not exported"
     lib.mucon_abi_version.restype = ctypes.c_int
-    assert lib.mucon_abi_version() == 1
+    assert lib.mucon_abi_version() == 2
 
 
 def test_host_only_queries():

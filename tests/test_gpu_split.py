@@ -87,3 +87,61 @@ def test_encoder_uses_split_kernel_and_agrees_with_f32_path():
     out, _ = _run_split(tape, P[0][:, :, 0].contiguous(), P[1], 1)
     assert (out.double() - x0).abs().max().item() <= 2e-6 * x0.abs().max().item() + 1e-6
     assert torch.isfinite(enc).all()
+
+
+def _f32_first_conv(tape, W, bias):
+    from mucon_amd import _lib
+    lib = _lib.load()
+    B, T, D = tape.shape
+    out32 = torch.full((B * T, 128), float("nan"), device=DEV)
+    _lib.check(lib.mucon_test_gemm_nt(_lib.ptr(tape), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out32), B * T, D, 0,
+                                      _lib.current_stream_ptr()), "gemm_nt")
+    return out32.reshape(B, T, 128)
+
+
+def test_split_first_conv_wide_dynamic_range():
+    """Tape channels scaled by 2^-60 ... 2^60 (the weights by the inverse, so that every product matters): each output is
+    judged against sum |a| |w|, next to the f32-MFMA kernel."""
+    B, T, D = 1, 300, 512
+    g = torch.Generator().manual_seed(41)
+    e = torch.linspace(-60, 60, D).round()
+    tape = ((torch.rand(B, T, D, generator=g) * 2 - 1) * torch.exp2(e)).to(DEV)
+    W = ((torch.rand(128, D, generator=g) * 2 - 1) * torch.exp2(-e) * 0.05).to(DEV)
+    bias = torch.zeros(128, device=DEV)
+    ref = tape.double() @ W.double().T
+    mag = tape.double().abs() @ W.double().abs().T
+    out, _ = _run_split(tape, W, bias, 0)
+    out32 = _f32_first_conv(tape, W, bias)
+    assert torch.isfinite(out).all()
+    rel_s = ((out.double() - ref).abs() / mag).max().item()
+    rel_f = ((out32.double() - ref).abs() / mag).max().item()
+    print(f"error / sum|a||w|: split {rel_s:.3e}  f32-MFMA {rel_f:.3e}")
+    assert rel_s <= 2e-7 + 4 * rel_f
+
+
+def test_split_first_conv_nan_inf_subnormal_in_the_tape():
+    """A NaN stays a NaN and stays in its frame; an infinity makes its frame non-finite (NaN where an fp32 chain gives +-inf:
+    inf - bf16(inf) is NaN -- never a finite number); subnormal features cost at most their own magnitude."""
+    B, T, D = 1, 260, 256
+    tape = torch.tensor(synth.uniform_pm1(42, (B, T, D)), device=DEV)
+    W = torch.tensor(synth.uniform_pm1(43, (128, D)), device=DEV) * 0.05
+    bias = torch.tensor(synth.uniform_pm1(44, (128,)), device=DEV)
+    clean, _ = _run_split(tape, W, bias, 0)
+    keep = torch.ones(T, dtype=torch.bool, device=DEV)
+    keep[100] = False
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        t = tape.clone()
+        t[0, 100, 37] = bad
+        out, _ = _run_split(t, W, bias, 0)
+        assert not torch.isfinite(out[0, 100]).any(), bad
+        if bad != bad:
+            assert torch.isnan(out[0, 100]).all()
+        torch.testing.assert_close(out[0, keep], clean[0, keep], rtol=0, atol=0)
+    t = tape.clone()
+    t[0, 100, :] = 1e-40        # a subnormal frame: the output is the bias up to ~D * 1e-40 * |w|
+    t[0, 7, 5] = 2e-39
+    out, _ = _run_split(t, W, bias, 0)
+    assert torch.isfinite(out).all()
+    assert (out[0, 100] - bias).abs().max().item() <= 1e-37
+    ref7 = t[0, 7].double() @ W.double().T + bias.double()
+    torch.testing.assert_close(out[0, 7], ref7.float(), rtol=1e-5, atol=1e-5)
