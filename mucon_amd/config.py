@@ -131,7 +131,9 @@ _DEFAULTS = {
             "transcript_weight_background_index": 0,
             "fully_supervised": {"mul_classification": 1.0, "mul_supervised_length": 1.0},
             "smoothing": {"log_softmax_before": True, "clamp": True, "clamp_min": 0, "clamp_max": 16},
-            "mucon": {"type": "flint", "template": "box", "overlap": 0.0},
+            # align_corners is this build's one added key: the reference's masks.py calls affine_grid / grid_sample without it,
+            # and the PyTorch 1.1 its Dockerfile pins behaves as True (upstream recipe); False = a current torch's default
+            "mucon": {"type": "flint", "template": "box", "overlap": 0.0, "align_corners": True},
         },
         "ft": {
             "type": "wavenet", "stages": [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024],

@@ -60,6 +60,16 @@ def last_in_dict_order(K: int, J: int, n_lim: int) -> Optional[Tuple[int, int]]:
     return best
 
 
+class NoHypothesisError(AttributeError):
+    """The decode ran out of hypotheses (empty transcript, every hypothesis past max_length, NaN length model from the first
+    state on).  The reference fails with this AttributeError text in its traceback (viterbi.py:147); the subclass lets callers
+    (the evaluator) catch the decoder's own degenerate outcomes and nothing else."""
+
+
+class ShortSequenceError(IndexError):
+    """Fewer frames than one frame_sampling step: the reference's IndexError (viterbi.py:87)."""
+
+
 class Viterbi(object):
     class Segment(object):
         def __init__(self, label, length=0):
@@ -103,9 +113,9 @@ class Viterbi(object):
         tr = np.asarray(self.grammar.transcript, dtype=np.int32)
         N = len(tr)
         if N == 0:
-            raise AttributeError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
+            raise NoHypothesisError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
         if T < fs:
-            raise IndexError(f"index {fs - 1} is out of bounds for axis 0 with size {T}")
+            raise ShortSequenceError(f"index {fs - 1} is out of bounds for axis 0 with size {T}")
         P = self._table(tr)
         J = P.shape[0]
         K = T // fs
@@ -117,9 +127,9 @@ class Viterbi(object):
         if n_lim < N or K < N:
             force = last_in_dict_order(K, J, n_lim)
             if force is None:
-                raise AttributeError("'NoneType' object has no attribute 'label'")
+                raise NoHypothesisError("'NoneType' object has no attribute 'label'")
         elif K > J * N:
-            raise AttributeError("'NoneType' object has no attribute 'label'")
+            raise NoHypothesisError("'NoneType' object has no attribute 'label'")
         return tr, P, force
 
     # ------------------------------------------------------------------------------ decode
@@ -150,9 +160,9 @@ class Viterbi(object):
         out = []
         for r, t in zip(res, trs):
             if r.status == _lib.VIT_INDEX_ERROR:
-                raise IndexError("frame_sampling exceeds the sequence length")
+                raise ShortSequenceError("frame_sampling exceeds the sequence length")
             if r.status == _lib.VIT_NO_HYPOTHESIS:
-                raise AttributeError("'NoneType' object has no attribute 'label'")
+                raise NoHypothesisError("'NoneType' object has no attribute 'label'")
             segs = [Viterbi.Segment(int(t[s]), int(r.seg_len[s])) for s in range(r.n_seg)]
             out.append((r.score, r.labels.tolist(), segs))
         return out

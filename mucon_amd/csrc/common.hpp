@@ -76,10 +76,22 @@ struct DropCfg {
 __device__ __forceinline__ float drop_mul(const DropCfg &d, uint32_t idx) {
     return mix32((idx ^ d.s0) * 0x9E3779B1U + d.s1) >= d.thresh ? d.scale : 0.f;
 }
+static inline uint32_t mix32_host(uint32_t x) {   // mix32 on the host
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+// Both element keys come from the mixer applied to the WHOLE 64-bit seed and the site: two steps (seeds that differ in a
+// few low bits) or two data-parallel ranks get unrelated (s0, s1) pairs, not masks that are index permutations of each other.
 static inline DropCfg make_drop(uint64_t seed, int site, float p, bool training) {
     DropCfg d;
-    d.s0 = (uint32_t)(seed & 0xffffffffu) ^ (0x85EBCA6Bu * (uint32_t)(site + 1));
-    d.s1 = (uint32_t)(seed >> 32) + 0xC2B2AE35u * (uint32_t)(site + 1);
+    const uint32_t lo = (uint32_t)(seed & 0xffffffffu), hi = (uint32_t)(seed >> 32);
+    const uint32_t k = mix32_host(hi ^ mix32_host(lo + 0x9E3779B9u * (uint32_t)(site + 1)));
+    d.s0 = k;
+    d.s1 = mix32_host(k ^ 0x85EBCA6Bu) + hi;
     if (!training || p <= 0.f) {
         d.thresh = 0;
         d.scale = 1.f;

@@ -8,9 +8,13 @@
 // The loss is a scalar, so the forward computes the gradients too (scaled by the multipliers); the autograd backward
 // only multiplies by the upstream scalar.
 //
-// Masks.  mask[n][t] = bilinear sample of a 100-point template at ix = ((x + 1) * 100 - 1) / 2,
-// x = scale_n * ((2t + 1) / T - 1) + shift_n, zero outside the template (torch's affine_grid / grid_sample with
-// align_corners=False; the sampled image has one row, y = 0 hits it exactly).  With
+// Masks.  mask[n][t] = bilinear sample of a 100-point template at ix, zero outside the template (torch's affine_grid /
+// grid_sample; the sampled image has one row, y = 0 hits it exactly), in either convention of those two functions:
+//   align_corners = 1 (PyTorch <= 1.2, i.e. the 1.1 the reference pins in docker/pytorch1.1/Dockerfile -- the upstream recipe):
+//       x = scale_n * (2t / (T - 1) - 1) + shift_n,   ix = (x + 1) / 2 * 99
+//   align_corners = 0 (the default since 1.3, what the reference's unchanged code computes under a current torch):
+//       x = scale_n * ((2t + 1) / T - 1) + shift_n,   ix = ((x + 1) * 100 - 1) / 2
+// With
 //   A = T softmax(lengths), start = cumsum(A) - A, L = A (1 + 2 ov), start' = start - L ov / 2,
 //   scale = T / L, shift = (start' + L/2 - T/2) / (-L/2)
 // (create_masks rescales the lengths IN PLACE, so the "flint" division uses L, not A).
@@ -35,6 +39,7 @@ struct LossDims {
     int smoothing_clamp, transcript_average;
     float overlap, clamp_min, clamp_max, length_width;
     float mul_transcript, mul_length, mul_mucon, mul_smoothing;
+    int align_corners;       // convention of affine_grid / grid_sample: 1 = PyTorch <= 1.2 (the reference's pinned 1.1), 0 = the later default
 };
 
 struct LossBufs {
@@ -83,11 +88,14 @@ __device__ __forceinline__ float loss_ordered_sum(const float *p, long stride, i
 }
 
 // mask value and its derivative w.r.t. the pixel coordinate ix
-__device__ __forceinline__ void mask_sample(const float *tmpl, float scale, float shift, int t, int T, float &val, float &dval,
+// (align_corners: base grid linspace(-1, 1, T) and ix = (x + 1) / 2 * (W - 1), the corner pixels' CENTRES at -1 and 1; otherwise
+// the half-pixel forms.  d ix / d x is mask_dix(ac).)
+__device__ __forceinline__ float mask_dix(int ac) { return ac ? (float)(LOSS_TW - 1) * 0.5f : (float)LOSS_TW * 0.5f; }
+__device__ __forceinline__ void mask_sample(const float *tmpl, float scale, float shift, int t, int T, int ac, float &val, float &dval,
                                             float &xb) {
-    xb = (2.f * (float)t + 1.f) / (float)T - 1.f;
+    xb = ac ? (T > 1 ? 2.f * (float)t / (float)(T - 1) - 1.f : 0.f) : (2.f * (float)t + 1.f) / (float)T - 1.f;
     const float x = scale * xb + shift;
-    const float ix = ((x + 1.f) * (float)LOSS_TW - 1.f) * 0.5f;
+    const float ix = ac ? (x + 1.f) * 0.5f * (float)(LOSS_TW - 1) : ((x + 1.f) * (float)LOSS_TW - 1.f) * 0.5f;
     const float f0 = floorf(ix);
     const float fx = ix - f0;
     // clamp before the int conversion: far-away segments give huge |ix|
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     for (int e = tid; e < N * LOSS_FB; e += 256) {
         const int n = e / LOSS_FB, f = e - n * LOSS_FB;
         float v = 0.f, dv, xb;
-        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, v, dv, xb);
+        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, d.align_corners, v, dv, xb);
         s_mask[n][f] = v;
     }
     // smoothing partial: sum over the chunk's frames t (t + 1 < T) of (x[t+1] - x[t])^2
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
     for (int e = tid; e < N * LOSS_FB; e += 256) {
         const int n = e / LOSS_FB, f = e - n * LOSS_FB;
         float v = 0.f, dv = 0.f, xb = 0.f;
-        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, v, dv, xb);
+        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, d.align_corners, v, dv, xb);
         s_mask[n][f] = v;
         s_dmask[n][f] = dv;
         if (n == 0) s_xb[f] = xb;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
                 const int tg = (int)b.mtarget[n];
                 gm = -b.geo[5 * LOSS_MAXN + n] * (s_seg[lane][tg] - s_lse[lane]) * invT;
             }
-            gx = gm * s_dmask[n][lane] * ((float)LOSS_TW * 0.5f);
+            gx = gm * s_dmask[n][lane] * mask_dix(d.align_corners);
         }
         const float gsc = loss_wave_sum(lane < nf ? gx * s_xb[lane] : 0.f);
         const float gsh = loss_wave_sum(gx);

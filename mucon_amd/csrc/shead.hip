@@ -341,6 +341,7 @@ extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmen
     d.mul_length = cfg->mul_length;
     d.mul_mucon = cfg->mul_mucon;
     d.mul_smoothing = cfg->mul_smoothing;
+    d.align_corners = cfg->align_corners ? 1 : 0;
     LossBufs b;
     loss_layout(cfg, static_cast<float *>(workspace), &b);
     b.seg = segmentation;

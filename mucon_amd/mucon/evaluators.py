@@ -9,9 +9,10 @@ from typing import Iterable, List
 import numpy as np
 import torch
 
+from .models import EmptyTranscriptError
 from ..core.metrics import (AbsLenDiffMetric, Edit, F1Score, IoDMetric, IoUMetric, MatchingScoreMetric,  # noqa: F401
                             MoFAccuracyMetric)
-from ..core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+from ..core.viterbi import NoHypothesisError, PoissonModel, ShortSequenceError, SingleTranscriptGrammar, Viterbi
 
 
 def one_hot(a: np.ndarray, num_classes: int) -> np.ndarray:
@@ -103,8 +104,6 @@ class MuConEvaluator:
         s_transcript = pred.transcript[:-1]                       # the last word should be EOS
         rel_lengths = pred.lengths.detach().cpu().numpy()
         y_pred = pred.segmentation_logits.argmax(dim=1).cpu().numpy()
-        self.metrics["s_mat_score"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
-        self.metrics["s_len_diff"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
         result = {"y_prediction": y_pred}
         if self.enable_viterbi:
             transcript, lm = self.viterbi_inputs(pred, Tf)
@@ -113,6 +112,10 @@ class MuConEvaluator:
             self.vi_decoder.set_multi_length(False)
             score, labels, segments = self.vi_decoder.decode(pred.segmentation_logits)  # device tensor: no D2H of emissions
             result.update(viterbi_score=score, viterbi_labels=labels, viterbi_segments=segments)
+        # every per-video value exists from here on: only now do the metrics see the video (a decode that raises above leaves
+        # all of them untouched, so a skipped video is skipped by every metric alike)
+        self.metrics["s_mat_score"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
+        self.metrics["s_len_diff"].add(target_transcript=target_transcript, predicted_transcript=s_transcript)
         s_pred = create_segmentation_from_segments(np.array(s_transcript), rel_lengths, Tf)
         s_same = make_same_size_interpolate(s_pred, len(target))
         y_same = make_same_size_interpolate(y_pred, len(target))
@@ -149,29 +152,42 @@ class MuConEvaluator:
             m.reset()
         self._reset_lists()
         self.skipped = 0
+        self._evaluated = []     # dataset indices of the videos that made it into the lists
         for i in range(rank, len(self.test_db), world_size):
             batch = self.test_db[i].to(self.device)
             try:
                 forward_out = self.model.forward(batch)
                 self.batch_eval_calculation(batch, forward_out)
-            except (RuntimeError, AttributeError, IndexError) as e:
-                # An s-head that emits EOS as its first word leaves no length to stack (models.py:351), and a transcript
-                # the Viterbi grammar cannot fit raises in the decode: the reference's evaluation stops there.  Here the
-                # video is counted and skipped, so that an early-epoch evaluation of a barely trained model still reports.
-                if isinstance(e, RuntimeError) and "non-empty" not in str(e):
-                    raise
+                self._evaluated.append(i)
+            except (EmptyTranscriptError, NoHypothesisError, ShortSequenceError):
+                # The three degenerate outcomes the reference's evaluation dies on: an s-head that emits EOS as its first word
+                # (models.py:351), a transcript the decoder runs out of hypotheses for (viterbi.py:147), fewer frames than one
+                # decoding step (viterbi.py:87).  Here the video is counted and skipped, so that an early-epoch evaluation of a
+                # barely trained model still reports.  Anything else is a bug and propagates.
                 self.skipped += 1
         if world_size > 1:
             import torch.distributed as dist
             keys = sorted(self.metrics)
             sizes = [len(self.metrics[k].state()) for k in keys]
-            flat = torch.tensor([x for k in keys for x in np.nan_to_num(np.asarray(self.metrics[k].state(), dtype=np.float64))],
+            # NaN accumulators (an IoD / IoU over a video without target segments) stay NaN through the sum, as on one rank
+            flat = torch.tensor([x for k in keys for x in np.asarray(self.metrics[k].state(), dtype=np.float64)] + [float(self.skipped)],
                                 dtype=torch.float64, device=self.device)
             dist.all_reduce(flat)
             vals, off = flat.cpu().numpy(), 0
             for k, n in zip(keys, sizes):
                 self.metrics[k].load_state(list(vals[off:off + n]))
                 off += n
+            self.skipped = int(round(vals[off]))
+            # the per-video records (to_save, evaluators.py:259-267) of every rank, back in dataset order on every rank
+            lists = ("y_segs", "s_segs", "vit_segs", "s_lens", "s_transcript", "target_segs", "target_transcripts")
+            mine = {name: getattr(self, name) for name in lists}
+            mine["order"] = self._evaluated
+            gathered = [None] * world_size
+            dist.all_gather_object(gathered, mine)
+            order = np.argsort(np.concatenate([np.asarray(g["order"], dtype=np.int64) for g in gathered]), kind="stable")
+            for name in lists:
+                merged = [x for g in gathered for x in g[name]]
+                setattr(self, name, [merged[i] for i in order])
         result = self.on_finish_eval()
         if self.skipped:
             result["skipped_videos"] = self.skipped

@@ -1,8 +1,11 @@
 """Differentiable segment masks for the MuCon loss (reference src/mucon/masks.py:8-74).
 PyTorch-ROCm ops (tiny tensors: N segments x T frames); out of the hand-written hot path
 (SURVEY.md 2, row 9).  Same construction as the reference: a 100-sample template per segment is
-resampled onto the T frames through an affine grid (scale = T / length, shift = segment centre),
-with torch's current align_corners default -- the behaviour the goldens were captured under."""
+resampled onto the T frames through an affine grid (scale = T / length, shift = segment centre).
+
+`align_corners` is explicit here.  The reference calls affine_grid / grid_sample without it (masks.py:72-73), so what it
+computes depends on the PyTorch underneath: the 1.1 its Dockerfile pins behaves as align_corners=True (the upstream training
+recipe; the default of cfg.model.loss.mucon.align_corners), PyTorch >= 1.3 defaults to False.  Goldens exist for both."""
 import torch
 from torch import Tensor
 from torch.nn.functional import affine_grid, grid_sample, softmax
@@ -32,7 +35,7 @@ def _template(kind: str, n: int, like: Tensor) -> Tensor:
     return t.repeat((n, 1)).view(n, 1, -1).float().to(like.device)
 
 
-def create_masks(T: int, L: Tensor, overlap: float = 0.0, template: str = "box") -> Tensor:
+def create_masks(T: int, L: Tensor, overlap: float = 0.0, template: str = "box", align_corners: bool = True) -> Tensor:
     """[M] absolute lengths -> [M x T] soft masks.  NB: like the reference (masks.py:58-61) this
     rescales L in place by (1 + 2*overlap)."""
     n = L.size(0)
@@ -46,5 +49,5 @@ def create_masks(T: int, L: Tensor, overlap: float = 0.0, template: str = "box")
     theta[:, 0, 0] = scale
     theta[:, 0, 2] = shift
     theta[:, 1, 1] = scale
-    grid = affine_grid(theta.float(), torch.Size((n, 1, 1, T)))
-    return grid_sample(tmpl.view(n, 1, 1, TEMPLATE_WIDTH), grid).view(n, T)
+    grid = affine_grid(theta.float(), torch.Size((n, 1, 1, T)), align_corners=align_corners)
+    return grid_sample(tmpl.view(n, 1, 1, TEMPLATE_WIDTH), grid, align_corners=align_corners).view(n, T)

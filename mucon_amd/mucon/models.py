@@ -83,6 +83,11 @@ def create_model(cfg, num_classes: int, max_decoding_steps: int, input_feature_s
     raise Exception("Invalid model name")
 
 
+class EmptyTranscriptError(RuntimeError):
+    """The s-head emitted EOS as its first word: there is no length to stack.  The reference fails in torch.stack([])
+    (models.py:351) with this RuntimeError text; the subclass lets the evaluator tell it from every other RuntimeError."""
+
+
 class MuCon(nn.Module):
     def __init__(self, cfg, input_feature_size: int, num_classes: int, max_decoding_steps: int):
         super().__init__()
@@ -172,8 +177,16 @@ class MuCon(nn.Module):
                 z = self.ft_last_dropout(z)
             return z.permute(0, 2, 1).contiguous()
         self._step += 1
-        seed = (int(self.cfg.system.seed) << 32) ^ self._step if self.training else 0
+        seed = self._dropout_seed() if self.training else 0
         return self.ft.forward_time_major(input, self.ft_last_gn.weight, self.ft_last_gn.bias, self._encoder_spec(), seed)
+
+    dropout_rank = 0   # data-parallel rank (set by SimpleTrainer): every rank draws its own masks
+
+    def _dropout_seed(self) -> int:
+        """64-bit key of this step's dropout masks: (cfg seed, step counter) with the rank folded in by a golden-ratio
+        multiple, so ranks do not share masks; the kernels hash the whole word (csrc/common.hpp: make_drop)."""
+        seed = ((int(self.cfg.system.seed) << 32) ^ self._step) & 0xFFFFFFFFFFFFFFFF
+        return seed ^ ((int(self.dropout_rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
 
     def frame_classifier_forward(self, temporal_encoded: Tensor, target_length: int) -> Tensor:
         """[1 x Ds x Tz] -> [1 x num_classes x Tf] (reference models.py:567-582)."""
@@ -199,9 +212,11 @@ class MuCon(nn.Module):
         fused = self.__dict__.pop("_decoder_tensors", None)
         if fused is not None:      # the persistent decoder kernel's outputs, without the list round trip
             if fused[1].shape[0] < 2:
-                raise RuntimeError("stack expects a non-empty TensorList")   # EOS first: what torch.stack([]) raises (models.py:351)
+                raise EmptyTranscriptError("stack expects a non-empty TensorList")   # EOS first: what torch.stack([]) raises (models.py:351)
             out = MuConForwardOut(transcript=fused[0], lengths=fused[1][:-1], segmentation=segmentation)
         else:
+            if len(lengths) < 2:
+                raise EmptyTranscriptError("stack expects a non-empty TensorList")
             out = MuConForwardOut(transcript=torch.cat(transcripts, dim=0), lengths=torch.stack(lengths[:-1]),
                                   segmentation=segmentation)
         out._logp = logp  # the kernel's log-softmax, reused by predict() and the smoothing loss
@@ -229,7 +244,7 @@ class MuCon(nn.Module):
         feats = batch.feats
         Tf = feats.shape[1]
         self._step += 1
-        seed = (int(self.cfg.system.seed) << 32) ^ self._step
+        seed = self._dropout_seed()
         enc_params = self.ft.ordered_parameters() + [self.ft_last_gn.weight, self.ft_last_gn.bias]
         enc, c_enc = F_.run_forward(F_._EncoderFn, feats, self._encoder_spec(), True, int(seed), *enc_params)
         lstm = self.fs_encoder_lstm
@@ -439,7 +454,8 @@ class MuCon(nn.Module):
                             clamp_min=float(lc.smoothing.clamp_min), clamp_max=float(lc.smoothing.clamp_max),
                             length_width=float(lc.length_width), transcript_average=bool(lc.transcript_average),
                             mul_transcript=float(self.loss_mul_transcript), mul_length=float(self.loss_mul_length),
-                            mul_mucon=float(self.loss_mul_mucon), mul_smoothing=float(self.loss_mul_smoothing))
+                            mul_mucon=float(self.loss_mul_mucon), mul_smoothing=float(self.loss_mul_smoothing),
+                            align_corners=bool(lc.mucon.get("align_corners", True)))
 
     def smoothing_loss(self, batch: Batch, forward_out: MuConForwardOut) -> Tensor:
         sm = self.cfg.model.loss.smoothing
@@ -469,7 +485,8 @@ class MuCon(nn.Module):
         T = forward_out.segmentation.shape[0]
         absolute_lengths = project_lengths_softmax(T=T, L=forward_out.lengths)
         mc = self.cfg.model.loss.mucon
-        masks = create_masks(T=T, L=absolute_lengths, template=mc.template, overlap=mc.overlap)   # [N x T]
+        masks = create_masks(T=T, L=absolute_lengths, template=mc.template, overlap=mc.overlap,
+                             align_corners=bool(mc.get("align_corners", True)))   # [N x T]
         return self.calculate_mucon_loss_using_masks(absolute_lengths, masks, forward_out.segmentation, target)
 
     def _bg_weight(self, n, index, value, device):

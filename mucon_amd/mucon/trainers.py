@@ -31,37 +31,72 @@ def create_scheduler(cfg, optimizer):
     raise Exception("Invalid scheduler name (%s)" % s.name)
 
 
-def all_reduce_gradients(model, world_size: int):
-    """Average the gradients over ranks (1,643,298 floats = 6.57 MB for the default model) in two collectives:
-    gradients that are views of one flat buffer (the HIP encoder's backward writes all of its 50 gradients into one,
-    ops._EncoderFn.backward) are all-reduced in place; the remaining, individually allocated ones (s-head, y-head) are
-    packed into one buffer, all-reduced, and scattered back with one multi-tensor copy.  Parameters without a gradient on
-    this rank contribute zeros."""
+class GradBucket:
+    """ONE all-reduce per optimizer step whose size and layout are fixed by the parameter list alone -- never by which
+    gradients happen to exist, share a storage or were produced by the fused or the autograd path on this rank (ranks that
+    disagreed on any of that would issue mismatched collectives: a hang or silently mixed-up gradients).
+
+    Layout: every trainable parameter has a fixed slot in one persistent flat fp32 buffer, followed by one flag per parameter
+    ("this rank produced a gradient").  pack -> all_reduce(sum) -> scale by 1 / world_size -> unpack:
+      * a parameter that received a gradient on at least one rank gets the average (ranks without one contributed zeros),
+        its .grad becomes a view of the flat buffer (no copy back; the buffer is not touched again before the optimizer ran);
+      * a parameter without a gradient on ANY rank keeps grad = None on every rank -- exactly what a single process does (the
+        optimizer skips it: no weight decay, no momentum update), so N ranks and 1 rank treat unused parameters alike."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.sizes = [p.numel() for p in self.params]
+        self.n = sum(self.sizes)
+        self.flat = None
+
+    def _ensure(self):
+        if self.flat is None:
+            p0 = self.params[0]
+            self.flat = torch.zeros(self.n + len(self.params), dtype=torch.float32, device=p0.device)
+            self.views = [v.view_as(p) for v, p in zip(self.flat[:self.n].split(self.sizes), self.params)]
+
+    def all_reduce(self, world_size: int):
+        import torch.distributed as dist
+
+        if not self.params:
+            return
+        self._ensure()
+        have = [p.grad is not None for p in self.params]
+        dst_copy, src_copy, dst_zero = [], [], []
+        for p, v, h in zip(self.params, self.views, have):
+            if not h:
+                dst_zero.append(v)
+            elif p.grad.data_ptr() != v.data_ptr():     # (a gradient accumulated in place into last step's view is already there)
+                dst_copy.append(v)
+                src_copy.append(p.grad)
+        if dst_copy:
+            torch._foreach_copy_(dst_copy, src_copy)
+        if dst_zero:
+            torch._foreach_zero_(dst_zero)
+        self.flat[self.n:] = torch.tensor([1.0 if h else 0.0 for h in have], dtype=torch.float32).to(self.flat.device, non_blocking=True)
+        dist.all_reduce(self.flat)
+        self.flat[:self.n].mul_(1.0 / world_size)
+        counts = self.flat[self.n:].tolist()        # one small read-back per step: who has a gradient anywhere
+        for p, v, c in zip(self.params, self.views, counts):
+            p.grad = v if c > 0 else None
+
+
+def all_reduce_gradients(model, world_size: int, bucket: "GradBucket" = None):
+    """Average the gradients over ranks with one collective (1,643,298 floats = 6.57 MB for the default model + one flag per
+    parameter); see GradBucket.  `bucket` keeps the flat buffer between steps (SimpleTrainer owns one)."""
+    (bucket or GradBucket(model.parameters())).all_reduce(world_size)
+
+
+def broadcast_parameters(model, src: int = 0):
+    """Every rank starts from rank `src`'s parameters and buffers (equal seeds are not trusted): one flat broadcast."""
     import torch.distributed as dist
 
-    params = [p for p in model.parameters() if p.requires_grad]
-    by_storage = {}
-    for p in params:
-        if p.grad is not None:
-            by_storage.setdefault(p.grad.untyped_storage().data_ptr(), []).append(p)
-    loose = []
-    for p in params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-            loose.append(p)
-        elif len(by_storage[p.grad.untyped_storage().data_ptr()]) == 1:
-            loose.append(p)
-    for group in by_storage.values():
-        if len(group) > 1:   # one flat buffer behind several gradients: reduce it where it lies
-            g = group[0].grad
-            flat = torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage())
-            dist.all_reduce(flat)
-            flat /= world_size
-    if loose:
-        flat = torch.cat([p.grad.reshape(-1) for p in loose])
-        dist.all_reduce(flat)
-        flat /= world_size
-        torch._foreach_copy_([p.grad for p in loose], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in loose]), loose)])
+    tensors = [p.data for p in model.parameters()] + [b for b in model.buffers() if b.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src)
+    torch._foreach_copy_(tensors, [c.view_as(t) for c, t in zip(flat.split([t.numel() for t in tensors]), tensors)])
 
 
 class SimpleTrainer:
@@ -72,6 +107,12 @@ class SimpleTrainer:
         self.scheduler = create_scheduler(cfg, self.optimizer)
         self.clip_grad_norm: Optional[float] = cfg.trainer.clip_grad_norm_value if cfg.trainer.clip_grad_norm else None
         self.iter_num = 0
+        self.bucket = None
+        if world_size > 1:
+            broadcast_parameters(model, 0)
+            self.bucket = GradBucket(model.parameters())
+        # every rank draws its own dropout masks (the kernels' counter-based dropout is keyed by model.dropout_rank)
+        model.dropout_rank = int(rank)
         self.fused_step = self._make_fused_step()
         self.fuse_step = True   # False: always go through torch.autograd
 
@@ -118,7 +159,7 @@ class SimpleTrainer:
             (loss.main / acc).backward()
         last_of_group = iter_num % acc == (acc - 1)
         if last_of_group and self.world_size > 1:
-            all_reduce_gradients(self.model, self.world_size)
+            all_reduce_gradients(self.model, self.world_size, self.bucket)
         if self.fused_step is not None:
             self.fused_step.step()
             return loss, forward_out
@@ -153,3 +194,9 @@ class SimpleTrainer:
         if self.scheduler is not None and not isinstance(self.scheduler, ReduceLROnPlateau):
             self.scheduler.step()
         return torch.stack(losses).tolist() if losses else []
+
+    def step_scheduler_on_eval(self, eval_result) -> None:
+        """The plateau scheduler is driven by the evaluation: the reference feeds it eval_results[0].s_mof_nbg
+        (trainers.py:157-163, figure_scheduler_input).  Called by the training script after every evaluation."""
+        if isinstance(self.scheduler, ReduceLROnPlateau):
+            self.scheduler.step(float(eval_result["s_mof_nbg"]))

@@ -388,6 +388,7 @@ class LossSpec:
     mul_length: float = 0.1
     mul_mucon: float = 1.0
     mul_smoothing: float = 0.1
+    align_corners: bool = True   # cfg.model.loss.mucon.align_corners: the affine_grid / grid_sample convention of the masks
 
 
 class _LossFn(torch.autograd.Function):
@@ -412,7 +413,7 @@ class _LossFn(torch.autograd.Function):
                            smoothing_clamp=int(spec.smoothing_clamp), transcript_average=int(spec.transcript_average),
                            overlap=spec.overlap, clamp_min=spec.clamp_min, clamp_max=spec.clamp_max,
                            length_width=spec.length_width, mul_transcript=spec.mul_transcript, mul_length=spec.mul_length,
-                           mul_mucon=spec.mul_mucon, mul_smoothing=spec.mul_smoothing)
+                           mul_mucon=spec.mul_mucon, mul_smoothing=spec.mul_smoothing, align_corners=int(spec.align_corners))
         nbytes = lib.mucon_loss_workspace_bytes(ctypes.byref(cfg))
         if nbytes == 0:
             _lib.check(_lib.E_ARG, "mucon_loss_workspace_bytes")

@@ -85,6 +85,7 @@ def main(argv=None):
         if t.eval_every and epoch % t.eval_every == 0:
             evaluator.viterbi_mode(False)
             res = evaluator.evaluate(rank, world)
+            trainer.step_scheduler_on_eval(res)       # scheduler.name == "plateau" (every rank sees the same all-reduced result)
             if rank == 0:
                 print(f"epoch {epoch}: y_mof {res['y_mof']:.4f}  s_mof {res['s_mof']:.4f}  s_mat_score {res['s_mat_score']:.4f}", flush=True)
         if rank == 0 and t.save_every and epoch % t.save_every == 0:

@@ -4,8 +4,10 @@ CPU restatement of MuCon.loss in explicit float64 torch ari
 these formulas.  The mask construction is written out (no affine_grid / grid_sample):
 
   lengths -> masks   reference src/mucon/masks.py:8-15 (project_lengths_softmax), :44-74 (create_masks: in-place
-                     rescale of the lengths, affine grid x = scale * ((2t+1)/T - 1) + shift, bilinear sampling of
-                     the 100-point template with zero padding, align_corners=False), :19-41 (templates)
+                     rescale of the lengths, affine grid, bilinear sampling of the 100-point template with zero
+                     padding -- in both conventions of affine_grid / grid_sample: align_corners=True is what the
+                     PyTorch 1.1 the reference pins computes, False what a torch >= 1.3 does with the same code),
+                     :19-41 (templates)
   mucon loss         reference src/mucon/models.py:414-515 ("flint": mask-averaged logits / length -> log-softmax ->
                      nll; "arithmetic": mask-weighted per-frame cross-entropy / T)
   smoothing loss     reference src/mucon/models.py:398-412
@@ -46,6 +48,7 @@ class LossConfig:
     mucon_type: str = "flint"
     mucon_template: str = "box"
     mucon_overlap: float = 0.0
+    mucon_align_corners: bool = True   # affine_grid / grid_sample convention (True: the PyTorch 1.1 the reference pins; False: torch >= 1.3)
 
     @staticmethod
     def from_overrides(pairs):
@@ -75,7 +78,7 @@ def template(kind: str) -> torch.Tensor:
     return torch.from_numpy(t.astype(np.float32).astype(np.float64))
 
 
-def masks_and_lengths(lengths: torch.Tensor, T: int, overlap: float, kind: str):
+def masks_and_lengths(lengths: torch.Tensor, T: int, overlap: float, kind: str, align_corners: bool = True):
     """raw length logits [N] -> (masks [N, T], rescaled absolute lengths [N])."""
     A = T * torch.softmax(lengths, dim=0)
     start = torch.cumsum(A, 0) - A
@@ -84,9 +87,12 @@ def masks_and_lengths(lengths: torch.Tensor, T: int, overlap: float, kind: str):
     scale = T / L
     shift = (start + L / 2 - T / 2) / (-(L / 2))
     t = torch.arange(T, dtype=lengths.dtype)
-    xb = (2 * t + 1) / T - 1
+    if align_corners:      # base grid linspace(-1, 1, T); pixel centres of the template's ends at -1 and +1
+        xb = 2 * t / (T - 1) - 1 if T > 1 else torch.zeros_like(t)
+    else:                  # half-pixel convention
+        xb = (2 * t + 1) / T - 1
     x = scale[:, None] * xb[None, :] + shift[:, None]
-    ix = ((x + 1) * TEMPLATE_WIDTH - 1) / 2
+    ix = (x + 1) / 2 * (TEMPLATE_WIDTH - 1) if align_corners else ((x + 1) * TEMPLATE_WIDTH - 1) / 2
     i0 = torch.floor(ix.detach())
     fx = ix - i0
     tm = template(kind).to(lengths.dtype)
@@ -123,7 +129,7 @@ def loss(cfg: LossConfig, segmentation, transcript_logp, lengths, mucon_target, 
     w = cfg.length_width
     l_loss = torch.relu(lengths - w).sum() + torch.relu(-w - lengths).sum()
     # mucon
-    masks, L = masks_and_lengths(lengths, T, cfg.mucon_overlap, cfg.mucon_template)
+    masks, L = masks_and_lengths(lengths, T, cfg.mucon_overlap, cfg.mucon_template, cfg.mucon_align_corners)
     mw = class_weight(M, cfg.mucon_weight_background, cfg.mucon_weight_background_index, cfg.mucon_weight_background_value, dt)
     if cfg.mucon_type == "flint":
         windows = (masks @ segmentation) / L[:, None]

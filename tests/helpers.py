@@ -40,8 +40,19 @@ def dropout_keep_np(n, seed, site, p):
     """numpy replay of the kernels' counter-based dropout (mucon_amd/csrc/common.hpp: mix32 / make_drop):
     keep[e] for element index e of dropout site `site`."""
     M = 0xFFFFFFFF
-    s0 = ((seed & M) ^ ((0x85EBCA6B * (site + 1)) & M)) & M
-    s1 = ((seed >> 32) + 0xC2B2AE35 * (site + 1)) & M
+
+    def mix(x):
+        x &= M
+        x ^= x >> 16
+        x = (x * 0x7feb352d) & M
+        x ^= x >> 15
+        x = (x * 0x846ca68b) & M
+        x ^= x >> 16
+        return x
+
+    lo, hi = seed & M, (seed >> 32) & M
+    s0 = mix(hi ^ mix(lo + 0x9E3779B9 * (site + 1)))
+    s1 = (mix(s0 ^ 0x85EBCA6B) + hi) & M
     t = p * 4294967296.0
     thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
     with np.errstate(over="ignore"):

@@ -25,27 +25,37 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mucon_amd.mucon.trainers import all_reduce_gradients
+    from mucon_amd.mucon.trainers import GradBucket, all_reduce_gradients, broadcast_parameters
 
-    torch.manual_seed(0)  # identical replicas
-    model = nn.Sequential(nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 4), nn.Linear(4, 2))
-    for p in model[2].parameters():      # a parameter set that receives no gradient on rank 1
-        p.requires_grad_(True)
-    x = torch.randn(5, 16, generator=torch.Generator().manual_seed(100 + rank))
-    h = model[1](model[0](x))
-    y = model[3](model[2](h)) if rank == 0 else h[:, :2] * 1.0
-    y.sum().backward()
-    local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
-    # like the HIP encoder's backward, the first layer's gradients are views of ONE flat buffer (reduced in place)
-    ps = list(model[0].parameters())
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    off = 0
-    for p in ps:
-        p.grad = flat[off: off + p.numel()].view_as(p)
-        off += p.numel()
-    all_reduce_gradients(model, world)
-    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in ps)
-    torch.save({"local": local, "avg": [p.grad.clone() for p in model.parameters()]}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.manual_seed(rank)  # replicas that start DIFFERENT: the broadcast has to make them equal
+    model = nn.Sequential(nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 4), nn.Linear(4, 2), nn.Linear(3, 3))
+    broadcast_parameters(model, 0)
+    start = [p.detach().clone() for p in model.parameters()]
+    bucket = GradBucket(model.parameters())
+    out = {"start": start, "steps": []}
+    for step in range(2):                # twice: the second step meets .grad tensors that are views of the flat buffer
+        for p in model.parameters():
+            p.grad = None
+        x = torch.randn(5, 16, generator=torch.Generator().manual_seed(100 + rank + 10 * step))
+        h = model[1](model[0](x))
+        # model[2], model[3] receive a gradient on rank 0 only; model[4] on no rank; which tensors share a storage differs too
+        y = model[3](model[2](h)) if rank == 0 else h[:, :2] * 1.0
+        y.sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+        if rank == 1:    # like the HIP encoder's backward: this rank's first-layer gradients are views of ONE buffer
+            ps = list(model[0].parameters())
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            off = 0
+            for p in ps:
+                p.grad = flat[off: off + p.numel()].view_as(p)
+                off += p.numel()
+        all_reduce_gradients(model, world, bucket)
+        for p in model[4].parameters():
+            assert p.grad is None                       # unused everywhere: stays None, as in a single process
+        for p in list(model.parameters())[:6]:
+            assert p.grad.untyped_storage().data_ptr() == bucket.flat.untyped_storage().data_ptr()
+        out["steps"].append({"local": local, "avg": [None if p.grad is None else p.grad.clone() for p in model.parameters()]})
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
 
     # shard arithmetic of SimpleTrainer.train_epoch: disjoint, same count on every rank
     n = 11
@@ -69,8 +79,14 @@ def test_gradient_all_reduce_world2(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
-        assert torch.equal(a0, a1)                      # every rank ends with the same averaged gradient
-        z = torch.zeros_like(a0)
-        want = ((l0 if l0 is not None else z) + (l1 if l1 is not None else z)) / 2
-        torch.testing.assert_close(a0, want, rtol=1e-6, atol=1e-7)
+    for a, b in zip(r0["start"], r1["start"]):
+        assert torch.equal(a, b)                        # broadcast_parameters: identical replicas
+    for s0, s1 in zip(r0["steps"], r1["steps"]):
+        for a0, a1, l0, l1 in zip(s0["avg"], s1["avg"], s0["local"], s1["local"]):
+            if l0 is None and l1 is None:
+                assert a0 is None and a1 is None        # no gradient anywhere: None on every rank
+                continue
+            assert torch.equal(a0, a1)                  # every rank ends with the same averaged gradient
+            z = torch.zeros_like(a0)
+            want = ((l0 if l0 is not None else z) + (l1 if l1 is not None else z)) / 2
+            torch.testing.assert_close(a0, want, rtol=1e-6, atol=1e-7)

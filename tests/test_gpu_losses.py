@@ -1,5 +1,7 @@
 """GPU: the fused HIP loss kernels (csrc/loss.hpp) through the C ABI against (1) the reference's own
-MuCon.loss values and gradients (tests/golden/loss_cases.npz) and (2) oracle/losses.py in float64 at other sizes.
+MuCon.loss values and gradients (tests/golden/loss_cases.npz: every configuration under both conventions of affine_grid /
+grid_sample -- "<case>@ac" = align_corners True, the PyTorch 1.1 the reference pins; "<case>" = False, a current torch's
+default) and (2) oracle/losses.py in float64 at other sizes, both conventions.
 Tolerances: loss values 3e-5 relative; gradients 1e-3 relative L2 against the float32 golden and 5e-4 against the
 float64 oracle (the mask-boundary terms are O(T) multiples of float32 rounding in the frame coordinate)."""
 import json
@@ -31,7 +33,8 @@ def _spec_and_consts(ocfg, M):
     spec = ops.LossSpec(mucon_type=ocfg.mucon_type, overlap=ocfg.mucon_overlap, smoothing_clamp=ocfg.smoothing_clamp,
                         clamp_min=ocfg.smoothing_clamp_min, clamp_max=ocfg.smoothing_clamp_max, length_width=ocfg.length_width,
                         transcript_average=ocfg.transcript_average, mul_transcript=ocfg.mul_transcript,
-                        mul_length=ocfg.mul_length, mul_mucon=ocfg.mul_mucon, mul_smoothing=ocfg.mul_smoothing)
+                        mul_length=ocfg.mul_length, mul_mucon=ocfg.mul_mucon, mul_smoothing=ocfg.mul_smoothing,
+                        align_corners=ocfg.mucon_align_corners)
     tmpl = _template(ocfg.mucon_template, 1, torch.zeros(1, device=DEV)).reshape(-1)
     mw = tw = None
     if ocfg.mucon_weight_background:
@@ -81,9 +84,10 @@ def test_fused_loss_matches_reference_golden(case):
     (9000, 25, 64, ["model.loss.mucon.type", "arithmetic", "model.loss.mucon.template", "trapezoid"]),
     (777, 9, 48, ["model.loss.mucon.overlap", 0.3, "model.loss.mucon_weight_background", True,
                   "model.loss.smoothing.log_softmax_before", False, "model.loss.smoothing.clamp", False])])
-def test_fused_loss_against_float64_oracle(T, N, M, over):
+@pytest.mark.parametrize("align_corners", [True, False])
+def test_fused_loss_against_float64_oracle(T, N, M, over, align_corners):
     from oracle import losses
-    ocfg = losses.LossConfig.from_overrides(over)
+    ocfg = losses.LossConfig.from_overrides(list(over) + ["model.loss.mucon.align_corners", align_corners])
     g = torch.Generator().manual_seed(T + N)
     seg = ((torch.rand((T, M), generator=g) * 2 - 1) * 3).float()
     tl = torch.log_softmax(((torch.rand((N + 1, M + 1), generator=g) * 2 - 1) * 2).double(), dim=1).float()
@@ -123,7 +127,8 @@ def test_model_native_loss_equals_torch_formulation():
     from test_gpu_model import make_batch, seeded_value
     from mucon_amd.config import get_cfg_defaults, update_config
     from mucon_amd.mucon.models import create_model
-    for over in ([], ["model.loss.mucon.type", "arithmetic"], ["model.loss.mucon.template", "gaussian", "model.loss.mucon.overlap", "0.1"]):
+    for over in ([], ["model.loss.mucon.type", "arithmetic"], ["model.loss.mucon.template", "gaussian", "model.loss.mucon.overlap", "0.1"],
+                 ["model.loss.mucon.align_corners", "False"], ["model.loss.mucon.align_corners", "False", "model.loss.mucon.type", "arithmetic"]):
         cfg = update_config(get_cfg_defaults(), [], [over])
         model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
         with torch.no_grad():

@@ -56,7 +56,13 @@ def main():
     from mucon.models import MuConForwardOut, create_model
 
     out = {}
-    for case, (T, N, seed, tf, over) in CASES.items():
+    meta = {}
+    # every configuration under both grid conventions: "<case>" = align_corners False (this container's torch default, the
+    # round-1 goldens), "<case>@ac" = True (the reference's pinned PyTorch 1.1; ref_harness.set_grid_convention)
+    for case, (T, N, seed, tf, over), ac in [(c + ("@ac" if a else ""), v, a) for c, v in CASES.items() for a in (False, True)]:
+        ref_harness.set_grid_convention(ac)
+        meta[case] = {"T": T, "N": N, "seed": seed, "teacher_forcing": tf,
+                      "overrides": list(over) + ["model.loss.mucon.align_corners", ac]}
         cfg = get_cfg_defaults()
         for key, val in zip(over[::2], over[1::2]):   # the harness's CfgNode stub has no merge_from_list
             node = cfg
@@ -92,8 +98,7 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "loss_cases.npz"), **out)
     import json
     with open(os.path.join(ROOT, "tests", "golden", "loss_cases.json"), "w") as f:
-        json.dump({k: {"T": v[0], "N": v[1], "seed": v[2], "teacher_forcing": v[3], "overrides": v[4]} for k, v in CASES.items()},
-                  f, indent=1)
+        json.dump(meta, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -150,3 +150,19 @@ def install():
 
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)
+    set_grid_convention(True)
+
+
+def set_grid_convention(align_corners):
+    """The reference's create_masks calls affine_grid / grid_sample WITHOUT align_corners (masks.py:70-71), so what it
+    computes depends on the PyTorch underneath: the 1.1 its Dockerfile pins (docker/pytorch1.1/Dockerfile:25) has no such
+    argument and behaves as align_corners=True -- base grid linspace(-1, 1, T), ix = (x + 1) / 2 * (W - 1) -- while this
+    container's torch 2.10 defaults to False.  True (the harness default) makes the reference compute what it computes in
+    its own pinned environment; False leaves today's default; the loss goldens are captured under both."""
+    import functools
+
+    import torch.nn.functional as F
+
+    import mucon.masks as m
+    m.affine_grid = functools.partial(F.affine_grid, align_corners=bool(align_corners))
+    m.grid_sample = functools.partial(F.grid_sample, align_corners=bool(align_corners))
