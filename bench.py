@@ -8,14 +8,21 @@ tapes (T x 2048), plus Viterbi ms/video as extra fields.  One step = one pass of
 one batch of synthetic tapes that are already resident in HBM:
     encoder fwd (training mode, dropout on) -> y-head fwd (log-softmax) -> dL/dlogp given ->
     y-head bwd -> encoder bwd -> [N>1: RCCL all-reduce of the flat gradient] -> SGD update.
-Workload: BASELINE config 3 shape per GPU (B=8 videos x T=4096 frames x D=2048, 48 classes) --
-268 MB of tape per step, i.e. larger than the 256 MiB Infinity Cache.  Weak scaling: every rank
-has its own batch; videos are independent, the only exchange is the gradient all-reduce.
+Workload: BASELINE config 3 shape per GPU (B=8 videos x T=4096 frames x D=2048, 48 classes).  FOUR distinct
+tape batches (4 x 256 MiB = 1 GiB) are rotated, one per step: between two uses of a batch more than 768 MiB of
+other tape (plus every activation) has streamed through the 256 MiB Infinity Cache, so every tape read comes
+from HBM.  Weak scaling: every rank has its own batches; videos are independent, the only exchange is the
+gradient all-reduce.
+
+Timing: W warm-up steps, then the region of EXACTLY K steps (barrier + synchronize on both sides, max over ranks)
+is timed `--repeats` times back to back (default 5); `value` / `ms_per_step` are the MEDIAN region's, every region
+is listed in `ms_per_step_repeats` (a single 20-step region is 18 ms: too short to be stable against clock ramps).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      dominant kernel, timed per launch with HIP events inside the timed region
-  cpu_baseline  the oracle's CPU path (torch CPU ops, fp32, all host cores) on a bounded sample
-  viterbi       decode latency (single video, and amortised over a batch of videos) vs the C oracle
+  roofline          dominant kernel (the one batched weight-gradient launch), timed per launch with HIP events on its stream
+  roofline_viterbi  Viterbi decode against its algorithmic bytes (single video and 256 videos in flight)
+  cpu_baseline      the dense path as the torch module graph the reference runs, fp32, physical host cores, best of 3
+  viterbi           decode latency vs the C oracle on one host core and on all of them
 """
 import argparse
 import ctypes
@@ -39,8 +46,10 @@ BYTES_PER_FRAME_FWD_BWD = 16768  # tape read twice (fwd + first-co
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
+    ap.add_argument("--tapes", type=int, default=4, help="distinct tape batches rotated through the steps (4 x 256 MiB)")
     ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
     ap.add_argument("--frames", type=int, default=4096, help="frames per video")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,45 +78,75 @@ def make_params(spec, C, dev):
     return names, [sd[k].to(dev).contiguous().requires_grad_(True) for k in names]
 
 
-def cpu_baseline(spec, C, T, budget_s=20.0):
-    """The oracle's dense path (same torch ops the reference issues: conv/matmul, pooling, GroupNorm,
-    nearest upsample, log_softmax) fp32 on the host cores, fwd+bwd, on a bounded sample of the workload."""
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(spec, C, T, B=8):
+    """The dense hot path as the torch MODULE graph the reference runs (nn.Conv1d on [B, C, T], max_pool1d, GroupNorm,
+    interpolate, log_softmax: oracle/dense.py:module_graph), fp32, fwd+bwd on one batch of the bench's own
+    shape (B=8 x T=4096), one thread per PHYSICAL core, best of 3 passes after a warm-up pass."""
     from oracle import dense as od
 
     ocfg = od.EncoderConfig(in_dim=spec.in_dim, hidden=spec.hidden, num_classes=C, stages=list(spec.stages),
                             pooling=spec.pooling, pooling_type=spec.pooling_type, pooling_layers=list(spec.pooling_layers),
                             leaky_relu=spec.leaky_relu, last_gn=spec.last_gn, last_gn_num_groups=spec.last_gn_num_groups,
                             last_relu=spec.last_relu)
-    params = od.to_torch(od.seeded_params(ocfg, 1), torch.float32, requires_grad=True)
-    B = 2
-    tape = torch.randn(B, T, spec.in_dim)
-    w = torch.randn(B, T, C)
-    frames, t_used = 0, 0.0
-    for it in range(100):
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        torch.manual_seed(5)
+        model = od.module_graph(ocfg)
+        tape = torch.randn(B, T, spec.in_dim)
+        w = torch.randn(B, C, T)
+        times = []
+        for it in range(4):
+            model.zero_grad()
+            t0 = time.perf_counter()
+            (w * model(tape)).sum().backward()
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(B * T / best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/dense.py:module_graph (nn.Conv1d / max_pool1d / GroupNorm / interpolate / log_softmax) fwd+bwd fp32, "
+                      f"B={B} x T={T} x D={spec.in_dim}, best of 3 passes ({', '.join(f'{t:.2f}' for t in times[1:])} s) after one warm-up, "
+                      f"{cores} threads = physical cores"}
+
+
+def _cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, n_videos, cores):
+    """ms per video with `cores` host threads decoding `n_videos` videos (the C oracle is a ctypes call: no GIL held)."""
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+
+    lps = [lp_h.copy() for _ in range(min(n_videos, 32))]     # distinct buffers (the decode only reads them)
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        list(pool.map(lambda i: oracle.viterbi_decode_table(lps[i % len(lps)], tr, P, fs, max_len), range(cores)))   # warm the pool
         t0 = time.perf_counter()
-        enc = od.encoder_forward(tape, params, ocfg)
-        _, logp = od.head_forward(enc, params, ocfg, T)
-        (w * logp).sum().backward()
-        dt = time.perf_counter() - t0
-        if it > 0:  # first pass warms the allocator
-            frames += B * T
-            t_used += dt
-        if t_used > budget_s:
-            break
-    return {"value": round(frames / t_used, 1), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/dense.py fwd+bwd fp32, B={B} x T={T} x D={spec.in_dim}, {frames // (B * T)} passes in {t_used:.1f}s"}
+        list(pool.map(lambda i: oracle.viterbi_decode_table(lps[i % len(lps)], tr, P, fs, max_len), range(n_videos)))
+        return (time.perf_counter() - t0) / n_videos * 1e3
 
 
 def viterbi_bench(dev, C=48):
-    """BASELINE config 5 shape: T=16384, 64-state transcript.  Single-stream latency and amortised
-    latency with 64 videos per launch; the C oracle (1 core) on the same input beside it."""
+    """Breakfast-typical (T=2000, N=6) and BASELINE config 5 (T=16384, 64-state transcript): single-stream latency and amortised
+    latency with many videos per launch; beside them the C oracle on ONE host core and on ALL physical cores (one video per
+    thread), which is the CPU figure the amortised GPU number has to be read against."""
     import oracle
     from mucon_amd import ops
     from mucon_amd.core.viterbi import PoissonModel
 
     fs, max_len = 30, 2000
+    cores = physical_cores()
     g = torch.Generator(device="cpu").manual_seed(7)
-    out = {}
+    out = {"cpu_cores": cores}
     # a Breakfast-typical video first (T ~ 2000 frames, 6 actions), single stream
     T, N = 2000, 6
     tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
@@ -119,25 +158,29 @@ def viterbi_bench(dev, C=48):
         ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(50):
         ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len)
     torch.cuda.synchronize()
-    out["ms_per_video_T2000_N6_single"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    out["ms_per_video_T2000_N6_single"] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
     lps256 = [torch.log_softmax(3 * torch.randn(T, C, device=dev), dim=1) for _ in range(256)]   # 256 videos in flight
     ops.viterbi_decode_batch(lps256, [tr] * 256, [P] * 256, fs, max_len)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(5):
         ops.viterbi_decode_batch(lps256, [tr] * 256, [P] * 256, fs, max_len)
     torch.cuda.synchronize()
-    out["ms_per_video_T2000_N6_batch256"] = round((time.perf_counter() - t0) / 3 / 256 * 1e3, 5)
+    out["ms_per_video_T2000_N6_batch256"] = round((time.perf_counter() - t0) / 5 / 256 * 1e3, 5)
     del lps256
     lp_h = lp.cpu().numpy()
-    t0 = time.perf_counter()
-    for _ in range(5):
+    best = float("inf")
+    for _ in range(20):
+        t0 = time.perf_counter()
         oracle.viterbi_decode_table(lp_h, tr, P, fs, max_len)
-    out["cpu_oracle_ms_per_video_T2000_N6"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        best = min(best, time.perf_counter() - t0)
+    out["cpu_oracle_ms_per_video_T2000_N6"] = round(best * 1e3, 4)
+    out["cpu_oracle_all_cores_ms_per_video_T2000_N6"] = round(_cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, 16 * cores, cores), 5)
     out["reference_python_ms_per_video_T2000_N6"] = 68.0   # measured in the build container, context only
+    bytes_small = T * C * 4 + T * 4
 
     T, N = 16384, 64
     tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
@@ -160,13 +203,33 @@ def viterbi_bench(dev, C=48):
         torch.cuda.synchronize()
         out[f"ms_per_video_{label}"] = round((time.perf_counter() - t0) / reps / nv * 1e3, 4)
     lp_h = lp.cpu().numpy()
-    t0 = time.perf_counter()
-    oracle.viterbi_decode_table(lp_h, tr, P, fs, max_len)
-    out["cpu_oracle_ms_per_video"] = round((time.perf_counter() - t0) * 1e3, 3)
-    out["config"] = (f"ms_per_video_single/batch64/batch256 and cpu_oracle_ms_per_video: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
-                     f"(K=546 columns, 64x66 hypotheses); every timing includes the upload of the job table and the result D2H")
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.viterbi_decode_table(lp_h, tr, P, fs, max_len)
+        best = min(best, time.perf_counter() - t0)
+    out["cpu_oracle_ms_per_video"] = round(best * 1e3, 3)
+    out["cpu_oracle_all_cores_ms_per_video"] = round(_cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, 4 * cores, cores), 4)
+    out["config"] = (f"ms_per_video_single/batch64/batch256 and cpu_oracle_*: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
+                     f"(K=546 columns, 64x66 hypotheses); every GPU timing includes the upload of the job table and the result D2H; "
+                     f"cpu_oracle_all_cores_*: {cores} threads, one video each, {cores} physical cores")
     out["algorithmic_bytes_per_video"] = T * C * 4 + T * 4
+    out["algorithmic_bytes_per_video_T2000_N6"] = bytes_small
     return out
+
+
+def viterbi_roofline(v):
+    """Viterbi against its algorithmic bytes (emissions read once + labels written: SURVEY.md 8d): a latency-bound DP, so the
+    fraction of the HBM peak is tiny by construction; it is reported, not hidden."""
+    def leg(ms, nbytes):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"ms_per_video": ms, "achieved": round(gbs, 3), "frac": round(gbs / PEAK_HBM_GBS, 6)}
+    b5, b2 = v["algorithmic_bytes_per_video"], v["algorithmic_bytes_per_video_T2000_N6"]
+    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": "viterbi_framescore_kernel + viterbi_dp_kernel",
+            "config5_T16384_N64": {"algorithmic_bytes_per_video": b5, "single": leg(v["ms_per_video_single"], b5),
+                                   "batch256": leg(v["ms_per_video_batch256"], b5)},
+            "T2000_N6": {"algorithmic_bytes_per_video": b2, "single": leg(v["ms_per_video_T2000_N6_single"], b2),
+                         "batch256": leg(v["ms_per_video_T2000_N6_batch256"], b2)}}
 
 
 def end_to_end_bench(dev, steps=40):
@@ -284,12 +347,17 @@ def main():
     enc_params, wc, bc = params[:-2], params[-2], params[-1]
     flat_params = params
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    tape = torch.randn(B, T, spec.in_dim, device=dev, generator=g)      # resident in HBM
+    # resident in HBM; several distinct batches, rotated, so that no tape read is served by the 256 MiB Infinity Cache
+    tapes = [torch.randn(B, T, spec.in_dim, device=dev, generator=g) for _ in range(max(1, args.tapes))]
     dlogp = torch.randn(B, T, C, device=dev, generator=g) / (B * T)     # dL/dlogp handed to the backward
     lr, wd = 0.01, 0.005                                                # reference default.py:21-24
     import types
     sgd = ops.FusedClipSGD([flat_params], None,                         # SGD(lr, weight_decay) in one launch (csrc/optim.hpp)
                            types.SimpleNamespace(param_groups=[{"lr": lr, "weight_decay": wd, "momentum": 0.0}]))
+    if dist is not None:   # identical replicas whatever the seeds did
+        for p_ in params:
+            dist.broadcast(p_.data, 0)
+    rank_key = (rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF          # every rank draws its own dropout masks
 
     wc2 = wc.reshape(wc.shape[0], wc.shape[1]) if wc.dim() == 3 else wc
 
@@ -297,7 +365,8 @@ def main():
         # forward and backward of the hot path as direct calls of the autograd Functions (the same C entry points in the
         # same order as logp.backward() would issue them; ops.run_forward / run_backward) -- no graph walk on the host, so
         # the step stays GPU-bound also on a busy host (the autograd route needs ~1.0 ms of host time per 1.2 ms step)
-        enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, int(i), *enc_params)
+        tape = tapes[i % len(tapes)]
+        enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, int(i) ^ rank_key, *enc_params)
         (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
         d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
         wc.grad, bc.grad = d_w.view_as(wc), d_b
@@ -333,19 +402,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    _lib.check(lib.mucon_profile_begin(args.steps), "profile_begin")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    sync()
-    elapsed = time.perf_counter() - t0
+    _lib.check(lib.mucon_profile_begin(args.steps * args.repeats), "profile_begin")
+    regions = []
+    for r in range(args.repeats):        # each region: exactly --steps steps between two (barrier + synchronize) brackets
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + r * args.steps + i)
+        sync()
+        regions.append(time.perf_counter() - t0)
     tot_ms = (ctypes.c_float * 2)()
     cnt = (ctypes.c_int32 * 2)()
     _lib.check(lib.mucon_profile_end(tot_ms, cnt), "profile_end")
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor(regions, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        regions = t.tolist()
+    elapsed = sorted(regions)[len(regions) // 2]       # the median region
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -363,16 +436,24 @@ def main():
                 rows //= 2
         flops_wg += 2.0 * B * rows * spec.hidden * spec.hidden
         bytes_wg += 2.0 * B * rows * spec.hidden * 4
-        # dominant kernel = the longest launch of the step: the batched weight gradients (f32-input MFMA, exact fp32)
-        dom = ("tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)", k_wg_ms)
+        # dominant kernel = the longest launch of the step: the batched weight gradients.  They run on the bf16 MFMA with exactly
+        # split fp32 operands (six bf16 MFMAs per fp32 product block: csrc/gemm_tn_split.hpp), so two fractions are given: the
+        # ALGORITHMIC fp32 FLOP rate against the f32-MFMA peak (what an exact-f32 instruction stream is capped at; it can pass 1)
+        # and the bf16 FLOPs actually issued against the dense bf16 peak -- the number that says how far the kernel is from ITS roof
+        split_tn = os.environ.get("MUCON_TN_SPLIT", "1") != "0"
+        dom = (("ts_batched_kernel: all weight gradients of the step in one launch (bf16 MFMA on exactly split fp32 operands)"
+                if split_tn else "tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)"), k_wg_ms)
         achieved = flops_wg / (dom[1] * 1e-3) / 1e12
-        traffic = traffic_fwd = None   # HBM bytes per launch from the rocprofv3 --pmc passes of tools/profile_round.sh (profiles/)
+        traffic = traffic_fwd = traffic_src = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+            with open(cands[-1]) as f:
                 tj = json.load(f)
+            traffic_src = "profiles/" + os.path.basename(cands[-1])
             traffic = tj.get("weight_gradients", {}).get("hbm_bytes_per_launch")
             traffic_fwd = tj.get("first_conv_fwd", {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
+        except (OSError, ValueError, IndexError):
             pass
         bytes_fwd = B * T * (spec.in_dim + spec.hidden) * 4.0
         out = {
@@ -384,11 +465,19 @@ def main():
                                    f"hidden {spec.hidden}, 11 dilated layers (BASELINE config 3 shape); training mode "
                                    f"(dropout on), fwd+bwd+SGD, tapes resident in HBM",
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
+            "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
+            "tape_batches_rotated": len(tapes), "tape_bytes_resident": len(tapes) * B * T * spec.in_dim * 4,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
-                         "flops_per_launch": flops_wg, "all_weight_gradients_launch_ms": round(k_wg_ms, 4),
-                         "rocprof_summary": "profiles/r01_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
+                         "flops_per_launch": flops_wg, "launches_timed": int(cnt[1]),
+                         "issued_bf16_tflops": round((6 if split_tn else 1) * achieved, 1) if split_tn else None,
+                         "frac_of_bf16_mfma_peak": round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4) if split_tn else None,
+                         "hbm_frac": round(bytes_wg / (dom[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "note": "achieved = algorithmic fp32 FLOP / launch time; peak = f32-input MFMA (dtype f32); the launch issues 6 bf16 "
+                                 "MFMA FLOP per algorithmic FLOP, frac_of_bf16_mfma_peak prices those against the 2.5 PFLOP/s dense bf16 peak",
+                         "rocprof_summary": "profiles/r02_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
@@ -403,13 +492,15 @@ def main():
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(value / world * BYTES_PER_FRAME_FWD_BWD / 1e9 / PEAK_HBM_GBS, 4),
                                         "bytes_per_frame": BYTES_PER_FRAME_FWD_BWD,
-                                        "note": "per GPU; the path is f32-compute-bound (2.52 MFLOP/frame): ceiling 13% of HBM peak"},
+                                        "note": "per GPU; 2.52 MFLOP/frame: an exact-f32 instruction stream caps this at 13% of the HBM peak, "
+                                                "the split-bf16 kernels at about 35%"},
             "fp32_fraction_whole_path": round(value / world * 2.517e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
         if not args.no_viterbi:
             out["viterbi"] = viterbi_bench(dev, C)
+            out["roofline_viterbi"] = viterbi_roofline(out["viterbi"])
             out["end_to_end"] = end_to_end_bench(dev)
             out["evaluation"] = eval_bench(dev)
     if dist is not None:

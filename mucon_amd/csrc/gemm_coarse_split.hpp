@@ -1,0 +1,274 @@
+// The two-stage residual-layer launches of the COARSE levels (< 16,384 rows in the batch: T/4 ... T/16, and every launch of a
+// batch-1 step) on the bf16 MFMA with exact three-way operand splitting -- same arithmetic, same weight images and the same
+// register-resident hand-over between the two products as gemm_fused_split.hpp, organised for latency instead of throughput.
+//
+// These launches are chains: with 16 rows per workgroup a level has 128 ... 512 workgroups, and what a workgroup costs is the
+// length of its dependent sequence (the f32-MFMA kernels: 16 k-tiles of LDS store / barrier / LDS read / MFMA, 8 - 20 us a
+// launch at 5 - 25 % MFMA utilisation).  Here the four waves of a workgroup SPLIT K:
+//   stage 1  wave w multiplies channels 32 w .. 32 w + 31 of every tap (one 32-deep step per tap) -- 48 MFMAs per tap instead of
+//            192 -- and loads exactly the activation values and weight fragments it multiplies: every weight fragment of the
+//            layer is used by ONE wave of the workgroup, once, so it goes straight from L2 into operand registers (the images of
+//            fs_pack_kernel are lane-linear: one coalesced 1 KB load per fragment), no LDS staging, no barrier in the loop;
+//   reduce   the four partial tiles meet in LDS (one barrier); wave w finishes channel blocks 2 w, 2 w + 1: bias / non-linearity
+//            (FWD) or residual / mask / max-pool un-routing / dropout replay (BWD) -- which are exactly the 32 channels that
+//            form 32-deep step w of stage 2's reduction, in accumulator order;
+//   stage 2  wave w multiplies that step (48 MFMAs), second reduction, wave w finishes output blocks 2 w, 2 w + 1.
+// The dependent sequence is 192 MFMAs and two LDS exchanges instead of 768 MFMAs and 16 barriers; sums are taken in a fixed
+// order (wave 0 .. 3): bitwise reproducible, a video alone == the same video inside a batch.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+#include "gemm_fused.hpp"
+#include "gemm_fused_split.hpp"
+
+// TAPS = 1: a 1x1 product (a dilated conv whose dilation reaches past the sequence -- W1img then points at the centre tap's four
+// steps -- or last_conv); ONE: stage 1 only; PRO_ACT: the non-linearity on the loaded rows (last_conv's input, temporal.py:144).
+template <bool BWD, int POOL, int TAPS, bool ONE, bool PRO_ACT>
+__global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img) {
+    constexpr bool UNPOOL = BWD && POOL >= 3;
+    constexpr int R2 = UNPOOL ? 2 : 1;
+    __shared__ f32x4 red1[4 * 8 * 64];            // [wave][channel block][lane]: 32 KB
+    __shared__ f32x4 red2[ONE ? 1 : 4 * R2 * 8 * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int trow_raw = blockIdx.x * 16 + c;
+    const bool valid = trow_raw < p.Trows;
+    const int tcl = min(trow_raw, p.Trows - 1);
+    const long vbase = (long)b * p.Trows;
+    const long grow = (vbase + tcl) * 128 + 4 * g;
+    const long grow2 = UNPOOL ? ((long)b * p.Tfine + 2 * tcl) * 128 + 4 * g : grow;
+
+    // ---- loads: the wave's activation slices, then its weight fragments in the order they are multiplied
+    f32x4 ra[TAPS][2];
+    bool rok[TAPS];
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) {
+        const int ts = trow_raw + (i - TAPS / 2) * p.tap_step;
+        rok[i] = valid && ts >= 0 && ts < p.Trows;
+        const float *src = p.A + (vbase + min(max(ts, 0), p.Trows - 1)) * 128 + 32 * w + 8 * g;
+        ra[i][0] = *reinterpret_cast<const f32x4 *>(src);
+        ra[i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+    }
+    constexpr int NP = TAPS * 8;      // (tap, channel block) pairs of stage 1, three plane fragments each
+    constexpr int D = 8;              // pairs in flight
+    bf16x8 wf[D][3];
+    const uint16_t *w1 = W1img + (long)w * FS_WSTEP + lane * 8;      // step (tap * 4 + w): + tap * 4 * FS_WSTEP
+    auto loadW1 = [&](int i, int slot) {
+        const uint16_t *src = w1 + (long)(i >> 3) * (4 * FS_WSTEP) + (i & 7) * 512;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = *reinterpret_cast<const bf16x8 *>(src + pl * (128 * 32));
+    };
+#pragma unroll
+    for (int i = 0; i < D && i < NP; ++i) loadW1(i, i);
+
+    struct Planes { bf16x8 pl[3]; };
+    auto split8 = [&](const float (&x)[8]) {
+        u32x4 hh, mm, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t a, bb, cc;
+            sp_split2(x[2 * e], x[2 * e + 1], a, bb, cc);
+            hh[e] = a;
+            mm[e] = bb;
+            ll[e] = cc;
+        }
+        Planes P;
+        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
+        return P;
+    };
+    auto mfma6 = [&](f32x4 a, const bf16x8 (&wv)[3], const Planes &X) {
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], X.pl[1], a, 0, 0, 0);   // small terms first
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[2], X.pl[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], X.pl[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[0], a, 0, 0, 0);
+        return a;
+    };
+
+    // epilogue operands of the two channel blocks this wave finishes (2 w, 2 w + 1): requested now, used after the reductions
+    f32x4 aux1[2], msk1[2], aux2[R2][2], bia2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = 2 * w + j;
+        if (!BWD) aux1[j] = p.bias1 ? *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else aux1[j] = p.res1 ? *reinterpret_cast<const f32x4 *>(p.res1 + grow + 16 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BWD && p.mask1) msk1[j] = *reinterpret_cast<const f32x4 *>(p.mask1 + grow + 16 * nb);
+        if (!ONE) {
+#pragma unroll
+            for (int r = 0; r < R2; ++r)
+                aux2[r][j] = *reinterpret_cast<const f32x4 *>((BWD ? p.mask2 : p.res2) + grow2 + 128 * r + 16 * nb);
+            if (!BWD) bia2[j] = *reinterpret_cast<const f32x4 *>(p.bias2 + 16 * nb + 4 * g);
+        }
+    }
+
+    // ---- stage 1
+    Planes xa[TAPS];
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = ra[i][0][e];
+            x[4 + e] = ra[i][1][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (PRO_ACT) x[e] = act_f(x[e], p.slope);
+            x[e] = rok[i] ? x[e] : 0.f;
+        }
+        xa[i] = split8(x);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stage 2's fragments (step w of W2) ride behind stage 1's in the same ring
+    const uint16_t *w2 = ONE ? nullptr : W2img + (long)w * FS_WSTEP + lane * 8;
+    auto loadW2 = [&](int nb, int slot) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = *reinterpret_cast<const bf16x8 *>(w2 + pl * (128 * 32) + nb * 512);
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        acc[i & 7] = mfma6(acc[i & 7], wf[i % D], xa[i >> 3]);
+        if (i + D < NP) loadW1(i + D, i % D);
+        else if (!ONE) loadW2(i + D - NP, i % D);      // NP is a multiple of D: slots line up
+    }
+
+    // ---- first reduction (fixed order), stage-1 epilogue on blocks 2 w, 2 w + 1
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) red1[(w * 8 + nb) * 64 + lane] = acc[nb];
+    __syncthreads();
+    f32x4 h[R2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = 2 * w + j;
+        f32x4 x = ((red1[(0 * 8 + nb) * 64 + lane] + red1[(1 * 8 + nb) * 64 + lane]) + red1[(2 * 8 + nb) * 64 + lane]) +
+                  red1[(3 * 8 + nb) * 64 + lane];
+        x += aux1[j];
+        if (!BWD) {
+            if (!ONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+            }
+        } else if (p.mask1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] *= act_grad(msk1[j][e], p.slope);
+        }
+        if constexpr (!UNPOOL) {
+            if (valid) *reinterpret_cast<f32x4 *>(p.out1 + grow + 16 * nb) = x;
+            if (BWD && p.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(grow + 16 * nb + e));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[0][j][e] = valid ? x[e] : 0.f;
+        } else {
+            f32x4 u0 = x, u1 = x;
+            if (POOL == 3) {
+                const f32x4 y0 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2 + 16 * nb);
+                const f32x4 y1 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2 + 128 + 16 * nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool second = y1[e] > y0[e];
+                    u0[e] = second ? 0.f : x[e];
+                    u1[e] = second ? x[e] : 0.f;
+                }
+            }
+            if (valid) {
+                *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 16 * nb) = u0;
+                *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 128 + 16 * nb) = u1;
+                if (trow_raw == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
+                    *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4 *>(p.out2 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (p.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u0[e] *= drop_mul(p.drop, (uint32_t)(grow2 + 16 * nb + e));
+                    u1[e] *= drop_mul(p.drop, (uint32_t)(grow2 + 128 + 16 * nb + e));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[0][j][e] = valid ? u0[e] : 0.f;
+                h[R2 - 1][j][e] = valid ? u1[e] : 0.f;
+            }
+        }
+    }
+    if constexpr (ONE) return;
+
+    // ---- stage 2: this wave's 32 channels are step w of the reduction, in accumulator order
+    Planes x2[R2];
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = h[r][0][e];
+            x[4 + e] = h[r][1][e];
+        }
+        x2[r] = split8(x);
+    }
+    f32x4 acc2[R2][8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) acc2[r][nb] = mfma6(f32x4{0.f, 0.f, 0.f, 0.f}, wf[nb % D], x2[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R2; ++r)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) red2[((w * R2 + r) * 8 + nb) * 64 + lane] = acc2[r][nb];
+    __syncthreads();
+
+    // ---- second reduction, stage-2 epilogue on output blocks 2 w, 2 w + 1
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const long gr = grow2 + 128 * r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = 2 * w + j;
+            f32x4 x = ((red2[((0 * R2 + r) * 8 + nb) * 64 + lane] + red2[((1 * R2 + r) * 8 + nb) * 64 + lane]) +
+                       red2[((2 * R2 + r) * 8 + nb) * 64 + lane]) + red2[((3 * R2 + r) * 8 + nb) * 64 + lane];
+            if (!BWD) {
+                x += bia2[j];
+                if (p.drop.thresh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(gr + 16 * nb + e));
+                }
+                x += aux2[r][j];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= act_grad(aux2[r][j][e], p.slope);
+            }
+            if (BWD || POOL == 0) {
+                if (valid) *reinterpret_cast<f32x4 *>(p.out2 + gr + 16 * nb) = x;
+            } else {
+                if (POOL == 1 && valid) *reinterpret_cast<f32x4 *>(p.out_pre + gr + 16 * nb) = x;
+                f32x4 y;   // rows 2u, 2u + 1 sit on neighbouring lanes
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = __shfl_xor(x[e], 1);
+                    y[e] = POOL == 1 ? fmaxf(x[e], o) : x[e] + o;
+                }
+                if ((trow_raw & 1) == 0 && trow_raw + 1 < p.Trows)
+                    *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (p.Trows >> 1) + (trow_raw >> 1)) * 128 + 4 * g + 16 * nb) = y;
+            }
+        }
+    }
+}
+
+template <bool BWD, int POOL, int TAPS, bool ONE = false, bool PRO_ACT = false>
+static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
+    dim3 grid((p.Trows + 15) / 16, B);
+    hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT>), grid, dim3(256), 0, s, p, W1img, W2img);
+    return hipGetLastError();
+}

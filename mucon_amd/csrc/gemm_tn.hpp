@@ -217,10 +217,12 @@ struct TnJob {
     TnParams p;
     int block0, nkc;      // first block of the job, k-chunks per time chunk
     int x0_act, dual;
+    int nmc;              // time chunks (gemm_tn_split.hpp)
 };
 struct TnBatch {
     TnJob j[TN_MAX_BATCH];
     int njobs, nblocks;
+    int xcd_order;        // gemm_tn_split.hpp
 };
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void tn_batched_kernel(const TnBatch tb) {

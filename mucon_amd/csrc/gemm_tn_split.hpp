@@ -31,7 +31,8 @@
 #define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
 #endif
 constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 32-step G image (24,576 B)
-constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2;       // two buffers x two images: 98,304 B
+constexpr int TS_XT_FLOATS = 32 * 32;                   // a wave's X tile [32 time steps][32 columns] (4 KB), transposed through LDS
+constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS_XT_FLOATS * 4;   // two buffers x two images + eight X tiles: 131,072 B
 
 template <bool TWO_G, bool DROP>
 __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
@@ -59,7 +60,11 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     const int ldx = second ? 128 : p.ldx;
     const int Tx = second ? p.Trows : p.Tx;
     const float *Xu = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;   // wave-uniform
-    const uint32_t x_lane = (uint32_t)((8 * h) * ldx + cg * 32 + r) * 4u;                             // per-lane byte offset
+    // X is fetched in 16-byte pieces: lane -> (row lane >> 3 of 8, columns 4 (lane & 7) .. + 3), four instructions per 32-step tile
+    // (a 4-byte load per element costs the memory pipeline as much per instruction: 16 of them per tile were its bottleneck)
+    const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
+    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;                              // per-lane byte offset
+    float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS_XT_FLOATS;               // this wave's transposition tile
 
     // staging role: SAME image -> unit (s, h) = (wave >> 2, (wave >> 1) & 1); TWO_G -> image wave >> 2, s = (wave >> 1) & 1, units h = 0, 1
     const int sn = tid & 127;
@@ -78,7 +83,8 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + lane_bytes);
     };
 
-    float rx[2][2][8];       // X: [set][step][time slot], two tiles in flight
+    f32x4 rx[2][4];          // X: [set][8-row group], two tiles in flight
+    float rawT[8];           // the eight time steps of this lane's column for the next MFMA step (read back from the X tile)
     float rgA[NU][4], rgB[NU][4];   // G: time slots 0-3 / 4-7 of the next image
     float bsum[NU];
 #pragma unroll
@@ -97,19 +103,27 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         if (x_int(tile)) {
             const float *ub = Xu + (long)(tbeg + tile * 32 + xoff) * ldx;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) rx[Q][s][j] = ld_su(ub + (long)(16 * s + j) * ldx, x_lane);
+            for (int i = 0; i < 4; ++i)
+                rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ub + (long)(8 * i) * ldx) + x_lane);
         } else {
-            const int row0 = tbeg + tile * 32 + 8 * h + xoff;
+            const int row0 = tbeg + tile * 32 + xrow + xoff;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ts = min(max(row0 + 16 * s + j, 0), Tx - 1);
-                    rx[Q][s][j] = Xu[(long)ts * ldx + cg * 32 + r];
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int ts = min(max(row0 + 8 * i, 0), Tx - 1);
+                rx[Q][i] = *reinterpret_cast<const f32x4 *>(Xu + (long)ts * ldx + cg * 32 + xc4);
+            }
         }
+    };
+    // a tile's 32 x 32 values go through the wave's own LDS tile: written as they were loaded (rows), read back by column into
+    // the MFMA operand order (lane (r, h): column r, time steps 8h .. 8h + 7 of step s).  Wave-private: program order is all it needs.
+    auto stageX = [&](auto SET) {
+        constexpr int Q = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 32 + xc4) = rx[Q][i];
+    };
+    auto readX = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rawT[j] = xT[(16 * s + 8 * h + j) * 32 + r];
     };
     auto fixX = [&](float (&raw)[8], int tile, int s) {   // non-linearity of the last_conv job, zero padding, chunk end
 #pragma unroll
@@ -250,7 +264,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
     };
     Planes cur;
-    {   // prologue: image of tile 0, X of tiles 0 and 1, first half of image 1, operand of step (0, 0)
+    {   // prologue: image of tile 0, X of tiles 0 .. 2 requested, tile 0 staged, first half of image 1, operand of step (0, 0)
         gloadG(0, I0{});
         gloadG(0, I1{});
         gloadX(0, I0{});
@@ -262,43 +276,52 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         splitstoreG(0, 0, I0{}, 1.f);
         splitstoreG(0, 0, I1{}, 1.f);
         gloadG(min(1, last), I0{});
-        if (!x_int(0)) fixX(rx[0][0], 0, 0);
-        cur = convertX(rx[0][0]);
+        stageX(I0{});
+        gloadX(min(2, last), I0{});
+        readX(0);
+        if (!x_int(0)) fixX(rawT, 0, 0);
+        cur = convertX(rawT);
         __syncthreads();
     }
 
-    // tile mt (image in buffer Q, X in set Q):
-    //   { second half of image mt+1 requested } { MFMAs of step 0 | split of X step 1, first half of image mt+1 -> buffer O }
-    //   { first half of image mt+2 and X of tile mt+2 requested } { MFMAs of step 1 | split of X (mt+1, step 0), second half of image mt+1 }
+    // tile mt (image in buffer Q; the wave's X tile holds tile mt; set O holds tile mt+1, set Q tile mt+2 on its way):
+    //   { second half of image mt+1 requested; X step 1 read back }
+    //   { MFMAs of step 0 | split of X step 1, first half of image mt+1 -> buffer O }
+    //   { X tile <- tile mt+1 (set O), set O <- tile mt+3 requested; first half of image mt+2 requested; X (mt+1, step 0) read back }
+    //   { MFMAs of step 1 | split of X (mt+1, step 0), second half of image mt+1 }
     auto tile = [&](int mt, auto SET, auto OTHER) {
         constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
-        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last);
+        (void)Q;
+        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n3 = min(mt + 3, last);
         const float bw = mt < last ? 1.f : 0.f;
         if (!(TS_ABL & 8)) gloadG(n1, I1{});
-        if (!x_int(mt)) fixX(rx[Q][1], mt, 1);
-        if (!x_int(n1)) fixX(rx[O][0], n1, 0);
+        readX(1);
+        if (!x_int(mt)) fixX(rawT, mt, 1);
         if (!g_int(n1)) fixG(n1, I0{});
         __builtin_amdgcn_sched_barrier(0);
-        pin(rx[Q][1]);   // (keeps the splits below in this block: without it they are duplicated into the fix-up branches, outside the weave)
+        pin(rawT);   // (keeps the splits below in this block: without it they are duplicated into the fix-up branches, outside the weave)
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgA[u]);
         mfma_step(Q, 0, cur);
-        Planes nxt = convertX(rx[Q][1]);
+        Planes nxt = convertX(rawT);
         if (!(TS_ABL & 4)) splitstoreG(n1, O, I0{}, bw);
         weave();
         use(nxt);   // (a use inside the phase: otherwise the split is sunk behind the branches below, out of the weave)
         __builtin_amdgcn_sched_barrier(0);
+        stageX(OTHER);
         if (!(TS_ABL & 8)) {
             gloadG(n2, I0{});
-            gloadX(n2, SET);
+            gloadX(n3, OTHER);
         }
+        readX(0);
+        if (!x_int(n1)) fixX(rawT, n1, 0);
         if (!g_int(n1)) fixG(n1, I1{});
         __builtin_amdgcn_sched_barrier(0);
-        pin(rx[O][0]);
+        pin(rawT);
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgB[u]);
         mfma_step(Q, 1, nxt);
-        cur = convertX(rx[O][0]);
+        cur = convertX(rawT);
         if (!(TS_ABL & 4)) splitstoreG(n1, O, I1{}, bw);
         weave();
         use(cur);
@@ -346,15 +369,30 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
     int ji = 0;
     while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
     const TnJob &job = tb.j[ji];
+    if ((int)blockIdx.x - job.block0 >= ((job.nkc + 1) >> 1) * job.nmc) return;   // padding block between two jobs
     const int nkc2 = (job.nkc + 1) >> 1;
     const int local = blockIdx.x - job.block0;
-    const int mc = local / nkc2, kc2 = local - mc * nkc2;
+    int mc = local / nkc2, kc2 = local - mc * nkc2;
+    if (tb.xcd_order) {
+        // The nkc2 workgroups of a time chunk read the same gradient rows.  Workgroups are dealt round-robin over the 8 XCDs
+        // (block b and b + 8 share one -- observed, used for speed only), so inside every run of 8 * nkc2 blocks the chunk is
+        // the block index mod 8: the workgroups that share rows share an L2 (4 MB per XCD; first_conv's 1 MB of rows per chunk
+        // is fetched from the Infinity Cache once instead of eight times).
+        const int nmc = job.nmc, grp = 8 * nkc2;
+        const int G = local / grp;
+        if ((G + 1) * 8 <= nmc) {
+            const int in = local - G * grp;
+            mc = G * 8 + (in & 7);
+            kc2 = in >> 3;
+        }
+    }
     const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
     if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
     else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
     else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
 }
 
+extern int g_ts_xcd;   // XCD-aware block order of the batched launch (MUCON_TS_XCD)
 static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
     static bool attr_set = false;
@@ -372,9 +410,12 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
         const TnJob &src = tb.j[tb.njobs - 1 - i];
         lb.j[i] = src;
         lb.j[i].block0 = blocks;
-        blocks += ((src.nkc + 1) / 2) * src.block0;   // block0 carried the time-chunk count while queued
+        lb.j[i].nmc = src.block0;                     // block0 carried the time-chunk count while queued
+        blocks += ((src.nkc + 1) / 2) * src.block0;
+        if (g_ts_xcd) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
     }
     lb.nblocks = blocks;
+    lb.xcd_order = g_ts_xcd;
     hipLaunchKernelGGL(ts_batched_kernel, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();

@@ -17,8 +17,12 @@
 #include "gemm_tn.hpp"
 #include "gemm_split.hpp"
 #include "gemm_tn_split.hpp"
+#include "gemm_fused_split.hpp"
+#include "gemm_coarse_split.hpp"
 #include "small_kernels.hpp"
 
+int g_ts_xcd = 1;             // the split weight-gradient launch keeps the workgroups that share gradient rows on one XCD (MUCON_TS_XCD=0: plain order)
+int g_fs_nw = 0;              // waves per workgroup of the split-bf16 two-stage kernels: 0 = by level size, 4 / 8 forced (MUCON_FUSED_SPLIT_NW)
 int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
 int g_first_conv_8w = 1;   // 1: first_conv forward as 128-row 8-wave workgroups; 2: every full-resolution NT launch; 0: off
 int g_nt_force_bm = 0;
@@ -65,6 +69,9 @@ int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, o
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
 int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
+int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
+int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; MUCON_FUSED_SPLIT=0: f32 MFMA)
+long g_fs_rows = 16384;       // ... from this many rows in the batch (MUCON_FUSED_SPLIT_ROWS)
 int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
 int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false) {
@@ -83,6 +90,7 @@ struct Plan {
     size_t W1f, W1b, W2t, Wlt;
     size_t W0s;  // first_conv.weight as pre-split bf16 fragment images (gemm_split.hpp)
     size_t Wd0s; // layer 0's data-gradient operand (W1b) likewise: 3*128*384 bf16
+    size_t Wfs;  // per layer: the four split images of gemm_fused_split.hpp (W1f, W1b, W2, W2t)
     size_t x[MUCON_MAX_LAYERS + 1], h[MUCON_MAX_LAYERS], ypre[MUCON_MAX_LAYERS];
     size_t z, gnstat, gnpart;
     size_t gz, g[MUCON_MAX_LAYERS + 1], dpre[MUCON_MAX_LAYERS], dyd[MUCON_MAX_LAYERS];
@@ -135,6 +143,7 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.Wlt = take(16384);
     p.W0s = take((size_t)3 * 128 * p.D / 2);
     p.Wd0s = take((size_t)3 * 128 * 384 / 2);
+    p.Wfs = take((size_t)(p.L + 1) * FS_LAYER_ELEMS / 2);   // slot L: last_conv
     for (int l = 0; l <= p.L; ++l) p.x[l] = take((size_t)p.B * p.Tl[l] * 128);
     for (int l = 0; l < p.L; ++l) {
         p.h[l] = take((size_t)p.B * p.Tl[l] * 128);
@@ -172,6 +181,16 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
 }
 
 void prof_mark(int slot, bool stop, hipStream_t s);
+
+// Layer l's level fills the chip and its dilation reaches inside the sequence: its launches take the split-bf16 two-stage kernels
+inline bool fs_level(const mucon_encoder_cfg *cfg, const Plan &pl, int l) {
+    return g_fs && !g_no_fuse && l >= 0 && l < pl.L && (long)pl.B * pl.Tl[l] >= g_fs_rows && cfg->dilation[l] < pl.Tl[l];
+}
+inline bool cs_on() { return g_cs && !g_no_fuse; }
+inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t
+    const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : (mat == 2 ? 2L * FS_IMG_K384 : 2L * FS_IMG_K384 + FS_IMG_K128));
+    return reinterpret_cast<const uint16_t *>(ws + pl.Wfs) + (long)l * FS_LAYER_ELEMS + off;
+}
 
 // Second stream for the weight-gradient launches (they hang off the data-gradient chain and are not on its
 // critical path; the coarse levels leave most CUs idle).  Created on first use; MUCON_NO_OVERLAP=1 disables it.
@@ -316,6 +335,7 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
         one.j[0].p = t;
         one.j[0].nkc = t.Ktot / 128;
         one.j[0].block0 = nmc;
+        one.j[0].nmc = nmc;
         one.j[0].x0_act = a.x0_act ? 1 : 0;
         one.j[0].dual = dual ? 1 : 0;
         if (prof_slot >= 0) prof_mark(prof_slot, false, s);
@@ -419,6 +439,26 @@ static bool apply_knob(const char *name, const char *e) {
         if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
         return true;
     }
+    if (!strcmp(name, "MUCON_FUSED_SPLIT")) {
+        g_fs = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_COARSE_SPLIT")) {
+        g_cs = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSED_SPLIT_NW")) {
+        g_fs_nw = (atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_FUSED_SPLIT_ROWS")) {
+        g_fs_rows = atol(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TS_XCD")) {
+        g_ts_xcd = atoi(e) ? 1 : 0;
+        return true;
+    }
     if (!strcmp(name, "MUCON_TN_SPLIT")) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
@@ -489,7 +529,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
+static const char *const kKnobs[] = {"MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -601,6 +641,27 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(32, L + (split_dgrad0 ? 3 : (split_first ? 2 : 1))), dim3(PACK_THREADS), 0, s, pa);
     HIPCHK(hipGetLastError());
+    {   // split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp (a layer's images sit at its own slot)
+        int lo = -1, hi = -1;
+        for (int l = 0; l < L; ++l)
+            if (cs_on() || fs_level(cfg, pl, l)) {
+                if (lo < 0) lo = l;
+                hi = l;
+            }
+        if (lo >= 0) {
+            FsPackArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.nl = hi - lo + 1;
+            for (int l = lo; l <= hi; ++l) {
+                fa.dil_w[l - lo] = prm->dil_w[l];
+                fa.pw_w[l - lo] = prm->pw_w[l];
+            }
+            fa.last_w = (cs_on() && hi == L - 1) ? prm->last_w : nullptr;
+            fa.img = reinterpret_cast<uint16_t *>(ws + pl.Wfs) + (long)lo * FS_LAYER_ELEMS;
+            hipLaunchKernelGGL(fs_pack_kernel, dim3(64, fa.nl + (fa.last_w ? 1 : 0)), dim3(256), 0, s, fa);
+            HIPCHK(hipGetLastError());
+        }
+    }
 
     // first_conv + non-linearity (temporal.py:133); the tape is consumed row-major, no permute
     {
@@ -653,6 +714,26 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             f.out_pre = pool == 1 ? ws + pl.ypre[l] : nullptr;
             f.slope = slope;
             f.drop = dl;
+            if (fs_level(cfg, pl, l) && f.bias1 && f.bias2) {
+                const uint16_t *w1 = fs_img(ws, pl, l, 0), *w2 = fs_img(ws, pl, l, 2);
+                if (pool == 0) HIPCHK((launch_fs<false, 0>(f, w1, w2, B, s)));
+                else if (pool == 1) HIPCHK((launch_fs<false, 1>(f, w1, w2, B, s)));
+                else HIPCHK((launch_fs<false, 2>(f, w1, w2, B, s)));
+                continue;
+            }
+            if (cs_on() && f.bias1 && f.bias2) {
+                const uint16_t *w1 = fs_img(ws, pl, l, 0) + (centre_only ? 4 * FS_WSTEP : 0), *w2 = fs_img(ws, pl, l, 2);
+                if (centre_only) {
+                    if (pool == 0) HIPCHK((launch_cs<false, 0, 1>(f, w1, w2, B, s)));
+                    else if (pool == 1) HIPCHK((launch_cs<false, 1, 1>(f, w1, w2, B, s)));
+                    else HIPCHK((launch_cs<false, 2, 1>(f, w1, w2, B, s)));
+                } else {
+                    if (pool == 0) HIPCHK((launch_cs<false, 0, 3>(f, w1, w2, B, s)));
+                    else if (pool == 1) HIPCHK((launch_cs<false, 1, 3>(f, w1, w2, B, s)));
+                    else HIPCHK((launch_cs<false, 2, 3>(f, w1, w2, B, s)));
+                }
+                continue;
+            }
             if (pool == 0) HIPCHK((launch_fused<false, 0>(f, B, s)));
             else if (pool == 1) HIPCHK((launch_fused<false, 1>(f, B, s)));
             else HIPCHK((launch_fused<false, 2>(f, B, s)));
@@ -682,9 +763,22 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     {   // non-linearity + last_conv (temporal.py:144-145)
         const int Tz = pl.Tz;
+        if (cs_on() && prm->last_b && !g_no_fuse && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.Trows = Tz;
+            f.A = ws + pl.x[L];
+            f.taps = 1;
+            f.bias1 = prm->last_b;
+            f.out1 = ws + pl.z;
+            f.slope = slope;
+            f.drop = make_drop(0, 0, 0.f, false);
+            HIPCHK((launch_cs<false, 0, 1, true, true>(f, fs_img(ws, pl, L, 2), nullptr, B, s)));
+        } else {
         NtParams p = nt_base(ws + pl.x[L], (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, prm->last_w, prm->last_b,
                              ws + pl.z, slope);
         HIPCHK((launch_nt<true, false, false, false, false, false, 0>(p, B, s)));
+        }
     }
     {   // GroupNorm, ReLU, Dropout (models.py:759-768)
         GnArgs g;
@@ -796,7 +890,8 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             f.mask1 = ws + pl.x[L];
             f.out1 = ws + pl.g[L];
             fused_tail(f, L - 1);
-            HIPCHK((launch_fused<true, 0>(f, B, s)));
+            if (cs_on()) HIPCHK((launch_cs<true, 0, 1>(f, fs_img(ws, pl, L, 3), fs_img(ws, pl, L - 1, 3), B, s)));
+            else HIPCHK((launch_fused<true, 0>(f, B, s)));
             have_dpre = true;
         } else {
             NtParams p = nt_base(gz, (long)Tz * 128, 128, Tz, Tz, 1, 0, 128, ws + pl.Wlt, nullptr, ws + pl.g[L], slope);
@@ -875,7 +970,12 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                 f.res1 = dyd;
                 f.out1 = ws + pl.g[l];
                 fused_tail(f, l - 1);
-                HIPCHK((launch_fused<true, 0>(f, B, s)));
+                if (fs_level(cfg, pl, l) && fs_level(cfg, pl, l - 1)) HIPCHK((launch_fs<true, 0>(f, fs_img(ws, pl, l, 1), fs_img(ws, pl, l - 1, 3), B, s)));
+                else if (cs_on()) {
+                    const uint16_t *w1 = fs_img(ws, pl, l, 1) + (centre_only ? 4 * FS_WSTEP : 0), *w2 = fs_img(ws, pl, l - 1, 3);
+                    if (centre_only) HIPCHK((launch_cs<true, 0, 1>(f, w1, w2, B, s)));
+                    else HIPCHK((launch_cs<true, 0, 3>(f, w1, w2, B, s)));
+                } else HIPCHK((launch_fused<true, 0>(f, B, s)));
                 have_dpre = true;
             } else if (!g_no_fuse && g_pool_fuse && l >= 1 && cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= g_fuse_max_rows) {
                 // pooled boundary: dilated-conv data gradient on this (coarse) level, max-pool backward in its epilogue,
@@ -893,7 +993,19 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                 f.ypre = cfg->pool_type == 0 ? ws + pl.ypre[l - 1] : nullptr;
                 f.Tfine = pl.Tl[l - 1];
                 fused_tail(f, l - 1);
-                if (cfg->pool_type == 0) HIPCHK((launch_fused<true, 3>(f, B, s)));
+                if (fs_level(cfg, pl, l) && fs_level(cfg, pl, l - 1)) {
+                    if (cfg->pool_type == 0) HIPCHK((launch_fs<true, 3>(f, fs_img(ws, pl, l, 1), fs_img(ws, pl, l - 1, 3), B, s)));
+                    else HIPCHK((launch_fs<true, 4>(f, fs_img(ws, pl, l, 1), fs_img(ws, pl, l - 1, 3), B, s)));
+                } else if (cs_on()) {
+                    const uint16_t *w1 = fs_img(ws, pl, l, 1) + (centre_only ? 4 * FS_WSTEP : 0), *w2 = fs_img(ws, pl, l - 1, 3);
+                    if (cfg->pool_type == 0) {
+                        if (centre_only) HIPCHK((launch_cs<true, 3, 1>(f, w1, w2, B, s)));
+                        else HIPCHK((launch_cs<true, 3, 3>(f, w1, w2, B, s)));
+                    } else {
+                        if (centre_only) HIPCHK((launch_cs<true, 4, 1>(f, w1, w2, B, s)));
+                        else HIPCHK((launch_cs<true, 4, 3>(f, w1, w2, B, s)));
+                    }
+                } else if (cfg->pool_type == 0) HIPCHK((launch_fused<true, 3>(f, B, s)));
                 else HIPCHK((launch_fused<true, 4>(f, B, s)));
                 have_dpre = true;
                 unpooled_by_producer = true;
@@ -912,6 +1024,36 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                     if (cfg->pool_type == 0) HIPCHK((launch_nt<false, false, false, false, true, true, 3>(p, B, s)));
                     else HIPCHK((launch_nt<false, false, false, false, true, true, 4>(p, B, s)));
                     unpooled_by_producer = true;
+                } else if (l == 0 && fs_level(cfg, pl, 0)) {
+                    // layer 0's dilated-conv data gradient (+ residual, through first_conv's non-linearity): stage 1 of the split-bf16
+                    // two-stage kernel on its own (16x16x32 tiles, no k-split across waves)
+                    FusedParams f;
+                    memset(&f, 0, sizeof(f));
+                    f.Trows = Tl;
+                    f.A = dpre;
+                    f.taps = 3;
+                    f.tap_step = -cfg->dilation[0];
+                    f.res1 = dyd;
+                    f.mask1 = ws + pl.x[0];
+                    f.out1 = ws + pl.g[0];
+                    f.slope = slope;
+                    f.drop = make_drop(0, 0, 0.f, false);
+                    HIPCHK((launch_fs<true, 0, true>(f, fs_img(ws, pl, 0, 1), nullptr, B, s)));
+                } else if (l == 0 && cs_on()) {   // ... and below the chip-filling sizes on the k-split kernel, stage 1 alone
+                    FusedParams f;
+                    memset(&f, 0, sizeof(f));
+                    f.Trows = Tl;
+                    f.A = dpre;
+                    f.taps = centre_only ? 1 : 3;
+                    f.tap_step = -cfg->dilation[0];
+                    f.res1 = dyd;
+                    f.mask1 = ws + pl.x[0];
+                    f.out1 = ws + pl.g[0];
+                    f.slope = slope;
+                    f.drop = make_drop(0, 0, 0.f, false);
+                    const uint16_t *w1 = fs_img(ws, pl, 0, 1) + (centre_only ? 4 * FS_WSTEP : 0);
+                    if (centre_only) HIPCHK((launch_cs<true, 0, 1, true>(f, w1, nullptr, B, s)));
+                    else HIPCHK((launch_cs<true, 0, 3, true>(f, w1, nullptr, B, s)));
                 } else if (l == 0 && !centre_only && g_nt_split && (long)B * Tl >= g_first_conv_split_rows) {
                     // bf16 MFMA on exactly split operands (gemm_split.hpp); the W1b image was written by the forward's pack_weights
                     HIPCHK((launch_nt_split<false, true, true, true>(p, reinterpret_cast<const uint16_t *>(ws + pl.Wd0s), B, s)));

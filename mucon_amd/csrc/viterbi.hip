@@ -129,6 +129,89 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
     }
 }
 
+// The same chain at its own speed (fs <= 256, C a multiple of 4): a chunk holds WHOLE columns (cols x fs rows), so wave 0
+// walks it in fixed 16-row batches -- batch b + 1 is read from LDS into registers while batch b is added: the chain never
+// waits for a read (the kernel above alternates six reads and six adds, ~20 ns per row; this one is bound by the dependent
+// float32 add itself).  A column's tail batch is padded with -0.0f, the additive identity of IEEE addition for every x
+// including both zeros: the padded adds change no bit.
+constexpr int FSC_B = 16;
+__global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_cols_kernel(const mucon_viterbi_job *jobs, const float *lp,
+                                                                             char *ws, int C, int fs, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][cols * fs * C]
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int K = job.T / fs;
+    if (K < 1) return;
+    float *F = reinterpret_cast<float *>(ws + job.ws_off);
+    const int tid = threadIdx.x;
+    const float *src = lp + job.lp_off;
+    const int rows_c = cols * fs;                 // rows per chunk
+    const int chunk4 = rows_c * C / 4;            // float4 per chunk
+    const int nchunks = (K + cols - 1) / cols;
+    const long total4 = (long)K * fs * C / 4;
+    const int nper = (chunk4 + FS_THREADS - 1) / FS_THREADS;   // <= 15 (256 rows x 64 classes)
+    vit_f32x4 r[16];
+    auto gload = [&](int ci) {
+        const long base4 = (long)ci * chunk4;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u < nper) {
+                long e = base4 + u * FS_THREADS + tid;
+                e = e < total4 - 1 ? e : total4 - 1;
+                r[u] = reinterpret_cast<const vit_f32x4 *>(src)[e];
+            }
+    };
+    auto sstore = [&](int buf) {
+        vit_f32x4 *dst = reinterpret_cast<vit_f32x4 *>(fs_smem + buf * rows_c * C);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u < nper && u * FS_THREADS + tid < chunk4) dst[u * FS_THREADS + tid] = r[u];
+    };
+    const int nb = (fs + FSC_B - 1) / FSC_B;      // batches per column
+    float run = -0.0f, prev = 0.f;
+    int k = 0;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int cur = ci & 1;
+        gload(ci + 1 < nchunks ? ci + 1 : ci);
+        if (tid < 64) {
+            const float *col0 = fs_smem + cur * rows_c * C + (tid < C ? tid : C - 1);
+            const int ncols = min(cols, K - ci * cols);
+            const int nsteps = ncols * nb;
+            float va[FSC_B], vb[FSC_B];
+            auto load = [&](int step, float (&v)[FSC_B]) {
+                const int cc = step / nb, bb = step - cc * nb;
+                const float *p0 = col0 + (cc * fs + bb * FSC_B) * C;
+                const int left = fs - bb * FSC_B;      // rows of this column from the batch's first row on (wave-uniform)
+#pragma unroll
+                for (int u = 0; u < FSC_B; ++u) v[u] = u < left ? p0[u * C] : -0.0f;
+            };
+            auto add = [&](int step, const float (&v)[FSC_B]) {
+#pragma unroll
+                for (int u = 0; u < FSC_B; ++u) run = run + v[u];          // sequential float32 chain
+                const int cc = step / nb, bb = step - cc * nb;
+                if (bb == nb - 1) {                                         // end of column k
+                    if (tid < C) F[(long)k * C + tid] = (k == 0) ? run : run - prev;
+                    prev = run;
+                    ++k;
+                }
+            };
+            load(0, va);
+            for (int step = 0; step < nsteps; step += 2) {
+                if (step + 1 < nsteps) load(step + 1, vb);
+                add(step, va);
+                if (step + 1 < nsteps) {
+                    if (step + 2 < nsteps) load(step + 2, va);
+                    add(step + 1, vb);
+                }
+            }
+        }
+        sstore(cur ^ 1);
+        __syncthreads();
+    }
+}
+
 struct Cand {
     double v;
     int j;
@@ -199,7 +282,8 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     const int T = job.T, N = job.N;
     const int K = T / fs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwaves = VIT_THREADS / 64;
+    const int nthreads = blockDim.x;             // 64 x (waves that own a transcript state), at least 8 C: see the launch
+    const int nwaves = nthreads >> 6;
     const int vid = blockIdx.x;
 
     if (K < 1) {  // frame_scores[fs-1] does not exist: IndexError in the reference (viterbi.py:87)
@@ -234,13 +318,13 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     const size_t f_bytes = ((size_t)K * C * sizeof(float) + 15) & ~(size_t)15;
     uint8_t *bp = reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes);  // [K][N]
 
-    for (int e = tid; e < N; e += VIT_THREADS) a[e] = transcripts[job.tr_off + e];
-    for (int e = tid; e < N * J; e += VIT_THREADS) {
+    for (int e = tid; e < N; e += nthreads) a[e] = transcripts[job.tr_off + e];
+    for (int e = tid; e < N * J; e += nthreads) {
         const int n = e / J, j = e - n * J;
         Pl[e] = tables[job.p_off + (size_t)j * N + n];
     }
     // frame-score chunks 0 and 1
-    for (int e = tid; e < 2 * VIT_FCHUNK * C; e += VIT_THREADS) {
+    for (int e = tid; e < 2 * VIT_FCHUNK * C; e += nthreads) {
         const int col = e / C;
         Fs[e] = (col < K) ? F[e] : 0.f;
     }
@@ -257,7 +341,7 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     int jr0 = (J - (lane % J)) % J;                    // c = 0, r = lane       (lane < J assumed for r)
     int jr1 = (J - ((lane + 64) % J)) % J;             // c = 0, r = lane + 64
     const bool has0 = lane < J, has1 = lane + 64 < J;  // J <= 128 slots per state
-    float fpre = 0.f;
+    float fpre[2] = {0.f, 0.f};
 
     // per-wave state set, hoisted out of the column loop
     int sm[SPW], sam[SPW], sapm[SPW];
@@ -278,12 +362,20 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
         // stage frame scores: chunk q+1 is fetched at the start of chunk q and stored half way
         const int kin = k & (VIT_FCHUNK - 1);
         const int q = k / VIT_FCHUNK;
-        if (kin == 0 && k >= VIT_FCHUNK) {
-            const int col = (q + 1) * VIT_FCHUNK + tid / C;
-            fpre = (tid < VIT_FCHUNK * C && col < K) ? F[(size_t)(q + 1) * VIT_FCHUNK * C + tid] : 0.f;
+        if (kin == 0 && k >= VIT_FCHUNK) {   // two elements per thread: nthreads >= 8 C covers the 16 C of a chunk
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * nthreads;
+                const int col = (q + 1) * VIT_FCHUNK + e / C;
+                fpre[u] = (e < VIT_FCHUNK * C && col < K) ? F[(size_t)(q + 1) * VIT_FCHUNK * C + e] : 0.f;
+            }
         }
         if (kin == VIT_FCHUNK / 2 && k >= VIT_FCHUNK) {
-            if (tid < VIT_FCHUNK * C) Fs[((q + 1) & 1) * VIT_FCHUNK * C + tid] = fpre;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * nthreads;
+                if (e < VIT_FCHUNK * C) Fs[((q + 1) & 1) * VIT_FCHUNK * C + e] = fpre[u];
+            }
         }
         const float *Fk = Fs + (q & 1) * VIT_FCHUNK * C + kin * C;
         const int c_old = k - 1;
@@ -424,7 +516,7 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     __syncthreads();
     // ... and labelled, at the START of the video, with the last segment's label
     int32_t *lab = labels + job.label_off;
-    for (int t = tid; t < T; t += VIT_THREADS) {
+    for (int t = tid; t < T; t += nthreads) {
         int l;
         if (t < missing) {
             l = a[nseg - 1];
@@ -499,17 +591,32 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     const size_t fs_smem = (size_t)2 * FS_ROWS * C * sizeof(float);
     if (!fs_attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
             VIT_FAIL(MUCON_E_HIP);
         }
         fs_attr = true;
     }
-    hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
-                       static_cast<char *>(workspace), C, fs);
+    if (fs <= FS_ROWS && (C & 3) == 0) {   // whole columns per chunk: the pipelined chain
+        const int cols = FS_ROWS / fs;
+        hipLaunchKernelGGL(viterbi_framescore_cols_kernel, dim3(n_videos), dim3(FS_THREADS), (size_t)2 * cols * fs * C * sizeof(float), s,
+                           jobs, lp, static_cast<char *>(workspace), C, fs, cols);
+    } else {
+        hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
+                           static_cast<char *>(workspace), C, fs);
+    }
     const int spw = (max_N + 15) / 16;   // transcript states per wave
+    // one wave per SPW transcript states; fewer waves make the per-column barrier cheaper (a Breakfast-typical transcript has 6
+    // states: 6 waves instead of 16); the frame-score staging needs 8 C threads (two elements each)
+    const int spwt = spw <= 1 ? 1 : (spw <= 2 ? 2 : (spw <= 4 ? 4 : 8));   // the instantiated states-per-wave
+    int dp_threads = 64 * ((max_N + spwt - 1) / spwt);
+    const int min_threads = (8 * C + 63) / 64 * 64;
+    dp_threads = dp_threads < min_threads ? min_threads : dp_threads;
+    dp_threads = dp_threads > VIT_THREADS ? VIT_THREADS : dp_threads;
 #define VIT_LAUNCH(SPW)                                                                                              \
-    hipLaunchKernelGGL(viterbi_dp_kernel<SPW>, dim3(n_videos), dim3(VIT_THREADS), smem, s, jobs, transcripts,          \
+    hipLaunchKernelGGL(viterbi_dp_kernel<SPW>, dim3(n_videos), dim3(dp_threads), smem, s, jobs, transcripts,           \
                        length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J)
     if (spw <= 1) VIT_LAUNCH(1);
     else if (spw <= 2) VIT_LAUNCH(2);

@@ -172,7 +172,8 @@ class MuConEvaluator:
             # NaN accumulators (an IoD / IoU over a video without target segments) stay NaN through the sum, as on one rank
             flat = torch.tensor([x for k in keys for x in np.asarray(self.metrics[k].state(), dtype=np.float64)] + [float(self.skipped)],
                                 dtype=torch.float64, device=self.device)
-            dist.all_reduce(flat)
+            from .trainers import dist_all_reduce
+            dist_all_reduce(flat)
             vals, off = flat.cpu().numpy(), 0
             for k, n in zip(keys, sizes):
                 self.metrics[k].load_state(list(vals[off:off + n]))

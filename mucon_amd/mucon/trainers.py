@@ -31,6 +31,30 @@ def create_scheduler(cfg, optimizer):
     raise Exception("Invalid scheduler name (%s)" % s.name)
 
 
+def dist_all_reduce(t: torch.Tensor):
+    """all_reduce(sum) of a tensor in place.  RCCL ("nccl") reduces device tensors directly; under the gloo backend (CPU tests,
+    and several ranks sharing ONE GPU, which RCCL refuses) a device tensor travels through a host copy."""
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+
+
+def dist_broadcast(t: torch.Tensor, src: int = 0):
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+
+
 class GradBucket:
     """ONE all-reduce per optimizer step whose size and layout are fixed by the parameter list alone -- never by which
     gradients happen to exist, share a storage or were produced by the fused or the autograd path on this rank (ranks that
@@ -74,7 +98,7 @@ class GradBucket:
         if dst_zero:
             torch._foreach_zero_(dst_zero)
         self.flat[self.n:] = torch.tensor([1.0 if h else 0.0 for h in have], dtype=torch.float32).to(self.flat.device, non_blocking=True)
-        dist.all_reduce(self.flat)
+        dist_all_reduce(self.flat)
         self.flat[:self.n].mul_(1.0 / world_size)
         counts = self.flat[self.n:].tolist()        # one small read-back per step: who has a gradient anywhere
         for p, v, c in zip(self.params, self.views, counts):
@@ -95,7 +119,7 @@ def broadcast_parameters(model, src: int = 0):
     if not tensors:
         return
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    dist.broadcast(flat, src)
+    dist_broadcast(flat, src)
     torch._foreach_copy_(tensors, [c.view_as(t) for c, t in zip(flat.split([t.numel() for t in tensors]), tensors)])
 
 

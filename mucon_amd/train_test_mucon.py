@@ -57,11 +57,12 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = cfg.system.device
     if device.startswith("cuda"):
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # one process per GPU; more ranks than visible GPUs (tests on a 1-GPU box) wrap around and then need MUCON_DIST_BACKEND=gloo
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
         device = f"cuda:{torch.cuda.current_device()}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl" if device.startswith("cuda") else "gloo")
+        dist.init_process_group(os.environ.get("MUCON_DIST_BACKEND", "nccl" if device.startswith("cuda") else "gloo"))
     if rank == 0:
         print(cfg.dump())
     torch.manual_seed(int(cfg.system.seed))

@@ -212,3 +212,67 @@ def hot_path_grads(tape_np, params_np, cfg: EncoderConfig, w_logp, w_enc, dtype=
     L = (torch.tensor(w_logp, dtype=dtype) * logp).sum() + (torch.tensor(w_enc, dtype=dtype) * enc).sum()
     L.backward()
     return {k: v.grad.numpy() for k, v in p.items()}, float(L.detach())
+
+
+# ---------------------------------------------------------------------------------------- CPU baseline (bench.py only)
+def module_graph(cfg: EncoderConfig, params_np=None):
+    """The dense hot path as the torch MODULE graph the reference runs: nn.Conv1d on [B, C, T] tensors,
+    F.max_pool1d / avg_pool1d, nn.GroupNorm, F.interpolate(mode='nearest'), F.log_softmax -- the same calls, in the same order,
+    as WaveNetBlock.forward (temporal.py:128-147), WaveNetLayer.forward (:43-53), temporal_modeling_forward
+    (models.py:746-773: permute, encoder, GroupNorm, ReLU) and frame_classifier_forward + predict's log-softmax (models.py:567-582,
+    :368).  Dropout is left out (eval-mode function, as the rest of this file).  bench.py's cpu_baseline leg times it."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class Layer(nn.Module):
+        def __init__(self, H, d):
+            super().__init__()
+            self.dilated_conv = nn.Conv1d(H, H, 3, dilation=d, padding=d)
+            self.conv_1x1 = nn.Conv1d(H, H, 1)
+
+        def forward(self, x):
+            y = self.dilated_conv(x)
+            y = F.leaky_relu(y) if cfg.leaky_relu else F.relu(y)
+            y = self.conv_1x1(y)
+            return y + x
+
+    class HotPath(nn.Module):
+        def __init__(self):
+            super().__init__()
+            H = cfg.hidden
+            self.first_conv = nn.Conv1d(cfg.in_dim, H, 1)
+            self.layers = nn.ModuleList([Layer(H, d) for d in cfg.stages])
+            self.last_conv = nn.Conv1d(H, H, 1)
+            self.gn = nn.GroupNorm(cfg.last_gn_num_groups, H, eps=cfg.gn_eps) if cfg.last_gn else None
+            self.classifier = nn.Conv1d(H, cfg.num_classes, 1)
+
+        def forward(self, feats):                      # [B, T, D]
+            act = F.leaky_relu if cfg.leaky_relu else F.relu
+            x = feats.permute(0, 2, 1)                 # models.py:753
+            x = act(self.first_conv(x))
+            for i, l in enumerate(self.layers):
+                x = l(x)
+                if cfg.pooling and i in cfg.pooling_layers:
+                    x = F.max_pool1d(x, kernel_size=2) if cfg.pooling_type == "max" else F.avg_pool1d(x, kernel_size=2) * 2
+            x = self.last_conv(act(x))
+            if self.gn is not None:
+                x = self.gn(x)
+            if cfg.last_relu:
+                x = F.relu(x)
+            up = F.interpolate(x, size=feats.shape[1], mode="nearest")    # models.py:574
+            return F.log_softmax(self.classifier(up), dim=1)              # [B, C, T]
+
+    m = HotPath()
+    if params_np is not None:
+        with torch.no_grad():
+            sd = {"first_conv": "ft.first_conv", "last_conv": "ft.last_conv", "gn": "ft_last_gn", "classifier": "conv_classifier"}
+            for ours, theirs in sd.items():
+                mod = getattr(m, ours)
+                if mod is not None:
+                    mod.weight.copy_(torch.from_numpy(params_np[theirs + ".weight"]))
+                    mod.bias.copy_(torch.from_numpy(params_np[theirs + ".bias"]))
+            for i, l in enumerate(m.layers):
+                for part in ("dilated_conv", "conv_1x1"):
+                    getattr(l, part).weight.copy_(torch.from_numpy(params_np[f"ft.l_{i}.{part}.weight"]))
+                    getattr(l, part).bias.copy_(torch.from_numpy(params_np[f"ft.l_{i}.{part}.bias"]))
+    return m
