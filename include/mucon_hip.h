@@ -95,6 +95,21 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                       size_t workspace_bytes, const mucon_encoder_params *grads, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Encoder variant "noft": no temporal modelling, one position-wise linear map of the tape
+ * ---------------------------------------------------------------------------------------- */
+/* Replaces NoFt.forward (reference src/core/modules/temporal.py:56-74: a single kernel-size-1 nn.Conv1d, selected by
+ * cfg.model.ft.type = "noft", src/mucon/models.py:181-185):  out [B][T][128] = tape [B][T][D] * w [128][D]^T + b.
+ * It is first_conv without its non-linearity and runs on the same kernels (f32 MFMA; the split-bf16 kernel from 8,192
+ * frames per launch); the backward is first_conv's weight-gradient job (the tape needs no gradient).
+ * D a positive multiple of 128, 128 output channels. */
+size_t mucon_linear_workspace_bytes(int32_t B, int32_t T, int32_t D);
+int mucon_linear_fwd(int32_t B, int32_t T, int32_t D, const float *tape, const float *w, const float *b, float *out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+/* d_out [B][T][128] -> d_w [128][D], d_b [128] */
+int mucon_linear_bwd(int32_t B, int32_t T, int32_t D, const float *tape, const float *d_out, float *d_w, float *d_b,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * y-head: nearest upsample Tz -> Tf, 1x1 conv H -> C, log-softmax over C
  * ---------------------------------------------------------------------------------------- */
 size_t mucon_head_workspace_bytes(int32_t B, int32_t Tz, int32_t H, int32_t C);

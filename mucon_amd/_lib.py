@@ -93,6 +93,9 @@ SYMBOLS = {
     "mucon_encoder_fwd": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(EncoderParams), _vp, _vp, _vp, _sz, _vp]),
     "mucon_encoder_bwd": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(EncoderParams), _vp, _vp, _vp, _sz,
                                          ctypes.POINTER(EncoderParams), _vp]),
+    "mucon_linear_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "mucon_linear_fwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_linear_bwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_head_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_head_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

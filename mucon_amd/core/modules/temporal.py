@@ -5,9 +5,8 @@ default initialisation as the reference, so reference checkpoints load); the ari
 the gfx950 kernels behind mucon_amd.ops.encoder_forward.
 
 The default encoder (cfg.model.ft.type == "wavenet") is the hand-written path.  The two non-default variants
-(no shipped configuration selects them) keep the reference's names and state_dict keys and run on
-library ops on the GPU -- NoFt is one plain GEMM (hipBLASLt through torch.matmul on the row-major tape, no permuted
-copy), MSTCNPPFirstStage's dilated convolutions go through MIOpen:
+(no shipped configuration selects them) keep the reference's names and state_dict keys: NoFt runs on
+first_conv's kernels (mucon_linear_fwd / _bwd), MSTCNPPFirstStage on library ops on the GPU (MIOpen's dilated convolutions):
   NoFt               reference temporal.py:56-74    last_conv
   MSTCNPPFirstStage  reference temporal.py:150-204  conv_1x1_in, conv_dilated_1.{i}, conv_dilated_2.{i}, conv_fusion.{i}, conv_out"""
 from typing import Iterable, List
@@ -98,7 +97,12 @@ class NoFt(nn.Module):
         self.last_conv = nn.Conv1d(in_chnnels, out_dims, kernel_size)
 
     def forward_time_major(self, tape: Tensor) -> Tensor:
-        """[B, T, Cin] row-major -> [B, T, out_dims]: a single GEMM on the tape as it lies in memory."""
+        """[B, T, Cin] row-major -> [B, T, out_dims] on the tape as it lies in memory: first_conv's kernels without the
+        non-linearity (ops.linear_forward: f32 MFMA, split-bf16 from 8,192 frames; weight gradient = first_conv's job).
+        Shapes those kernels are not built for (out_dims != 128, Cin not a multiple of 128) and CPU tensors (the CPU test of
+        the module surface) take one torch GEMM."""
+        if tape.is_cuda and self.out_dims == 128 and self.in_chnnels % 128 == 0 and tape.dtype == torch.float32:
+            return ops.linear_forward(tape, self.last_conv.weight, self.last_conv.bias)
         return torch.matmul(tape, self.last_conv.weight[:, :, 0].t()) + self.last_conv.bias
 
     def forward(self, x: Tensor) -> Tensor:

@@ -24,35 +24,44 @@
 
 // TAPS = 1: a 1x1 product (a dilated conv whose dilation reaches past the sequence -- W1img then points at the centre tap's four
 // steps -- or last_conv); ONE: stage 1 only; PRO_ACT: the non-linearity on the loaded rows (last_conv's input, temporal.py:144).
-template <bool BWD, int POOL, int TAPS, bool ONE, bool PRO_ACT>
+template <bool BWD, int POOL, int TAPS, bool ONE, bool PRO_ACT, int RB>
 __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img) {
     constexpr bool UNPOOL = BWD && POOL >= 3;
     constexpr int R2 = UNPOOL ? 2 : 1;
-    __shared__ f32x4 red1[4 * 8 * 64];            // [wave][channel block][lane]: 32 KB
-    __shared__ f32x4 red2[ONE ? 1 : 4 * R2 * 8 * 64];
+    // one exchange buffer for both reductions ([wave][row set][channel block][lane]): RB * R2 * 32 KB
+    __shared__ f32x4 red[4 * RB * R2 * 8 * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const int trow_raw = blockIdx.x * 16 + c;
-    const bool valid = trow_raw < p.Trows;
-    const int tcl = min(trow_raw, p.Trows - 1);
     const long vbase = (long)b * p.Trows;
-    const long grow = (vbase + tcl) * 128 + 4 * g;
-    const long grow2 = UNPOOL ? ((long)b * p.Tfine + 2 * tcl) * 128 + 4 * g : grow;
+    // RB row blocks of 16 time steps per workgroup: every weight fragment is loaded once and multiplies all of them
+    int trow_raw[RB];
+    bool valid[RB];
+    long grow[RB], grow2[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        trow_raw[rb] = (blockIdx.x * RB + rb) * 16 + c;
+        valid[rb] = trow_raw[rb] < p.Trows;
+        const int tcl = min(trow_raw[rb], p.Trows - 1);
+        grow[rb] = (vbase + tcl) * 128 + 4 * g;
+        grow2[rb] = UNPOOL ? ((long)b * p.Tfine + 2 * tcl) * 128 + 4 * g : grow[rb];
+    }
 
     // ---- loads: the wave's activation slices, then its weight fragments in the order they are multiplied
-    f32x4 ra[TAPS][2];
-    bool rok[TAPS];
+    f32x4 ra[RB][TAPS][2];
+    bool rok[RB][TAPS];
 #pragma unroll
-    for (int i = 0; i < TAPS; ++i) {
-        const int ts = trow_raw + (i - TAPS / 2) * p.tap_step;
-        rok[i] = valid && ts >= 0 && ts < p.Trows;
-        const float *src = p.A + (vbase + min(max(ts, 0), p.Trows - 1)) * 128 + 32 * w + 8 * g;
-        ra[i][0] = *reinterpret_cast<const f32x4 *>(src);
-        ra[i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
-    }
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < TAPS; ++i) {
+            const int ts = trow_raw[rb] + (i - TAPS / 2) * p.tap_step;
+            rok[rb][i] = valid[rb] && ts >= 0 && ts < p.Trows;
+            const float *src = p.A + (vbase + min(max(ts, 0), p.Trows - 1)) * 128 + 32 * w + 8 * g;
+            ra[rb][i][0] = *reinterpret_cast<const f32x4 *>(src);
+            ra[rb][i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
     constexpr int NP = TAPS * 8;      // (tap, channel block) pairs of stage 1, three plane fragments each
     constexpr int D = 8;              // pairs in flight
     bf16x8 wf[D][3];
@@ -93,41 +102,48 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
     };
 
     // epilogue operands of the two channel blocks this wave finishes (2 w, 2 w + 1): requested now, used after the reductions
-    f32x4 aux1[2], msk1[2], aux2[R2][2], bia2[2];
+    f32x4 aux1[RB][2], msk1[RB][2], aux2[RB][R2][2], bia1[2], bia2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int nb = 2 * w + j;
-        if (!BWD) aux1[j] = p.bias1 ? *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        else aux1[j] = p.res1 ? *reinterpret_cast<const f32x4 *>(p.res1 + grow + 16 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (BWD && p.mask1) msk1[j] = *reinterpret_cast<const f32x4 *>(p.mask1 + grow + 16 * nb);
-        if (!ONE) {
+        if (!BWD) bia1[j] = p.bias1 ? *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!BWD && !ONE) bia2[j] = *reinterpret_cast<const f32x4 *>(p.bias2 + 16 * nb + 4 * g);
 #pragma unroll
-            for (int r = 0; r < R2; ++r)
-                aux2[r][j] = *reinterpret_cast<const f32x4 *>((BWD ? p.mask2 : p.res2) + grow2 + 128 * r + 16 * nb);
-            if (!BWD) bia2[j] = *reinterpret_cast<const f32x4 *>(p.bias2 + 16 * nb + 4 * g);
+        for (int rb = 0; rb < RB; ++rb) {
+            if (BWD) aux1[rb][j] = p.res1 ? *reinterpret_cast<const f32x4 *>(p.res1 + grow[rb] + 16 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BWD && p.mask1) msk1[rb][j] = *reinterpret_cast<const f32x4 *>(p.mask1 + grow[rb] + 16 * nb);
+            if (!ONE) {
+#pragma unroll
+                for (int r = 0; r < R2; ++r)
+                    aux2[rb][r][j] = *reinterpret_cast<const f32x4 *>((BWD ? p.mask2 : p.res2) + grow2[rb] + 128 * r + 16 * nb);
+            }
         }
     }
 
     // ---- stage 1
-    Planes xa[TAPS];
+    Planes xa[RB][TAPS];
 #pragma unroll
-    for (int i = 0; i < TAPS; ++i) {
-        float x[8];
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x[e] = ra[i][0][e];
-            x[4 + e] = ra[i][1][e];
+        for (int i = 0; i < TAPS; ++i) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = ra[rb][i][0][e];
+                x[4 + e] = ra[rb][i][1][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (PRO_ACT) x[e] = act_f(x[e], p.slope);
+                x[e] = rok[rb][i] ? x[e] : 0.f;
+            }
+            xa[rb][i] = split8(x);
         }
+    f32x4 acc[RB][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (PRO_ACT) x[e] = act_f(x[e], p.slope);
-            x[e] = rok[i] ? x[e] : 0.f;
-        }
-        xa[i] = split8(x);
-    }
-    f32x4 acc[8];
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < 8; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // stage 2's fragments (step w of W2) ride behind stage 1's in the same ring
     const uint16_t *w2 = ONE ? nullptr : W2img + (long)w * FS_WSTEP + lane * 8;
     auto loadW2 = [&](int nb, int slot) {
@@ -136,139 +152,166 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
     };
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        acc[i & 7] = mfma6(acc[i & 7], wf[i % D], xa[i >> 3]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb][i & 7] = mfma6(acc[rb][i & 7], wf[i % D], xa[rb][i >> 3]);
         if (i + D < NP) loadW1(i + D, i % D);
         else if (!ONE) loadW2(i + D - NP, i % D);      // NP is a multiple of D: slots line up
     }
 
     // ---- first reduction (fixed order), stage-1 epilogue on blocks 2 w, 2 w + 1
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) red1[(w * 8 + nb) * 64 + lane] = acc[nb];
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) red[((w * RB + rb) * 8 + nb) * 64 + lane] = acc[rb][nb];
     __syncthreads();
-    f32x4 h[R2][2];
+    f32x4 h[RB][R2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nb = 2 * w + j;
-        f32x4 x = ((red1[(0 * 8 + nb) * 64 + lane] + red1[(1 * 8 + nb) * 64 + lane]) + red1[(2 * 8 + nb) * 64 + lane]) +
-                  red1[(3 * 8 + nb) * 64 + lane];
-        x += aux1[j];
-        if (!BWD) {
-            if (!ONE) {
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+        for (int j = 0; j < 2; ++j) {
+            const int nb = 2 * w + j;
+            f32x4 x = ((red[((0 * RB + rb) * 8 + nb) * 64 + lane] + red[((1 * RB + rb) * 8 + nb) * 64 + lane]) +
+                       red[((2 * RB + rb) * 8 + nb) * 64 + lane]) + red[((3 * RB + rb) * 8 + nb) * 64 + lane];
+            if (!BWD) {
+                x += bia1[j];
+                if (!ONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+                }
+            } else {
+                x += aux1[rb][j];
+                if (p.mask1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] *= act_grad(msk1[rb][j][e], p.slope);
+                }
             }
-        } else if (p.mask1) {
+            if constexpr (!UNPOOL) {
+                if (valid[rb]) *reinterpret_cast<f32x4 *>(p.out1 + grow[rb] + 16 * nb) = x;
+                if (BWD && p.drop.thresh) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] *= act_grad(msk1[j][e], p.slope);
-        }
-        if constexpr (!UNPOOL) {
-            if (valid) *reinterpret_cast<f32x4 *>(p.out1 + grow + 16 * nb) = x;
-            if (BWD && p.drop.thresh) {
+                    for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(grow[rb] + 16 * nb + e));
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(grow + 16 * nb + e));
-            }
+                for (int e = 0; e < 4; ++e) h[rb][0][j][e] = valid[rb] ? x[e] : 0.f;
+            } else {
+                f32x4 u0 = x, u1 = x;
+                if (POOL == 3) {
+                    const f32x4 y0 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2[rb] + 16 * nb);
+                    const f32x4 y1 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2[rb] + 128 + 16 * nb);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[0][j][e] = valid ? x[e] : 0.f;
-        } else {
-            f32x4 u0 = x, u1 = x;
-            if (POOL == 3) {
-                const f32x4 y0 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2 + 16 * nb);
-                const f32x4 y1 = *reinterpret_cast<const f32x4 *>(p.ypre + grow2 + 128 + 16 * nb);
+                    for (int e = 0; e < 4; ++e) {
+                        const bool second = y1[e] > y0[e];
+                        u0[e] = second ? 0.f : x[e];
+                        u1[e] = second ? x[e] : 0.f;
+                    }
+                }
+                if (valid[rb]) {
+                    *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 16 * nb) = u0;
+                    *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 128 + 16 * nb) = u1;
+                    if (trow_raw[rb] == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
+                        *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4 *>(p.out2 + grow2[rb] + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (p.drop.thresh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        u0[e] *= drop_mul(p.drop, (uint32_t)(grow2[rb] + 16 * nb + e));
+                        u1[e] *= drop_mul(p.drop, (uint32_t)(grow2[rb] + 128 + 16 * nb + e));
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool second = y1[e] > y0[e];
-                    u0[e] = second ? 0.f : x[e];
-                    u1[e] = second ? x[e] : 0.f;
+                    h[rb][0][j][e] = valid[rb] ? u0[e] : 0.f;
+                    h[rb][R2 - 1][j][e] = valid[rb] ? u1[e] : 0.f;
                 }
-            }
-            if (valid) {
-                *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 16 * nb) = u0;
-                *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 128 + 16 * nb) = u1;
-                if (trow_raw == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
-                    *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4 *>(p.out2 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            if (p.drop.thresh) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u0[e] *= drop_mul(p.drop, (uint32_t)(grow2 + 16 * nb + e));
-                    u1[e] *= drop_mul(p.drop, (uint32_t)(grow2 + 128 + 16 * nb + e));
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[0][j][e] = valid ? u0[e] : 0.f;
-                h[R2 - 1][j][e] = valid ? u1[e] : 0.f;
             }
         }
-    }
     if constexpr (ONE) return;
 
     // ---- stage 2: this wave's 32 channels are step w of the reduction, in accumulator order
-    Planes x2[R2];
+    Planes x2[RB][R2];
 #pragma unroll
-    for (int r = 0; r < R2; ++r) {
-        float x[8];
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x[e] = h[r][0][e];
-            x[4 + e] = h[r][1][e];
+        for (int r = 0; r < R2; ++r) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = h[rb][r][0][e];
+                x[4 + e] = h[rb][r][1][e];
+            }
+            x2[rb][r] = split8(x);
         }
-        x2[r] = split8(x);
-    }
-    f32x4 acc2[R2][8];
+    f32x4 acc2[RB][R2][8];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
-        for (int r = 0; r < R2; ++r) acc2[r][nb] = mfma6(f32x4{0.f, 0.f, 0.f, 0.f}, wf[nb % D], x2[r]);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < R2; ++r) acc2[rb][r][nb] = mfma6(f32x4{0.f, 0.f, 0.f, 0.f}, wf[nb % D], x2[rb][r]);
     }
+    __syncthreads();   // every wave has read its blocks of the first exchange: the buffer is free
 #pragma unroll
-    for (int r = 0; r < R2; ++r)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) red2[((w * R2 + r) * 8 + nb) * 64 + lane] = acc2[r][nb];
+        for (int r = 0; r < R2; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) red[(((w * RB + rb) * R2 + r) * 8 + nb) * 64 + lane] = acc2[rb][r][nb];
     __syncthreads();
 
     // ---- second reduction, stage-2 epilogue on output blocks 2 w, 2 w + 1
 #pragma unroll
-    for (int r = 0; r < R2; ++r) {
-        const long gr = grow2 + 128 * r;
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nb = 2 * w + j;
-            f32x4 x = ((red2[((0 * R2 + r) * 8 + nb) * 64 + lane] + red2[((1 * R2 + r) * 8 + nb) * 64 + lane]) +
-                       red2[((2 * R2 + r) * 8 + nb) * 64 + lane]) + red2[((3 * R2 + r) * 8 + nb) * 64 + lane];
-            if (!BWD) {
-                x += bia2[j];
-                if (p.drop.thresh) {
+        for (int r = 0; r < R2; ++r) {
+            const long gr = grow2[rb] + 128 * r;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(gr + 16 * nb + e));
+            for (int j = 0; j < 2; ++j) {
+                const int nb = 2 * w + j;
+                f32x4 x = ((red[(((0 * RB + rb) * R2 + r) * 8 + nb) * 64 + lane] + red[(((1 * RB + rb) * R2 + r) * 8 + nb) * 64 + lane]) +
+                           red[(((2 * RB + rb) * R2 + r) * 8 + nb) * 64 + lane]) + red[(((3 * RB + rb) * R2 + r) * 8 + nb) * 64 + lane];
+                if (!BWD) {
+                    x += bia2[j];
+                    if (p.drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] *= drop_mul(p.drop, (uint32_t)(gr + 16 * nb + e));
+                    }
+                    x += aux2[rb][r][j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] *= act_grad(aux2[rb][r][j][e], p.slope);
                 }
-                x += aux2[r][j];
-            } else {
+                if (BWD || POOL == 0) {
+                    if (valid[rb]) *reinterpret_cast<f32x4 *>(p.out2 + gr + 16 * nb) = x;
+                } else {
+                    if (POOL == 1 && valid[rb]) *reinterpret_cast<f32x4 *>(p.out_pre + gr + 16 * nb) = x;
+                    f32x4 y;   // rows 2u, 2u + 1 sit on neighbouring lanes
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] *= act_grad(aux2[r][j][e], p.slope);
-            }
-            if (BWD || POOL == 0) {
-                if (valid) *reinterpret_cast<f32x4 *>(p.out2 + gr + 16 * nb) = x;
-            } else {
-                if (POOL == 1 && valid) *reinterpret_cast<f32x4 *>(p.out_pre + gr + 16 * nb) = x;
-                f32x4 y;   // rows 2u, 2u + 1 sit on neighbouring lanes
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float o = __shfl_xor(x[e], 1);
-                    y[e] = POOL == 1 ? fmaxf(x[e], o) : x[e] + o;
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = __shfl_xor(x[e], 1);
+                        y[e] = POOL == 1 ? fmaxf(x[e], o) : x[e] + o;
+                    }
+                    if ((trow_raw[rb] & 1) == 0 && trow_raw[rb] + 1 < p.Trows)
+                        *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (p.Trows >> 1) + (trow_raw[rb] >> 1)) * 128 + 4 * g + 16 * nb) = y;
                 }
-                if ((trow_raw & 1) == 0 && trow_raw + 1 < p.Trows)
-                    *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (p.Trows >> 1) + (trow_raw >> 1)) * 128 + 4 * g + 16 * nb) = y;
             }
         }
-    }
 }
 
+// Rows per workgroup: 16.  (32 -- two row blocks sharing every weight fragment, half the L2 -> register weight traffic -- is
+// built and tested, MUCON_COARSE_RB=2, and measured slower at every level: 0.832 vs 0.802 ms per step at B=8 x T=4096, 1.17 vs
+// 1.11 ms per video at batch 1.  What a launch costs is the latency of its chain, not the weight bytes.)
+extern int g_cs_rb;   // 0 / 1 = 16 rows, 2 = 32 rows (MUCON_COARSE_RB)
 template <bool BWD, int POOL, int TAPS, bool ONE = false, bool PRO_ACT = false>
 static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
-    dim3 grid((p.Trows + 15) / 16, B);
-    hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT>), grid, dim3(256), 0, s, p, W1img, W2img);
+    const int rb = g_cs_rb == 2 ? 2 : 1;
+    if (rb == 2) {
+        dim3 grid((p.Trows + 31) / 32, B);
+        hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img);
+    } else {
+        dim3 grid((p.Trows + 15) / 16, B);
+        hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p, W1img, W2img);
+    }
     return hipGetLastError();
 }

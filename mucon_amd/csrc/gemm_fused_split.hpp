@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
 
     f32x4 ra[2][4];       // two k-tiles of this lane's activation values in flight: [set][2 steps x 2 halves]
     bool rok[2] = {true, true};
-    u32x4 rws[NQ];        // this thread's share of the next W tile
+    u32x4 rws[2][NQ];     // this thread's share of the next TWO W tiles (a tile is requested two tiles before it is multiplied)
     auto gloadA = [&](int S, auto SET) {      // k-tile S of stage 1: tap S >> 1, channels 64 (S & 1) ..
         constexpr int Q = decltype(SET)::value;
         const int tap = S >> 1;
@@ -117,14 +117,16 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[Q][i] = *reinterpret_cast<const f32x4 *>(src + 32 * (i >> 1) + 4 * (i & 1));
     };
-    auto gloadW = [&](int v) {                // tile v of the unified sequence: 0..5 W1, 6..7 W2
+    auto gloadW = [&](int v, auto SET) {      // tile v of the unified sequence: 0..5 W1, 6..7 W2
+        constexpr int Q = decltype(SET)::value;
         const uint16_t *src = (v < 6 ? W1img + (long)v * FS_WTILE : W2img + (long)(v - 6) * FS_WTILE) + tid * 8;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) rws[q] = *reinterpret_cast<const u32x4 *>(src + q * (NTHR * 8));
+        for (int q = 0; q < NQ; ++q) rws[Q][q] = *reinterpret_cast<const u32x4 *>(src + q * (NTHR * 8));
     };
-    auto storeW = [&](int buf) {
+    auto storeW = [&](int buf, auto SET) {
+        constexpr int Q = decltype(SET)::value;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4 *>(fs_smem + buf * FS_WTILE + tid * 8 + q * (NTHR * 8)) = rws[q];
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4 *>(fs_smem + buf * FS_WTILE + tid * 8 + q * (NTHR * 8)) = rws[Q][q];
     };
     struct Planes { bf16x8 pl[3]; };
     auto split8 = [&](const float (&x)[8]) {
@@ -217,15 +219,16 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
 
     // ---------------------------------------------------------------- stage 1: six 64-deep tiles (3 taps x 128 channels)
     zero_acc();
-    gloadW(0);
+    gloadW(0, I0{});
     gloadA(0, I0{});
     gloadA(1, I1{});
-    storeW(0);
+    gloadW(1, I1{});
+    storeW(0, I0{});
     Planes cur = convertA(ra[0][0], ra[0][1], rok[0]);
     __syncthreads();
     auto tile1 = [&](int S, int buf, auto SET, auto OTHER) {
         constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
-        if (!ONE || S < 5) gloadW(S + 1);    // S = 5: the first W2 tile
+        if (S + 2 < (ONE ? 6 : 8)) gloadW(S + 2, SET);   // tiles 6, 7: W2
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 0, cur);
         Planes nxt = convertA(ra[Q][2], ra[Q][3], rok[Q]);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 1, nxt);
         cur = convertA(ra[O][0], ra[O][1], rok[O]);
-        if (!ONE || S < 5) storeW(buf ^ 1);
+        if (!ONE || S < 5) storeW(buf ^ 1, OTHER);
         weave(std::true_type{});
         use(cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -373,8 +376,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
 #pragma unroll
         for (int r = 0; r < R2; ++r) use(P.r[r]);
     };
-    gloadW(7);
-    Planes2 c2 = hstep(0);
+    Planes2 c2 = hstep(0);          // (W2 tile 0 sits in buffer 0, tile 1 is on its way in register set 1: requested at S = 5)
     __builtin_amdgcn_sched_barrier(0);
     mfma_step2(0, 0, c2);
     Planes2 n2 = hstep(1);
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     __builtin_amdgcn_sched_barrier(0);
     mfma_step2(0, 1, n2);
     c2 = hstep(2);
-    storeW(1);
+    storeW(1, I1{});
     weave2(std::true_type{});
     use2(c2);
     __builtin_amdgcn_sched_barrier(0);

@@ -22,6 +22,7 @@
 #include "small_kernels.hpp"
 
 int g_ts_xcd = 1;             // the split weight-gradient launch keeps the workgroups that share gradient rows on one XCD (MUCON_TS_XCD=0: plain order)
+int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
 int g_fs_nw = 0;              // waves per workgroup of the split-bf16 two-stage kernels: 0 = by level size, 4 / 8 forced (MUCON_FUSED_SPLIT_NW)
 int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
 int g_first_conv_8w = 1;   // 1: first_conv forward as 128-row 8-wave workgroups; 2: every full-resolution NT launch; 0: off
@@ -443,6 +444,10 @@ static bool apply_knob(const char *name, const char *e) {
         g_fs = atoi(e) ? 1 : 0;
         return true;
     }
+    if (!strcmp(name, "MUCON_COARSE_RB")) {
+        g_cs_rb = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 0;
+        return true;
+    }
     if (!strcmp(name, "MUCON_COARSE_SPLIT")) {
         g_cs = atoi(e) ? 1 : 0;
         return true;
@@ -529,7 +534,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
+static const char *const kKnobs[] = {"MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -1175,6 +1180,92 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     Reducer red(s);
     red.add(a.w_slabs, (int)nblk, (long)C * H, C * H, 0, 1, C * H, d_w, 0);
     red.add(a.b_slabs, (int)nblk, C, C, 0, 1, C, d_b, 0);
+    HIPCHK(red.run());
+    return MUCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------ noft
+__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D);
+namespace {
+struct LinearPlan {
+    size_t planes, slabs, bslabs, total;   // floats
+    Plan pl;
+};
+bool linear_plan(int B, int T, int D, LinearPlan &lp) {
+    if (B < 1 || T < 1 || D < 128 || D % 128 != 0) return false;
+    memset(&lp.pl, 0, sizeof(lp.pl));
+    lp.pl.B = B;
+    int mc = pick_mc(B, T, D / 128);
+    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, T, D / 128, (v & 1) != 0, (v & 2) != 0));
+    const size_t nmc = (size_t)B * ((T + mc - 1) / mc);
+    size_t o = 0;
+    lp.planes = o;
+    o += align64((size_t)3 * 128 * D / 2);
+    lp.slabs = o;
+    lp.pl.slabs = o;
+    lp.pl.slab_floats = align64(nmc * 128 * D);
+    o += lp.pl.slab_floats;
+    lp.bslabs = o;
+    lp.pl.bslabs = o;
+    lp.pl.bslab_floats = align64(nmc * 256);
+    o += lp.pl.bslab_floats;
+    lp.total = o;
+    return true;
+}
+}  // namespace
+
+size_t mucon_linear_workspace_bytes(int32_t B, int32_t T, int32_t D) {
+    LinearPlan lp;
+    if (!linear_plan(B, T, D, lp)) {
+        fail(MUCON_E_ARG, "linear: B=%d T=%d D=%d (D must be a positive multiple of 128)", B, T, D);
+        return 0;
+    }
+    return lp.total * sizeof(float);
+}
+
+int mucon_linear_fwd(int32_t B, int32_t T, int32_t D, const float *tape, const float *w, const float *b, float *out,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+    LinearPlan lp;
+    if (!linear_plan(B, T, D, lp)) return fail(MUCON_E_ARG, "linear: B=%d T=%d D=%d (D must be a positive multiple of 128)", B, T, D);
+    if (!tape || !w || !b || !out || !workspace) return fail(MUCON_E_ARG, "null pointer argument");
+    if (workspace_bytes < lp.total * sizeof(float)) return fail(MUCON_E_WORKSPACE, "linear workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *ws = static_cast<float *>(workspace);
+    NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 1.f);   // slope 1: the activation slot is the identity
+    if (g_first_conv_split && (long)B * T >= g_first_conv_split_rows) {
+        uint16_t *P = reinterpret_cast<uint16_t *>(ws + lp.planes);
+        hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
+        HIPCHK(hipGetLastError());
+        HIPCHK((launch_nt_split<false>(p, P, B, s)));
+    } else {
+        HIPCHK((launch_nt<true, false, false, false, false, false, 0>(p, B, s)));
+    }
+    return MUCON_OK;
+}
+
+int mucon_linear_bwd(int32_t B, int32_t T, int32_t D, const float *tape, const float *d_out, float *d_w, float *d_b,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+    LinearPlan lp;
+    if (!linear_plan(B, T, D, lp)) return fail(MUCON_E_ARG, "linear: B=%d T=%d D=%d (D must be a positive multiple of 128)", B, T, D);
+    if (!tape || !d_out || !d_w || !d_b || !workspace) return fail(MUCON_E_ARG, "null pointer argument");
+    if (workspace_bytes < lp.total * sizeof(float)) return fail(MUCON_E_WORKSPACE, "linear workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Y0 = d_out;
+    a.X0 = tape;
+    a.x_bstride = (long)T * D;
+    a.ldx = D;
+    a.Tx = T;
+    a.taps = 1;
+    a.nk0 = D / 128;
+    a.out_w0 = d_w;
+    a.out_b0 = d_b;
+    a.drop = make_drop(0, 0, 0.f, false);
+    Reducer red(s);
+    size_t arena = 0, barena = 0;
+    int rc = wgrad(lp.pl, static_cast<float *>(workspace), arena, barena, T, a, 0.f, red, s);
+    if (rc != MUCON_OK) return rc;
     HIPCHK(red.run());
     return MUCON_OK;
 }

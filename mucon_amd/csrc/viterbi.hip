@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mucon_hip.h"
 
@@ -129,85 +130,158 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
     }
 }
 
-// The same chain at its own speed (fs <= 256, C a multiple of 4): a chunk holds WHOLE columns (cols x fs rows), so wave 0
-// walks it in fixed 16-row batches -- batch b + 1 is read from LDS into registers while batch b is added: the chain never
-// waits for a read (the kernel above alternates six reads and six adds, ~20 ns per row; this one is bound by the dependent
-// float32 add itself).  A column's tail batch is padded with -0.0f, the additive identity of IEEE addition for every x
-// including both zeros: the padded adds change no bit.
-constexpr int FSC_B = 16;
-__global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_cols_kernel(const mucon_viterbi_job *jobs, const float *lp,
-                                                                             char *ws, int C, int fs, int cols) {
-    extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][cols * fs * C]
+// The same chain at its own speed (fs <= 256, C a multiple of 4).  One wave issues an instruction every ~4-5 cycles and a
+// dependent float32 add returns after ~7 (tools/chain_probe.hip: 2.8 ns per add from registers), so what a row costs is the
+// number of instructions wave 0 spends on it; the kernel above spends a read, an address and a wait on every add.  Here
+//   * a chunk holds WHOLE columns and lies TRANSPOSED in LDS ([class][row], each column padded to a multiple of four rows
+//     with -0.0f, the additive identity of IEEE addition for every x including both zeros: the padded adds change no bit), so
+//     lane c fetches four consecutive rows of class c with one ds_read_b128 at an immediate offset, eight reads in flight;
+//   * wave 0 does nothing but add: after every read's four adds it drops the running sum into LDS (one ds_write_b32, no
+//     column bookkeeping, no branch), and its loop body is 16 adds, 4 reads, 4 writes;
+//   * waves 1..7 do the rest: global float4 -> four transposed LDS words one chunk ahead of the chain (the global loads two
+//     chunks ahead), and the fs-strided differences of the previous chunk's running sums -> F.
+constexpr int FSC_THREADS = 512;
+constexpr int FSC_STAGE = FSC_THREADS - 64;  // staging threads
+constexpr int FSC_NPER = 10;                 // tiles per staging wave per chunk: ceil(16 row blocks x 4 float4 blocks / 7)
+constexpr int FSC_MAX_LDS = 160 * 1024;
+constexpr int FSC_DEPTH = 8;                 // b128 reads in flight
+constexpr int FSC_SLACK = 8 * FSC_DEPTH;     // rows the read-ahead and the last round may run past a chunk's end
+__host__ __device__ inline int fsc_pitch(int rows) { return ((rows + FSC_SLACK + 15) & ~15) + 4; }   // = 4 mod 16, in floats
+__host__ __device__ inline int fsc_floats(int C, int fs, int cols) {                                 // dynamic LDS, in floats
+    const int nq = (fs + 3) >> 2;
+    return 2 * C * fsc_pitch(cols * nq * 4) + 2 * (cols * nq + FSC_DEPTH) * 64;
+}
+template <bool W4>   // the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column
+__global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(const mucon_viterbi_job *jobs, const float *lp,
+                                                                              char *ws, int C, int fs, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
     if (K < 1) return;
     float *F = reinterpret_cast<float *>(ws + job.ws_off);
     const int tid = threadIdx.x;
-    const float *src = lp + job.lp_off;
-    const int rows_c = cols * fs;                 // rows per chunk
-    const int chunk4 = rows_c * C / 4;            // float4 per chunk
+    const int nq = (fs + 3) >> 2;                 // b128 reads per column
+    const int P = nq * 4;                         // LDS rows per column
+    const int pitch = fsc_pitch(cols * P);
+    const int bufsz = C * pitch;
+    const int runsz = (cols * nq + FSC_DEPTH) * 64;   // (the unrolled loop's last round may write up to seven sums too many)
+    float *runs = fs_smem + 2 * bufsz;
+    const int C4 = C >> 2;
+    const int chunk4 = cols * fs * C4;            // float4 per chunk in memory (contiguous: whole columns)
     const int nchunks = (K + cols - 1) / cols;
-    const long total4 = (long)K * fs * C / 4;
-    const int nper = (chunk4 + FS_THREADS - 1) / FS_THREADS;   // <= 15 (256 rows x 64 classes)
-    vit_f32x4 r[16];
-    auto gload = [&](int ci) {
-        const long base4 = (long)ci * chunk4;
+    {
+        vit_f32x4 *z = reinterpret_cast<vit_f32x4 *>(fs_smem);
+        for (int i = tid; i < bufsz / 2; i += FSC_THREADS) z[i] = vit_f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
+    }
+    __syncthreads();
+    if (tid >= 64) {
+        // ---- waves 1..7: staging and the column differences ----
+        const int j = tid - 64;
+        const vit_f32x4 *src4 = reinterpret_cast<const vit_f32x4 *>(lp + job.lp_off);
+        const int total4 = K * fs * C4;               // < 2^31: T * C / 4
+        const unsigned inv_fs = (1u << 20) / fs + 1;  // x / fs == (x * inv_fs) >> 20 for x < 4096
+        // One wave instruction moves a tile of 16 rows x 4 float4 (lane = 4 * row + float4): the global load reads 64
+        // contiguous bytes per row, and each of the four transposed ds_write_b32 hits 64 different banks (consecutive rows are
+        // consecutive words; 4 * pitch = 16 mod 64 spreads the four float4) -- with one float4 per lane in memory order the
+        // twelve float4 of a row land on two banks, and the conflicts stall the chain's own reads.
+        const int wv = j >> 6, l = j & 63;
+        const int ncb = (C4 + 3) >> 2;                // tiles across the classes
+        int dsto[FSC_NPER], srco[FSC_NPER];           // LDS word / chunk-relative float4 of this thread's u-th element; -1 = none
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (u < nper) {
-                long e = base4 + u * FS_THREADS + tid;
-                e = e < total4 - 1 ? e : total4 - 1;
-                r[u] = reinterpret_cast<const vit_f32x4 *>(src)[e];
+        for (int u = 0; u < FSC_NPER; ++u) {
+            const int t = u * (FSC_STAGE / 64) + wv;
+            const int rb = t / ncb, cb = t - rb * ncb;
+            const int row = rb * 16 + (l >> 2), c4 = cb * 4 + (l & 3);
+            const int col = (int)(((unsigned)row * inv_fs) >> 20);
+            const bool on = row < cols * fs && c4 < C4;
+            dsto[u] = on ? 4 * c4 * pitch + row + col * (P - fs) : -1;
+            srco[u] = row * C4 + c4;
+        }
+        vit_f32x4 r[FSC_NPER];
+        auto gload = [&](int ci) {
+            const int base4 = ci * chunk4;
+#pragma unroll
+            for (int u = 0; u < FSC_NPER; ++u)
+                if (dsto[u] >= 0) r[u] = src4[min(base4 + srco[u], total4 - 1)];
+        };
+        auto sstore = [&](int ci) {
+            float *dst = fs_smem + (ci & 1) * bufsz;
+            const int left4 = total4 - ci * chunk4;   // the last chunk may be short: keep the clamped re-loads out
+#pragma unroll
+            for (int u = 0; u < FSC_NPER; ++u)
+                if (dsto[u] >= 0 && srco[u] < left4) {
+                    float *d = dst + dsto[u];
+                    d[0] = r[u].x;
+                    d[pitch] = r[u].y;
+                    d[2 * pitch] = r[u].z;
+                    d[3 * pitch] = r[u].w;
+                }
+        };
+        // F[k][c] = run(end of column k) - run(end of column k - 1) for the columns of chunk ci (frame_score, viterbi.py:68-72).
+        // Runs while wave 0 fills the OTHER sums buffer, so the end of the chunk before travels in a register (threads j < 64
+        // own column 0 of every chunk).
+        float carry = 0.f;
+        auto diffs = [&](int ci) {
+            const float *rn = runs + (ci & 1) * runsz;
+            const int ncols = min(cols, K - ci * cols);
+            for (int i = j; i < ncols * 64; i += FSC_STAGE) {
+                const int kc = i >> 6, c = i & 63;
+                if (c < C) {
+                    const float hi = rn[((kc + 1) * nq - 1) * 64 + c];
+                    const float lo = kc > 0 ? rn[(kc * nq - 1) * 64 + c] : carry;
+                    const int k = ci * cols + kc;
+                    F[(long)k * C + c] = k == 0 ? hi : hi - lo;
+                }
             }
-    };
-    auto sstore = [&](int buf) {
-        vit_f32x4 *dst = reinterpret_cast<vit_f32x4 *>(fs_smem + buf * rows_c * C);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (u < nper && u * FS_THREADS + tid < chunk4) dst[u * FS_THREADS + tid] = r[u];
-    };
-    const int nb = (fs + FSC_B - 1) / FSC_B;      // batches per column
-    float run = -0.0f, prev = 0.f;
-    int k = 0;
-    gload(0);
-    sstore(0);
+            if (j < 64) carry = rn[(cols * nq - 1) * 64 + j];   // (a short last chunk has no successor)
+        };
+        gload(0);
+        sstore(0);
+        if (nchunks > 1) gload(1);
+        __syncthreads();
+        for (int ci = 0; ci < nchunks; ++ci) {
+            if (ci + 1 < nchunks) sstore(ci + 1);
+            if (ci + 2 < nchunks) gload(ci + 2);
+            if (ci > 0) diffs(ci - 1);
+            __syncthreads();
+        }
+        diffs(nchunks - 1);
+        return;
+    }
+    // ---- wave 0: the chain ----
+    const int lane_c = tid < C ? tid : C - 1;
+    float run = -0.0f;
+    __builtin_amdgcn_s_setprio(3);                 // the chain goes first on the SIMD it shares with a staging wave
     __syncthreads();
     for (int ci = 0; ci < nchunks; ++ci) {
-        const int cur = ci & 1;
-        gload(ci + 1 < nchunks ? ci + 1 : ci);
-        if (tid < 64) {
-            const float *col0 = fs_smem + cur * rows_c * C + (tid < C ? tid : C - 1);
-            const int ncols = min(cols, K - ci * cols);
-            const int nsteps = ncols * nb;
-            float va[FSC_B], vb[FSC_B];
-            auto load = [&](int step, float (&v)[FSC_B]) {
-                const int cc = step / nb, bb = step - cc * nb;
-                const float *p0 = col0 + (cc * fs + bb * FSC_B) * C;
-                const int left = fs - bb * FSC_B;      // rows of this column from the batch's first row on (wave-uniform)
+        const vit_f32x4 *q = reinterpret_cast<const vit_f32x4 *>(fs_smem + (ci & 1) * bufsz + lane_c * pitch);
+        float *w = runs + (ci & 1) * runsz + tid;
+        const int nquads = min(cols, K - ci * cols) * nq;
+        auto addq = [&](vit_f32x4 v, float *o, bool keep) {
+            run = run + v.x;                       // sequential float32 chain
+            run = run + v.y;
+            run = run + v.z;
+            run = run + v.w;
+            if (keep) *o = run;
+        };
+        // eight reads in flight (an LDS read that waves 1..7 are writing into takes ~150 cycles to return, a read's four adds
+        // ~27); the sched_barriers keep each re-load right behind the adds that free its registers.  The last round may add up
+        // to seven reads too many: their sums land in the slack of `runs` and `run` is restored from the last real one.
+        vit_f32x4 qr[FSC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < FSC_B; ++u) v[u] = u < left ? p0[u * C] : -0.0f;
-            };
-            auto add = [&](int step, const float (&v)[FSC_B]) {
+        for (int u = 0; u < FSC_DEPTH; ++u) qr[u] = q[u];
+        for (int s = 0; s < nquads; s += FSC_DEPTH) {
+            q += FSC_DEPTH;
 #pragma unroll
-                for (int u = 0; u < FSC_B; ++u) run = run + v[u];          // sequential float32 chain
-                const int cc = step / nb, bb = step - cc * nb;
-                if (bb == nb - 1) {                                         // end of column k
-                    if (tid < C) F[(long)k * C + tid] = (k == 0) ? run : run - prev;
-                    prev = run;
-                    ++k;
-                }
-            };
-            load(0, va);
-            for (int step = 0; step < nsteps; step += 2) {
-                if (step + 1 < nsteps) load(step + 1, vb);
-                add(step, va);
-                if (step + 1 < nsteps) {
-                    if (step + 2 < nsteps) load(step + 2, va);
-                    add(step + 1, vb);
-                }
+            for (int u = 0; u < FSC_DEPTH; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                addq(qr[u], w + u * 64, !W4 || (u & 3) == 3);
+                qr[u] = q[u];                      // behind the chunk's end: slack rows
             }
+            __builtin_amdgcn_sched_barrier(0);
+            w += FSC_DEPTH * 64;
         }
-        sstore(cur ^ 1);
+        if (nquads & (FSC_DEPTH - 1)) run = runs[(ci & 1) * runsz + (nquads - 1) * 64 + tid];
         __syncthreads();
     }
 }
@@ -592,17 +666,25 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     if (!fs_attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
             VIT_FAIL(MUCON_E_HIP);
         }
         fs_attr = true;
     }
     if (fs <= FS_ROWS && (C & 3) == 0) {   // whole columns per chunk: the pipelined chain
-        const int cols = FS_ROWS / fs;
-        hipLaunchKernelGGL(viterbi_framescore_cols_kernel, dim3(n_videos), dim3(FS_THREADS), (size_t)2 * cols * fs * C * sizeof(float), s,
-                           jobs, lp, static_cast<char *>(workspace), C, fs, cols);
+        // columns padded to whole b128 reads in LDS; as many columns per chunk as 256 rows and the LDS hold
+        int cols = FS_ROWS / ((fs + 3) & ~3);
+        while (cols > 1 && fsc_floats(C, fs, cols) * 4 > FSC_MAX_LDS) --cols;
+        if ((((fs + 3) >> 2) & 3) == 0)
+            hipLaunchKernelGGL(viterbi_framescore_cols_kernel<true>, dim3(n_videos), dim3(FSC_THREADS), (size_t)fsc_floats(C, fs, cols) * sizeof(float), s,
+                               jobs, lp, static_cast<char *>(workspace), C, fs, cols);
+        else
+            hipLaunchKernelGGL(viterbi_framescore_cols_kernel<false>, dim3(n_videos), dim3(FSC_THREADS), (size_t)fsc_floats(C, fs, cols) * sizeof(float), s,
+                               jobs, lp, static_cast<char *>(workspace), C, fs, cols);
     } else {
         hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
                            static_cast<char *>(workspace), C, fs);

@@ -173,6 +173,44 @@ def encoder_forward(tape: torch.Tensor, params: Sequence[torch.Tensor], spec: En
     return _EncoderFn.apply(tape, spec, bool(training), int(seed), *params)
 
 
+class _LinearFn(torch.autograd.Function):
+    """out [B,T,128] = tape [B,T,D] @ w[128,D]^T + b on the first_conv kernels (the encoder variant "noft",
+    reference core/modules/temporal.py:56-74).  The tape gets no gradient (it is the dataset's features)."""
+
+    @staticmethod
+    def forward(ctx, tape, w, b):
+        lib = _lib.load()
+        _check_dev(tape, w, b)
+        tape, w, b = tape.contiguous(), w.contiguous(), b.contiguous()
+        B, T, D = tape.shape
+        nbytes = lib.mucon_linear_workspace_bytes(B, T, D)
+        if nbytes == 0:
+            _lib.check(_lib.E_ARG, "mucon_linear_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=tape.device)
+        out = torch.empty((B, T, 128), dtype=torch.float32, device=tape.device)
+        _lib.check(lib.mucon_linear_fwd(B, T, D, _lib.ptr(tape), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                        _lib.current_stream_ptr()), "mucon_linear_fwd")
+        ctx.dims, ctx.ws, ctx.nbytes = (B, T, D), ws, nbytes
+        ctx.save_for_backward(tape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        (tape,) = ctx.saved_tensors
+        B, T, D = ctx.dims
+        d_w = torch.empty((128, D), dtype=torch.float32, device=tape.device)
+        d_b = torch.empty(128, dtype=torch.float32, device=tape.device)
+        _lib.check(lib.mucon_linear_bwd(B, T, D, _lib.ptr(tape), _lib.ptr(d_out.contiguous()), _lib.ptr(d_w), _lib.ptr(d_b),
+                                        _lib.ptr(ctx.ws), ctx.nbytes, _lib.current_stream_ptr()), "mucon_linear_bwd")
+        return None, d_w, d_b
+
+
+def linear_forward(tape: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """tape [B,T,D] -> [B,T,128]; weight [128,D] (or the Conv1d form [128,D,1])."""
+    return _LinearFn.apply(tape, weight.reshape(weight.shape[0], weight.shape[1]), bias)
+
+
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, w, b, Tf, want_logits, want_logp):

@@ -64,3 +64,24 @@ def test_variant_on_gpu_and_training_step(kind):
     before = model.conv_classifier.weight.detach().clone()
     loss, _ = tr._train_1_batch(0, batch)
     assert torch.isfinite(loss.main) and not torch.equal(before, model.conv_classifier.weight)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 640), (2, 4500)])
+def test_noft_kernels_against_float64(B, T):
+    """NoFt on first_conv's kernels through the C ABI (mucon_linear_fwd / _bwd): forward and the two gradients against float64,
+    below and above the size where the forward switches to the split-bf16 kernel (8,192 frames)."""
+    from mucon_amd import ops
+    g = torch.Generator().manual_seed(3)
+    tape = torch.randn(B, T, 2048, generator=g).cuda()
+    w = (torch.randn(128, 2048, generator=g) * 0.03).cuda().requires_grad_()
+    b = torch.randn(128, generator=g).cuda().requires_grad_()
+    u = torch.randn(B, T, 128, generator=g).cuda()
+    out = ops.linear_forward(tape, w, b)
+    (out * u).sum().backward()
+    ref = tape.double() @ w.detach().double().t() + b.detach().double()
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    dw = (u.double().reshape(-1, 128).t() @ tape.double().reshape(-1, 2048))
+    db = u.double().sum((0, 1))
+    assert float((w.grad.double() - dw).abs().max()) <= 2e-5 * float(dw.abs().max())
+    assert float((b.grad.double() - db).abs().max()) <= 2e-5 * float(db.abs().max())

@@ -469,6 +469,20 @@ def test_fused_split_layer_kernels_at_every_size():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("rb", ["1", "2"])
+def test_coarse_split_kernel_row_blocks(rb):
+    """The coarse-level k-split kernel (csrc/gemm_coarse_split.hpp) takes 16 or 32 rows per workgroup by level size; MUCON_COARSE_RB
+    forces either at every size: goldens, oracle forward / backward, dropout replay (fresh interpreter)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MUCON_COARSE_RB=rb)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or oracle_f64 or dropout"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_f32_fused_layer_kernels_at_every_size():
     """MUCON_COARSE_SPLIT=0 MUCON_FUSED_SPLIT=0 keeps every level on the f32-MFMA two-stage kernels (csrc/gemm_fused.hpp), which
     by default only the configurations the split kernels do not take still reach: goldens, oracle forward / backward, dropout."""
