@@ -344,6 +344,295 @@ __device__ __forceinline__ double add_frame(double s, float f, int n) {
     return n == 0 ? (double)t32 : t64;
 }
 
+// The tail both DP kernels share: thread 0 walks the back-pointers (viterbi.py:140-158), then the workgroup expands the
+// segments into per-frame labels.  `pre` is an LDS scratch of N + 1 ints, `a` the transcript in LDS.
+__device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job &job, int vid, int fin_n, int fin_j, double fin_score,
+                                                         bool forced, const uint8_t *bp, const int *a, int *pre, int32_t *labels,
+                                                         int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int fs) {
+    const int T = job.T, N = job.N, K = T / fs;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    // traceback
+    const int nseg = fin_n + 1;
+    const int missing = T - K * fs;
+    if (tid == 0) {
+        int n = fin_n, j = fin_j, k = K - 1;
+        int32_t *sl = seg_len + job.seg_off;
+        for (int s = nseg - 1; s >= 0; --s) {
+            sl[s] = (j + 1) * fs;
+            const int k0 = k - j;
+            if (n > 0) {
+                j = bp[(size_t)k0 * N + n];
+                k = k0 - 1;
+                --n;
+            }
+        }
+        int acc = 0;
+        for (int s = 0; s < nseg; ++s) {
+            pre[s] = acc;
+            acc += sl[s];
+        }
+        pre[nseg] = acc;
+        sl[nseg - 1] += missing;  // leftover frames are added to the last segment's length
+        for (int s = nseg; s < N; ++s) sl[s] = 0;
+        n_seg[vid] = nseg;
+        score[vid] = fin_score;
+        status[vid] = forced ? MUCON_VIT_TRUNCATED : MUCON_VIT_OK;
+    }
+    __syncthreads();
+    // ... and labelled, at the START of the video, with the last segment's label
+    int32_t *lab = labels + job.label_off;
+    for (int t = tid; t < T; t += nthreads) {
+        int l;
+        if (t < missing) {
+            l = a[nseg - 1];
+        } else {
+            const int u = t - missing;
+            int lo = 0, hi = nseg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pre[mid] <= u) lo = mid;
+                else hi = mid - 1;
+            }
+            l = a[lo];
+        }
+        lab[t] = l;
+    }
+}
+
+// Phase 2, transcripts of up to 64 states and J <= 66 length slots (every shipped configuration: max_len 2000, fs 30): ONE wave
+// runs the whole DP with the hypothesis scores in REGISTERS, no barrier and no LDS round trip per column.
+//
+// Lane n * G + g owns state n's hypotheses with length index j in [g * JG, (g + 1) * JG) -- G = 8, 4, 2, 1 lanes per state
+// for N <= 8, 16, 32, 64.  Indexing by LENGTH instead of by entry column turns "every hypothesis grows by one column" into
+// S[j] = S[j-1] + f with a different destination register (the shift costs nothing; across a lane boundary it is one DPP
+// row_shr), and makes every table index a compile-time constant: the length scores Pl[n][j] sit in registers too.  Dead
+// hypotheses hold -inf (-inf + f stays -inf: emissions are log-probabilities), so the column has no liveness test:
+//     S[j]  = S[j-1] + f                         stay in state n (viterbi.py:96-104); slot J only feeds the candidates
+//     cand  = S[j] + Pl[n][j-1]                   leave state n after (old) length index j-1 (viterbi.py:105-121)
+//     (v,j) = arg max, the larger j among equals   HypDict.update's `<=` (viterbi.py:27) -> enters state n + 1 at index 0
+// The arg max is a compare-and-select per slot, then log2(G) DPP steps; one ds_bpermute hands it to the next state's lane.
+// If every candidate is -inf the reference still picks the longest LIVE one: that index is the closed form min(J, k-n) - 1.
+// The reference's `+ 0.0` on every candidate only turns -0.0 into +0.0; comparisons do not see the sign of zero, so it is
+// applied once, to the winner.  State 0 holds a single hypothesis (entered at column 0) whose score is float32 + float32
+// (NumPy promotion, see add_frame): a scalar side chain, its one candidate enters state 1 directly.
+// ~6 instructions per slot and column: 0.2 us per column at N <= 8, 0.8 us at N = 64 (the LDS kernel below: 0.9 and 4 us).
+constexpr int VL_THREADS = 256;   // wave 0 decodes; waves 1..3 wait at the barrier and help to expand the labels
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
+template <int G, int JG>
+__global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
+    int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
+    constexpr bool PL_LDS = JG > 40;        // one lane per state: 2 x 67 doubles do not fit the registers, Pl goes to LDS
+    constexpr int VL_CH = PL_LDS ? 8 : 32;  // columns of frame scores staged at a time (one register each while in flight)
+    __shared__ double PlL[PL_LDS ? JG : 1][64];   // [slot][lane]: immediate offsets, no bank conflict
+    __shared__ float Fb[2][VL_CH][64];      // frame scores of the lanes' own labels, two chunks
+    __shared__ double Pl0[128];             // state 0's length scores (runtime index: its hypothesis has j = column)
+    __shared__ int a[64], pre[65];
+    __shared__ double fin_score;
+    __shared__ int fin_n, fin_j;
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int T = job.T, N = job.N;
+    const int K = T / fs;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int vid = blockIdx.x;
+    if (K < 1) {  // frame_scores[fs-1] does not exist: IndexError in the reference (viterbi.py:87)
+        if (tid == 0) {
+            status[vid] = MUCON_VIT_INDEX_ERROR;
+            n_seg[vid] = 0;
+            score[vid] = -INFINITY;
+        }
+        return;
+    }
+    if (job.force_n < 0 && K > J * N) {  // every hypothesis has outlived max_length: empty set
+        if (tid == 0) {
+            status[vid] = MUCON_VIT_NO_HYPOTHESIS;
+            n_seg[vid] = 0;
+            score[vid] = -INFINITY;
+        }
+        return;
+    }
+    const float *F = reinterpret_cast<const float *>(ws + job.ws_off);
+    const size_t f_bytes = ((size_t)K * C * sizeof(float) + 15) & ~(size_t)15;
+    uint8_t *bp = reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes);  // [K][N]
+    const bool forced = job.force_n >= 0 || K < N;
+    if (tid < 64) a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
+    for (int j = tid; j < J; j += VL_THREADS) Pl0[j] = tables[job.p_off + (size_t)j * N];
+    __syncthreads();
+
+    if (tid < 64) {
+        const int n = lane / G, g = lane - n * G;        // this lane's state and slot group
+        const int an = a[n < N ? n : 0];
+        const bool state_on = n >= 1 && n < N;
+        const double NEG = -INFINITY;
+        // length scores against the slot index s = j + 1 (the candidate of slot s uses the OLD length index s - 1)
+        double PlS[JG], S[JG];   // (PlS unused, and optimised away, when PL_LDS)
+#pragma unroll
+        for (int i = 0; i < JG; ++i) {
+            const int sidx = g * JG + i;
+            const double pl = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
+            if constexpr (PL_LDS) PlL[i][lane] = pl;
+            else PlS[i] = pl;
+            S[i] = NEG;
+        }
+        // frame scores: chunk q in Fb[q & 1]; the loads of chunk q + 1 are issued at the start of chunk q
+        float fq[VL_CH];
+        auto fetch = [&](int q) {
+#pragma unroll
+            for (int u = 0; u < VL_CH; ++u) {
+                const int col = q * VL_CH + u;
+                fq[u] = F[(size_t)(col < K ? col : K - 1) * C + an];
+            }
+        };
+        auto stash = [&](int q) {
+#pragma unroll
+            for (int u = 0; u < VL_CH; ++u) Fb[q & 1][u][lane] = fq[u];
+        };
+        fetch(0);
+        stash(0);
+        // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32
+        float s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Fb[0][0][lane])));
+        const int nchunks = (K + VL_CH - 1) / VL_CH;
+        // The entry a column produces is first read by the NEXT column's S[1] = S[0] + f, so it stays pending across the
+        // loop edge: its ds_bpermute returns behind the shifts of the other slots instead of in front of an idle wave.
+        double e_v = NEG;                                                // pending entry of this lane's state (g == 0)
+        for (int q = 0; q < nchunks; ++q) {
+            if (q + 1 < nchunks) fetch(q + 1);
+            const int k_lo = q == 0 ? 1 : q * VL_CH, k_hi = min(K, (q + 1) * VL_CH);
+            const float *fcol = &Fb[q & 1][0][lane];
+            float f_nx = fcol[(k_lo & (VL_CH - 1)) * 64];
+            double pl0_nx = Pl0[min(k_lo - 1, J - 1)];
+            for (int k = k_lo; k < k_hi; ++k) {
+                const int c_old = k - 1;
+                const float f = f_nx;
+                const double pl0 = pl0_nx;
+                f_nx = fcol[(min(k + 1, k_hi - 1) & (VL_CH - 1)) * 64];   // the next column's reads overlap this column
+                pl0_nx = Pl0[min(k, J - 1)];
+                const double fd = (double)f;
+                // every hypothesis grows by one column
+                const double in = dpp_f64<0x111>(S[JG - 1]);            // row_shr:1 -- from the slot group below
+#pragma unroll
+                for (int i = JG - 1; i >= 2; --i) S[i] = S[i - 1] + fd;
+                // state 0: one hypothesis, float32 chain; its candidate for state 1
+                const float f0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f)));
+                const float t0 = s0 + f0;
+                const double cand01 = c_old < J ? (double)t0 + pl0 : NEG;
+                s0 = t0;
+                S[1] = (g == 0 ? e_v : S[0]) + fd;
+                S[0] = g == 0 ? NEG : in + fd;
+                // the best candidate of this lane's slots; equal scores: the later (longer) one
+                double vb = NEG;
+                int ib = 0;
+                constexpr int PLD = 6;                                  // LDS reads of Pl in flight (PL_LDS)
+                double plq[PL_LDS ? JG : 1];
+                if constexpr (PL_LDS) {
+#pragma unroll
+                    for (int i = 0; i < PLD; ++i) plq[i] = PlL[i][lane];
+                }
+#pragma unroll
+                for (int i = 0; i < JG; ++i) {
+                    double pl;
+                    if constexpr (PL_LDS) {
+                        if (i + PLD < JG) plq[i + PLD] = PlL[i + PLD][lane];
+                        pl = plq[i];
+                    } else {
+                        pl = PlS[i];
+                    }
+                    const double c = S[i] + pl;
+                    const bool take = c >= vb;
+                    vb = take ? c : vb;
+                    ib = take ? i : ib;
+                    // (keeps each compare next to its three selects: left alone, the scheduler runs the index chain slots behind
+                    // the score chain and spills the masks in between)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ... of the state: the maximum, then the largest index among the lanes that hold it
+                double vm = vb;
+                if (G >= 2) vm = fmax(vm, dpp_f64<0xB1>(vm));           // quad_perm [1,0,3,2]
+                if (G >= 4) vm = fmax(vm, dpp_f64<0x4E>(vm));           // quad_perm [2,3,0,1]
+                if (G >= 8) vm = fmax(vm, dpp_f64<0x141>(vm));          // row_half_mirror
+                int jm = vb == vm ? g * JG + ib - 1 : -1;
+                if (G >= 2) jm = max(jm, dpp_i32<0xB1>(jm));
+                if (G >= 4) jm = max(jm, dpp_i32<0x4E>(jm));
+                if (G >= 8) jm = max(jm, dpp_i32<0x141>(jm));
+                if (vm == NEG) jm = min(J, k - n) - 1;                  // all -inf: the longest live hypothesis
+                vm = vm + 0.0;
+                // hand over to the next state (lane - G); state 1 takes state 0's candidate
+                double vin = __shfl_up(vm, G);
+                int jin = __shfl_up(jm, G);
+                if (n == 1) {
+                    vin = cand01 + 0.0;
+                    jin = c_old;
+                }
+                const bool enter = state_on && k >= n && k <= J * n;
+                e_v = enter ? vin : NEG;
+                if (g == 0 && enter) bp[(size_t)k * N + n] = (uint8_t)jin;
+            }
+            if (q + 1 < nchunks) stash(q + 1);
+        }
+        if (g == 0) S[0] = e_v;                                          // the last column's entries
+
+        // finalize_decoding (viterbi.py:125-138)
+        if (forced) {
+            // Degenerate outcomes of the reference, see viterbi_dp_kernel
+            if (tid == 0) {
+                fin_n = job.force_n >= 0 ? job.force_n : K - 1;
+                fin_j = job.force_n >= 0 ? job.force_j : 0;
+                fin_score = -INFINITY;
+            }
+        } else {
+            const int nf = N - 1, c = K - 1;
+            Cand best;
+            best.v = NEG;
+            best.j = -1;
+            if (nf == 0) {
+                if (c < J) {
+                    best.v = ((double)s0 + Pl0[c]) + 0.0;
+                    best.j = c;
+                }
+            } else if (n == nf) {
+                // live length indices at the last column: entered at k0 = c - j with nf <= k0 <= J nf, and j < J
+                const int j_lo = max(0, c - J * nf), j_hi = min(J - 1, c - nf);
+#pragma unroll
+                for (int i = 0; i < JG; ++i) {
+                    const int j = g * JG + i;
+                    // Pl[nf][j] = the candidates' table one slot up (the one-lane-per-state variant keeps it in LDS)
+                    const double pl = PL_LDS ? PlL[PL_LDS ? min(i + 1, JG - 1) : 0][lane]
+                                             : tables[job.p_off + (size_t)min(j, J - 1) * N + nf];
+                    Cand d;
+                    d.v = (S[i] + pl) + 0.0;
+                    d.j = j;
+                    if (j >= j_lo && j <= j_hi) best = better(best, d);
+                }
+            }
+            best = wave_best(best);
+            if (lane == 0) {
+                fin_n = nf;
+                fin_j = best.j;
+                fin_score = best.v;
+            }
+        }
+    }
+    __syncthreads();
+    if (fin_j < 0) {  // no comparable final hypothesis (NaN scores): traceback is None in the reference
+        if (tid == 0) {
+            status[vid] = MUCON_VIT_NO_HYPOTHESIS;
+            n_seg[vid] = 0;
+            score[vid] = -INFINITY;
+        }
+        return;
+    }
+    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs);
+}
+
+
 // SPW = transcript states per wave (a wave owns states wave, wave+16, ...): the per-state work of a column is
 // written out SPW times in straight-line code -- all LDS reads first, then the adds, then the SPW independent
 // DPP reductions, then the writes -- so that the LDS and DPP latencies of the states overlap instead of adding up.
@@ -560,57 +849,14 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
         return;
     }
 
-    // traceback (viterbi.py:140-158)
-    const int nseg = fin_n + 1;
-    const int missing = T - K * fs;
-    if (tid == 0) {
-        int n = fin_n, j = fin_j, k = K - 1;
-        int32_t *sl = seg_len + job.seg_off;
-        for (int s = nseg - 1; s >= 0; --s) {
-            sl[s] = (j + 1) * fs;
-            const int k0 = k - j;
-            if (n > 0) {
-                j = bp[(size_t)k0 * N + n];
-                k = k0 - 1;
-                --n;
-            }
-        }
-        int acc = 0;
-        for (int s = 0; s < nseg; ++s) {
-            pre[s] = acc;
-            acc += sl[s];
-        }
-        pre[nseg] = acc;
-        sl[nseg - 1] += missing;  // leftover frames are added to the last segment's length
-        for (int s = nseg; s < N; ++s) sl[s] = 0;
-        n_seg[vid] = nseg;
-        score[vid] = fin_score;
-        status[vid] = forced ? MUCON_VIT_TRUNCATED : MUCON_VIT_OK;
-    }
-    __syncthreads();
-    // ... and labelled, at the START of the video, with the last segment's label
-    int32_t *lab = labels + job.label_off;
-    for (int t = tid; t < T; t += nthreads) {
-        int l;
-        if (t < missing) {
-            l = a[nseg - 1];
-        } else {
-            const int u = t - missing;
-            int lo = 0, hi = nseg - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (pre[mid] <= u) lo = mid;
-                else hi = mid - 1;
-            }
-            l = a[lo];
-        }
-        lab[t] = l;
-    }
+    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs);
 }
 
 thread_local char g_err[256];
 
 }  // namespace
+
+int g_vit_lanes = 1;   // MUCON_VIT_LANES=0: always the one-wave-per-state LDS kernel (tests)
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 #define VIT_FAIL(code)                    \
@@ -689,6 +935,23 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
         hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
                            static_cast<char *>(workspace), C, fs);
     }
+    // the DP: transcripts of up to 64 states with up to 66 length slots run in one wave's registers ...
+#define VL_LAUNCH(G, JG)                                                                                              \
+    hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG>), dim3(n_videos), dim3(VL_THREADS), 0, s, jobs, transcripts,     \
+                       length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J)
+    if (g_vit_lanes && max_N <= 64 && J <= 66) {
+        if (max_N <= 8) VL_LAUNCH(8, 9);
+        else if (max_N <= 16) VL_LAUNCH(4, 17);
+        else if (max_N <= 32) VL_LAUNCH(2, 34);
+        else VL_LAUNCH(1, 67);
+#undef VL_LAUNCH
+        if (hipGetLastError() != hipSuccess) {
+            snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
+            VIT_FAIL(MUCON_E_HIP);
+        }
+        return MUCON_OK;
+    }
+    // ... longer transcripts or more slots: one wave per state, the column in LDS
     const int spw = (max_N + 15) / 16;   // transcript states per wave
     // one wave per SPW transcript states; fewer waves make the per-column barrier cheaper (a Breakfast-typical transcript has 6
     // states: 6 waves instead of 16); the frame-score staging needs 8 C threads (two elements each)
