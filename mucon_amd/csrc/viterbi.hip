@@ -426,22 +426,25 @@ __device__ __forceinline__ double dpp_f64(double v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 
-template <int G, int JG>
-__global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
+template <int G, int JG, int NW>   // NW = 1: wave 0 decodes, three more waves only help with the labels; NW = 2: two decoding waves
+__global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_kernel(
     const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
     constexpr bool PL_LDS = JG > 40;        // one lane per state: 2 x 67 doubles do not fit the registers, Pl goes to LDS
     constexpr int VL_CH = PL_LDS ? 8 : 32;  // columns of frame scores staged at a time (one register each while in flight)
-    __shared__ double PlL[PL_LDS ? JG : 1][64];   // [slot][lane]: immediate offsets, no bank conflict
-    __shared__ float Fb[2][VL_CH][64];      // frame scores of the lanes' own labels, two chunks
+    constexpr int NL = 64 * NW;             // decoding lanes
+    __shared__ double PlL[PL_LDS ? JG : 1][NL];   // [slot][lane]: immediate offsets, no bank conflict
+    __shared__ float Fb[2][VL_CH][NL];      // frame scores of the lanes' own labels, two chunks
+    __shared__ double xch_v[2];             // NW = 2: wave 0's last state hands its best candidate to wave 1's first
+    __shared__ int xch_j[2];
     __shared__ double Pl0[128];             // state 0's length scores (runtime index: its hypothesis has j = column)
-    __shared__ int a[64], pre[65];
+    __shared__ int a[NL], pre[NL + 1];
     __shared__ double fin_score;
     __shared__ int fin_n, fin_j;
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int T = job.T, N = job.N;
     const int K = T / fs;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vid = blockIdx.x;
     if (K < 1) {  // frame_scores[fs-1] does not exist: IndexError in the reference (viterbi.py:87)
         if (tid == 0) {
@@ -463,12 +466,12 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
     const size_t f_bytes = ((size_t)K * C * sizeof(float) + 15) & ~(size_t)15;
     uint8_t *bp = reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes);  // [K][N]
     const bool forced = job.force_n >= 0 || K < N;
-    if (tid < 64) a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
-    for (int j = tid; j < J; j += VL_THREADS) Pl0[j] = tables[job.p_off + (size_t)j * N];
+    if (tid < NL) a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
+    for (int j = tid; j < J; j += blockDim.x) Pl0[j] = tables[job.p_off + (size_t)j * N];
     __syncthreads();
 
-    if (tid < 64) {
-        const int n = lane / G, g = lane - n * G;        // this lane's state and slot group
+    if (tid < NL) {
+        const int n = tid / G, g = tid - n * G;          // this lane's state and slot group
         const int an = a[n < N ? n : 0];
         const bool state_on = n >= 1 && n < N;
         const double NEG = -INFINITY;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
         for (int i = 0; i < JG; ++i) {
             const int sidx = g * JG + i;
             const double pl = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
-            if constexpr (PL_LDS) PlL[i][lane] = pl;
+            if constexpr (PL_LDS) PlL[i][tid] = pl;
             else PlS[i] = pl;
             S[i] = NEG;
         }
@@ -493,12 +496,12 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
         };
         auto stash = [&](int q) {
 #pragma unroll
-            for (int u = 0; u < VL_CH; ++u) Fb[q & 1][u][lane] = fq[u];
+            for (int u = 0; u < VL_CH; ++u) Fb[q & 1][u][tid] = fq[u];
         };
         fetch(0);
         stash(0);
         // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32
-        float s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Fb[0][0][lane])));
+        float s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Fb[0][0][tid])));
         const int nchunks = (K + VL_CH - 1) / VL_CH;
         // The entry a column produces is first read by the NEXT column's S[1] = S[0] + f, so it stays pending across the
         // loop edge: its ds_bpermute returns behind the shifts of the other slots instead of in front of an idle wave.
@@ -506,14 +509,14 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
         for (int q = 0; q < nchunks; ++q) {
             if (q + 1 < nchunks) fetch(q + 1);
             const int k_lo = q == 0 ? 1 : q * VL_CH, k_hi = min(K, (q + 1) * VL_CH);
-            const float *fcol = &Fb[q & 1][0][lane];
-            float f_nx = fcol[(k_lo & (VL_CH - 1)) * 64];
+            const float *fcol = &Fb[q & 1][0][tid];
+            float f_nx = fcol[(k_lo & (VL_CH - 1)) * NL];
             double pl0_nx = Pl0[min(k_lo - 1, J - 1)];
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c_old = k - 1;
                 const float f = f_nx;
                 const double pl0 = pl0_nx;
-                f_nx = fcol[(min(k + 1, k_hi - 1) & (VL_CH - 1)) * 64];   // the next column's reads overlap this column
+                f_nx = fcol[(min(k + 1, k_hi - 1) & (VL_CH - 1)) * NL];   // the next column's reads overlap this column
                 pl0_nx = Pl0[min(k, J - 1)];
                 const double fd = (double)f;
                 // every hypothesis grows by one column
@@ -534,13 +537,13 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
                 double plq[PL_LDS ? JG : 1];
                 if constexpr (PL_LDS) {
 #pragma unroll
-                    for (int i = 0; i < PLD; ++i) plq[i] = PlL[i][lane];
+                    for (int i = 0; i < PLD; ++i) plq[i] = PlL[i][tid];
                 }
 #pragma unroll
                 for (int i = 0; i < JG; ++i) {
                     double pl;
                     if constexpr (PL_LDS) {
-                        if (i + PLD < JG) plq[i + PLD] = PlL[i + PLD][lane];
+                        if (i + PLD < JG) plq[i + PLD] = PlL[i + PLD][tid];
                         pl = plq[i];
                     } else {
                         pl = PlS[i];
@@ -567,6 +570,17 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
                 // hand over to the next state (lane - G); state 1 takes state 0's candidate
                 double vin = __shfl_up(vm, G);
                 int jin = __shfl_up(jm, G);
+                if constexpr (NW == 2) {                                 // across the wave boundary: through LDS, one barrier per column
+                    if (tid == 63) {
+                        xch_v[k & 1] = vm;
+                        xch_j[k & 1] = jm;
+                    }
+                    __syncthreads();
+                    if (wave == 1 && lane < G) {
+                        vin = xch_v[k & 1];
+                        jin = xch_j[k & 1];
+                    }
+                }
                 if (n == 1) {
                     vin = cand01 + 0.0;
                     jin = c_old;
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
                 for (int i = 0; i < JG; ++i) {
                     const int j = g * JG + i;
                     // Pl[nf][j] = the candidates' table one slot up (the one-lane-per-state variant keeps it in LDS)
-                    const double pl = PL_LDS ? PlL[PL_LDS ? min(i + 1, JG - 1) : 0][lane]
+                    const double pl = PL_LDS ? PlL[PL_LDS ? min(i + 1, JG - 1) : 0][tid]
                                              : tables[job.p_off + (size_t)min(j, J - 1) * N + nf];
                     Cand d;
                     d.v = (S[i] + pl) + 0.0;
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(VL_THREADS) void viterbi_dp_lanes_kernel(
                 }
             }
             best = wave_best(best);
-            if (lane == 0) {
+            if (lane == 0 && wave == (nf * G) / 64) {                     // the wave that holds the last state
                 fin_n = nf;
                 fin_j = best.j;
                 fin_score = best.v;
@@ -890,7 +904,8 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     }
     const size_t smem = 16 + (size_t)3 * max_N * J * sizeof(double) + (size_t)2 * VIT_FCHUNK * C * sizeof(float) +
                         (size_t)(2 * max_N + 1) * sizeof(int) + 16;
-    if (smem > 160 * 1024 - 64) {
+    const bool lanes = g_vit_lanes && max_N <= 128 && J <= 66;   // the register kernel (below) needs no such table
+    if (!lanes && smem > 160 * 1024 - 64) {
         snprintf(g_err, sizeof(g_err), "viterbi: transcript of %d states x %d slots needs %zu B of LDS (> 160 KiB)",
                  max_N, J, smem);
         VIT_FAIL(MUCON_E_ARG);
@@ -935,15 +950,17 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
         hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
                            static_cast<char *>(workspace), C, fs);
     }
-    // the DP: transcripts of up to 64 states with up to 66 length slots run in one wave's registers ...
-#define VL_LAUNCH(G, JG)                                                                                              \
-    hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG>), dim3(n_videos), dim3(VL_THREADS), 0, s, jobs, transcripts,     \
-                       length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J)
-    if (g_vit_lanes && max_N <= 64 && J <= 66) {
-        if (max_N <= 8) VL_LAUNCH(8, 9);
-        else if (max_N <= 16) VL_LAUNCH(4, 17);
-        else if (max_N <= 32) VL_LAUNCH(2, 34);
-        else VL_LAUNCH(1, 67);
+    // the DP: up to 66 length slots run in the registers of one wave (<= 32 states) or two (<= 128) ...
+#define VL_LAUNCH(G, JG, NW)                                                                                          \
+    hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG, NW>), dim3(n_videos), dim3(NW == 1 ? VL_THREADS : 128), 0, s, jobs, \
+                       transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, \
+                       fs, J)
+    if (lanes) {
+        if (max_N <= 8) VL_LAUNCH(8, 9, 1);
+        else if (max_N <= 16) VL_LAUNCH(4, 17, 1);
+        else if (max_N <= 32) VL_LAUNCH(2, 34, 1);
+        else if (max_N <= 64) VL_LAUNCH(2, 34, 2);
+        else VL_LAUNCH(1, 67, 2);
 #undef VL_LAUNCH
         if (hipGetLastError() != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");

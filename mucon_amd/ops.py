@@ -643,7 +643,7 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     o_seg = o_lab + up8(4 * lab_off)
     o_nseg = o_seg + up8(4 * seg_off)
     o_stat = o_nseg + up8(4 * nv)
-    d_out = torch.zeros(o_stat + up8(4 * nv), dtype=torch.uint8, device=dev)
+    d_out = torch.empty(o_stat + up8(4 * nv), dtype=torch.uint8, device=dev)   # every field read below is written by the kernels
     ws = torch.empty(max(ws_off, 256), dtype=torch.uint8, device=dev)
     base_in, base_out = d_in.data_ptr(), d_out.data_ptr()
     vp = ctypes.c_void_p

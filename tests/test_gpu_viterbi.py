@@ -142,3 +142,41 @@ def test_other_sampling_and_slot_counts(fs, max_len):
         want = oracle.viterbi_decode_table(lp, tr, P, fs, max_len)
         v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], 12), PoissonModel(mu, max_length=max_len), frame_sampling=fs)
         _check(v.decode(torch.from_numpy(lp).cuda()), *want)
+
+
+def _oracle_case(seed, T, N, informative=True):
+    tr = synth.transcript(seed, N, C)
+    lp = synth.emissions(seed + 1, T, C, labels=synth.segment_labels(seed + 2, T, tr) if informative else None)
+    mu = np.ones(C)
+    mu[np.unique(tr)] = T / N
+    return lp, tr, mu
+
+
+@pytest.mark.parametrize("N", [9, 16, 17, 32, 33, 48, 64, 65, 100, 128])
+def test_every_lane_layout_of_the_register_kernel(N):
+    """The DP keeps the hypotheses in registers, 8 / 4 / 2 / 1 lanes per transcript state on one wave (N <= 8, 16, 32) or two
+    (N <= 64, 128); each layout against the oracle, with informative and with uninformative emissions (ties, -inf lengths)."""
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    for seed, T, informative in ((400 + N, 45 * N + 300, True), (500 + N, 120 * N + 17, False)):
+        lp, tr, mu = _oracle_case(seed, T, N, informative)
+        want = oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN)
+        v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], C), PoissonModel(mu), frame_sampling=FS)
+        _check(v.decode(torch.from_numpy(lp).cuda()), *want)
+
+
+def test_lds_kernel_on_the_golden_cases():
+    """The one-wave-per-state LDS kernel (more than 66 length slots, or more than 128 states) on the cases the register kernel
+    normally takes: both must give the reference's bits."""
+    from mucon_amd import _lib
+    _lib.set_knob("MUCON_VIT_LANES", 0)
+    try:
+        for cs in META["cases"]:
+            nm = cs["name"]
+            got = _decode(torch.from_numpy(viterbi_case_inputs(Z, cs)).cuda(), Z[f"{nm}__transcript"], Z[f"{nm}__P"])
+            _check(got, Z[f"{nm}__score"][0], Z[f"{nm}__labels"], Z[f"{nm}__seg_label"], Z[f"{nm}__seg_len"])
+        lp, tr, mu = _oracle_case(77, 16384, 64)
+        from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+        v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], C), PoissonModel(mu), frame_sampling=FS)
+        _check(v.decode(torch.from_numpy(lp).cuda()), *oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN))
+    finally:
+        _lib.set_knob("MUCON_VIT_LANES", 1)
