@@ -225,7 +225,7 @@ def viterbi_roofline(v):
         gbs = nbytes / (ms * 1e-3) / 1e9
         return {"ms_per_video": ms, "achieved": round(gbs, 3), "frac": round(gbs / PEAK_HBM_GBS, 6)}
     b5, b2 = v["algorithmic_bytes_per_video"], v["algorithmic_bytes_per_video_T2000_N6"]
-    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": "viterbi_framescore_kernel + viterbi_dp_kernel",
+    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": "viterbi_framescore_cols_kernel + viterbi_dp_lanes_kernel",
             "config5_T16384_N64": {"algorithmic_bytes_per_video": b5, "single": leg(v["ms_per_video_single"], b5),
                                    "batch256": leg(v["ms_per_video_batch256"], b5)},
             "T2000_N6": {"algorithmic_bytes_per_video": b2, "single": leg(v["ms_per_video_T2000_N6_single"], b2),

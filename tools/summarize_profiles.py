@@ -34,11 +34,13 @@ if hot:
     print("hot-path leg only (top 6):")
     for r in rows[:6]:
         print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} {float(r['Percentage']):6.2f}%")
-trace = one("trace/*/*_kernel_trace.csv")
-if trace:
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_summary.py"), trace, "v"], capture_output=True, text=True).stdout
+trace_hot = one("trace_hot/*/*_kernel_trace.csv")      # the hot-path leg alone: its last step is a training step of the bench shape
+if trace_hot:
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_summary.py"), trace_hot, "v"], capture_output=True, text=True).stdout
     open(os.path.join(dst, f"{tag}_step_timeline.txt"), "w").write(out)
     print(out.split("\n")[0])
+trace = one("trace/*/*_kernel_trace.csv")
+if trace:
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "e2e_trace_summary.py"), trace, "v"], capture_output=True, text=True).stdout
     open(os.path.join(dst, f"{tag}_e2e_step_timeline.txt"), "w").write(out)
     print(out.split("\n")[0])
@@ -56,7 +58,7 @@ def pmc(pattern, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if ("nt_split_kernel" in k or "nt_gemm_kernel" in k) and "pack_weights" in prev:
+        if "nt_split_kernel<true, false, false, false>" in k or ("nt_gemm_kernel" in k and "pack" in prev):
             fwd.append(float(r["Counter_Value"]))
         if "tn_batched_kernel" in k or "ts_batched_kernel" in k:
             wg.append(float(r["Counter_Value"]))
