@@ -315,3 +315,185 @@ static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const u
     }
     return hipGetLastError();
 }
+
+// ---- chained row-local launches ---------------------------------------------------------------------------------------------
+// At the coarsest level the dilation of a residual layer reaches past the sequence (d = 512, 1024 at T/16): its dilated conv is the
+// centre tap alone, the layer is ROW-LOCAL, and so is last_conv.  A row-local product that follows another needs nothing but the
+// rows its own workgroup just produced -- and after cs_kernel's second reduction wave w holds, in accumulator order, exactly the
+// 32 channels that are its k-slice of the next product.  ct_kernel therefore walks a LIST of products in one launch: product 0
+// reads its operand from memory (natural-order image), every later one takes the previous product's finished values from the
+// registers (accumulator-order images: a layer's W2 / W2t, and images 4 / 5 of fs_pack_kernel for the dilated convs' centre taps
+// and last_conv).  Every intermediate the backward pass or the weight gradients need is still written.
+//   forward   layers L-2, L-1 and last_conv:  W1c -> ReLU -> W2, dropout, +x -> W1c -> ReLU -> W2, dropout, +x -> ReLU -> W_last
+//             (3 launches -> 1; reference temporal.py:43-53, :144-145)
+//   backward  last_conv's and layer L-1's data gradients:  W_last^T, x ReLU' -> W2^T, x ReLU' -> W1c^T, + g -> W2^T, x ReLU'  (2 -> 1)
+// Arithmetic, reduction order and dropout keys are those of cs_kernel; only the k order inside a 32-deep step of the products that
+// used to read memory differs (accumulator order instead of natural).
+// What product s of a chain does is fixed by the chain (compile-time): with the descriptors indexed by constants, every pointer is
+// an ordinary kernel argument, loaded once up front -- indexed at run time, each product began with a dependent scalar-cache miss
+// (descriptor -> pointer -> load), ~0.7 us in front of its loads.
+//   CT_ADD_KEEP: + the kept rows;  CT_ACT: non-linearity;  CT_SET_KEEP: keep the result;  CT_ACT_NEXT: hand on act(result)
+enum : int { CT_ADD_KEEP = 1, CT_ACT = 2, CT_SET_KEEP = 4, CT_ACT_NEXT = 8, CT_BIAS = 16, CT_MASK = 32, CT_DROP_PRE = 64, CT_DROP_POST = 128 };
+constexpr int ct_stages(bool bwd) { return bwd ? 4 : 5; }
+constexpr int ct_flags(bool bwd, int s) {
+    return bwd ? (s == 0 ? CT_MASK | CT_SET_KEEP | CT_DROP_POST : s == 1 ? CT_MASK : s == 2 ? CT_ADD_KEEP | CT_DROP_POST : CT_MASK)
+               : (s == 0 || s == 2 ? CT_BIAS | CT_ACT
+                  : s == 1 ? CT_BIAS | CT_DROP_PRE | CT_ADD_KEEP | CT_SET_KEEP
+                  : s == 3 ? CT_BIAS | CT_DROP_PRE | CT_ADD_KEEP | CT_ACT_NEXT : CT_BIAS);
+}
+struct CtStage {
+    const uint16_t *img;    // [4 steps][FS_WSTEP]: product 0 natural order, the others accumulator order
+    const float *bias;      // CT_BIAS: + bias
+    const float *mask;      // CT_MASK: x act'(mask[row][c])
+    float *out;             // [B][Trows][128]
+    DropCfg drop;           // CT_DROP_PRE: dropout of the sum before the residual (forward conv_1x1);
+                            // CT_DROP_POST: dropout of the value handed on (backward: the NEXT product is a conv_1x1^T)
+};
+constexpr int CT_MAX_STAGES = 5;
+struct CtParams {
+    const float *A;         // operand of product 0: [B][Trows][128]
+    const float *keep0;     // forward: the first layer's input (its residual)
+    int Trows;
+    float slope;
+    CtStage st[CT_MAX_STAGES];
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void ct_kernel(const CtParams p) {
+    __shared__ f32x4 red[2][4 * 8 * 64];   // the exchange of product s uses buffer s & 1: one barrier per product
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const long vbase = (long)b * p.Trows;
+    const int trow_raw = blockIdx.x * 16 + c;
+    const bool valid = trow_raw < p.Trows;
+    const int tcl = min(trow_raw, p.Trows - 1);
+    const long grow = (vbase + tcl) * 128 + 4 * g;
+
+    // two register sets of weight fragments: product s + 1's 24 KB per wave are requested before product s multiplies, so their
+    // trip from L2 (~1 us at this grid size: one wave per SIMD, nothing else to hide it) is covered by a whole product
+    bf16x8 wf[2][8][3];
+    auto loadW = [&](const uint16_t *img, auto SET) {   // this wave's step (w) of a K = 128 image: 8 channel blocks x 3 planes
+        constexpr int Q = decltype(SET)::value;
+        const uint16_t *src = img + (long)w * FS_WSTEP + lane * 8;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[Q][nb][pl] = *reinterpret_cast<const bf16x8 *>(src + pl * (128 * 32) + nb * 512);
+    };
+    struct Planes { bf16x8 pl[3]; };
+    auto split8 = [&](const float (&x)[8]) {
+        u32x4 hh, mm, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t a, bb, cc;
+            sp_split2(x[2 * e], x[2 * e + 1], a, bb, cc);
+            hh[e] = a;
+            mm[e] = bb;
+            ll[e] = cc;
+        }
+        Planes P;
+        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
+        return P;
+    };
+    auto mfma6 = [&](const bf16x8 (&wv)[3], const Planes &X) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], X.pl[1], a, 0, 0, 0);   // small terms first
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[2], X.pl[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], X.pl[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], X.pl[0], a, 0, 0, 0);
+        return a;
+    };
+
+    // product 0's operand: this wave's 32 channels of its rows, natural order
+    loadW(p.st[0].img, std::integral_constant<int, 0>{});
+    Planes X;
+    {
+        const float *src = p.A + (vbase + tcl) * 128 + 32 * w + 8 * g;
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(src), r1 = *reinterpret_cast<const f32x4 *>(src + 4);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = valid ? r0[e] : 0.f;
+            x[4 + e] = valid ? r1[e] : 0.f;
+        }
+        X = split8(x);
+    }
+    f32x4 keep[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        keep[j] = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(p.keep0 + grow + 16 * (2 * w + j));
+
+    constexpr int NS = ct_stages(BWD);
+    auto product = [&](auto SI) {
+        constexpr int S = decltype(SI)::value, Q = S & 1, F = ct_flags(BWD, S);
+        const CtStage &st = p.st[S];
+        // the epilogue's operands travel under the MFMAs; they are requested BEFORE the next product's fragments (the memory
+        // counter is in order: waiting for them must not mean waiting for the 24 fragment loads behind them)
+        f32x4 bia[2], msk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = 2 * w + j;
+            if (F & CT_BIAS) bia[j] = *reinterpret_cast<const f32x4 *>(st.bias + 16 * nb + 4 * g);
+            if (F & CT_MASK) msk[j] = *reinterpret_cast<const f32x4 *>(st.mask + grow + 16 * nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S + 1 < NS) loadW(p.st[S + 1 < NS ? S + 1 : S].img, std::integral_constant<int, Q ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[8];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) acc[nb] = mfma6(wf[Q][nb], X);
+        f32x4 *rd = red[Q];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) rd[(w * 8 + nb) * 64 + lane] = acc[nb];
+        __syncthreads();
+        float h[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = 2 * w + j;
+            f32x4 x = ((rd[(0 * 8 + nb) * 64 + lane] + rd[(1 * 8 + nb) * 64 + lane]) + rd[(2 * 8 + nb) * 64 + lane]) + rd[(3 * 8 + nb) * 64 + lane];
+            if (F & CT_BIAS) x += bia[j];
+            if ((F & CT_DROP_PRE) && st.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= drop_mul(st.drop, (uint32_t)(grow + 16 * nb + e));
+            }
+            if (F & CT_ADD_KEEP) x += keep[j];
+            if (F & CT_MASK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= act_grad(msk[j][e], p.slope);
+            }
+            if (F & CT_ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+            }
+            if (valid) *reinterpret_cast<f32x4 *>(st.out + grow + 16 * nb) = x;
+            if (F & CT_SET_KEEP) keep[j] = x;
+            if ((F & CT_DROP_POST) && st.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= drop_mul(st.drop, (uint32_t)(grow + 16 * nb + e));
+            }
+            if (F & CT_ACT_NEXT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[4 * j + e] = valid ? x[e] : 0.f;
+        }
+        if constexpr (S + 1 < NS) X = split8(h);   // channel blocks 2 w, 2 w + 1 in accumulator order = step w of the next product
+    };
+    product(std::integral_constant<int, 0>{});
+    product(std::integral_constant<int, 1>{});
+    product(std::integral_constant<int, 2>{});
+    product(std::integral_constant<int, 3>{});
+    if constexpr (NS > 4) product(std::integral_constant<int, 4>{});
+}
+template <bool BWD>
+static hipError_t launch_ct(const CtParams &p, int B, hipStream_t s) {
+    hipLaunchKernelGGL(ct_kernel<BWD>, dim3((p.Trows + 15) / 16, B), dim3(256), 0, s, p);
+    return hipGetLastError();
+}

@@ -33,7 +33,7 @@ constexpr int FS_WTILE = 2 * FS_WSTEP;          // 64-deep LDS tile: 24,576 elem
 constexpr int FS_SMEM_BYTES = 2 * FS_WTILE * 2; // double buffered: 98,304 B
 constexpr int FS_IMG_K384 = 3 * 128 * 384;      // elements of a K = 384 image
 constexpr int FS_IMG_K128 = 3 * 128 * 128;
-constexpr int FS_LAYER_ELEMS = 2 * FS_IMG_K384 + 2 * FS_IMG_K128;   // W1f, W1b, W2, W2t of one layer (786,432 B)
+constexpr int FS_LAYER_ELEMS = 2 * FS_IMG_K384 + 4 * FS_IMG_K128;   // W1f, W1b, W2, W2t, W1fc', W1bc' of one layer (983,040 B)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
@@ -41,37 +41,42 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // Fragment (k-step q, channel block nb, lane (r, g)): the 8 k of channel n = 16 nb + r that lane group g feeds the MFMA:
 //   natural order      k32 = 8 g + j                      (stage 1: the lane loads 8 consecutive channels of its row)
 //   accumulator order  k32 = 16 (j >> 2) + 4 g + (j & 3)  (stage 2: the lane's accumulator registers of two channel blocks)
+// Images 4 and 5 are the CENTRE taps of W1f / W1b in accumulator order: what a dilated conv whose dilation reaches past the sequence
+// multiplies when its operand is the previous product's accumulator (the chained launches of gemm_coarse_split.hpp: ct_kernel).
 struct FsPackArgs {
     const float *dil_w[16];   // [o][i][tap]
     const float *pw_w[16];    // [m][n]
-    const float *last_w;      // [o][i]: slot nl (when non-null) holds last_conv's two images in the W2 / W2t positions, NATURAL order
+    const float *last_w;      // [o][i]: slot nl (when non-null) holds last_conv's two images in the W2 / W2t positions, NATURAL order,
+                              // and last_conv's forward image once more in position 4, accumulator order
     uint16_t *img;            // [slot][FS_LAYER_ELEMS]
     int nl;
 };
 __global__ __launch_bounds__(256) void fs_pack_kernel(const FsPackArgs a) {
     const int slot = blockIdx.y;
-    const int f = blockIdx.x * 256 + threadIdx.x;   // fragment index over the four matrices: 6144 + 6144 + 2048 + 2048
-    if (f >= 16384) return;
+    const int f = blockIdx.x * 256 + threadIdx.x;   // fragment index over the six matrices: 6144 + 6144 + 2048 + 2048 + 2048 + 2048
+    if (f >= 20480) return;
     const bool last = slot == a.nl;
-    if (last && f < 12288) return;
+    if (last && (f < 12288 || f >= 18432)) return;
     const float *dw = last ? nullptr : a.dil_w[slot], *pw = last ? a.last_w : a.pw_w[slot];
     int mat, q;
     if (f < 6144) { mat = 0; q = f; }
     else if (f < 12288) { mat = 1; q = f - 6144; }
-    else if (f < 14336) { mat = 2; q = f - 12288; }
-    else { mat = 3; q = f - 14336; }
+    else { mat = 2 + ((f - 12288) >> 11); q = (f - 12288) & 2047; }
     const int kstep = q >> 9, rem = q & 511;
     const int nb = rem >> 6, g = (rem >> 4) & 3, r = rem & 15;
     const int n = nb * 16 + r;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k32 = (mat < 2 || last) ? 8 * g + j : 16 * (j >> 2) + 4 * g + (j & 3);
+        const bool natural = mat < 2 || (last && mat < 4);
+        const int k32 = natural ? 8 * g + j : 16 * (j >> 2) + 4 * g + (j & 3);
         const int k = kstep * 32 + k32;
         if (mat == 0) v[j] = dw[((long)n * 128 + (k & 127)) * 3 + (k >> 7)];          // W1f[o = n][tap*128 + i]
         else if (mat == 1) v[j] = dw[((long)(k & 127) * 128 + n) * 3 + (k >> 7)];     // W1b[i = n][tap*128 + o]
         else if (mat == 2) v[j] = pw[(long)n * 128 + k];                              // W2[m = n][n']
-        else v[j] = pw[(long)k * 128 + n];                                            // W2t[n][m]
+        else if (mat == 3) v[j] = pw[(long)k * 128 + n];                              // W2t[n][m]
+        else if (mat == 4) v[j] = last ? pw[(long)n * 128 + k] : dw[((long)n * 128 + k) * 3 + 1];   // centre tap of W1f (last_conv: W)
+        else v[j] = dw[((long)k * 128 + n) * 3 + 1];                                  // centre tap of W1b
     }
     u32x4 hh, mm, ll;
 #pragma unroll
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void fs_pack_kernel(const FsPackArgs a) {
         mm[e] = y;
         ll[e] = z;
     }
-    const long moff = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : (mat == 2 ? 2L * FS_IMG_K384 : 2L * FS_IMG_K384 + FS_IMG_K128));
+    const long moff = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : 2L * FS_IMG_K384 + (long)(mat - 2) * FS_IMG_K128);
     uint16_t *dst = a.img + (long)slot * FS_LAYER_ELEMS + moff + (long)kstep * FS_WSTEP + rem * 8;
     *reinterpret_cast<u32x4 *>(dst) = hh;
     *reinterpret_cast<u32x4 *>(dst + 128 * 32) = mm;

@@ -188,9 +188,21 @@ inline bool fs_level(const mucon_encoder_cfg *cfg, const Plan &pl, int l) {
     return g_fs && !g_no_fuse && l >= 0 && l < pl.L && (long)pl.B * pl.Tl[l] >= g_fs_rows && cfg->dilation[l] < pl.Tl[l];
 }
 inline bool cs_on() { return g_cs && !g_no_fuse; }
-inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t
-    const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : (mat == 2 ? 2L * FS_IMG_K384 : 2L * FS_IMG_K384 + FS_IMG_K128));
+int g_tail_chain = 1;   // MUCON_TAIL_CHAIN=0: the row-local launches at the coarsest level one by one (cs_kernel) instead of chained (ct_kernel)
+inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t, 4 / 5 centre taps of W1f / W1b in accumulator order
+    const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : 2L * FS_IMG_K384 + (long)(mat - 2) * FS_IMG_K128);
     return reinterpret_cast<const uint16_t *>(ws + pl.Wfs) + (long)l * FS_LAYER_ELEMS + off;
+}
+
+// The last two residual layers and last_conv are row-local (dilation past the sequence, no pooling in between) and run on the
+// k-split kernels: they can be chained in one launch (ct_kernel).  The backward chain (last_conv's and layer L-1's data gradients)
+// needs the same of layer L-1 only, but both directions switch together.
+static bool tail_chain_ok(const mucon_encoder_cfg *cfg, const Plan &pl, const mucon_encoder_params *prm, int B) {
+    const int L = pl.L;
+    if (!g_tail_chain || !cs_on() || L < 2) return false;
+    for (int l = L - 2; l < L; ++l)
+        if (cfg->pool_after[l] || cfg->dilation[l] < pl.Tl[l] || fs_level(cfg, pl, l) || !prm->dil_b[l] || !prm->pw_b[l]) return false;
+    return prm->last_b && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows;
 }
 
 // Second stream for the weight-gradient launches (they hang off the data-gradient chain and are not on its
@@ -417,6 +429,10 @@ __global__ void dropout_mask_kernel(uint8_t *mask, long n, DropCfg d) {
 // mucon_test_set_knob applies the same parsing at run time (tests compare code paths inside one process).
 extern int g_vit_lanes;   // viterbi.hip
 static bool apply_knob(const char *name, const char *e) {
+    if (!strcmp(name, "MUCON_TAIL_CHAIN")) {
+        if (e) g_tail_chain = atoi(e);
+        return true;
+    }
     if (!strcmp(name, "MUCON_VIT_LANES")) {
         if (e) g_vit_lanes = atoi(e);
         return true;
@@ -539,7 +555,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
+static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -668,7 +684,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
             fa.last_w = (cs_on() && hi == L - 1) ? prm->last_w : nullptr;
             fa.img = reinterpret_cast<uint16_t *>(ws + pl.Wfs) + (long)lo * FS_LAYER_ELEMS;
-            hipLaunchKernelGGL(fs_pack_kernel, dim3(64, fa.nl + (fa.last_w ? 1 : 0)), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(fs_pack_kernel, dim3(80, fa.nl + (fa.last_w ? 1 : 0)), dim3(256), 0, s, fa);
             HIPCHK(hipGetLastError());
         }
     }
@@ -697,6 +713,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         }
         prof_mark(0, true, s);
     }
+    bool tail_done = false;   // layers L-2, L-1 and last_conv ran as one chained launch
     for (int l = 0; l < L; ++l) {
         const int Tl = pl.Tl[l];
         // When the dilation reaches past the sequence (d >= T_l, e.g. d = 512, 1024 at T/16) the outer taps only
@@ -704,6 +721,32 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         const bool centre_only = cfg->dilation[l] >= Tl;
         const DropCfg dl = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
         const int pool = !cfg->pool_after[l] ? 0 : (cfg->pool_type == 0 ? 1 : 2);
+        if (l == L - 2 && tail_chain_ok(cfg, pl, prm, B)) {
+            // the last two residual layers (centre tap only: row-local) and last_conv as ONE launch (gemm_coarse_split.hpp: ct_kernel)
+            CtParams c;
+            memset(&c, 0, sizeof(c));
+            c.A = ws + pl.x[l];
+            c.keep0 = ws + pl.x[l];
+            c.Trows = Tl;
+            c.slope = slope;
+            for (int i = 0; i < 2; ++i) {
+                const int li = l + i;
+                CtStage &a = c.st[2 * i], &b2 = c.st[2 * i + 1];
+                a.img = i == 0 ? fs_img(ws, pl, li, 0) + 4 * FS_WSTEP : fs_img(ws, pl, li, 4);
+                a.bias = prm->dil_b[li];
+                a.out = ws + pl.h[li];
+                b2.img = fs_img(ws, pl, li, 2);
+                b2.bias = prm->pw_b[li];
+                b2.drop = make_drop(cfg->seed, li, cfg->p_drop_layer, cfg->training != 0);
+                b2.out = ws + pl.x[li + 1];
+            }
+            c.st[4].img = fs_img(ws, pl, L, 4);
+            c.st[4].bias = prm->last_b;
+            c.st[4].out = ws + pl.z;
+            HIPCHK(launch_ct<false>(c, B, s));
+            tail_done = true;
+            break;
+        }
         if (!g_no_fuse && (long)B * Tl <= g_fuse_max_rows) {
             // one launch per residual layer: dilated_conv + non-linearity (temporal.py:48-49), then conv_1x1,
             // dropout, residual (:50-52) and the pooling of WaveNetBlock (:137-142); h crosses through LDS
@@ -771,7 +814,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
-    {   // non-linearity + last_conv (temporal.py:144-145)
+    if (!tail_done) {   // non-linearity + last_conv (temporal.py:144-145)
         const int Tz = pl.Tz;
         if (cs_on() && prm->last_b && !g_no_fuse && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
             FusedParams f;
@@ -871,6 +914,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         f.drop = make_drop(cfg->seed, l, cfg->p_drop_layer, cfg->training != 0);
     };
     bool have_dpre = false;  // dpre[l] already produced by the previous (fused) launch
+    bool tail_chained = false;  // ... and so are g[L-1] and dpre[L-2]: layer L-1's data gradient ran inside the chained launch
     bool unpooled_by_producer = false;  // dyd[l] (un-pooled gradient) already written by the launch that produced g[l+1]
     {   // last_conv backward: weight gradient queued (or on the side stream), data gradient on the chain
         if (!batch && overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
@@ -889,7 +933,30 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.drop = nodrop;
         rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw, -1, batch);
         if (rc != MUCON_OK) return rc;
-        if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
+        if (tail_chain_ok(cfg, pl, prm, B)) {
+            // last_conv's and layer L-1's data gradients (both row-local) as ONE launch: g[L], dpre[L-1], g[L-1], dpre[L-2]
+            CtParams c;
+            memset(&c, 0, sizeof(c));
+            c.A = gz;
+            c.Trows = Tz;
+            c.slope = slope;
+            c.st[0].img = fs_img(ws, pl, L, 3);
+            c.st[0].mask = ws + pl.x[L];
+            c.st[0].out = ws + pl.g[L];
+            c.st[0].drop = make_drop(cfg->seed, L - 1, cfg->p_drop_layer, cfg->training != 0);
+            c.st[1].img = fs_img(ws, pl, L - 1, 3);
+            c.st[1].mask = ws + pl.h[L - 1];
+            c.st[1].out = ws + pl.dpre[L - 1];
+            c.st[2].img = fs_img(ws, pl, L - 1, 5);
+            c.st[2].out = ws + pl.g[L - 1];
+            c.st[2].drop = make_drop(cfg->seed, L - 2, cfg->p_drop_layer, cfg->training != 0);
+            c.st[3].img = fs_img(ws, pl, L - 2, 3);
+            c.st[3].mask = ws + pl.h[L - 2];
+            c.st[3].out = ws + pl.dpre[L - 2];
+            HIPCHK(launch_ct<true>(c, B, s));
+            have_dpre = true;
+            tail_chained = true;
+        } else if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
             FusedParams f;
             memset(&f, 0, sizeof(f));
             f.Trows = Tz;
@@ -964,7 +1031,9 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, side ? sw : s, -1, batch);
             if (rc != MUCON_OK) return rc;
         }
-        {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
+        if (tail_chained && l == L - 1) {
+            have_dpre = true;   // dpre[L-2] exists
+        } else {   // data gradient of the dilated conv + the residual branch -> gradient w.r.t. the layer input
             const bool centre_only = cfg->dilation[l] >= Tl;
             const float *W1b = ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0);
             have_dpre = false;

@@ -534,3 +534,17 @@ def test_head_kernels_against_torch(B, Tz, Tf, H, C):
     for name, a_, b_ in zip(("logits", "logp", "d_enc", "d_w", "d_b"), got, want):
         scale = b_.abs().max().item() + 1e-12
         assert (a_.double() - b_).abs().max().item() <= 1e-5 * scale + 1e-6, name
+
+
+def test_unchained_coarsest_level():
+    """The two row-local residual layers at the coarsest level and last_conv normally run as ONE chained launch (forward), as do
+    last_conv's and the last layer's data gradients (csrc/gemm_coarse_split.hpp: ct_kernel); MUCON_TAIL_CHAIN=0 keeps them one
+    launch each (cs_kernel): goldens, oracle forward / backward, dropout replay (fresh interpreter)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MUCON_TAIL_CHAIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or oracle_f64 or dropout"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
