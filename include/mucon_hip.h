@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 2
+#define MUCON_ABI_VERSION 3
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -108,6 +108,26 @@ int mucon_linear_fwd(int32_t B, int32_t T, int32_t D, const float *tape, const f
 /* d_out [B][T][128] -> d_w [128][D], d_b [128] */
 int mucon_linear_bwd(int32_t B, int32_t T, int32_t D, const float *tape, const float *d_out, float *d_w, float *d_b,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder variant "mstcnpp": the 128-channel temporal convolutions of MSTCNPPFirstStage
+ * ---------------------------------------------------------------------------------------- */
+/* The building block of MSTCNPPFirstStage (reference src/core/modules/temporal.py:150-204, selected by
+ * cfg.model.ft.type = "mstcnpp", src/mucon/models.py:172-179): nn.Conv1d(128, 128, taps, padding = dilation, dilation) with
+ * taps = 3 (conv_dilated_1 / conv_dilated_2) or taps = 1 (the halves of conv_fusion, conv_out), time-major:
+ *     y [B][T][128] = sum_tap x [B][t + (tap - taps/2) * dilation][128] * w[:, :, tap]^T + b        (zero rows outside [0, T))
+ * on the encoder's f32-MFMA kernels (gemm_nt.hpp / gemm_tn.hpp).  The three entry points are the three linear maps autograd needs;
+ * non-linearity, dropout, the residual and the max-pooling of a layer stay element-wise operations of the caller.
+ *   fwd    w_fwd [128][taps * 128] = w[o][i][tap] at column tap * 128 + i;  b [128] or NULL
+ *   dgrad  g [B][T][128] -> d_x [B][T][128];  w_bwd [128][taps * 128] = w[o][i][tap] at row i, column tap * 128 + o
+ *   wgrad  g, x -> d_w [128][128][taps] (the nn.Conv1d layout), d_b [128] (may be NULL) */
+size_t mucon_conv128_workspace_bytes(int32_t B, int32_t T, int32_t taps);
+int mucon_conv128_fwd(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *x, const float *w_fwd, const float *b,
+                      float *y, void *stream);
+int mucon_conv128_dgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *w_bwd, float *d_x,
+                        void *stream);
+int mucon_conv128_wgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *x, float *d_w,
+                        float *d_b, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * y-head: nearest upsample Tz -> Tf, 1x1 conv H -> C, log-softmax over C

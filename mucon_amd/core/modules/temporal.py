@@ -6,7 +6,8 @@ the gfx950 kernels behind mucon_amd.ops.encoder_forward.
 
 The default encoder (cfg.model.ft.type == "wavenet") is the hand-written path.  The two non-default variants
 (no shipped configuration selects them) keep the reference's names and state_dict keys: NoFt runs on
-first_conv's kernels (mucon_linear_fwd / _bwd), MSTCNPPFirstStage on library ops on the GPU (MIOpen's dilated convolutions):
+first_conv's kernels (mucon_linear_fwd / _bwd), MSTCNPPFirstStage on mucon_linear_fwd + the 128-channel convolution entry points
+(mucon_conv128_fwd / _dgrad / _wgrad: the encoder's f32-MFMA kernels):
   NoFt               reference temporal.py:56-74    last_conv
   MSTCNPPFirstStage  reference temporal.py:150-204  conv_1x1_in, conv_dilated_1.{i}, conv_dilated_2.{i}, conv_fusion.{i}, conv_out"""
 from typing import Iterable, List
@@ -126,8 +127,33 @@ class MSTCNPPFirstStage(nn.Module):
         self.dropout = nn.Dropout()
         self.conv_out = nn.Conv1d(num_f_maps, output_dim, 1)
 
+    def _hip_ok(self, x: Tensor) -> bool:
+        return (x.is_cuda and x.dtype == torch.float32 and self.conv_1x1_in.out_channels == 128
+                and self.conv_1x1_in.in_channels % 128 == 0 and self.conv_out.out_channels == 128)
+
+    def forward_time_major(self, tape: Tensor) -> Tensor:
+        """[B, T, Cin] row-major -> [B, Tz, output_dim] on the encoder's kernels through the C ABI: conv_1x1_in = first_conv without
+        its non-linearity (mucon_linear_fwd), every 128-channel convolution = mucon_conv128_fwd / _dgrad / _wgrad (f32 MFMA);
+        conv_fusion over the concatenation = the sum of two 1x1 convolutions over its halves.  ReLU, dropout, residual and the
+        max-pooling are element-wise torch ops on the time-major rows."""
+        f = ops.linear_forward(tape, self.conv_1x1_in.weight, self.conv_1x1_in.bias)
+        for i, (far, near, fuse) in enumerate(zip(self.conv_dilated_1, self.conv_dilated_2, self.conv_fusion)):
+            a = ops.conv128_forward(f, far.weight, far.bias, far.dilation[0])
+            b = ops.conv128_forward(f, near.weight, near.bias, near.dilation[0])
+            u = ops.conv128_forward(a, fuse.weight[:, :128], fuse.bias, 1) + ops.conv128_forward(b, fuse.weight[:, 128:], None, 1)
+            f = f + self.dropout(torch.relu(u))
+            if i in self.pooling_layers:
+                B, T, Cc = f.shape
+                pairs = f[:, :2 * (T // 2)].reshape(B, T // 2, 2, Cc)
+                f = torch.where(pairs[:, :, 1] > pairs[:, :, 0], pairs[:, :, 1], pairs[:, :, 0])   # max_pool1d: the first wins a tie
+        return ops.conv128_forward(f, self.conv_out.weight, self.conv_out.bias, 1)
+
     def forward(self, x: Tensor) -> Tensor:
-        """[B, Cin, T] -> [B, output_dim, Tz]."""
+        """[B, Cin, T] -> [B, output_dim, Tz].  On the GPU with the reference's sizes (128 feature maps, Cin a multiple of 128): the
+        hand-written kernels (a permuted view of a row-major [B, T, Cin] tensor is consumed without a copy); other sizes and CPU
+        tensors (the CPU test of the module surface): library ops."""
+        if self._hip_ok(x):
+            return self.forward_time_major(x.permute(0, 2, 1)).permute(0, 2, 1)
         f = self.conv_1x1_in(x)
         for i, (far, near, fuse) in enumerate(zip(self.conv_dilated_1, self.conv_dilated_2, self.conv_fusion)):
             both = torch.cat((far(f), near(f)), dim=1)

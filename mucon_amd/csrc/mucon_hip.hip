@@ -1344,6 +1344,86 @@ int mucon_linear_bwd(int32_t B, int32_t T, int32_t D, const float *tape, const f
     return MUCON_OK;
 }
 
+// ------------------------------------------------------------------------------------------ mstcnpp building block
+namespace {
+bool conv128_plan(int B, int T, int taps, Plan &pl) {
+    if (B < 1 || T < 1 || (taps != 1 && taps != 3)) return false;
+    memset(&pl, 0, sizeof(pl));
+    pl.B = B;
+    int mc = pick_mc(B, T, taps);
+    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, T, taps, (v & 1) != 0, (v & 2) != 0));
+    const size_t nmc = (size_t)B * ((T + mc - 1) / mc);
+    pl.slabs = 0;
+    pl.slab_floats = align64(nmc * 128 * 128 * taps);
+    pl.bslabs = pl.slab_floats;
+    pl.bslab_floats = align64(nmc * 256);
+    return true;
+}
+}  // namespace
+
+size_t mucon_conv128_workspace_bytes(int32_t B, int32_t T, int32_t taps) {
+    Plan pl;
+    if (!conv128_plan(B, T, taps, pl)) {
+        fail(MUCON_E_ARG, "conv128: B=%d T=%d taps=%d (taps must be 1 or 3)", B, T, taps);
+        return 0;
+    }
+    return (pl.slab_floats + pl.bslab_floats) * sizeof(float);
+}
+
+int mucon_conv128_fwd(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *x, const float *w_fwd, const float *b,
+                      float *y, void *stream) {
+    if (B < 1 || T < 1 || (taps != 1 && taps != 3) || dilation < 0) return fail(MUCON_E_ARG, "conv128: B=%d T=%d taps=%d dilation=%d", B, T, taps, dilation);
+    if (!x || !w_fwd || !y) return fail(MUCON_E_ARG, "null pointer argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // taps that only ever read zero padding (dilation >= T) are dropped: the centre tap's 128 columns of w_fwd
+    const bool centre_only = taps == 3 && dilation >= T;
+    NtParams p = nt_base(x, (long)T * 128, 128, T, T, centre_only ? 1 : taps, dilation, 128, w_fwd + (centre_only ? 128 : 0), b, y, 1.f);
+    p.ldw = taps * 128;
+    HIPCHK((launch_nt<true, false, false, false, false, false, 0>(p, B, s)));   // slope 1: the activation slot is the identity
+    return MUCON_OK;
+}
+
+int mucon_conv128_dgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *w_bwd, float *d_x,
+                        void *stream) {
+    if (B < 1 || T < 1 || (taps != 1 && taps != 3) || dilation < 0) return fail(MUCON_E_ARG, "conv128: B=%d T=%d taps=%d dilation=%d", B, T, taps, dilation);
+    if (!g || !w_bwd || !d_x) return fail(MUCON_E_ARG, "null pointer argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool centre_only = taps == 3 && dilation >= T;
+    NtParams p = nt_base(g, (long)T * 128, 128, T, T, centre_only ? 1 : taps, -dilation, 128, w_bwd + (centre_only ? 128 : 0), nullptr, d_x, 1.f);
+    p.ldw = taps * 128;
+    HIPCHK((launch_nt<true, false, false, false, false, false, 0>(p, B, s)));
+    return MUCON_OK;
+}
+
+int mucon_conv128_wgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *x, float *d_w,
+                        float *d_b, void *workspace, size_t workspace_bytes, void *stream) {
+    Plan pl;
+    if (!conv128_plan(B, T, taps, pl) || dilation < 0) return fail(MUCON_E_ARG, "conv128: B=%d T=%d taps=%d dilation=%d", B, T, taps, dilation);
+    if (!g || !x || !d_w || !workspace) return fail(MUCON_E_ARG, "null pointer argument");
+    if (workspace_bytes < (pl.slab_floats + pl.bslab_floats) * sizeof(float)) return fail(MUCON_E_WORKSPACE, "conv128 workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Y0 = g;
+    a.X0 = x;
+    a.x_bstride = (long)T * 128;
+    a.ldx = 128;
+    a.Tx = T;
+    a.taps = taps;
+    a.tap_step = dilation;
+    a.nk0 = taps;
+    a.mode0 = taps == 3 ? 1 : 0;      // [o][i][tap] for the three-tap weight
+    a.out_w0 = d_w;
+    a.out_b0 = d_b;
+    a.drop = make_drop(0, 0, 0.f, false);
+    Reducer red(s);
+    size_t arena = 0, barena = 0;
+    int rc = wgrad(pl, static_cast<float *>(workspace), arena, barena, T, a, 0.f, red, s);
+    if (rc != MUCON_OK) return rc;
+    HIPCHK(red.run());
+    return MUCON_OK;
+}
+
 // ------------------------------------------------------------------------------------------ helpers
 int mucon_test_gemm_nt(const float *A, const float *W, const float *bias, float *out, int32_t M, int32_t K,
                        int32_t relu, void *stream) {

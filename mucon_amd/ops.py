@@ -206,6 +206,56 @@ class _LinearFn(torch.autograd.Function):
         return None, d_w, d_b
 
 
+class _Conv128Fn(torch.autograd.Function):
+    """y [B,T,128] = conv1d over time of x [B,T,128] with w [128,128,taps] (nn.Conv1d layout), padding = dilation -- the building
+    block of the encoder variant "mstcnpp" (reference core/modules/temporal.py:150-204) on the encoder's f32-MFMA kernels
+    (mucon_conv128_fwd / _dgrad / _wgrad).  The weight re-layouts are two small permutes."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dilation):
+        lib = _lib.load()
+        _check_dev(x, w)
+        x, w = x.contiguous(), w.contiguous()
+        B, T, Cc = x.shape
+        taps = int(w.shape[2])
+        assert Cc == 128 and tuple(w.shape[:2]) == (128, 128) and taps in (1, 3)
+        w_fwd = w.permute(0, 2, 1).contiguous()                      # [o][tap][i]
+        y = torch.empty_like(x)
+        _lib.check(lib.mucon_conv128_fwd(B, T, taps, int(dilation), _lib.ptr(x), _lib.ptr(w_fwd),
+                                         _lib.ptr(b.contiguous()) if b is not None else None, _lib.ptr(y),
+                                         _lib.current_stream_ptr()), "mucon_conv128_fwd")
+        ctx.dims = (B, T, taps, int(dilation), b is not None)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        B, T, taps, dilation, has_b = ctx.dims
+        g = g.contiguous()
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            w_bwd = w.permute(1, 2, 0).contiguous()                  # [i][tap][o]
+            d_x = torch.empty_like(x)
+            _lib.check(lib.mucon_conv128_dgrad(B, T, taps, dilation, _lib.ptr(g), _lib.ptr(w_bwd), _lib.ptr(d_x),
+                                               _lib.current_stream_ptr()), "mucon_conv128_dgrad")
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            nbytes = lib.mucon_conv128_workspace_bytes(B, T, taps)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            d_w = torch.empty_like(w)
+            d_b = torch.empty(128, dtype=torch.float32, device=x.device) if has_b else None
+            _lib.check(lib.mucon_conv128_wgrad(B, T, taps, dilation, _lib.ptr(g), _lib.ptr(x), _lib.ptr(d_w),
+                                               _lib.ptr(d_b) if has_b else None, _lib.ptr(ws), nbytes,
+                                               _lib.current_stream_ptr()), "mucon_conv128_wgrad")
+        return d_x, d_w, d_b, None
+
+
+def conv128_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1) -> torch.Tensor:
+    """x [B,T,128] time-major -> [B,T,128]; weight [128,128,1|3] (nn.Conv1d layout), zero padding = dilation."""
+    return _Conv128Fn.apply(x, weight, bias, dilation)
+
+
 def linear_forward(tape: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """tape [B,T,D] -> [B,T,128]; weight [128,D] (or the Conv1d form [128,D,1])."""
     return _LinearFn.apply(tape, weight.reshape(weight.shape[0], weight.shape[1]), bias)

@@ -85,3 +85,43 @@ def test_noft_kernels_against_float64(B, T):
     db = u.double().sum((0, 1))
     assert float((w.grad.double() - dw).abs().max()) <= 2e-5 * float(dw.abs().max())
     assert float((b.grad.double() - db).abs().max()) <= 2e-5 * float(db.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,taps,dilation", [(1, 640, 3, 1), (2, 333, 3, 64), (1, 200, 3, 512), (2, 4500, 1, 1), (1, 77, 3, 7)])
+def test_conv128_kernels_against_float64(B, T, taps, dilation):
+    """The 128-channel temporal convolution of MSTCNPPFirstStage through the C ABI (mucon_conv128_fwd / _dgrad / _wgrad): forward
+    and all three gradients against a float64 nn.functional.conv1d, incl. a dilation that reaches past the sequence."""
+    from mucon_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, T, 128, generator=g).cuda().requires_grad_()
+    w = (torch.randn(128, 128, taps, generator=g) * 0.08).cuda().requires_grad_()
+    b = torch.randn(128, generator=g).cuda().requires_grad_()
+    u = torch.randn(B, T, 128, generator=g).cuda()
+    y = ops.conv128_forward(x, w, b, dilation)
+    (y * u).sum().backward()
+    xd, wd, bd = (t.detach().double().cpu().requires_grad_() for t in (x, w, b))
+    ref = torch.nn.functional.conv1d(xd.permute(0, 2, 1), wd, bd, padding=dilation * (taps // 2), dilation=dilation).permute(0, 2, 1)
+    (ref * u.double().cpu()).sum().backward()
+    for got, want in ((y, ref), (x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-5 * float(want.detach().abs().max())
+
+
+@pytest.mark.gpu
+def test_mstcnpp_hip_path_gradients_match_library_ops():
+    """MSTCNPPFirstStage on the HIP kernels vs the same module on library ops in float64 (CPU): output and every parameter gradient."""
+    from mucon_amd.core.modules.temporal import MSTCNPPFirstStage
+    torch.manual_seed(5)
+    m = MSTCNPPFirstStage(num_layers=5, num_f_maps=128, input_dim=256, output_dim=128, pooling_layers=(1, 3)).eval()
+    ref = MSTCNPPFirstStage(num_layers=5, num_f_maps=128, input_dim=256, output_dim=128, pooling_layers=(1, 3)).double().eval()
+    ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m = m.cuda()
+    x = torch.randn(2, 256, 203)
+    u = torch.randn(2, 128, 203 // 4)
+    out = m(x.cuda())
+    (out * u.cuda()).sum().backward()
+    want = ref(x.double())
+    (want * u.double()).sum().backward()
+    assert float((out.double().cpu() - want).abs().max()) <= 5e-5 * float(want.abs().max())
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 1e-4 * float(q.grad.abs().max()) + 1e-9, n
