@@ -130,6 +130,26 @@ int mucon_conv128_wgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, co
                         float *d_b, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluation counters on the device: frame accuracy and segment overlap (MoF / IoD / IoU)
+ * ---------------------------------------------------------------------------------------- */
+/* The counters of MoFAccuracyMetric, IoDMetric and IoUMetric (reference src/core/metrics/segmentation.py:16-91 and the
+ * isba_code.py:23-109 they call) for labellings that live on the device.  Video v owns frames offsets[v] .. offsets[v+1] of
+ * targets / predictions (int32 labels; offsets has n_videos + 1 entries, all device pointers).
+ *   mof [n_videos][2]                 frames whose target is not in ignore_ids: those with target == prediction, and their number
+ *   n_runs [n_videos][3]              runs (maximal constant stretches) of the targets, of the predictions, and the predicted runs
+ *                                     whose label is not in ignore_ids
+ *   run_label, iod, iou [n_videos][MUCON_METRICS_MAX_RUNS]
+ *                                     per TARGET run: its label and the largest intersection / predicted-run length (iod) and
+ *                                     intersection / union span (iou) over the predicted runs with the same label (-inf if none);
+ *                                     valid when both run counts are <= MUCON_METRICS_MAX_RUNS
+ * The quotients are single float64 divisions of integers, so mean(max(., 0)) over the runs whose label is not ignored reproduces the
+ * host metric's value bit for bit (mucon_amd/core/metrics/device.py). */
+#define MUCON_METRICS_MAX_RUNS 1024
+int mucon_metrics_overlap(int32_t n_videos, const int64_t *offsets, const int32_t *targets, const int32_t *predictions,
+                          const int32_t *ignore_ids, int32_t n_ignore, int64_t *mof, int32_t *n_runs, int32_t *run_label,
+                          double *iod, double *iou, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * y-head: nearest upsample Tz -> Tf, 1x1 conv H -> C, log-softmax over C
  * ---------------------------------------------------------------------------------------- */
 size_t mucon_head_workspace_bytes(int32_t B, int32_t Tz, int32_t H, int32_t C);

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
 ABI_VERSION = 3
+METRICS_MAX_RUNS = 1024   # MUCON_METRICS_MAX_RUNS
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
 VIT_OK, VIT_INDEX_ERROR, VIT_NO_HYPOTHESIS, VIT_TRUNCATED = 0, 1, 2, 3
@@ -96,6 +97,7 @@ SYMBOLS = {
     "mucon_linear_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mucon_linear_fwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_linear_bwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_metrics_overlap": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_conv128_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mucon_conv128_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mucon_conv128_dgrad": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -2,9 +2,9 @@
 
     python -m mucon_amd.build [--force]
 
-Three translation units: mucon_hip.hip (encoder / head, FMA contraction allowed), viterbi.hip
-(-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires) and
-shead.hip (the s-head's bidirectional LSTM).
+Four translation units: mucon_hip.hip (encoder / head, FMA contraction allowed), viterbi.hip
+(-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires),
+shead.hip (the s-head's bidirectional LSTM) and metrics.hip (evaluation counters).
 The .so lands next to this file (git-ignored; gpurun ships it to the GPU box)."""
 import os
 import subprocess
@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmucon_hip.so")
 ARCH = "gfx950"
-SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shead.hip", [])]
+SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shead.hip", []), ("metrics.hip", ["-ffp-contract=off"])]
 DEPS = ["common.hpp", "gemm_nt.hpp", "gemm_split.hpp", "gemm_tn.hpp", "gemm_tn_split.hpp", "gemm_fused_split.hpp", "gemm_coarse_split.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "decoder.hpp", "loss.hpp", "optim.hpp", "../../include/mucon_hip.h", "../../include/mucon_hip_test.h"]
 
 

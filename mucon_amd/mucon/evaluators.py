@@ -59,6 +59,9 @@ class MuConEvaluator:
             raise NotImplementedError("evaluator.viterbi.multi_length is broken in the reference "
                                       "(MultiPoissonModel.score raises); not supported")
         self.vi_decoder = Viterbi(None, None, frame_sampling=30)
+        # y-head MoF / IoD / IoU from the device-resident arg max and ground truth (mucon_metrics_overlap) instead of the host
+        # arrays: same values bit for bit (tests/test_gpu_metrics_device.py); the host keeps edit / F1 and the saved lists
+        self.device_overlap = False
         bg = getattr(test_db, "background_class_ids", [0])
         m = self.metrics = {}
         for head in ("y", "s", "vit"):
@@ -95,6 +98,17 @@ class MuConEvaluator:
             for n in names:
                 self.metrics[f"{head}_{n}"](targets=target, predictions=prediction)
 
+    def _add_y_from_device(self, target_dev, pred_dev, target, y_same):
+        from ..core.metrics.device import add_to_metrics, overlap_counters
+        m = self.metrics
+        plain = overlap_counters([target_dev], [pred_dev], ())[0]
+        add_to_metrics(plain, m["y_mof"], m["y_iod"], m["y_iou"])
+        nbg = overlap_counters([target_dev], [pred_dev], m["y_mof_nbg"].ignore_ids)[0]
+        add_to_metrics(nbg, m["y_mof_nbg"])
+        with np.errstate(all="ignore"):
+            for n in ("edit_score", "f1_score"):
+                m[f"y_{n}"](targets=target, predictions=y_same)
+
     def batch_eval_calculation(self, batch, forward_out):
         """One test video (reference evaluators.py:121-257)."""
         pred = self.model.predict(batch, forward_out)
@@ -120,7 +134,10 @@ class MuConEvaluator:
         s_same = make_same_size_interpolate(s_pred, len(target))
         y_same = make_same_size_interpolate(y_pred, len(target))
         self._add("s", target, s_same, True)
-        self._add("y", target, y_same, False)
+        if self.device_overlap and batch.gt_label.is_cuda and len(y_pred) == len(target):
+            self._add_y_from_device(batch.gt_label.reshape(-1), pred.segmentation_logits.argmax(dim=1).reshape(-1), target, y_same)
+        else:
+            self._add("y", target, y_same, False)
         if self.enable_viterbi:
             vit_same = make_same_size_interpolate(np.array(result["viterbi_labels"]), len(target))
             self._add("vit", target, vit_same, True)

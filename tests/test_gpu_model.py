@@ -121,3 +121,7 @@ def test_train_steps_and_viterbi_eval_on_synthetic_breakfast(tmp_path):
         from mucon_amd.mucon.evaluators import RESULT_FIELDS
         assert set(res) == set(RESULT_FIELDS) and 0.0 <= res["vit_mof"] <= 1.0 and len(res["vit_f1_score"]) == 3
         assert len(ev.to_save["vit_segs"]) == len(test_db) and 0.0 <= res["s_mat_score"] <= 1.0
+        ev.device_overlap = True          # y-head MoF / IoD / IoU from device counters: the same record
+        res_dev = ev.evaluate()
+        for k in RESULT_FIELDS:
+            assert np.array_equal(np.asarray(res[k], dtype=np.float64), np.asarray(res_dev[k], dtype=np.float64), equal_nan=True), k
