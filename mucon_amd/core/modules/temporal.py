@@ -73,8 +73,39 @@ class WaveNetBlock(nn.Module):
     def forward_time_major(self, tape: Tensor, gn_weight: Tensor, gn_bias: Tensor, spec: ops.EncoderSpec,
                            seed: int = 0) -> Tensor:
         """tape [B, T, Cin] (row-major, as the dataset delivers it) -> [B, Tz, out_dims]."""
-        return ops.encoder_forward(tape, self.ordered_parameters() + [gn_weight, gn_bias], spec,
-                                   training=self.training, seed=seed)
+        if self.out_dims == 128:
+            return ops.encoder_forward(tape, self.ordered_parameters() + [gn_weight, gn_bias], spec,
+                                       training=self.training, seed=seed)
+        if self.out_dims > 128:
+            raise NotImplementedError("the HIP encoder is built for hidden sizes up to 128")
+        return self._forward_padded(tape, gn_weight, gn_bias, spec, seed)
+
+    def _forward_padded(self, tape: Tensor, gn_weight: Tensor, gn_bias: Tensor, spec: ops.EncoderSpec, seed: int) -> Tensor:
+        """Hidden sizes below 128 (the constructor default of the reference's WaveNetBlock is 64, temporal.py:82) on the
+        128-channel kernels: every parameter is zero-padded to 128 channels.  A padded channel is 0 after first_conv (zero weights,
+        zero bias, ReLU) and stays 0 through every layer (its rows and columns of every weight are zero, dropout of 0 is 0, the
+        residual adds 0), and the real channels only ever add exact zeros to their sums: the first out_dims channels of the
+        result ARE the out_dims-channel network's, not an approximation of it; the gradients of the padding are sliced away by
+        autograd.  GroupNorm / ReLU / dropout of the wrapper (models.py:759-768) run on the sliced rows as torch ops (the
+        kernel's GroupNorm is laid out for 128 channels).  Costs the FLOPs of the 128-channel network."""
+        import dataclasses
+
+        import torch.nn.functional as F
+        H, pad = self.out_dims, 128 - self.out_dims
+        ps = self.ordered_parameters()
+        padded = [F.pad(ps[0], (0, 0, 0, 0, 0, pad)), F.pad(ps[1], (0, pad))]              # first_conv [H, Cin, 1], [H]
+        for w in ps[2:]:
+            padded.append(F.pad(w, (0, 0, 0, pad, 0, pad)) if w.dim() == 3 else F.pad(w, (0, pad)))
+        spec128 = dataclasses.replace(spec, hidden=128, last_gn=False, last_relu=False, last_dropout=False)
+        ones = torch.ones(128, device=tape.device)
+        z = ops.encoder_forward(tape, padded + [ones, torch.zeros_like(ones)], spec128, training=self.training, seed=seed)[..., :H]
+        if spec.last_gn:
+            z = F.group_norm(z.permute(0, 2, 1), spec.last_gn_num_groups, gn_weight, gn_bias, spec.gn_eps).permute(0, 2, 1)
+        if spec.last_relu:
+            z = torch.relu(z)
+        if spec.last_dropout:
+            z = F.dropout(z, p=spec.last_dropout_rate, training=self.training)
+        return z.contiguous()
 
     def forward(self, x: Tensor) -> Tensor:
         """Reference signature (temporal.py:128-147): x [B, Cin, T] -> [B, out_dims, Tz].  A permuted view of a

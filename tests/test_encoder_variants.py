@@ -125,3 +125,56 @@ def test_mstcnpp_hip_path_gradients_match_library_ops():
     assert float((out.double().cpu() - want).abs().max()) <= 5e-5 * float(want.abs().max())
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 1e-4 * float(q.grad.abs().max()) + 1e-9, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,groups", [(64, 32), (32, 8), (96, 32)])
+def test_hidden_sizes_below_128_against_float64_oracle(H, groups):
+    """WaveNetBlock with a hidden size below 128 (the reference's constructor default is 64) runs on the 128-channel kernels with
+    zero-padded parameters: output of the encoder wrapper and every parameter gradient against the float64 oracle of the
+    H-channel network (eval mode)."""
+    from oracle import dense as od
+    from mucon_amd.core.modules.temporal import WaveNetBlock
+    cfg = od.EncoderConfig(in_dim=256, hidden=H, stages=[1, 2, 4, 8, 16], pooling_layers=[1, 3], last_gn_num_groups=groups)
+    pn = od.seeded_params(cfg, 9)
+    blk = WaveNetBlock(256, stages=cfg.stages, out_dims=H, pooling_layers=cfg.pooling_layers, dropout_rate=0.25).cuda().eval()
+    sd = {k[len("ft."):]: torch.from_numpy(v) for k, v in pn.items() if k.startswith("ft.")}
+    blk.load_state_dict(sd)
+    gw = torch.from_numpy(pn["ft_last_gn.weight"]).cuda().requires_grad_()
+    gb = torch.from_numpy(pn["ft_last_gn.bias"]).cuda().requires_grad_()
+    B, T = 2, 333
+    tape_np = synth.uniform_pm1(77, (B, T, 256))
+    spec = blk.spec(last_gn=True, last_gn_num_groups=groups, last_relu=True, last_dropout=True, last_dropout_rate=0.25)
+    z = blk.forward_time_major(torch.from_numpy(tape_np).cuda(), gw, gb, spec)
+    u = torch.from_numpy(synth.uniform_pm1(78, tuple(z.shape)))
+    (z * u.cuda()).sum().backward()
+    pt = od.to_torch(pn, requires_grad=True)
+    want = od.encoder_forward(torch.from_numpy(tape_np).double(), pt, cfg)
+    (want * u.double()).sum().backward()
+    assert tuple(z.shape) == tuple(want.shape) == (B, T // 4, H)
+    assert float((z.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    got = {"ft." + n: p.grad for n, p in blk.named_parameters()}
+    got.update({"ft_last_gn.weight": gw.grad, "ft_last_gn.bias": gb.grad})
+    for n, g in got.items():
+        w = pt[n].grad
+        assert tuple(g.shape) == tuple(w.shape), n
+        assert float((g.double().cpu() - w).norm()) <= 2e-4 * float(w.norm()) + 1e-12, n
+
+
+@pytest.mark.gpu
+def test_model_with_hidden_64_trains():
+    """cfg.model.ft.hidden_size = 64 end to end: forward, loss, backward, optimizer step on the GPU."""
+    from test_gpu_model import make_batch
+    from mucon_amd.mucon.trainers import SimpleTrainer
+    cfg = update_config(get_cfg_defaults(), [], [["model.ft.hidden_size", "64"]])
+    model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048).cuda()
+    tr = SimpleTrainer(cfg, model, "cuda")
+    tr.on_start_epoch(0)
+    model.train()
+    before = model.ft.first_conv.weight.detach().clone()
+    loss, _ = tr._train_1_batch(0, make_batch(640, 5).to("cuda"))
+    assert torch.isfinite(loss.main) and not torch.equal(before, model.ft.first_conv.weight)
+    model.eval()
+    with torch.no_grad():
+        enc = model.temporal_modeling_forward(make_batch(640, 5).to("cuda").feats)
+    assert tuple(enc.shape) == (1, 40, 64)
