@@ -326,6 +326,26 @@ int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *tensors, int3
                         float lr, float weight_decay, float momentum, float *group_norms, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The same step tail with torch.optim.Adam (reference src/mucon/trainers.py:31-36: optimizer "Adam", amsgrad=True): group-wise
+ * clipping as above, then per element the sequence of torch's Adam -- u = grad + weight_decay * param, exp_avg += (u - exp_avg)(1 - beta1),
+ * exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) u u, max_exp_avg_sq = max(., exp_avg_sq) (when the pointer is non-NULL: AMSGrad),
+ * param -= lr / (1 - beta1^step) * exp_avg / (sqrt(max_exp_avg_sq or exp_avg_sq) / sqrt(1 - beta2^step) + eps).  `step` is the
+ * 1-based step count AFTER this call; the state buffers are torch's optimizer.state tensors, so checkpoints stay interchangeable. */
+typedef struct mucon_adam_tensor {
+    float *param;
+    float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    float *max_exp_avg_sq; /* NULL: plain Adam */
+    int64_t n;
+    int32_t group;
+    int32_t reserved;
+} mucon_adam_tensor;
+size_t mucon_adam_workspace_bytes(int32_t n_tensors, int64_t total_elements);
+int mucon_adam_clip_step(int32_t n_tensors, const mucon_adam_tensor *tensors, int32_t n_groups, const float *max_norm,
+                         double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                         float *group_norms, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,11 @@ class SgdTensor(ctypes.Structure):
                 ("n", ctypes.c_int64), ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("max_exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64), ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # every symbol include/mucon_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
@@ -127,6 +132,9 @@ SYMBOLS = {
     "mucon_sgd_workspace_bytes": (_sz, [_i32, _i64]),
     "mucon_sgd_clip_step": (ctypes.c_int, [_i32, ctypes.POINTER(SgdTensor), _i32, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, _vp, _vp, _sz, _vp]),
+    "mucon_adam_workspace_bytes": (_sz, [_i32, _i64]),
+    "mucon_adam_clip_step": (ctypes.c_int, [_i32, ctypes.POINTER(AdamTensor), _i32, ctypes.POINTER(ctypes.c_float), ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i64, _vp, _vp, _sz, _vp]),
     "mucon_decoder_workspace_bytes": (_sz, [ctypes.POINTER(DecoderCfg)]),
     "mucon_decoder_fwd": (ctypes.c_int, [ctypes.POINTER(DecoderCfg), ctypes.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -19,7 +19,8 @@ struct SgdTensor {   // mirrors mucon_sgd_tensor + the launch bookkeeping
     int group, block0;
 };
 
-__device__ __forceinline__ int sgd_find(const SgdTensor *tab, int nt, int block) {
+template <class TAB>
+__device__ __forceinline__ int sgd_find(const TAB *tab, int nt, int block) {
     int lo = 0, hi = nt - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -38,9 +39,10 @@ __device__ __forceinline__ float sgd_block_sum(float v, float *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void sgd_norm_kernel(const SgdTensor *tab, int nt, float *partial) {
+template <class TAB>
+__global__ __launch_bounds__(256) void sgd_norm_kernel(const TAB *tab, int nt, float *partial) {
     __shared__ float red[4];
-    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    const TAB t = tab[sgd_find(tab, nt, blockIdx.x)];
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     float acc = 0.f;
@@ -141,5 +143,68 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
         t.g[e] = og;
         t.p[e] = op;
         if (t.mom) t.mom[e] = om;
+    }
+}
+
+// ---- Adam (torch.optim.Adam, optionally AMSGrad) behind the same group-wise clipping -----------------------------------------
+//   g *= coef (written back);  u = g + wd * p;  m += (u - m) (1 - beta1);  v = v beta2 + (1 - beta2) u u;
+//   vmax = max(vmax, v) (amsgrad);  p -= step_size * m / (sqrt(vmax or v) / sqrt(1 - beta2^t) + eps),  step_size = lr / (1 - beta1^t)
+// -- the element-wise sequence of torch's _single_tensor_adam; the scalars are formed on the host in double, as torch forms them.
+struct AdamTensor {
+    float *p, *g, *m, *v, *vmax;   // vmax: null without amsgrad
+    long n;
+    int group, block0;
+};
+struct AdamHyper {
+    float max_norm[SGD_MAXGROUPS];
+    float step_size, one_minus_beta1, beta2, one_minus_beta2, sqrt_bc2, eps, weight_decay;
+    int ngroups, nblocks, any_clip;
+};
+__global__ __launch_bounds__(256) void adam_apply_kernel(const AdamTensor *tab, int nt, const float *partial, AdamHyper h, float *norms_out) {
+    __shared__ float red[4];
+    const AdamTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    float acc = 0.f;
+    if (h.any_clip) {
+        for (int b = threadIdx.x; b < h.nblocks; b += 256)
+            if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
+    }
+    const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
+    const float mx = h.max_norm[t.group];
+    const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
+    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
+        bool first = true;
+        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
+        if (first) norms_out[t.group] = norm;
+    }
+    const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
+    const long b1 = min(t.n, b0 + SGD_CHUNK);
+    // four elements per thread and round, all loads of a round issued before its arithmetic
+    for (long base = b0; base < b1; base += 1024) {
+        float g[4], p[4], m[4], v[4], vm[4];
+        long e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = min(base + threadIdx.x + 256 * j, b1 - 1);          // clamped: loads are never under a branch
+            g[j] = t.g[e[j]];
+            p[j] = t.p[e[j]];
+            m[j] = t.m[e[j]];
+            v[j] = t.v[e[j]];
+            vm[j] = t.vmax ? t.vmax[e[j]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (base + threadIdx.x + 256 * j >= b1) continue;
+            const float gc = g[j] * coef;
+            const float u = h.weight_decay != 0.f ? gc + h.weight_decay * p[j] : gc;
+            const float mn = m[j] + (u - m[j]) * h.one_minus_beta1;
+            const float vn = v[j] * h.beta2 + h.one_minus_beta2 * u * u;
+            const float vx = t.vmax ? fmaxf(vm[j], vn) : vn;
+            const float denom = sqrtf(vx) / h.sqrt_bc2 + h.eps;
+            t.g[e[j]] = gc;
+            t.m[e[j]] = mn;
+            t.v[e[j]] = vn;
+            if (t.vmax) t.vmax[e[j]] = vx;
+            t.p[e[j]] = p[j] - h.step_size * (mn / denom);
+        }
     }
 }

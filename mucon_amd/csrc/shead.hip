@@ -2,6 +2,7 @@
 // and the attention decoder (decoder.hpp); of the fused losses (8f row 2, loss.hpp) and of the
 // clip + SGD step (optim.hpp).  Declared in include/mucon_hip.h.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -446,8 +447,65 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     h.nblocks = blocks;
     h.any_clip = 0;
     for (int g = 0; g < n_groups; ++g) h.any_clip |= max_norm[g] > 0.f;
-    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel, dim3(blocks), dim3(256), 0, s, use_tab, n_tensors, partial);
+    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel<SgdTensor>, dim3(blocks), dim3(256), 0, s, use_tab, n_tensors, partial);
     hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, use_tab, n_tensors, partial, h, group_norms);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------ clip + Adam
+extern "C" size_t mucon_adam_workspace_bytes(int32_t n_tensors, int64_t total_elements) {
+    if (n_tensors < 1 || total_elements < 1) return 0;
+    const size_t blocks = (size_t)(total_elements / SGD_CHUNK) + n_tensors;
+    return al64(sizeof(AdamTensor) * n_tensors) + sizeof(float) * al64(blocks);
+}
+
+extern "C" int mucon_adam_clip_step(int32_t n_tensors, const mucon_adam_tensor *tensors, int32_t n_groups, const float *max_norm,
+                                    double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                                    float *group_norms, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_tensors < 1 || !tensors || !workspace) return sfail(MUCON_E_ARG, "adam: no tensors");
+    if (n_groups < 1 || n_groups > SGD_MAXGROUPS || !max_norm) return sfail(MUCON_E_ARG, "adam: %d clipping groups (1..%d)", n_groups, SGD_MAXGROUPS);
+    if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1)) return sfail(MUCON_E_ARG, "adam: step %lld, betas %g %g", (long long)step, beta1, beta2);
+    std::vector<AdamTensor> tab(n_tensors);
+    long total = 0;
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const mucon_adam_tensor &t = tensors[i];
+        if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || t.n < 1) return sfail(MUCON_E_ARG, "adam: tensor %d: null pointer or empty", i);
+        if (t.group < 0 || t.group >= n_groups) return sfail(MUCON_E_ARG, "adam: tensor %d: group %d outside 0..%d", i, t.group, n_groups - 1);
+        tab[i].p = t.param;
+        tab[i].g = t.grad;
+        tab[i].m = t.exp_avg;
+        tab[i].v = t.exp_avg_sq;
+        tab[i].vmax = t.max_exp_avg_sq;
+        tab[i].n = t.n;
+        tab[i].group = t.group;
+        tab[i].block0 = blocks;
+        blocks += (int)((t.n + SGD_CHUNK - 1) / SGD_CHUNK);
+        total += t.n;
+    }
+    if (workspace_bytes < mucon_adam_workspace_bytes(n_tensors, total)) return sfail(MUCON_E_WORKSPACE, "adam workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AdamTensor *dtab = static_cast<AdamTensor *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + al64(sizeof(AdamTensor) * n_tensors));
+    // (the table is uploaded on every call: a pageable source is staged by the runtime before the call returns)
+    SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(AdamTensor) * n_tensors, hipMemcpyHostToDevice, s));
+    AdamHyper h;
+    for (int g = 0; g < SGD_MAXGROUPS; ++g) h.max_norm[g] = g < n_groups ? max_norm[g] : 0.f;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    h.step_size = (float)(lr / bc1);
+    h.one_minus_beta1 = (float)(1.0 - beta1);
+    h.beta2 = (float)beta2;
+    h.one_minus_beta2 = (float)(1.0 - beta2);
+    h.sqrt_bc2 = (float)sqrt(bc2);
+    h.eps = (float)eps;
+    h.weight_decay = (float)weight_decay;
+    h.ngroups = n_groups;
+    h.nblocks = blocks;
+    h.any_clip = 0;
+    for (int g = 0; g < n_groups; ++g) h.any_clip |= max_norm[g] > 0.f;
+    if (h.any_clip) hipLaunchKernelGGL(sgd_norm_kernel<AdamTensor>, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial, h, group_norms);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

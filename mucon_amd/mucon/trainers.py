@@ -141,16 +141,18 @@ class SimpleTrainer:
         self.fuse_step = True   # False: always go through torch.autograd
 
     def _make_fused_step(self):
-        """The two clip_grad_norm_ calls + SGD.step() as ops.FusedClipSGD (two launches) when the configuration is the
-        one those kernels implement: SGD on the GPU, no gradient accumulation, group-wise or global clipping."""
+        """The two clip_grad_norm_ calls + optimizer.step() as ops.FusedClipSGD / ops.FusedClipAdam (two launches) when the
+        configuration is one those kernels implement: SGD or Adam (the reference's two optimizers, trainers.py:31-36) on the GPU,
+        no gradient accumulation, group-wise or global clipping."""
         from .. import ops
         t = self.cfg.trainer
-        if not isinstance(self.optimizer, optim.SGD) or (t.accumulate_grad_every or 1) != 1:
+        adam = type(self.optimizer) is optim.Adam
+        if not (isinstance(self.optimizer, optim.SGD) or adam) or (t.accumulate_grad_every or 1) != 1:
             return None
         if not str(self.device).startswith("cuda") or len(self.optimizer.param_groups) != 1:
             return None
         pg = self.optimizer.param_groups[0]
-        if pg.get("nesterov") or pg.get("dampening") or pg.get("maximize"):
+        if pg.get("nesterov") or pg.get("dampening") or pg.get("maximize") or pg.get("capturable") or pg.get("differentiable"):
             return None
         if self.clip_grad_norm is None:
             groups, mx = [list(self.model.parameters())], None
@@ -163,7 +165,7 @@ class SimpleTrainer:
             return None
         else:
             groups, mx = [list(self.model.parameters())], self.clip_grad_norm
-        return ops.FusedClipSGD(groups, mx, self.optimizer)
+        return (ops.FusedClipAdam if adam else ops.FusedClipSGD)(groups, mx, self.optimizer)
 
     def on_start_epoch(self, epoch_num: int):
         self.model.set_teacher_forcing(self.cfg.model.teacher_forcing)

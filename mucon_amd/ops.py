@@ -597,6 +597,68 @@ class FusedClipSGD:
             self.optimizer._opt_called = True
 
 
+class FusedClipAdam:
+    """clip_grad_norm_ per parameter group + torch.optim.Adam.step() (optionally AMSGrad: the reference builds Adam with
+    amsgrad=True, trainers.py:31-36) in two launches.  The moment buffers and the step counter are the torch optimizer's own
+    `state` entries (created here on first use, with torch's keys), so `optimizer.state_dict()` checkpoints stay interchangeable;
+    lr / betas / eps / weight_decay are read from `param_groups[0]` at every step."""
+
+    def __init__(self, groups, max_norm, optimizer):
+        self.groups, self.max_norm, self.optimizer = [list(g) for g in groups], max_norm, optimizer
+        if not 1 <= len(self.groups) <= 8:
+            raise ValueError("FusedClipAdam: 1..8 clipping groups")
+        self._ws = None
+        self.last_norms = None
+
+    def step(self):
+        lib = _lib.load()
+        pg = self.optimizer.param_groups[0]
+        amsgrad = bool(pg.get("amsgrad", False))
+        entries, step_no = [], None
+        for gi, params in enumerate(self.groups):
+            for p in params:
+                if p.grad is None:
+                    continue
+                _check_dev(p, p.grad)
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise _lib.MuconHipError("FusedClipAdam needs contiguous parameters and gradients")
+                st = self.optimizer.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if amsgrad:
+                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                entries.append((p, st, gi))
+        if not entries:
+            return
+        n = len(entries)
+        tab = (_lib.AdamTensor * n)()
+        total = 0
+        for i, (p, st, gi) in enumerate(entries):
+            tab[i].param, tab[i].grad = p.data_ptr(), p.grad.data_ptr()
+            tab[i].exp_avg, tab[i].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            tab[i].max_exp_avg_sq = st["max_exp_avg_sq"].data_ptr() if amsgrad else None
+            tab[i].n, tab[i].group = p.numel(), gi
+            total += p.numel()
+        steps = {int(st["step"]) for _, st, _ in entries}
+        if len(steps) != 1:
+            raise _lib.MuconHipError("FusedClipAdam: parameters at different step counts (torch keeps one per tensor; this kernel one per call)")
+        nbytes = lib.mucon_adam_workspace_bytes(n, total)
+        dev = entries[0][0].device
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.last_norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
+        mx = (ctypes.c_float * len(self.groups))(*[float(self.max_norm) if self.max_norm is not None else 0.0] * len(self.groups))
+        b1, b2 = pg["betas"]
+        _lib.check(lib.mucon_adam_clip_step(n, tab, len(self.groups), mx, float(pg["lr"]), float(b1), float(b2), float(pg["eps"]),
+                                            float(pg["weight_decay"]), steps.pop(), _lib.ptr(self.last_norms), _lib.ptr(self._ws),
+                                            self._ws.numel(), _lib.current_stream_ptr()), "mucon_adam_clip_step")
+        if isinstance(self.optimizer, torch.optim.Optimizer):
+            self.optimizer._opt_called = True
+
+
 # --------------------------------------------------------------------------------------- graph-free execution
 class PlainCtx:
     """Stand-in for torch.autograd's context object: lets the Functions above run their forward / backward as plain

@@ -99,3 +99,59 @@ def test_trainer_uses_the_fused_step_and_matches_the_torch_tail():
     for n in finals[0]:
         a, b = finals[0][n].double(), finals[1][n].double()
         assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7, n
+
+
+@pytest.mark.parametrize("amsgrad,max_norm,wd", [(True, 5.0, 0.005), (False, 100.0, 0.0), (True, None, 0.005)])
+def test_fused_clip_adam_matches_torch(amsgrad, max_norm, wd):
+    """ops.FusedClipAdam against clip_grad_norm_ per group + torch.optim.Adam.step() (the reference's second optimizer,
+    trainers.py:31-36: Adam with amsgrad=True) over five steps: parameters, moment buffers (torch's own state entries) and norms."""
+    from mucon_amd import ops
+    pa, ga = _params(5, 1.0)
+    pb, _ = _params(5, 1.0)
+    split = 4
+    opt_a = torch.optim.Adam(pa, lr=0.003, weight_decay=wd, amsgrad=amsgrad)
+    opt_b = torch.optim.Adam(pb, lr=0.003, weight_decay=wd, amsgrad=amsgrad)
+    fused = ops.FusedClipAdam([pb[:split], pb[split:]], max_norm, opt_b)
+    g = torch.Generator().manual_seed(9)
+    for step in range(5):
+        for p, q, g0 in zip(pa, pb, ga):
+            noise = torch.randn(g0.shape, generator=g).to(DEV)
+            p.grad = g0.clone() * (0.5 + step) + noise
+            q.grad = p.grad.clone()
+        norms = []
+        if max_norm is not None:
+            norms = [clip_grad_norm_(pa[:split], max_norm), clip_grad_norm_(pa[split:], max_norm)]
+        opt_a.step()
+        fused.step()
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (step, i, float((p - q).abs().max()))
+            sa, sb = opt_a.state[p], opt_b.state[q]
+            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+                assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-7), (step, i, k)   # (lerp near a zero crossing: absolute, not relative)
+        if norms:
+            assert torch.allclose(torch.stack(norms), fused.last_norms, rtol=2e-6)
+    # the state is torch's: a checkpoint of one loads into the other
+    opt_a.load_state_dict(opt_b.state_dict())
+
+
+def test_trainer_with_adam_takes_the_fused_step():
+    """cfg.trainer.optimizer = "Adam": SimpleTrainer builds torch's Adam (amsgrad) and steps it through ops.FusedClipAdam."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_model import make_batch
+    from mucon_amd import ops
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.models import create_model
+    from mucon_amd.mucon.trainers import SimpleTrainer
+    cfg = update_config(get_cfg_defaults(), [], [["trainer.optimizer", "Adam", "trainer.learning_rate", "0.001"]])
+    model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048).cuda()
+    tr = SimpleTrainer(cfg, model, "cuda")
+    assert isinstance(tr.fused_step, ops.FusedClipAdam)
+    tr.on_start_epoch(0)
+    model.train()
+    before = model.ft.first_conv.weight.detach().clone()
+    for i in range(2):
+        loss, _ = tr._train_1_batch(i, make_batch(640, 5).to("cuda"))
+    assert torch.isfinite(loss.main) and not torch.equal(before, model.ft.first_conv.weight)
+    assert float(tr.optimizer.state[model.ft.first_conv.weight]["step"]) == 2
