@@ -326,6 +326,12 @@ int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *tensors, int3
                         float lr, float weight_decay, float momentum, float *group_norms, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The clipping alone -- an iteration of a gradient-accumulation group that does not step (reference trainers.py:131-147 clips the
+ * accumulated gradient at EVERY iteration and steps at the last of the group): grad *= min(max_norm[g] / (norm_g + 1e-6), 1) per group.
+ * Same table and workspace as mucon_sgd_clip_step (param and momentum_buf are not touched). */
+int mucon_clip_grads(int32_t n_tensors, const mucon_sgd_tensor *tensors, int32_t n_groups, const float *max_norm,
+                     float *group_norms, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same step tail with torch.optim.Adam (reference src/mucon/trainers.py:31-36: optimizer "Adam", amsgrad=True): group-wise
  * clipping as above, then per element the sequence of torch's Adam -- u = grad + weight_decay * param, exp_avg += (u - exp_avg)(1 - beta1),
  * exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) u u, max_exp_avg_sq = max(., exp_avg_sq) (when the pointer is non-NULL: AMSGrad),

@@ -132,6 +132,7 @@ SYMBOLS = {
     "mucon_sgd_workspace_bytes": (_sz, [_i32, _i64]),
     "mucon_sgd_clip_step": (ctypes.c_int, [_i32, ctypes.POINTER(SgdTensor), _i32, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, _vp, _vp, _sz, _vp]),
+    "mucon_clip_grads": (ctypes.c_int, [_i32, ctypes.POINTER(SgdTensor), _i32, ctypes.POINTER(ctypes.c_float), _vp, _vp, _sz, _vp]),
     "mucon_adam_workspace_bytes": (_sz, [_i32, _i64]),
     "mucon_adam_clip_step": (ctypes.c_int, [_i32, ctypes.POINTER(AdamTensor), _i32, ctypes.POINTER(ctypes.c_float), ctypes.c_double,
                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i64, _vp, _vp, _sz, _vp]),

@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
     }
 }
 
+// ---- the clipping alone (an iteration of a gradient-accumulation group that does not step: reference trainers.py:131-147) ----
+__global__ __launch_bounds__(256) void clip_apply_kernel(const SgdTensor *tab, int nt, const float *partial, SgdHyper h, float *norms_out) {
+    __shared__ float red[4];
+    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < h.nblocks; b += 256)
+        if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
+    const float norm = sqrtf(sgd_block_sum(acc, red));
+    const float mx = h.max_norm[t.group];
+    const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
+    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
+        bool first = true;
+        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
+        if (first) norms_out[t.group] = norm;
+    }
+    if (coef == 1.f) return;    // torch multiplies by a clamped 1.0 too: the same bits
+    const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
+    const long b1 = min(t.n, b0 + SGD_CHUNK);
+    for (long e = b0 + threadIdx.x; e < b1; e += 256) t.g[e] *= coef;
+}
+
 // ---- Adam (torch.optim.Adam, optionally AMSGrad) behind the same group-wise clipping -----------------------------------------
 //   g *= coef (written back);  u = g + wd * p;  m += (u - m) (1 - beta1);  v = v beta2 + (1 - beta2) u u;
 //   vmax = max(vmax, v) (amsgrad);  p -= step_size * m / (sqrt(vmax or v) / sqrt(1 - beta2^t) + eps),  step_size = lr / (1 - beta1^t)

@@ -453,6 +453,43 @@ extern "C" int mucon_sgd_clip_step(int32_t n_tensors, const mucon_sgd_tensor *te
     return MUCON_OK;
 }
 
+// ------------------------------------------------------------------------------------------ clip alone
+extern "C" int mucon_clip_grads(int32_t n_tensors, const mucon_sgd_tensor *tensors, int32_t n_groups, const float *max_norm,
+                                float *group_norms, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_tensors < 1 || !tensors || !workspace) return sfail(MUCON_E_ARG, "clip: no tensors");
+    if (n_groups < 1 || n_groups > SGD_MAXGROUPS || !max_norm) return sfail(MUCON_E_ARG, "clip: %d clipping groups (1..%d)", n_groups, SGD_MAXGROUPS);
+    std::vector<SgdTensor> tab(n_tensors);
+    long total = 0;
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const mucon_sgd_tensor &t = tensors[i];
+        if (!t.grad || t.n < 1) return sfail(MUCON_E_ARG, "clip: tensor %d: null pointer or empty", i);
+        if (t.group < 0 || t.group >= n_groups) return sfail(MUCON_E_ARG, "clip: tensor %d: group %d outside 0..%d", i, t.group, n_groups - 1);
+        tab[i].p = t.param;
+        tab[i].g = t.grad;
+        tab[i].mom = nullptr;
+        tab[i].n = t.n;
+        tab[i].group = t.group;
+        tab[i].block0 = blocks;
+        blocks += (int)((t.n + SGD_CHUNK - 1) / SGD_CHUNK);
+        total += t.n;
+    }
+    if (workspace_bytes < mucon_sgd_workspace_bytes(n_tensors, total)) return sfail(MUCON_E_WORKSPACE, "clip workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SgdTensor *dtab = static_cast<SgdTensor *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + al64(sizeof(SgdTensor) * n_tensors));
+    SHIPCHK(hipMemcpyAsync(dtab, tab.data(), sizeof(SgdTensor) * n_tensors, hipMemcpyHostToDevice, s));
+    SgdHyper h;
+    memset(&h, 0, sizeof(h));
+    for (int g = 0; g < SGD_MAXGROUPS; ++g) h.max_norm[g] = g < n_groups ? max_norm[g] : 0.f;
+    h.ngroups = n_groups;
+    h.nblocks = blocks;
+    hipLaunchKernelGGL(sgd_norm_kernel<SgdTensor>, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial);
+    hipLaunchKernelGGL(clip_apply_kernel, dim3(blocks), dim3(256), 0, s, dtab, n_tensors, partial, h, group_norms);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
 // ------------------------------------------------------------------------------------------ clip + Adam
 extern "C" size_t mucon_adam_workspace_bytes(int32_t n_tensors, int64_t total_elements) {
     if (n_tensors < 1 || total_elements < 1) return 0;

@@ -143,11 +143,11 @@ class SimpleTrainer:
     def _make_fused_step(self):
         """The two clip_grad_norm_ calls + optimizer.step() as ops.FusedClipSGD / ops.FusedClipAdam (two launches) when the
         configuration is one those kernels implement: SGD or Adam (the reference's two optimizers, trainers.py:31-36) on the GPU,
-        no gradient accumulation, group-wise or global clipping."""
+        group-wise or global clipping; with gradient accumulation the non-stepping iterations clip only (mucon_clip_grads)."""
         from .. import ops
         t = self.cfg.trainer
         adam = type(self.optimizer) is optim.Adam
-        if not (isinstance(self.optimizer, optim.SGD) or adam) or (t.accumulate_grad_every or 1) != 1:
+        if not (isinstance(self.optimizer, optim.SGD) or adam):
             return None
         if not str(self.device).startswith("cuda") or len(self.optimizer.param_groups) != 1:
             return None
@@ -187,7 +187,10 @@ class SimpleTrainer:
         if last_of_group and self.world_size > 1:
             all_reduce_gradients(self.model, self.world_size, self.bucket)
         if self.fused_step is not None:
-            self.fused_step.step()
+            if last_of_group:
+                self.fused_step.step()
+            else:
+                self.fused_step.clip_only()      # the reference clips the accumulated gradient at every iteration (trainers.py:131-147)
             return loss, forward_out
         if self.clip_grad_norm is not None:
             t = self.cfg.trainer

@@ -555,6 +555,10 @@ class FusedClipSGD:
         self._ws = None
         self.last_norms = None
 
+    def clip_only(self):
+        """An iteration of a gradient-accumulation group that does not step: the clipping alone."""
+        fused_clip_only(self.groups, self.max_norm, self)
+
     def step(self):
         lib = _lib.load()
         pg = self.optimizer.param_groups[0]
@@ -597,6 +601,36 @@ class FusedClipSGD:
             self.optimizer._opt_called = True
 
 
+def fused_clip_only(groups, max_norm, holder):
+    """clip_grad_norm_ per parameter group without an optimizer step (mucon_clip_grads): the non-stepping iterations of a
+    gradient-accumulation group.  `holder` keeps the workspace / norms tensors (a FusedClipSGD or FusedClipAdam)."""
+    if max_norm is None:
+        return
+    lib = _lib.load()
+    entries = [(p, gi) for gi, params in enumerate(groups) for p in params if p.grad is not None]
+    if not entries:
+        return
+    n = len(entries)
+    tab = (_lib.SgdTensor * n)()
+    total = 0
+    for i, (p, gi) in enumerate(entries):
+        _check_dev(p, p.grad)
+        if not p.grad.is_contiguous():
+            raise _lib.MuconHipError("fused clipping needs contiguous gradients")
+        tab[i].param, tab[i].grad, tab[i].momentum_buf = p.data_ptr(), p.grad.data_ptr(), None
+        tab[i].n, tab[i].group = p.numel(), gi
+        total += p.numel()
+    nbytes = lib.mucon_sgd_workspace_bytes(n, total)
+    dev = entries[0][0].device
+    if getattr(holder, "_clip_ws", None) is None or holder._clip_ws.numel() < nbytes or holder._clip_ws.device != dev:
+        holder._clip_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if holder.last_norms is None or holder.last_norms.device != dev:
+        holder.last_norms = torch.zeros(len(groups), dtype=torch.float32, device=dev)
+    mx = (ctypes.c_float * len(groups))(*[float(max_norm)] * len(groups))
+    _lib.check(lib.mucon_clip_grads(n, tab, len(groups), mx, _lib.ptr(holder.last_norms), _lib.ptr(holder._clip_ws),
+                                    holder._clip_ws.numel(), _lib.current_stream_ptr()), "mucon_clip_grads")
+
+
 class FusedClipAdam:
     """clip_grad_norm_ per parameter group + torch.optim.Adam.step() (optionally AMSGrad: the reference builds Adam with
     amsgrad=True, trainers.py:31-36) in two launches.  The moment buffers and the step counter are the torch optimizer's own
@@ -609,6 +643,10 @@ class FusedClipAdam:
             raise ValueError("FusedClipAdam: 1..8 clipping groups")
         self._ws = None
         self.last_norms = None
+
+    def clip_only(self):
+        """An iteration of a gradient-accumulation group that does not step: the clipping alone."""
+        fused_clip_only(self.groups, self.max_norm, self)
 
     def step(self):
         lib = _lib.load()

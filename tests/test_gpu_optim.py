@@ -155,3 +155,41 @@ def test_trainer_with_adam_takes_the_fused_step():
         loss, _ = tr._train_1_batch(i, make_batch(640, 5).to("cuda"))
     assert torch.isfinite(loss.main) and not torch.equal(before, model.ft.first_conv.weight)
     assert float(tr.optimizer.state[model.ft.first_conv.weight]["step"]) == 2
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
+def test_gradient_accumulation_with_the_fused_tail_matches_torch(optimizer):
+    """cfg.trainer.accumulate_grad_every = 2 (reference trainers.py:113-149: zero_grad at the start of a group, the accumulated
+    gradient clipped at EVERY iteration, the step at the last one): the fused tail (clip only / clip + step) against torch's
+    clip_grad_norm_ + optimizer.step() on the same seeded model, four iterations, dropout off."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_model import make_batch, seeded_value
+    import numpy as np
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.models import create_model
+    from mucon_amd.mucon.trainers import SimpleTrainer
+    cfg = update_config(get_cfg_defaults(), [], [["trainer.optimizer", optimizer, "trainer.learning_rate", "0.002", "trainer.accumulate_grad_every", "2",
+                                                   "trainer.clip_grad_norm", "True", "trainer.clip_grad_norm_value", "2.0",
+                                                   "model.ft.dropout_rate", "0.0", "model.ft.last_dropout_rate", "0.0",
+                                                   "model.fs.decoder.embedding_dropout", "0.0"]])
+    results = []
+    for fused in (True, False):
+        model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(torch.from_numpy(seeded_value(name, p.shape).astype(np.float32)))
+        model = model.cuda()
+        tr = SimpleTrainer(cfg, model, "cuda")
+        assert tr.fused_step is not None
+        if not fused:
+            tr.fused_step = None
+        tr.fuse_step = False
+        tr.on_start_epoch(0)
+        model.train()
+        for i in range(4):
+            tr._train_1_batch(i, make_batch(400 + 37 * i, 4).to("cuda"))
+        results.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in results[0]:
+        a, b = results[0][n], results[1][n]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n
