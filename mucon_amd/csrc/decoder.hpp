@@ -325,7 +325,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
                     m1[i] = m[lane + 64];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = v0 * tanhf(m0[i] + q0) + v1 * tanhf(m1[i] + q1);
+                for (int i = 0; i < 8; ++i) a[i] = v0 * tanh_f(m0[i] + q0) + v1 * tanh_f(m1[i] + q1);
                 const float sum = wave_sum_rows<8>(a);
                 const int t = t0 + ((lane >> 3) & 7);
                 if ((lane & 7) == 0 && t < Tz) s_score[t] = sum;
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, De
         __syncthreads();
         if (tid < DEC_D) {
             const float gi = sigmoid_f(s_gates[tid]), gf = sigmoid_f(s_gates[DEC_D + tid]);
-            const float gg = tanhf(s_gates[2 * DEC_D + tid]), go = sigmoid_f(s_gates[3 * DEC_D + tid]);
+            const float gg = tanh_f(s_gates[2 * DEC_D + tid]), go = sigmoid_f(s_gates[3 * DEC_D + tid]);
             const float c = gf * s_c[tid] + gi * gg;
-            const float h = go * tanhf(c);
+            const float h = go * tanh_f(c);
             s_c[tid] = c;
             s_h[tid] = h;
             float *gs = sv.gates + (long)s * 4 * DEC_D;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             const float *gs = sv.gates + (long)s * 4 * DEC_D;
             const float gi = gs[tid], gf = gs[DEC_D + tid], gg = gs[2 * DEC_D + tid], go = gs[3 * DEC_D + tid];
             const float ct = sv.c[(s + 1) * DEC_D + tid], cp = sv.c[s * DEC_D + tid];
-            const float dh = s_dh[tid], th = tanhf(ct);
+            const float dh = s_dh[tid], th = tanh_f(ct);
             const float dct = s_dc[tid] + dh * go * (1.f - th * th);
             const float dpi = dct * gg * gi * (1.f - gi), dpf = dct * cp * gf * (1.f - gf);
             const float dpg = dct * gi * (1.f - gg * gg), dpo = dh * th * go * (1.f - go);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
             float dq = 0.f;
 #pragma unroll 4
             for (int t = g; t < Tz; t += DEC_THREADS / DEC_D) {
-                const float u = tanhf(sv.mp[(long)t * DEC_D + k] + qk);
+                const float u = tanh_f(sv.mp[(long)t * DEC_D + k] + qk);
                 const float ds = s_ds[t];
                 dv_acc += ds * u;
                 dq += ds * vk * (1.f - u * u);
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void dec_attn_grad_kernel(DecSaved sv, DecDelt
         const float m = sv.mp[(long)t * DEC_D + j], vk = v[j];
         float acc = 0.f;
         for (int s = 0; s < S; ++s) {
-            const float u = tanhf(m + sv.q[s * DEC_D + j]);
+            const float u = tanh_f(m + sv.q[s * DEC_D + j]);
             acc += dl.score[(long)s * Tz + t] * vk * (1.f - u * u);
         }
         ds[j] = acc;

@@ -26,7 +26,11 @@ struct LstmGrads {
     float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// exp through the hardware exp2 and the hardware reciprocal (1 ulp each) instead of libm's expf / tanhf and an IEEE division:
+// the recurrences are chains of dependent vector instructions, and tanhf alone was ~30 of them.  |error| < 3e-7 absolute
+// (tanh as 1 - 2 / (1 + e^{2x}) cancels for tiny |x|: absolute, not relative accuracy -- what a gate needs).
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 constexpr int LSTM_IP_T = 4;   // time steps per workgroup of the input projection (8 left 32 workgroups for T = 125: 15 us)
 // grid (ceil(T/LSTM_IP_T), ndir), 512 threads: thread r holds W_ih[d][r] in registers
@@ -92,20 +96,25 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
         const int cur = s & 1;
-        float acc = gnext;
+        const float g0 = gnext;
         if (s + 1 < T) gnext = gx[(long)(d == 0 ? s + 1 : T - 2 - s) * LSTM_G];  // next step's input projection: in flight
+        // the step is bound by this wave's vector issue (two waves per SIMD, 128 multiply-adds each): packed FMAs, two
+        // accumulator pairs (v_pk_fma_f32: two per lane and instruction) -- 64 instead of 128 instructions
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
         for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
             const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][c4 * 4]);  // broadcast read
-            acc += wr[c4 * 4 + 0] * hv[0] + wr[c4 * 4 + 1] * hv[1] + wr[c4 * 4 + 2] * hv[2] + wr[c4 * 4 + 3] * hv[3];
+            a0 = f32x2{wr[c4 * 4 + 0], wr[c4 * 4 + 1]} * f32x2{hv[0], hv[1]} + a0;
+            a1 = f32x2{wr[c4 * 4 + 2], wr[c4 * 4 + 3]} * f32x2{hv[2], hv[3]} + a1;
         }
+        const float acc = g0 + ((a0[0] + a0[1]) + (a1[0] + a1[1]));
         const float sg = sigmoid_f(asc * acc);
         const float act = q == 2 ? 2.f * sg - 1.f : sg;
         gates[((long)d * T + t) * LSTM_G + r] = act;
         const float gf = __shfl(act, (lane & 15) + 16), gg = __shfl(act, (lane & 15) + 32), go = __shfl(act, (lane & 15) + 48);
         if (q == 0) {
             c = gf * c + act * gg;
-            const float h = go * tanhf(c);
+            const float h = go * tanh_f(c);
             cells[((long)d * T + t) * LSTM_H + unit] = c;
             out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] = h;
             hs[cur ^ 1][unit] = h;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
         {
             const float gi = in.gi, gf = in.gf, gg = in.gg, go = in.go, ct = in.ct, cp = in.cp;
             const float dh = in.dout + ((part[0][unit] + part[1][unit]) + (part[2][unit] + part[3][unit]));
-            const float th = tanhf(ct);
+            const float th = tanh_f(ct);
             const float dct = dc + dh * go * (1.f - th * th);
             dc = dct * gf;
             float dp;
@@ -183,13 +192,14 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
             dG[((long)d * T + t) * LSTM_G + q * LSTM_H + unit] = dp;
         }
         __syncthreads();
-        float acc = 0.f;
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};     // packed FMAs, as in the forward
 #pragma unroll
         for (int r4 = 0; r4 < LSTM_H / 4; ++r4) {
             const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[qq * LSTM_H + r4 * 4]);  // broadcast within a wave pair
-            acc += wt[r4 * 4 + 0] * gv[0] + wt[r4 * 4 + 1] * gv[1] + wt[r4 * 4 + 2] * gv[2] + wt[r4 * 4 + 3] * gv[3];
+            a0 = f32x2{wt[r4 * 4 + 0], wt[r4 * 4 + 1]} * f32x2{gv[0], gv[1]} + a0;
+            a1 = f32x2{wt[r4 * 4 + 2], wt[r4 * 4 + 3]} * f32x2{gv[2], gv[3]} + a1;
         }
-        part[qq][j] = acc;
+        part[qq][j] = (a0[0] + a0[1]) + (a1[0] + a1[1]);
         __syncthreads();
     }
 }
