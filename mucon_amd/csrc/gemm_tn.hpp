@@ -300,6 +300,7 @@ struct ReduceJob {
 };
 struct ReduceBatch {
     ReduceJob j[REDUCE_MAX_JOBS];
+    int first_block[REDUCE_MAX_JOBS];   // j[i].block0 once more, contiguous (unused entries: INT_MAX): see reduce_batch_kernel
     int njobs, nblocks;
 };
 
@@ -307,8 +308,13 @@ template <int G>
 __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch rb) {
     // a workgroup owns 256 consecutive elements of one job: 64 lanes x float4, G slab lanes
     __shared__ f32x4 part[G][64];
-    int ji = 0;
-    while (ji + 1 < rb.njobs && (int)blockIdx.x >= rb.j[ji + 1].block0) ++ji;
+    // Which job this workgroup belongs to: the number of jobs that start at or before it.  All first blocks are read at once
+    // (64 contiguous kernel-argument words, independent scalar loads) and compared in registers -- walking the table job by
+    // job was a chain of up to ~50 dependent scalar-cache round trips in front of every workgroup's first load (2 - 4 us each:
+    // the 3,900-workgroup pass took 21 us for 8 MB).
+    int ji = -1;
+#pragma unroll
+    for (int k = 0; k < REDUCE_MAX_JOBS; ++k) ji += (int)blockIdx.x >= rb.first_block[k] ? 1 : 0;
     const ReduceJob &J = rb.j[ji];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = (((int)blockIdx.x - J.block0) * 64 + lane) * 4;   // ncols, coff, ld are multiples of 4

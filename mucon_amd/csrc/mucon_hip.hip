@@ -2,6 +2,7 @@
 // the encoder / y-head forward and backward on the caller's stream.  No allocation, no
 // synchronisation (except the explicit bench helper); all state lives in the caller's workspace.
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -248,6 +249,7 @@ struct SideStream {
 struct Reducer {
     ReduceBatch rb;
     hipStream_t stream;
+    int max_slabs = 0;     // deepest job queued
     explicit Reducer(hipStream_t s) : stream(s) {
         rb.njobs = 0;
         rb.nblocks = 0;
@@ -267,6 +269,10 @@ struct Reducer {
         j.mode = mode;
         j.vec = ((ncols | coff | ld | j.n_elems) % 4 == 0 && slab_stride % 4 == 0) ? 1 : 0;
         j.block0 = rb.nblocks;
+        max_slabs = rb.njobs == 1 ? nslabs : std::max(max_slabs, nslabs);
+        if (rb.njobs == 1)
+            for (int k = 0; k < REDUCE_MAX_JOBS; ++k) rb.first_block[k] = INT_MAX;
+        rb.first_block[rb.njobs - 1] = j.block0;
         rb.nblocks += (j.n_elems + 255) / 256;
         return true;
     }
@@ -274,7 +280,9 @@ struct Reducer {
         if (rb.njobs == 0) return hipSuccess;
         // few, deep jobs (the y-head's 256 slabs of 6 K elements: 25 workgroups) want many slab lanes: the chain of dependent
         // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
-        switch (rb.nblocks <= 128 ? 16 : g_reduce_lanes) {
+        // ... and a pass whose jobs have one or two slabs (a batch-1 step: every time chunk is the whole video) is a copy:
+        // one wave per workgroup, no exchange
+        switch (rb.nblocks <= 128 ? 16 : (max_slabs <= 2 ? 1 : g_reduce_lanes)) {
             case 1: hipLaunchKernelGGL(reduce_batch_kernel<1>, dim3(rb.nblocks), dim3(64), 0, stream, rb); break;
             case 2: hipLaunchKernelGGL(reduce_batch_kernel<2>, dim3(rb.nblocks), dim3(128), 0, stream, rb); break;
             case 4: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
