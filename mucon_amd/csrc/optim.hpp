@@ -39,10 +39,53 @@ __device__ __forceinline__ float sgd_block_sum(float v, float *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Which tensor a workgroup belongs to, and which clipping group a block's partial sum counts for: the binary search over
+// the table in global memory is a chain of ~7 dependent L2 round trips (4 - 5 us in front of a 10 us kernel).  The two columns
+// it needs are copied into LDS once (one round trip, all threads in parallel) and searched there.
+constexpr int SGD_LDS_TAB = 1024;
+struct SgdIndex {
+    int *b0, *grp;
+    int nt;
+    bool lds;
+    template <class TAB>
+    __device__ __forceinline__ void init(const TAB *tab, int n, int *s_b0, int *s_grp) {
+        b0 = s_b0;
+        grp = s_grp;
+        nt = n;
+        lds = n <= SGD_LDS_TAB;
+        if (lds) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                s_b0[i] = tab[i].block0;
+                s_grp[i] = tab[i].group;
+            }
+            __syncthreads();
+        }
+    }
+    template <class TAB>
+    __device__ __forceinline__ int find(const TAB *tab, int block) const {
+        if (!lds) return sgd_find(tab, nt, block);
+        int lo = 0, hi = nt - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (b0[mid] <= block) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    }
+    template <class TAB>
+    __device__ __forceinline__ int group_of_block(const TAB *tab, int block) const {
+        const int i = find(tab, block);
+        return lds ? grp[i] : tab[i].group;
+    }
+};
+
 template <class TAB>
 __global__ __launch_bounds__(256) void sgd_norm_kernel(const TAB *tab, int nt, float *partial) {
     __shared__ float red[4];
-    const TAB t = tab[sgd_find(tab, nt, blockIdx.x)];
+    __shared__ int s_b0[SGD_LDS_TAB], s_grp[SGD_LDS_TAB];
+    SgdIndex ix;
+    ix.init(tab, nt, s_b0, s_grp);
+    const TAB t = tab[ix.find(tab, blockIdx.x)];
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     float acc = 0.f;
@@ -74,14 +117,17 @@ struct SgdHyper {
 __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, int nt, const float *partial, SgdHyper h,
                                                         float *norms_out) {
     __shared__ float red[4];
-    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    __shared__ int s_b0[SGD_LDS_TAB], s_grp[SGD_LDS_TAB];
+    SgdIndex ix;
+    ix.init(tab, nt, s_b0, s_grp);
+    const SgdTensor t = tab[ix.find(tab, blockIdx.x)];
     // squared norm of this block's group: partials of every tensor of the group, strided over the threads
     // (thread-strided over ALL blocks, each looked up in the table: walking the tensors one after the other made every
     // block of a 75-tensor model run 75 short dependent loops -- 14 us of the 24 us this kernel took there)
     float acc = 0.f;
     if (h.any_clip) {
         for (int b = threadIdx.x; b < h.nblocks; b += 256)
-            if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
+            if (ix.group_of_block(tab, b) == t.group) acc += partial[b];
     }
     const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];
@@ -149,10 +195,13 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
 // ---- the clipping alone (an iteration of a gradient-accumulation group that does not step: reference trainers.py:131-147) ----
 __global__ __launch_bounds__(256) void clip_apply_kernel(const SgdTensor *tab, int nt, const float *partial, SgdHyper h, float *norms_out) {
     __shared__ float red[4];
-    const SgdTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    __shared__ int s_b0[SGD_LDS_TAB], s_grp[SGD_LDS_TAB];
+    SgdIndex ix;
+    ix.init(tab, nt, s_b0, s_grp);
+    const SgdTensor t = tab[ix.find(tab, blockIdx.x)];
     float acc = 0.f;
     for (int b = threadIdx.x; b < h.nblocks; b += 256)
-        if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
+        if (ix.group_of_block(tab, b) == t.group) acc += partial[b];
     const float norm = sqrtf(sgd_block_sum(acc, red));
     const float mx = h.max_norm[t.group];
     const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
@@ -183,11 +232,14 @@ struct AdamHyper {
 };
 __global__ __launch_bounds__(256) void adam_apply_kernel(const AdamTensor *tab, int nt, const float *partial, AdamHyper h, float *norms_out) {
     __shared__ float red[4];
-    const AdamTensor t = tab[sgd_find(tab, nt, blockIdx.x)];
+    __shared__ int s_b0[SGD_LDS_TAB], s_grp[SGD_LDS_TAB];
+    SgdIndex ix;
+    ix.init(tab, nt, s_b0, s_grp);
+    const AdamTensor t = tab[ix.find(tab, blockIdx.x)];
     float acc = 0.f;
     if (h.any_clip) {
         for (int b = threadIdx.x; b < h.nblocks; b += 256)
-            if (tab[sgd_find(tab, nt, b)].group == t.group) acc += partial[b];
+            if (ix.group_of_block(tab, b) == t.group) acc += partial[b];
     }
     const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];

@@ -109,7 +109,7 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *cells = gates + al64(per * LSTM_G);
     hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir);
     hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(LSTM_G / 4, ndir), dim3(512), 0, s, dG, x, out, g, T, ndir);
-    hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(128), 0, s, dG, w, d_x, T, ndir);
+    hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(512), 0, s, dG, w, d_x, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

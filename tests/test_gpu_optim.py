@@ -192,4 +192,6 @@ def test_gradient_accumulation_with_the_fused_tail_matches_torch(optimizer):
         results.append({n: p.detach().clone() for n, p in model.named_parameters()})
     for n in results[0]:
         a, b = results[0][n], results[1][n]
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n
+        # (Adam divides by sqrt(v): where a gradient is rounding noise the update is +-lr whatever the optimizer, so the bound is a
+        # fraction of one learning-rate step, not of the parameter)
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + (5e-6 if optimizer == "Adam" else 1e-7), n
