@@ -215,10 +215,11 @@ size_t mucon_lstm_workspace_bytes(int32_t T, int32_t ndir);
 int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
                    float *out, float *hn, float *cn, void *workspace, size_t workspace_bytes, void *stream);
 /* Backward through time from d_out [T][ndir*H], d_hn, d_cn [ndir][H] (each may be NULL = zero) with the
- * workspace the forward filled.  Writes (not accumulates) d_x [T][I] and every tensor of d_params. */
+ * workspace the forward filled.  Writes d_x [T][I] = (d_x_add [T][I] when non-NULL, may alias d_x: the gradient another
+ * consumer of x already produced) + the LSTM's own, and every tensor of d_params. */
 int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
                    const float *out, const float *d_out, const float *d_hn, const float *d_cn, float *d_x,
-                   const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
+                   const float *d_x_add, const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- s-head attention decoder ---------------------------------------------------
  * Replaces the decoding loop of reference src/mucon/models.py:612-728 (sequence_generation_forward after
@@ -297,7 +298,8 @@ size_t mucon_loss_workspace_bytes(const mucon_loss_cfg *cfg);
  * (masks.py:26-41: box / gaussian / trapezoid); the class-weight vectors [M] / [NC] may be NULL (= ones).
  * Writes losses[5] = {main, transcript, length, mucon, smoothing} and the gradients of `main`:
  * d_segmentation [T][M] (mucon part), d_smoothing_input [T][M] (smoothing part; never aliases d_segmentation),
- * d_transcript_logp [S][NC], d_lengths [N]. */
+ * d_transcript_logp [S][NC], d_lengths [N + 1] (entry N is written 0: the decoder's backward takes the gradient of all S = N + 1
+ * step lengths, and the last step's -- EOS -- is read by no loss). */
 int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmentation, const float *smoothing_input,
                        const float *transcript_logp, const float *lengths, const int64_t *mucon_target,
                        const int64_t *transcript_target, const float *mask_template, const float *mucon_class_weight,

@@ -125,7 +125,7 @@ SYMBOLS = {
     "mucon_bench_first_conv": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_float), _vp]),
     "mucon_lstm_workspace_bytes": (_sz, [_i32, _i32]),
     "mucon_lstm_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mucon_lstm_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _vp,
+    "mucon_lstm_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, ctypes.POINTER(LstmParams), _vp, _vp, _vp, _vp, _vp, _vp,
                                       ctypes.POINTER(LstmParams), _vp, _sz, _vp]),
     "mucon_loss_workspace_bytes": (_sz, [ctypes.POINTER(LossCfg)]),
     "mucon_loss_fwd_bwd": (ctypes.c_int, [ctypes.POINTER(LossCfg)] + [_vp] * 15 + [_sz, _vp]),

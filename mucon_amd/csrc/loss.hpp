@@ -431,4 +431,5 @@ __global__ __launch_bounds__(64) void loss_fin_kernel(LossDims d, LossBufs b, in
         g += d.mul_length * ((l > d.length_width ? 1.f : 0.f) - (l < -d.length_width ? 1.f : 0.f));
         b.d_lengths[lane] = g;
     }
+    if (lane == 0) b.d_lengths[N] = 0.f;   // entry N: the decoder's EOS step, whose length no loss reads (d_lengths has N + 1 entries)
 }

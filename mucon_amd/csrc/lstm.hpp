@@ -243,10 +243,10 @@ __global__ __launch_bounds__(512) void lstm_wgrad_kernel(const float *dG, const 
     }
 }
 
-// dx[t][c] = sum_d sum_r dG[d][t][r] W_ih[d][r][c]; grid (T), 512 threads = 4 row quarters x 128 columns.  What a workgroup costs is
+// dx[t][c] = (dx_add[t][c]) + sum_d sum_r dG[d][t][r] W_ih[d][r][c]; grid (T), 512 threads = 4 row quarters x 128 columns.  What a workgroup costs is
 // its chain of weight loads (W_ih comes from L2): every thread walks a quarter of the rows with 32 loads in flight, the four
 // partial sums meet in LDS in quarter order.  (128 threads with 16 loads in flight: 64 dependent round trips, 18.6 us at T = 125.)
-__global__ __launch_bounds__(512) void lstm_dx_kernel(const float *dG, LstmWeights w, float *dx, int T, int ndir) {
+__global__ __launch_bounds__(512) void lstm_dx_kernel(const float *dG, LstmWeights w, float *dx, const float *dx_add, int T, int ndir) {
     __shared__ float gsm[2 * LSTM_G];
     __shared__ float part[4][LSTM_H];
     const int t = blockIdx.x, c = threadIdx.x & 127, k = threadIdx.x >> 7;
@@ -265,5 +265,6 @@ __global__ __launch_bounds__(512) void lstm_dx_kernel(const float *dG, LstmWeigh
     }
     part[k][c] = acc;
     __syncthreads();
-    if (k == 0) dx[(long)t * LSTM_H + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    const float base = dx_add ? dx_add[(long)t * LSTM_H + c] : 0.f;   // (requested before the row walk would be nicer; it is one load)
+    if (k == 0) dx[(long)t * LSTM_H + c] = base + ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
 }

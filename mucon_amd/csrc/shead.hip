@@ -86,7 +86,8 @@ extern "C" int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
 
 extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
                               const float *out, const float *d_out, const float *d_hn, const float *d_cn, float *d_x,
-                              const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes, void *stream) {
+                              const float *d_x_add, const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes,
+                              void *stream) {
     int rc = lstm_check(T, I, H, ndir);
     if (rc != MUCON_OK) return rc;
     if (!x || !params || !out || !d_x || !d_params || !workspace) return sfail(MUCON_E_ARG, "lstm: null pointer argument");
@@ -109,7 +110,7 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *cells = gates + al64(per * LSTM_G);
     hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir);
     hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(LSTM_G / 4, ndir), dim3(512), 0, s, dG, x, out, g, T, ndir);
-    hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(512), 0, s, dG, w, d_x, T, ndir);
+    hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(512), 0, s, dG, w, d_x, d_x_add, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

@@ -276,10 +276,10 @@ class MuCon(nn.Module):
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
         else:
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, (d_seg + d_sx).unsqueeze(0), None)[:3]
-        d_lens = torch.nn.functional.pad(d_len, (0, 1))                # the last step's length is not used by the losses
+        d_lens = c_loss.d_len_full                                      # [steps]: the loss kernel wrote the unused last entry as 0
         d_mem, d_hn, d_cn, _, _, _, *g_dec = F_.run_backward(F_._DecoderFn, c_dec, d_tlogp, d_lens)
-        d_x, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
-        d_enc[0] += d_x
+        c_lstm.dx_accumulate = d_enc[0]                                 # the LSTM's input gradient is added onto the y-head's in its kernel
+        _, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
         g_enc = F_.run_backward(F_._EncoderFn, c_enc, d_enc)[4:]
         for prm, g in zip(enc_params, g_enc):
             prm.grad = g

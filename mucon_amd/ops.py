@@ -342,10 +342,13 @@ class _LstmFn(torch.autograd.Function):
         d_out = d_out.contiguous() if d_out is not None else None
         d_hn = d_hn.contiguous() if d_hn is not None else None
         d_cn = d_cn.contiguous() if d_cn is not None else None
-        d_x = torch.empty_like(x)
+        # graph-free execution may hand in the gradient another consumer of x already produced (ctx.dx_accumulate, contiguous,
+        # x's shape): the kernel adds the LSTM's own into it instead of a separate element-wise launch
+        acc = getattr(ctx, "dx_accumulate", None)
+        d_x = acc if acc is not None else torch.empty_like(x)
         grads = [torch.empty_like(w) for w in weights]
         _lib.check(lib.mucon_lstm_bwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_lstm_params(weights, ndir)), _lib.ptr(out),
-                                      _lib.ptr(d_out), _lib.ptr(d_hn), _lib.ptr(d_cn), _lib.ptr(d_x),
+                                      _lib.ptr(d_out), _lib.ptr(d_hn), _lib.ptr(d_cn), _lib.ptr(d_x), _lib.ptr(acc),
                                       ctypes.byref(_lstm_params(grads, ndir)), _lib.ptr(ctx.ws), ctx.nbytes,
                                       _lib.current_stream_ptr()), "mucon_lstm_bwd")
         return (d_x, None, *grads)
@@ -508,11 +511,14 @@ class _LossFn(torch.autograd.Function):
         dev = seg.device
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         losses = torch.empty(5, dtype=torch.float32, device=dev)
-        d_seg, d_sx, d_tlogp, d_len = torch.empty_like(seg), torch.empty_like(sx), torch.empty_like(tlogp), torch.empty_like(lengths)
+        d_seg, d_sx, d_tlogp = torch.empty_like(seg), torch.empty_like(sx), torch.empty_like(tlogp)
+        d_len_full = torch.empty(N + 1, dtype=torch.float32, device=dev)   # entry N = 0: the gradient of the EOS step's length
+        d_len = d_len_full[:N]
+        ctx.d_len_full = d_len_full
         _lib.check(lib.mucon_loss_fwd_bwd(ctypes.byref(cfg), _lib.ptr(seg), _lib.ptr(sx), _lib.ptr(tlogp), _lib.ptr(lengths),
                                           _lib.ptr(mtarget), _lib.ptr(ttarget), _lib.ptr(tmpl.contiguous()),
                                           _lib.ptr(mweight), _lib.ptr(tweight), _lib.ptr(losses), _lib.ptr(d_seg), _lib.ptr(d_sx),
-                                          _lib.ptr(d_tlogp), _lib.ptr(d_len), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+                                          _lib.ptr(d_tlogp), _lib.ptr(d_len_full), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_loss_fwd_bwd")
         ctx.save_for_backward(d_seg, d_sx, d_tlogp, d_len)
         parts = losses[1:].clone()
