@@ -72,16 +72,17 @@ __device__ __forceinline__ float loss_wave_sum(float v) {
     return v;
 }
 
-// sum of p[c * stride] over c = 0 .. n-1 in order, eight loads in flight at a time (a term-at-a-time loop over the T/32 slab
+// sum of p[c * stride] over c = 0 .. n-1 in order, 32 loads in flight at a time (a term-at-a-time loop over the T/32 slab
 // chunks is a chain of dependent memory round trips: 25 us of the 29 us loss_mid_kernel took)
 __device__ __forceinline__ float loss_ordered_sum(const float *p, long stride, int n) {
     float acc = 0.f;
-    for (int c0 = 0; c0 < n; c0 += 8) {
-        float v[8];
+    constexpr int Q = 32;      // (eight in flight: still eight dependent round trips for the 63 chunks of a T = 2000 video)
+    for (int c0 = 0; c0 < n; c0 += Q) {
+        float v[Q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = p[(long)min(c0 + q, n - 1) * stride];
+        for (int q = 0; q < Q; ++q) v[q] = p[(long)min(c0 + q, n - 1) * stride];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < Q; ++q)
             if (c0 + q < n) acc += v[q];
     }
     return acc;

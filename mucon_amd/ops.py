@@ -521,7 +521,7 @@ class _LossFn(torch.autograd.Function):
                                           _lib.ptr(d_tlogp), _lib.ptr(d_len_full), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_loss_fwd_bwd")
         ctx.save_for_backward(d_seg, d_sx, d_tlogp, d_len)
-        parts = losses[1:].clone()
+        parts = losses[1:]          # (a view: a clone is one more launch on a GPU-bound step)
         ctx.mark_non_differentiable(parts)
         return losses[0], parts
 
