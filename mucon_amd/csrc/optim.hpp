@@ -132,11 +132,17 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
     const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];
     const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
-    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
-        // the first block of the group's first tensor reports the norm
-        bool first = true;
-        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
-        if (first) norms_out[t.group] = norm;
+    if (blockIdx.x == t.block0 && norms_out) {   // (uniform over the workgroup)
+        // the first block of the group's first tensor reports the norm: no earlier tensor of the same group -- asked of all
+        // table entries at once (thread i <-> tensor i; one thread walking the table was a chain of up to nt dependent loads
+        // in the blocks that finish last)
+        bool earlier = false;
+        if (ix.lds) {
+            for (int i = threadIdx.x; i < nt; i += 256) earlier |= ix.b0[i] < t.block0 && ix.grp[i] == t.group;
+        } else if (threadIdx.x == 0) {
+            for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
+        }
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
@@ -205,10 +211,14 @@ __global__ __launch_bounds__(256) void clip_apply_kernel(const SgdTensor *tab, i
     const float norm = sqrtf(sgd_block_sum(acc, red));
     const float mx = h.max_norm[t.group];
     const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
-    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
-        bool first = true;
-        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
-        if (first) norms_out[t.group] = norm;
+    if (blockIdx.x == t.block0 && norms_out) {
+        bool earlier = false;
+        if (ix.lds) {
+            for (int i = threadIdx.x; i < nt; i += 256) earlier |= ix.b0[i] < t.block0 && ix.grp[i] == t.group;
+        } else if (threadIdx.x == 0) {
+            for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
+        }
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
     if (coef == 1.f) return;    // torch multiplies by a clamped 1.0 too: the same bits
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
@@ -244,10 +254,14 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(const AdamTensor *tab, 
     const float norm = h.any_clip ? sqrtf(sgd_block_sum(acc, red)) : 0.f;
     const float mx = h.max_norm[t.group];
     const float coef = mx > 0.f ? fminf(mx / (norm + 1e-6f), 1.f) : 1.f;
-    if (threadIdx.x == 0 && blockIdx.x == t.block0 && norms_out) {
-        bool first = true;
-        for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) first = first && tab[i].group != t.group;
-        if (first) norms_out[t.group] = norm;
+    if (blockIdx.x == t.block0 && norms_out) {
+        bool earlier = false;
+        if (ix.lds) {
+            for (int i = threadIdx.x; i < nt; i += 256) earlier |= ix.b0[i] < t.block0 && ix.grp[i] == t.group;
+        } else if (threadIdx.x == 0) {
+            for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
+        }
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
