@@ -156,6 +156,11 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
         for (int rb = 0; rb < RB; ++rb) acc[rb][i & 7] = mfma6(acc[rb][i & 7], wf[i % D], xa[rb][i >> 3]);
         if (i + D < NP) loadW1(i + D, i % D);
         else if (!ONE) loadW2(i + D - NP, i % D);      // NP is a multiple of D: slots line up
+        // (pins every refill behind the MFMAs that free its slot: left to itself the scheduler sinks the loads towards their
+        // use, eight pairs later, and the ring degenerates to one or two fragments in flight -- s_waitcnt vmcnt(1..6) in the loop)
+#ifndef CS_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 
     // ---- first reduction (fixed order), stage-1 epilogue on blocks 2 w, 2 w + 1
