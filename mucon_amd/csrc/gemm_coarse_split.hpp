@@ -106,12 +106,14 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int nb = 2 * w + j;
-        if (!BWD) bia1[j] = p.bias1 ? *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // (unconditional loads from a valid address, the condition on the arithmetic: a load behind a branch makes the compiler wait for
+        // EVERYTHING in flight at the join -- here the whole weight ring, in front of the first MFMA)
+        if (!BWD) bia1[j] = *reinterpret_cast<const f32x4 *>((p.bias1 ? p.bias1 : p.A) + 16 * nb + 4 * g);
         if (!BWD && !ONE) bia2[j] = *reinterpret_cast<const f32x4 *>(p.bias2 + 16 * nb + 4 * g);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if (BWD) aux1[rb][j] = p.res1 ? *reinterpret_cast<const f32x4 *>(p.res1 + grow[rb] + 16 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (BWD && p.mask1) msk1[rb][j] = *reinterpret_cast<const f32x4 *>(p.mask1 + grow[rb] + 16 * nb);
+            if (BWD) aux1[rb][j] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : p.A) + grow[rb] + 16 * nb);
+            if (BWD) msk1[rb][j] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : p.A) + grow[rb] + 16 * nb);
             if (!ONE) {
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
@@ -178,13 +180,13 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
             f32x4 x = ((red[((0 * RB + rb) * 8 + nb) * 64 + lane] + red[((1 * RB + rb) * 8 + nb) * 64 + lane]) +
                        red[((2 * RB + rb) * 8 + nb) * 64 + lane]) + red[((3 * RB + rb) * 8 + nb) * 64 + lane];
             if (!BWD) {
-                x += bia1[j];
+                if (p.bias1) x += bia1[j];
                 if (!ONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
                 }
             } else {
-                x += aux1[rb][j];
+                if (p.res1) x += aux1[rb][j];
                 if (p.mask1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] *= act_grad(msk1[rb][j][e], p.slope);
