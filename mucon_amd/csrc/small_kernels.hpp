@@ -616,13 +616,17 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
             const int fb = first_frame(z0 + zi + 1, a.scale, a.Tz, a.Tf);
             // frames of the bin in order, eight loads in flight at a time (a bin has ~Tf/Tz frames)
             const int nfr = fb - fa;
+            // (both arrays are read unconditionally, a missing one through the other's pointer with weight 0: a load behind a
+            // branch costs a branch and a full wait per element)
+            const float *p1 = a.dlogits ? a.dlogits : a.dlogp, *p2 = a.dlogp ? a.dlogp : a.dlogits;
+            const float w1 = a.dlogits ? 1.f : 0.f, w2 = a.dlogp ? 1.f : 0.f;
             for (int base = 0; base < nfr; base += 8) {
                 float v1[8], v2[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const long gi = ((long)b * a.Tf + fa + min(base + j, nfr - 1)) * C + c;
-                    v1[j] = a.dlogits ? a.dlogits[gi] : 0.f;
-                    v2[j] = a.dlogp ? a.dlogp[gi] : 0.f;
+                    v1[j] = p1[gi];
+                    v2[j] = p2[gi];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -632,6 +636,8 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
                     }
                 }
             }
+            g1 *= w1;
+            g2 *= w2;
         }
         G1[zi][c] = g1;
         G2[zi][c] = g2;
