@@ -372,13 +372,15 @@ def main():
         (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
         d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
         wc.grad, bc.grad = d_w.view_as(wc), d_b
+        if dist is not None and os.environ.get("MUCON_BENCH_COALESCE") != "1":
+            c_enc.flat_extra = d_w.numel() + d_b.numel()          # room for the y-head's gradients behind the encoder's
         g_enc = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
         for p_, g_ in zip(enc_params, g_enc):
             p_.grad = g_
         if dist is not None:
             # the one exchange step: ONE all-reduce per optimizer step.  The encoder's gradients are views of one flat buffer;
             # the two y-head tensors are appended to a copy of it (every RCCL call costs ~25 us of stream hand-offs even at
-            # world size 1: three calls were +75 us per step, one is +30).  (Splitting the buffer so that all but first_conv's
+            # world size 1: three calls were +75 us per step, one packed call +37, one in-place call on the shared buffer less).  (Splitting the buffer so that all but first_conv's
             # part overlaps the last launch was tried: +35 us of extra launches at world size 1 -- left out.)
             bufs = ops.flat_grad_buffers(enc_params)
             if os.environ.get("MUCON_BENCH_COALESCE") == "1":   # one RCCL group call on the three tensors in place (A/B hook)
@@ -386,13 +388,14 @@ def main():
                     for t_ in bufs + [d_w, d_b]:
                         dist.all_reduce(t_, op=dist.ReduceOp.AVG)
             else:
-                parts = [b_.reshape(-1) for b_ in bufs] + [d_w.reshape(-1), d_b.reshape(-1)]
-                packed = torch.cat(parts)
-                dist.all_reduce(packed, op=dist.ReduceOp.AVG)
-                off = 0
-                for t_ in parts:
-                    t_.copy_(packed[off: off + t_.numel()])
-                    off += t_.numel()
+                # the encoder's gradients are views of one flat buffer with room behind them (flat_extra): the y-head's two
+                # tensors are copied there (one small launch), their .grad become views of it, and the whole buffer is reduced
+                # in place -- one collective, no 4 MB gather and scatter around it
+                tail = c_enc.flat_tail
+                torch.cat([d_w.reshape(-1), d_b.reshape(-1)], out=tail)
+                wc.grad, bc.grad = tail[:d_w.numel()].view_as(wc), tail[d_w.numel():]
+                assert len(bufs) == 1
+                dist.all_reduce(bufs[0], op=dist.ReduceOp.AVG)
         sgd.step()
 
     def sync():

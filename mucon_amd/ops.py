@@ -124,7 +124,11 @@ class _EncoderFn(torch.autograd.Function):
         # one flat gradient buffer, the per-parameter gradients are views into it: data-parallel training
         # all-reduces the flat buffer directly (flat_grad_buffers), no gather / scatter copies
         sizes = [(p.numel() + 63) // 64 * 64 for p in params]   # 256-byte aligned slots
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=tape.device)
+        # (ctx.flat_extra floats of room behind them for the caller's other gradients -- ctx.flat_tail: then ONE collective on
+        # one buffer reduces everything, with no gather copy)
+        extra = int(getattr(ctx, "flat_extra", 0))
+        flat = torch.empty(sum(sizes) + extra, dtype=torch.float32, device=tape.device)
+        ctx.flat_tail = flat[sum(sizes):]
         grads, off = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[off: off + p.numel()].view(p.shape))
