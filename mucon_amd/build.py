@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, extra in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, src), "-o", obj] + extra
+               "-c", os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("MUCON_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -116,7 +116,7 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
 }
 
 // ------------------------------------------------------------------------------------------ decoder
-constexpr int DEC_MAXTZ = 8192;
+constexpr int DEC_MAXTZ = 4096;   // 2 x 4 x Tz bytes of LDS for the attention weights; 65,536 frames at the default pooling
 
 static int dec_check(const mucon_decoder_cfg *c) {
     if (!c) return sfail(MUCON_E_ARG, "decoder: null cfg");
@@ -188,6 +188,16 @@ static int dec_params(DecParams &p, const mucon_decoder_params *q, const char *w
     return MUCON_OK;
 }
 
+// the step kernels keep attention_l2's weight (and the forward, when it fits, the attention projection) in dynamic LDS: more
+// than the 64 KB a kernel gets by default
+static int dec_lds_attr() {
+    static int rc = hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        DEC_MAX_DYN_LDS) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        DEC_MAX_DYN_LDS_BWD) != hipSuccess;
+    return rc ? sfail(MUCON_E_HIP, "decoder: hipFuncSetAttribute failed") : MUCON_OK;
+}
+
 static DecDims dec_dims(const mucon_decoder_cfg *c, int S) {
     DecDims d;
     d.Tz = c->Tz;
@@ -195,6 +205,7 @@ static DecDims dec_dims(const mucon_decoder_cfg *c, int S) {
     d.NC = c->NC;
     d.S = S;
     d.n_emb = c->n_emb;
+    d.mp_lds = 0;
     d.teacher_forcing = c->teacher_forcing;
     d.stop_on_eos = c->stop_on_eos;
     d.eos = c->eos;
@@ -212,10 +223,13 @@ extern "C" int mucon_decoder_fwd(const mucon_decoder_cfg *cfg, const mucon_decod
     if (workspace_bytes < mucon_decoder_workspace_bytes(cfg)) return sfail(MUCON_E_WORKSPACE, "decoder workspace too small");
     DecParams p;
     if ((rc = dec_params(p, params, "parameter")) != MUCON_OK) return rc;
+    if ((rc = dec_lds_attr()) != MUCON_OK) return rc;
     const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dec_memproj_kernel, dim3((cfg->Tz + 3) / 4), dim3(512), 0, s, memory, p.w1, L.sv.mp, cfg->Tz, cfg->ME);
-    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(1), dim3(DEC_THREADS), sizeof(float) * cfg->Tz, s, dec_dims(cfg, cfg->max_steps), p,
+    DecDims dm = dec_dims(cfg, cfg->max_steps);
+    const size_t lds = dec_fwd_lds_bytes(cfg->Tz, &dm.mp_lds);
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(1), dim3(DEC_THREADS), lds, s, dm, p,
                        L.sv, memory, hn, cn, reinterpret_cast<const long *>(tf_input), dropmask, logp, lengths, n_steps);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
@@ -234,11 +248,12 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     DecParams p, g;
     if ((rc = dec_params(p, params, "parameter")) != MUCON_OK) return rc;
     if ((rc = dec_params(g, d_params, "gradient")) != MUCON_OK) return rc;
+    if ((rc = dec_lds_attr()) != MUCON_OK) return rc;
     auto W = [](const float *q) { return const_cast<float *>(q); };
     const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int S = n_steps, Tz = cfg->Tz, ME = cfg->ME, NC = cfg->NC, CW = DEC_D + ME, LW = DEC_D + NC;
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), sizeof(float) * Tz, s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), dec_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
                        logp, d_logp, d_lengths, dropmask, d_memory, W(g.emb), W(g.v), d_hn, d_cn);
     OuterBatch ob;
     int nj = 0, blocks = 0;
