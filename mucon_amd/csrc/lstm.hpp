@@ -6,11 +6,12 @@
 //
 // MIOpen needs 5.9 ms for this forward and 11.9 ms with the backward (Tz = 125): the work is a chain of Tz
 // dependent 512x128 mat-vecs, i.e. pure latency.  Here ONE workgroup per direction stays resident for the
-// whole sequence: 512 threads, each keeps one row of W_hh (128 floats) in registers, h_{t-1} is broadcast
-// from LDS, the four gates of a hidden unit sit in one wave and meet through shuffles; one barrier per time step.
+// whole sequence: 512 threads, each keeps 128 weights of W_hh in registers (forward: a quarter of each of a unit's four
+// gate rows; backward: a 32 x 4 tile), h_{t-1} / the gate gradients are read from LDS, partial sums and the four gates of a
+// hidden unit meet through DPP inside a quad / a row of lanes; one barrier per time step.
 //   lstm_inproj_kernel      Gx[d][t][r] = W_ih[d][r] . x[t] + b_ih[d][r] + b_hh[d][r]     (all t at once)
 //   lstm_recur_fwd_kernel   the recurrence; saves gate activations and cell states for the backward
-//   lstm_recur_bwd_kernel   BPTT: thread (q, j) keeps column j of gate block q of W_hh, dh_{t-1} = W_hh^T dgates_t
+//   lstm_recur_bwd_kernel   BPTT: a lane keeps a 32 x 4 tile of W_hh, dh_{t-1} = W_hh^T dgates_t stays in registers (DPP row sums)
 //   lstm_wgrad_kernel       dW_ih, dW_hh, db from the saved pre-activation gradients dG (reductions over t)
 //   lstm_dx_kernel          dx[t] = sum_d W_ih[d]^T dG[d][t]
 #pragma once
@@ -65,59 +66,91 @@ __global__ __launch_bounds__(512) void lstm_inproj_kernel(const float *x, LstmWe
     }
 }
 
+// DPP moves inside a quad / a row of 16 lanes (VALU, no LDS trip)
+template <int CTRL>
+__device__ __forceinline__ float lstm_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {   // the same bits in all four lanes (float addition commutes)
+    v += lstm_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += lstm_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+// acc += w * g.lo / acc += w * g.hi for both halves of a packed pair: the op_sel modifiers broadcast one half of the second
+// operand, which a C expression f32x2{g, g} pays a v_mov for
+__device__ __forceinline__ void pk_fma_lo(f32x2 &acc, f32x2 w, f32x2 g) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(g));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2 &acc, f32x2 w, f32x2 g) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(g));
+}
+
 // grid (ndir), 512 threads.  out [T][ndir*128]; saves: gates [ndir][T][4][128] (post-activation i,f,g,o),
 // cells [ndir][T][128]; hn / cn [ndir][128].
-// Thread layout: wave w owns hidden units 16w .. 16w+15; lane (u = lane & 15, q = lane >> 4) holds row q*128 + 16w + u of
-// W_hh, i.e. the four gates of a unit sit in ONE wave: they meet through three wave shuffles instead of an LDS round trip
-// and a barrier, every lane applies its own gate's non-linearity (tanh x = 2 sigmoid(2x) - 1: branch-free), lanes 0-15
-// update the cell.  One barrier per time step (the new h for everybody).
+// Thread layout: a QUAD of lanes owns one hidden unit (wave w: units 16w .. 16w+15); lane p of the quad keeps columns
+// 32p .. 32p+31 of the unit's four gate rows of W_hh (4 x 32 = 128 registers).  A step is bound by what LDS returns to the
+// registers (128 B/clk per CU, broadcast or not): with a whole row per lane every lane read all 128 values of h -- 256 KB per
+// step, ~2,000 clocks; a quarter row per lane reads 32 of them (64 KB).  The four partial sums of a gate meet through two DPP
+// adds inside the quad, lane p applies the non-linearity of gate p (tanh x = 2 sigmoid(2x) - 1: branch-free), the four
+// activations are passed round the quad by DPP and all four lanes update the cell.  One barrier per time step (the new h for
+// everybody).  h sits in LDS as four 32-float segments 36 floats apart: the four lanes of a quad read four different
+// 16-byte bank groups.
+constexpr int LSTM_SEG = 36;
 __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, LstmWeights w, float *out, float *gates,
                                                              float *cells, float *hn, float *cn, int T, int ndir) {
-    __shared__ __attribute__((aligned(16))) float hs[2][LSTM_H];
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * LSTM_SEG];
     const int d = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, unit = wave * 16 + (lane & 15);
-    const int r = q * LSTM_H + unit;
-    float wr[LSTM_H];
+    const int p = lane & 3, unit = wave * 16 + (lane >> 2);
+    float wr[4][32];
 #pragma unroll
-    for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_hh[d] + (long)r * LSTM_H + c4 * 4);
-        wr[c4 * 4 + 0] = v[0];
-        wr[c4 * 4 + 1] = v[1];
-        wr[c4 * 4 + 2] = v[2];
-        wr[c4 * 4 + 3] = v[3];
-    }
-    if (tid < LSTM_H) hs[0][tid] = 0.f;
-    float c = 0.f;  // cell state of `unit` (lanes with q == 0)
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_hh[d] + (long)(q * LSTM_H + unit) * LSTM_H + 32 * p + c4 * 4);
+            wr[q][c4 * 4 + 0] = v[0];
+            wr[q][c4 * 4 + 1] = v[1];
+            wr[q][c4 * 4 + 2] = v[2];
+            wr[q][c4 * 4 + 3] = v[3];
+        }
+    if (tid < 4 * LSTM_SEG) hs[0][tid] = 0.f;
+    float c = 0.f;  // cell state of `unit` (identical in the four lanes)
+    const int r = p * LSTM_H + unit;   // the gate row whose input projection / activation this lane handles
     const float *gx = Gx + (long)d * T * LSTM_G + r;
     float gnext = gx[(long)(d == 0 ? 0 : T - 1) * LSTM_G];
-    const float asc = q == 2 ? 2.f : 1.f;   // gate g: tanh through the sigmoid
+    const float asc = p == 2 ? 2.f : 1.f;   // gate g: tanh through the sigmoid
+    const int hslot = (unit >> 5) * LSTM_SEG + (unit & 31);
     __syncthreads();
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
         const int cur = s & 1;
         const float g0 = gnext;
         if (s + 1 < T) gnext = gx[(long)(d == 0 ? s + 1 : T - 2 - s) * LSTM_G];  // next step's input projection: in flight
-        // the step is bound by this wave's vector issue (two waves per SIMD, 128 multiply-adds each): packed FMAs, two
-        // accumulator pairs (v_pk_fma_f32: two per lane and instruction) -- 64 instead of 128 instructions
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        // packed FMAs (v_pk_fma_f32: two per lane and instruction), one accumulator pair per gate
+        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][c4 * 4]);  // broadcast read
-            a0 = f32x2{wr[c4 * 4 + 0], wr[c4 * 4 + 1]} * f32x2{hv[0], hv[1]} + a0;
-            a1 = f32x2{wr[c4 * 4 + 2], wr[c4 * 4 + 3]} * f32x2{hv[2], hv[3]} + a1;
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][p * LSTM_SEG + c4 * 4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = f32x2{wr[q][c4 * 4 + 0], wr[q][c4 * 4 + 1]} * f32x2{hv[0], hv[1]} + a[q];
+                a[q] = f32x2{wr[q][c4 * 4 + 2], wr[q][c4 * 4 + 3]} * f32x2{hv[2], hv[3]} + a[q];
+            }
         }
-        const float acc = g0 + ((a0[0] + a0[1]) + (a1[0] + a1[1]));
-        const float sg = sigmoid_f(asc * acc);
-        const float act = q == 2 ? 2.f * sg - 1.f : sg;
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre[q] = quad_sum(a[q][0] + a[q][1]);
+        const float mine = p == 0 ? pre[0] : p == 1 ? pre[1] : p == 2 ? pre[2] : pre[3];
+        const float sg = sigmoid_f(asc * (g0 + mine));
+        const float act = p == 2 ? 2.f * sg - 1.f : sg;
         gates[((long)d * T + t) * LSTM_G + r] = act;
-        const float gf = __shfl(act, (lane & 15) + 16), gg = __shfl(act, (lane & 15) + 32), go = __shfl(act, (lane & 15) + 48);
-        if (q == 0) {
-            c = gf * c + act * gg;
-            const float h = go * tanh_f(c);
+        const float gi = lstm_dpp<0x00>(act), gf = lstm_dpp<0x55>(act), gg = lstm_dpp<0xAA>(act), go = lstm_dpp<0xFF>(act);
+        c = gf * c + gi * gg;
+        const float h = go * tanh_f(c);
+        if (p == 0) {
             cells[((long)d * T + t) * LSTM_H + unit] = c;
             out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] = h;
-            hs[cur ^ 1][unit] = h;
+            hs[cur ^ 1][hslot] = h;
             if (s == T - 1) {
                 hn[d * LSTM_H + unit] = h;
                 cn[d * LSTM_H + unit] = c;
@@ -127,31 +160,37 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
     }
 }
 
-// grid (ndir), 512 threads.  Same ownership as the forward for the gate gradients (lane (u, q) -> gate q of unit 16w + u:
-// every lane derives its own pre-activation gradient, the four lanes of a unit carry identical copies of dc); for
-// dh_{t-1} = W_hh^T dgates thread (qq = tid >> 7, j = tid & 127) keeps W_hh[qq*128 + r'][j], r' = 0..127, and the four
-// partial sums of a unit are added by the lanes that need them: two barriers per time step.
-// dG [ndir][T][512]: gradient at the gate pre-activations (input of the weight / input gradients).
+// grid (ndir), 512 threads.  dG [ndir][T][512]: gradient at the gate pre-activations (input of the weight / input gradients).
+// A ROW of 16 lanes (the unit DPP row operations work on) owns four hidden units j0 .. j0+3 (wave w: units 16w .. 16w+15)
+// in both roles of a step:
+//   * gate role: lane rho = 4 (unit - j0) + q derives the pre-activation gradient of gate q of its unit (the four lanes of a
+//     unit carry identical copies of dc) and posts it in LDS;
+//   * mat-vec role, dh_{t-1} = W_hh^T dgates_t: lane rho keeps W_hh[32 rho .. 32 rho + 31][j0 .. j0+3] (128 registers), reads
+//     its 32 gate gradients from LDS (64 KB per step for the workgroup instead of 256 KB with a whole column block per
+//     thread -- what LDS returns to the registers bounds the step), and the 16 partial sums of a column meet through four
+//     DPP adds inside the row -- after which every lane of the row holds dh of all four units, its own included.
+// So the recurrent dh never leaves the registers and a step needs ONE barrier (the gate gradients for everybody).
+// The gate gradients sit in LDS as sixteen 32-float segments 36 floats apart: the 16 lanes of a row read 16 different
+// 16-byte bank groups.
 __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, const float *out, const float *gates,
                                                              const float *cells, const float *d_out, const float *d_hn,
                                                              const float *d_cn, float *dG, int T, int ndir) {
-    __shared__ __attribute__((aligned(16))) float dgs[LSTM_G];
-    __shared__ float part[4][LSTM_H];
+    __shared__ __attribute__((aligned(16))) float dgs[2][16 * LSTM_SEG];
     const int d = blockIdx.x, tid = threadIdx.x;
-    const int qq = tid >> 7, j = tid & 127;                 // mat-vec role
     const int lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, unit = wave * 16 + (lane & 15);   // gate role
-    float wt[LSTM_H];
+    const int rho = lane & 15, j0 = wave * 16 + (lane >> 4) * 4;
+    const int q = rho & 3, unit = j0 + (rho >> 2);          // gate role
+    f32x2 wt[32][2];   // [row][columns (0,1) | (2,3)]
 #pragma unroll
-    for (int rr = 0; rr < LSTM_H; ++rr) wt[rr] = w.w_hh[d][(long)(qq * LSTM_H + rr) * LSTM_H + j];
-    float dc = d_cn ? d_cn[d * LSTM_H + unit] : 0.f;
-    if (tid < LSTM_H) {   // the recurrent dh of the first processed step = d_hn: park it in part[0], zeros in part[1..3]
-        part[0][tid] = d_hn ? d_hn[d * LSTM_H + tid] : 0.f;
-        part[1][tid] = 0.f;
-        part[2][tid] = 0.f;
-        part[3][tid] = 0.f;
+    for (int i = 0; i < 32; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_hh[d] + (long)(32 * rho + i) * LSTM_H + j0);
+        wt[i][0] = f32x2{v[0], v[1]};
+        wt[i][1] = f32x2{v[2], v[3]};
     }
-    __syncthreads();
+    float dc = d_cn ? d_cn[d * LSTM_H + unit] : 0.f;
+    float dh_rec = d_hn ? d_hn[d * LSTM_H + unit] : 0.f;    // the recurrent dh of the first processed step = d_hn
+    const int grow = q * LSTM_H + unit;                      // this lane's gate row ...
+    const int gslot = (grow >> 5) * LSTM_SEG + (grow & 31);  // ... and its place in the padded LDS vector
     // the saved activations / upstream gradient of a step do not depend on the recurrence: step s-1's are requested while
     // step s is processed (one L2 round trip per step would otherwise sit on the critical path)
     struct StepIn {
@@ -174,11 +213,12 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
     StepIn nx = load_step(T - 1);
     for (int s = T - 1; s >= 0; --s) {           // reverse of the processing order
         const int t = d == 0 ? s : T - 1 - s;
+        const int cur = s & 1;                   // double-buffered: a fast wave may post step s-1 while a slow one still reads s
         const StepIn in = nx;
         if (s > 0) nx = load_step(s - 1);
         {
             const float gi = in.gi, gf = in.gf, gg = in.gg, go = in.go, ct = in.ct, cp = in.cp;
-            const float dh = in.dout + ((part[0][unit] + part[1][unit]) + (part[2][unit] + part[3][unit]));
+            const float dh = in.dout + dh_rec;
             const float th = tanh_f(ct);
             const float dct = dc + dh * go * (1.f - th * th);
             dc = dct * gf;
@@ -187,20 +227,33 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
             else if (q == 1) dp = dct * cp * gf * (1.f - gf);
             else if (q == 2) dp = dct * gi * (1.f - gg * gg);
             else dp = dh * th * go * (1.f - go);
-            // (dgs was last read before the barrier that ended the previous step; part[] is rewritten only after the next one)
-            dgs[q * LSTM_H + unit] = dp;
-            dG[((long)d * T + t) * LSTM_G + q * LSTM_H + unit] = dp;
+            dgs[cur][gslot] = dp;
+            dG[((long)d * T + t) * LSTM_G + grow] = dp;
         }
         __syncthreads();
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};     // packed FMAs, as in the forward
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};     // packed FMAs: columns (0, 1) and (2, 3)
 #pragma unroll
-        for (int r4 = 0; r4 < LSTM_H / 4; ++r4) {
-            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[qq * LSTM_H + r4 * 4]);  // broadcast within a wave pair
-            a0 = f32x2{wt[r4 * 4 + 0], wt[r4 * 4 + 1]} * f32x2{gv[0], gv[1]} + a0;
-            a1 = f32x2{wt[r4 * 4 + 2], wt[r4 * 4 + 3]} * f32x2{gv[2], gv[3]} + a1;
+        for (int r4 = 0; r4 < 8; ++r4) {
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[cur][rho * LSTM_SEG + r4 * 4]);
+            const f32x2 g01 = {gv[0], gv[1]}, g23 = {gv[2], gv[3]};
+            pk_fma_lo(a0, wt[r4 * 4 + 0][0], g01);
+            pk_fma_lo(a1, wt[r4 * 4 + 0][1], g01);
+            pk_fma_hi(a0, wt[r4 * 4 + 1][0], g01);
+            pk_fma_hi(a1, wt[r4 * 4 + 1][1], g01);
+            pk_fma_lo(a0, wt[r4 * 4 + 2][0], g23);
+            pk_fma_lo(a1, wt[r4 * 4 + 2][1], g23);
+            pk_fma_hi(a0, wt[r4 * 4 + 3][0], g23);
+            pk_fma_hi(a1, wt[r4 * 4 + 3][1], g23);
         }
-        part[qq][j] = (a0[0] + a0[1]) + (a1[0] + a1[1]);
-        __syncthreads();
+        float col[4] = {a0[0], a0[1], a1[0], a1[1]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {               // sum over the 16 lanes of the row: the same bits in all of them
+            col[k] += lstm_dpp<0xB1>(col[k]);       // quad_perm [1,0,3,2]
+            col[k] += lstm_dpp<0x4E>(col[k]);       // quad_perm [2,3,0,1]
+            col[k] += lstm_dpp<0x141>(col[k]);      // row_half_mirror
+            col[k] += lstm_dpp<0x140>(col[k]);      // row_mirror
+        }
+        dh_rec = rho < 4 ? col[0] : rho < 8 ? col[1] : rho < 12 ? col[2] : col[3];
     }
 }
 
