@@ -230,7 +230,7 @@ class MuCon(nn.Module):
                 and self.fs_encoder_lstm.input_size == 128 and self.fs_encoder_lstm.hidden_size == 128
                 and self.fs_encoder_lstm.num_layers == 1 and lc.mucon.type in ("flint", "arithmetic")
                 and batch.feats.shape[1] >= 2 and self.num_classes <= 64 and 1 <= batch.transcript_tf_target.shape[0] - 1 <= 64
-                and batch.feats.shape[1] // 16 <= 8192)
+                and batch.feats.shape[1] // 16 <= 4096)
 
     @torch.no_grad()
     def fused_train_step(self, batch: Batch) -> MuConLoss:
@@ -352,7 +352,7 @@ class MuCon(nn.Module):
         d = self.fs_decoder_lstm
         return (self.native_decoder and enc_out.is_cuda and d.input_size == 128 and d.hidden_size == 128
                 and d.num_layers == 1 and enc_out.shape[2] <= 256 and self.num_classes + 1 <= 128
-                and self.fs_decoder_embedding.embedding_dim == 128 and enc_out.shape[1] <= 8192)
+                and self.fs_decoder_embedding.embedding_dim == 128 and enc_out.shape[1] <= 4096)
 
     def _embedding_drop_mask(self, steps: int, device):
         """[steps x 128] keep-mask / (1 - p) of the decoder's embedding dropout (None for p = 0), in ONE launch: dropout of a
