@@ -9,6 +9,20 @@ the former's score() raises in the reference, the latter is unused (SURVEY.md 2,
 import numpy as np
 
 
+_LOG_FACTORIALS = {}
+
+
+def _log_factorials(n):
+    """[log 0!, log 1!, ..., log (n-1)!] as the reference accumulates them (`logFak += np.log(k)`); one table per n (an
+    evaluation builds a PoissonModel per video with the same max_length)."""
+    t = _LOG_FACTORIALS.get(n)
+    if t is None:
+        with np.errstate(all="ignore"):
+            t = _LOG_FACTORIALS[n] = np.concatenate(([0.0], np.cumsum(np.log(np.arange(1, n)))))
+        t.setflags(write=False)
+    return t
+
+
 class LengthModel(object):
     def n_classes(self):
         return 0
@@ -31,7 +45,7 @@ class PoissonModel(LengthModel):
         mu = self.mean_lengths
         with np.errstate(all="ignore"):
             # log-factorial partial sums, accumulated sequentially from 0 like `logFak += np.log(k)`
-            lf = np.concatenate(([0.0], np.cumsum(np.log(np.arange(1, max(self.max_len, 2))))))  # lf[l] = sum_{k<=l} log k
+            lf = _log_factorials(max(self.max_len, 2))  # lf[l] = sum_{k<=l} log k
             self.norms = np.zeros(mu.shape)
             if renormalize:
                 self.norms = np.round(mu) * np.log(np.round(mu)) - np.round(mu)
@@ -39,9 +53,24 @@ class PoissonModel(LengthModel):
                 lf2 = np.concatenate(([0.0, 0.0], np.cumsum(np.log(np.arange(2, max(kmax + 1, 3))))))  # sum_{k=2..m} log k
                 m = np.where(np.isfinite(mu), mu, 0).astype(np.int64)
                 self.norms = self.norms - np.where(m >= 2, lf2[np.clip(m, 0, len(lf2) - 1)], 0)
-            ls = np.arange(self.max_len, dtype=np.int64)[:, None]
-            self.poisson = ls * np.log(mu)[None, :] - mu[None, :] - lf[: self.max_len, None] - self.norms[None, :]
-            self.poisson[0, :] = -np.inf  # length zero can not happen
+            self._lf, self._logmu, self._poisson = lf, np.log(mu), None
+
+    def _table(self, lengths, classes):
+        """score(l, c) for l in lengths (int64 array), c in classes: the reference's expression, element by element
+        (`l * log(mu_c) - mu_c - logFak(l) - norm_c`, left to right), so any subset carries the bits of the full table."""
+        with np.errstate(all="ignore"):
+            t = (lengths[:, None] * self._logmu[None, classes] - self.mean_lengths[None, classes] - self._lf[lengths, None]
+                 - self.norms[None, classes])
+        t[lengths == 0, :] = -np.inf  # length zero can not happen
+        return t
+
+    @property
+    def poisson(self):
+        """The full [max_len x classes] table of the reference (length_model.py:60-75), built on first use: the decoder only
+        ever reads the rows fs, 2 fs, ... of the transcript's classes (rows_for), an evaluation builds one model per video."""
+        if self._poisson is None:
+            self._poisson = self._table(np.arange(self.max_len, dtype=np.int64), np.arange(self.num_classes))
+        return self._poisson
 
     def n_classes(self):
         return self.num_classes
@@ -61,5 +90,5 @@ class PoissonModel(LengthModel):
         tr = np.asarray(transcript, dtype=np.int64)
         P = np.full((J, len(tr)), -np.inf, dtype=np.float64)
         ok = lengths < self.max_len
-        P[ok, :] = self.poisson[lengths[ok]][:, tr]
+        P[ok, :] = self._table(lengths[ok].astype(np.int64), tr)
         return np.ascontiguousarray(P)
