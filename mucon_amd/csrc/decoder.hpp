@@ -85,12 +85,6 @@ struct DecDeltas {  // backward: gradients at the pre-activations (workspace)
 // Wave-wide reductions on the VALU: DPP for the steps inside a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap
 // across rows.  (__shfl_xor is ds_bpermute: every step a trip through the LDS pipe, ~100 cycles of latency and 2 clocks of
 // LDS issue per wave -- the 16 waves' matvec reductions of one decoding step were ~1,000 of them.)
-// A workgroup barrier that orders LDS traffic only: global loads (and stores) in flight stay in flight across it.
-// (__syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0): a weight stream requested before it would have
-// to land first.)  Use where the next phase consumes only LDS data produced by this one.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {   // v of the lane DPP control CTRL names (all lanes valid for the controls used)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -143,20 +137,6 @@ __device__ __forceinline__ float block_sum(int tix, float v, float *red) {  // r
     __syncthreads();
     return red[DEC_WAVES];
 }
-__device__ __forceinline__ float block_max(int tix, float v, float *red) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((tix & 63) == 0) red[tix >> 6] = v;
-    __syncthreads();
-    if (tix < 64) {
-        float t = tix < DEC_WAVES ? red[tix] : -INFINITY;
-        t = wave_max(t);
-        if (tix == 0) red[DEC_WAVES] = t;
-    }
-    __syncthreads();
-    return red[DEC_WAVES];
-}
-
 // Sum R (8 or 4) per-lane values across the wave with 10 (7) shuffles instead of R x 6: after the call, the lanes
 // with (lane >> 3) & 7 == r  (R = 8)  or  (lane >> 4) & 3 == r  (R = 4)  hold the wave-wide sum of v[r].
 template <int R>
