@@ -372,23 +372,41 @@ __device__ __forceinline__ void matvec_cols_steps(int tix, const float *__restri
 }
 static_assert(DEC_SB * DEC_D == DEC_THREADS && DEC_SB * DEC_THREADS <= DEC_SCR, "matvec_cols_steps staging");
 
-// mp[t][k] = sum_j memory[t][j] W1[j][k]; grid (ceil(Tz/4)), 512 threads = 4 rows x 128 columns
+// mp[t][k] = sum_j memory[t][j] W1[j][k]; grid (ceil(Tz/4)), 512 threads = 4 quarters of j x 128 columns, every thread all 4 rows.
+// (A thread per (row, column) walking all ME values of j was a chain of dependent L2 round trips: 11 us at Tz = 125.  Here a
+// thread loads ME/4 weights, 16 in flight, each used for four rows, and the quarters meet in LDS in order.)
 __global__ __launch_bounds__(512) void dec_memproj_kernel(const float *memory, const float *w1, float *mp, int Tz, int ME) {
     __shared__ float ms[4][DEC_MAXME];
+    __shared__ float part[4][4][DEC_D];
     const int t0 = blockIdx.x * 4;
     for (int e = threadIdx.x; e < 4 * ME; e += 512) {
         const int t = t0 + e / ME;
         ms[e / ME][e % ME] = t < Tz ? memory[(long)t * ME + e % ME] : 0.f;
     }
     __syncthreads();
-    const int r = threadIdx.x >> 7, k = threadIdx.x & 127;
-    if (t0 + r >= Tz) return;
-    float acc = 0.f;
-    for (int j = 0; j < ME; ++j) acc += ms[r][j] * w1[(long)j * DEC_D + k];
-    mp[(long)(t0 + r) * DEC_D + k] = acc;
+    const int qj = threadIdx.x >> 7, k = threadIdx.x & 127;
+    const int jq = (ME + 3) / 4, j0 = qj * jq, j1 = min(ME, j0 + jq);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int jb = j0; jb < j1; jb += 16) {
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = w1[(long)min(jb + i, j1 - 1) * DEC_D + k];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (jb + i < j1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += ms[r][jb + i] * w[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[qj][r][k] = acc[r];
+    __syncthreads();
+    const int r = threadIdx.x >> 7;
+    if (t0 + r < Tz) mp[(long)(t0 + r) * DEC_D + k] = (part[0][r][k] + part[1][r][k]) + (part[2][r][k] + part[3][r][k]);
 }
 
-// dynamic LDS: Tz floats (attention scores / weights)
+// dynamic LDS: dec_fwd_lds_bytes()
 __global__ __launch_bounds__(DEC_THREADS) void decoder_fwd_kernel(DecDims dm, DecParams p, DecSaved sv, const float *memory,
                                                                   const float *hn, const float *cn, const long *tf_input,
                                                                   const float *dropmask, float *logp_out, float *len_out,
