@@ -33,39 +33,6 @@ struct LstmGrads {
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-constexpr int LSTM_IP_T = 4;   // time steps per workgroup of the input projection (8 left 32 workgroups for T = 125: 15 us)
-// grid (ceil(T/LSTM_IP_T), ndir), 512 threads: thread r holds W_ih[d][r] in registers
-__global__ __launch_bounds__(512) void lstm_inproj_kernel(const float *x, LstmWeights w, float *Gx, int T) {
-    __shared__ __attribute__((aligned(16))) float xs[LSTM_IP_T][LSTM_H];
-    const int d = blockIdx.y, r = threadIdx.x, t0 = blockIdx.x * LSTM_IP_T;
-    float wr[LSTM_H];
-#pragma unroll
-    for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_ih[d] + (long)r * LSTM_H + c4 * 4);
-        wr[c4 * 4 + 0] = v[0];
-        wr[c4 * 4 + 1] = v[1];
-        wr[c4 * 4 + 2] = v[2];
-        wr[c4 * 4 + 3] = v[3];
-    }
-    for (int e = threadIdx.x; e < LSTM_IP_T * LSTM_H; e += 512) {
-        const int tt = t0 + e / LSTM_H;
-        xs[e / LSTM_H][e % LSTM_H] = tt < T ? x[(long)tt * LSTM_H + e % LSTM_H] : 0.f;
-    }
-    __syncthreads();
-    const float bias = w.b_ih[d][r] + w.b_hh[d][r];
-    for (int i = 0; i < LSTM_IP_T; ++i) {
-        const int t = t0 + i;
-        if (t >= T) break;
-        float acc = 0.f;
-#pragma unroll
-        for (int c4 = 0; c4 < LSTM_H / 4; ++c4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xs[i][c4 * 4]);
-            acc += wr[c4 * 4 + 0] * xv[0] + wr[c4 * 4 + 1] * xv[1] + wr[c4 * 4 + 2] * xv[2] + wr[c4 * 4 + 3] * xv[3];
-        }
-        Gx[((long)d * T + t) * LSTM_G + r] = acc + bias;
-    }
-}
-
 // DPP moves inside a quad / a row of 16 lanes (VALU, no LDS trip)
 template <int CTRL>
 __device__ __forceinline__ float lstm_dpp(float v) {
@@ -85,20 +52,69 @@ __device__ __forceinline__ void pk_fma_hi(f32x2 &acc, f32x2 w, f32x2 g) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(g));
 }
 
+constexpr int LSTM_IP_T = 4;   // time steps per workgroup of the input projection (8 left 32 workgroups for T = 125: 15 us)
+// grid (ceil(T/LSTM_IP_T), ndir), 512 threads.  The recurrence's ownership: a quad of lanes keeps the four gate rows of one
+// hidden unit, lane p the columns {16 k + 4 p .. + 3 : k = 0..7} of each -- the four lanes of a quad load 64 contiguous bytes
+// of a row (a lane per whole row touched 64 cache lines per load instruction: 8 us of the kernel's 13), the partial sums meet
+// through DPP, lane p writes gate p.
+__global__ __launch_bounds__(512) void lstm_inproj_kernel(const float *x, LstmWeights w, float *Gx, int T) {
+    __shared__ __attribute__((aligned(16))) float xs[LSTM_IP_T][LSTM_H];
+    const int d = blockIdx.y, t0 = blockIdx.x * LSTM_IP_T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 3, unit = wave * 16 + (lane >> 2);
+    float wr[4][32];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_ih[d] + (long)(q * LSTM_H + unit) * LSTM_H + 16 * k + 4 * p);
+            wr[q][k * 4 + 0] = v[0];
+            wr[q][k * 4 + 1] = v[1];
+            wr[q][k * 4 + 2] = v[2];
+            wr[q][k * 4 + 3] = v[3];
+        }
+    for (int e = threadIdx.x; e < LSTM_IP_T * LSTM_H; e += 512) {
+        const int tt = t0 + e / LSTM_H;
+        xs[e / LSTM_H][e % LSTM_H] = tt < T ? x[(long)tt * LSTM_H + e % LSTM_H] : 0.f;
+    }
+    __syncthreads();
+    const int r = p * LSTM_H + unit;
+    const float bias = w.b_ih[d][r] + w.b_hh[d][r];
+    for (int i = 0; i < LSTM_IP_T; ++i) {
+        const int t = t0 + i;
+        if (t >= T) break;
+        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xs[i][16 * k + 4 * p]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = f32x2{wr[q][k * 4 + 0], wr[q][k * 4 + 1]} * f32x2{xv[0], xv[1]} + a[q];
+                a[q] = f32x2{wr[q][k * 4 + 2], wr[q][k * 4 + 3]} * f32x2{xv[2], xv[3]} + a[q];
+            }
+        }
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre[q] = quad_sum(a[q][0] + a[q][1]);
+        const float mine = p == 0 ? pre[0] : p == 1 ? pre[1] : p == 2 ? pre[2] : pre[3];
+        Gx[((long)d * T + t) * LSTM_G + r] = mine + bias;
+    }
+}
+
 // grid (ndir), 512 threads.  out [T][ndir*128]; saves: gates [ndir][T][4][128] (post-activation i,f,g,o),
 // cells [ndir][T][128]; hn / cn [ndir][128].
-// Thread layout: a QUAD of lanes owns one hidden unit (wave w: units 16w .. 16w+15); lane p of the quad keeps columns
-// 32p .. 32p+31 of the unit's four gate rows of W_hh (4 x 32 = 128 registers).  A step is bound by what LDS returns to the
-// registers (128 B/clk per CU, broadcast or not): with a whole row per lane every lane read all 128 values of h -- 256 KB per
-// step, ~2,000 clocks; a quarter row per lane reads 32 of them (64 KB).  The four partial sums of a gate meet through two DPP
-// adds inside the quad, lane p applies the non-linearity of gate p (tanh x = 2 sigmoid(2x) - 1: branch-free), the four
-// activations are passed round the quad by DPP and all four lanes update the cell.  One barrier per time step (the new h for
-// everybody).  h sits in LDS as four 32-float segments 36 floats apart: the four lanes of a quad read four different
-// 16-byte bank groups.
-constexpr int LSTM_SEG = 36;
+// Thread layout: a QUAD of lanes owns one hidden unit (wave w: units 16w .. 16w+15); lane p of the quad keeps the columns
+// {16 k + 4 p .. + 3 : k = 0..7} of the unit's four gate rows of W_hh (4 x 32 = 128 registers; the four lanes of a quad load 64
+// contiguous bytes of a row).  A step is bound by what LDS returns to the registers (128 B/clk per CU, broadcast or not): with a
+// whole row per lane every lane read all 128 values of h -- 256 KB per step, ~2,000 clocks; a quarter row per lane reads 32 of
+// them (64 KB; a quad reads 64 contiguous bytes, every quad the same: conflict-free).  The four partial sums of a gate meet
+// through two DPP adds inside the quad, lane p applies the non-linearity of gate p (tanh x = 2 sigmoid(2x) - 1: branch-free),
+// the four activations are passed round the quad by DPP and all four lanes update the cell.  One barrier per time step (the
+// new h for everybody).
+constexpr int LSTM_SEG = 36;   // backward: pitch of the sixteen 32-float segments of the gate gradients in LDS
 __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, LstmWeights w, float *out, float *gates,
                                                              float *cells, float *hn, float *cn, int T, int ndir) {
-    __shared__ __attribute__((aligned(16))) float hs[2][4 * LSTM_SEG];
+    __shared__ __attribute__((aligned(16))) float hs[2][LSTM_H];
     const int d = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 3, unit = wave * 16 + (lane >> 2);
@@ -107,19 +123,18 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_hh[d] + (long)(q * LSTM_H + unit) * LSTM_H + 32 * p + c4 * 4);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(w.w_hh[d] + (long)(q * LSTM_H + unit) * LSTM_H + 16 * c4 + 4 * p);
             wr[q][c4 * 4 + 0] = v[0];
             wr[q][c4 * 4 + 1] = v[1];
             wr[q][c4 * 4 + 2] = v[2];
             wr[q][c4 * 4 + 3] = v[3];
         }
-    if (tid < 4 * LSTM_SEG) hs[0][tid] = 0.f;
+    if (tid < LSTM_H) hs[0][tid] = 0.f;
     float c = 0.f;  // cell state of `unit` (identical in the four lanes)
     const int r = p * LSTM_H + unit;   // the gate row whose input projection / activation this lane handles
     const float *gx = Gx + (long)d * T * LSTM_G + r;
     float gnext = gx[(long)(d == 0 ? 0 : T - 1) * LSTM_G];
     const float asc = p == 2 ? 2.f : 1.f;   // gate g: tanh through the sigmoid
-    const int hslot = (unit >> 5) * LSTM_SEG + (unit & 31);
     __syncthreads();
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
         f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][p * LSTM_SEG + c4 * 4]);
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][16 * c4 + 4 * p]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 a[q] = f32x2{wr[q][c4 * 4 + 0], wr[q][c4 * 4 + 1]} * f32x2{hv[0], hv[1]} + a[q];
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
         if (p == 0) {
             cells[((long)d * T + t) * LSTM_H + unit] = c;
             out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] = h;
-            hs[cur ^ 1][hslot] = h;
+            hs[cur ^ 1][unit] = h;
             if (s == T - 1) {
                 hn[d * LSTM_H + unit] = h;
                 cn[d * LSTM_H + unit] = c;
