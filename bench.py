@@ -481,7 +481,8 @@ def main():
                          "frac_of_bf16_mfma_peak": round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4) if split_tn else None,
                          "hbm_frac": round(bytes_wg / (dom[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "note": "achieved = algorithmic fp32 FLOP / launch time; peak = f32-input MFMA (dtype f32); the launch issues 6 bf16 "
-                                 "MFMA FLOP per algorithmic FLOP, frac_of_bf16_mfma_peak prices those against the 2.5 PFLOP/s dense bf16 peak",
+                                 "MFMA FLOP per algorithmic FLOP, frac_of_bf16_mfma_peak prices those against the 2.5 PFLOP/s dense bf16 peak (the kernel's "
+                                 "own ceiling: frac can pass 1.0 on a fast box, the f32-input peak is what a plain fp32 kernel could reach)",
                          "rocprof_summary": "profiles/r02_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
