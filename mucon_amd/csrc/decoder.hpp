@@ -5,7 +5,10 @@
 // attention over the Tz encoder states, attn_combine, one LSTM cell, the transcript MLP, the length MLP,
 // log-softmax, arg-max feedback): ~600 launches per training step, 11.5 ms of pure launch latency.  Here ONE
 // workgroup (1024 threads) walks all steps: the recurrent state stays in LDS, weights stream from L2
-// (~1 MB per step), the memory [Tz x 2E] and its projection are read once per step.
+// (~0.8 MB per step: what a step costs is this ONE CU's L1 path and its instruction issue), the memory [Tz x 2E] is read
+// once per step; attention_l2's weight and (Tz permitting) the memory projection are LDS-resident; whatever does not feed
+// the recurrence -- the transcript / length heads under teacher forcing, all of their backward -- runs outside the serial
+// loops for all steps at once.
 //   dec_memproj_kernel   mp = memory @ W1                                        (all Tz rows, many workgroups)
 //   decoder_fwd_kernel   the step loop; saves every activation the backward needs
 //   decoder_bwd_kernel   back-propagation through the steps; per-step "delta" vectors go to the workspace
