@@ -72,7 +72,11 @@ class WaveNetBlock(nn.Module):
 
     def forward_time_major(self, tape: Tensor, gn_weight: Tensor, gn_bias: Tensor, spec: ops.EncoderSpec,
                            seed: int = 0) -> Tensor:
-        """tape [B, T, Cin] (row-major, as the dataset delivers it) -> [B, Tz, out_dims]."""
+        """tape [B, T, Cin] (row-major, as the dataset delivers it) -> [B, Tz, out_dims].  Device tensors run in the HIP kernels;
+        host tensors (cfg.system.device = "cpu", reference core/config.py:16) take the library-op plumbing path."""
+        if not tape.is_cuda:
+            from ... import cpu_plumbing
+            return cpu_plumbing.wavenet_forward(self, tape, gn_weight, gn_bias, spec)
         if self.out_dims == 128:
             return ops.encoder_forward(tape, self.ordered_parameters() + [gn_weight, gn_bias], spec,
                                        training=self.training, seed=seed)

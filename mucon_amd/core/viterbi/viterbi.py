@@ -141,6 +141,9 @@ class Viterbi(object):
         from ... import _lib, ops
 
         fs = self.frame_sampling
+        if len(log_frame_probs) and all(isinstance(lp, torch.Tensor) and not lp.is_cuda for lp in log_frame_probs):
+            # cfg.system.device = "cpu" (reference core/config.py:16): the plumbing path, mucon_amd/cpu_plumbing.py
+            return [self._decode_host(lp, tr, lm) for lp, tr, lm in zip(log_frame_probs, transcripts, length_models)]
         lps, trs, tabs, forces = [], [], [], []
         max_len = None
         for lp, tr, lm in zip(log_frame_probs, transcripts, length_models):
@@ -166,6 +169,17 @@ class Viterbi(object):
             segs = [Viterbi.Segment(int(t[s]), int(r.seg_len[s])) for s in range(r.n_seg)]
             out.append((r.score, r.labels.tolist(), segs))
         return out
+
+    def _decode_host(self, lp, transcript, length_model):
+        """One video on the host (CPU torch tensor in, the reference's triple out): plumbing only, no parity claim."""
+        from ... import cpu_plumbing
+
+        v = Viterbi(SingleTranscriptGrammar(transcript, lp.shape[1]), length_model, self.frame_sampling, self.max_hypotheses)
+        t, P, force = v._prepare(int(lp.shape[0]))
+        score, labels, seg_len, alive = cpu_plumbing.viterbi_decode(lp.detach().numpy(), t, P, self.frame_sampling, force)
+        if not alive:
+            raise NoHypothesisError("'NoneType' object has no attribute 'label'")
+        return score, labels, [Viterbi.Segment(int(t[s]), int(n)) for s, n in enumerate(seg_len)]
 
     def decode(self, log_frame_probs):
         """-> (score: np.float64, labels: list[int] of len T, segments: list of Segment(label, length))."""

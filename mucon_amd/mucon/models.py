@@ -191,12 +191,19 @@ class MuCon(nn.Module):
     def frame_classifier_forward(self, temporal_encoded: Tensor, target_length: int) -> Tensor:
         """[1 x Ds x Tz] -> [1 x num_classes x Tf] (reference models.py:567-582)."""
         enc = temporal_encoded.permute(0, 2, 1)
+        if not enc.is_cuda:      # cfg.system.device = "cpu": plumbing path (mucon_amd/cpu_plumbing.py)
+            from .. import cpu_plumbing
+            return cpu_plumbing.head_forward(enc, self.conv_classifier.weight, self.conv_classifier.bias, target_length)[0].permute(0, 2, 1)
         logits, _ = ops.head_forward(enc, self.conv_classifier.weight, self.conv_classifier.bias, target_length,
                                      want_logits=True, want_logp=False)
         return logits.permute(0, 2, 1)
 
     def _segmentation_and_logp(self, temporal_encoded: Tensor, Tf: int):
         """logits [Tf x M] and log-probs [Tf x M] from one kernel launch."""
+        if not temporal_encoded.is_cuda:      # cfg.system.device = "cpu": plumbing path (mucon_amd/cpu_plumbing.py)
+            from .. import cpu_plumbing
+            logits, logp = cpu_plumbing.head_forward(temporal_encoded, self.conv_classifier.weight, self.conv_classifier.bias, Tf)
+            return logits[0], logp[0]
         logits, logp = ops.head_forward(temporal_encoded, self.conv_classifier.weight, self.conv_classifier.bias, Tf)
         return logits[0], logp[0]
 
