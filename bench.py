@@ -119,7 +119,8 @@ def cpu_baseline(spec, C, T, B=8):
     return {"value": round(B * T / best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/dense.py:module_graph (nn.Conv1d / max_pool1d / GroupNorm / interpolate / log_softmax) fwd+bwd fp32, "
                       f"B={B} x T={T} x D={spec.in_dim}, best of 3 passes ({', '.join(f'{t:.2f}' for t in times[1:])} s) after one warm-up, "
-                      f"{cores} threads = physical cores"}
+                      f"{cores} threads = physical cores; the module graph does not scale with cores (8 cores give about the same rate: "
+                      f"SURVEY.md 6) -- a stated baseline, not a tuned CPU implementation"}
 
 
 def _cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, n_videos, cores):
@@ -336,6 +337,9 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
 
+        # single node, xGMI only (north_star): keep RCCL off any InfiniBand / RoCE NIC the box may have.  Defaults only:
+        # an operator's own NCCL_* settings win.
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -425,6 +429,30 @@ def main():
         regions = t.tolist()
     elapsed = sorted(regions)[len(regions) // 2]       # the median region
 
+    rccl = None
+    if dist is not None:
+        # the exchange step by itself, outside the timed regions: HIP events on the step's stream around the one collective (what the
+        # step waits for: RCCL's own stream, the hand-offs to it and back, the wire), on the buffer the step reduces
+        step(args.warmup + args.repeats * args.steps)
+        buf = ops.flat_grad_buffers(enc_params)[0]
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(20)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(20)]
+        sync()
+        for a, b in zip(e0, e1):
+            a.record()
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+            b.record()
+        sync()
+        ar = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+        t = torch.tensor([ar[len(ar) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rccl = {"world": world, "backend": dist.get_backend(), "bytes_per_step": int(buf.numel() * 4),
+                "allreduce_ms": round(float(t.item()), 4), "collectives_per_step": 1,
+                "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
+                "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                "note": "median of 20 all-reduces of the step's flat gradient buffer (encoder + y-head), HIP events on the step's stream, "
+                        "max over ranks; measured after the timed regions"}
+
     if rank == 0:
         frames = world * B * T * args.steps
         value = frames / elapsed
@@ -449,6 +477,9 @@ def main():
         dom = (("ts_batched_kernel: all weight gradients of the step in one launch (bf16 MFMA on exactly split fp32 operands)"
                 if split_tn else "tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)"), k_wg_ms)
         achieved = flops_wg / (dom[1] * 1e-3) / 1e12
+        # the kernel's OWN ceiling: it issues 6 bf16 MFMA FLOP per algorithmic fp32 FLOP, so 2.5 PFLOP/s dense bf16 / 6 = 416.7 TFLOP/s
+        # fp32-equivalent (the f32-input MFMA peak, 157.3, is what a plain fp32 kernel could reach -- kept as a secondary field)
+        peak_own = PEAK_BF16_MFMA_TFLOPS / 6.0 if split_tn else PEAK_F32_MFMA_TFLOPS
         traffic = traffic_fwd = traffic_src = None
         try:
             import glob
@@ -466,24 +497,30 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 storage / accumulate; GEMM operands split exactly into three bf16 (x = hi + mid + lo), 6 of the 9 partial "
+                          "products on the bf16 MFMA (the dropped three are < 2^-25 of the product); departs from north_star's 'no MFMA' "
+                          "because at hidden 128 the path is compute-bound (SURVEY.md 0.3); +-inf in a GEMM operand yields NaN (inf - inf in "
+                          "the split), fp32 subnormals may flush (INTEGRATION.md)",
             "config": {"workload": f"synthetic I3D tapes, B={B} videos/GPU x T={T} frames x D={spec.in_dim}, {C} classes, "
                                    f"hidden {spec.hidden}, 11 dilated layers (BASELINE config 3 shape); training mode "
                                    f"(dropout on), fwd+bwd+SGD, tapes resident in HBM",
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
             "tape_batches_rotated": len(tapes), "tape_bytes_resident": len(tapes) * B * T * spec.in_dim * 4,
-            "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(peak_own, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / peak_own, 4), "traffic": traffic,
+                         "traffic_source": (f"committed profile, builder's box ({traffic_src}): a constant of the profile run, "
+                                            f"not measured in this run") if traffic_src else None,
+                         "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
                          "flops_per_launch": flops_wg, "launches_timed": int(cnt[1]),
                          "issued_bf16_tflops": round((6 if split_tn else 1) * achieved, 1) if split_tn else None,
                          "frac_of_bf16_mfma_peak": round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4) if split_tn else None,
                          "hbm_frac": round(bytes_wg / (dom[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                         "note": "achieved = algorithmic fp32 FLOP / launch time; peak = f32-input MFMA (dtype f32); the launch issues 6 bf16 "
-                                 "MFMA FLOP per algorithmic FLOP, frac_of_bf16_mfma_peak prices those against the 2.5 PFLOP/s dense bf16 peak (the kernel's "
-                                 "own ceiling: frac can pass 1.0 on a fast box, the f32-input peak is what a plain fp32 kernel could reach)",
-                         "rocprof_summary": "profiles/r02_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
+                         "note": "achieved = algorithmic fp32 FLOP / launch time; peak = the kernel's own ceiling = 2.5 PFLOP/s dense bf16 MFMA / 6 "
+                                 "(it issues 6 bf16 MFMA FLOP per algorithmic FLOP), so frac = frac_of_bf16_mfma_peak <= 1; "
+                                 "frac_of_f32_mfma_peak prices the same FLOP against the 157.3 TFLOP/s f32-input MFMA peak a plain fp32 kernel is capped at",
+                         "rocprof_summary": "profiles/r03_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
@@ -502,6 +539,8 @@ def main():
                                                 "the split-bf16 kernels at about 35%"},
             "fp32_fraction_whole_path": round(value / world * 2.517e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
         if not args.no_viterbi:

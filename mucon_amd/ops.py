@@ -185,6 +185,11 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, tape, w, b):
         lib = _lib.load()
         _check_dev(tape, w, b)
+        if getattr(ctx, "needs_input_grad", (False,))[0]:
+            # first_conv's kernels produce no gradient for their input (the dataset's features need none): refuse loudly
+            # rather than hand autograd a silent None where nn.Conv1d would propagate
+            raise _lib.MuconHipError("linear_forward: the input tape requires a gradient, which the HIP path does not produce "
+                                     "(detach it, or use torch ops for this input)")
         tape, w, b = tape.contiguous(), w.contiguous(), b.contiguous()
         B, T, D = tape.shape
         nbytes = lib.mucon_linear_workspace_bytes(B, T, D)
@@ -662,7 +667,7 @@ class FusedClipAdam:
         lib = _lib.load()
         pg = self.optimizer.param_groups[0]
         amsgrad = bool(pg.get("amsgrad", False))
-        entries, step_no = [], None
+        entries = []
         for gi, params in enumerate(self.groups):
             for p in params:
                 if p.grad is None:
@@ -670,17 +675,24 @@ class FusedClipAdam:
                 _check_dev(p, p.grad)
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise _lib.MuconHipError("FusedClipAdam needs contiguous parameters and gradients")
-                st = self.optimizer.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if amsgrad:
-                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                entries.append((p, st, gi))
+                entries.append((p, self.optimizer.state[p], gi))
         if not entries:
             return
+        # validate BEFORE touching any state: torch keeps one step counter per tensor, this kernel takes one per call.  A
+        # parameter whose first gradient arrives later than the others' would make the counters differ -- refuse with the
+        # optimizer state untouched, so the caller can take torch's own optimizer.step() for this iteration
+        counts = {int(st["step"]) if len(st) else 0 for _, st, _ in entries}
+        if len(counts) != 1:
+            raise _lib.MuconHipError("FusedClipAdam: parameters at different step counts (torch keeps one per tensor; this kernel one "
+                                     "per call); the optimizer state was not modified")
+        for p, st, _ in entries:
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if amsgrad:
+                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
         n = len(entries)
         tab = (_lib.AdamTensor * n)()
         total = 0
@@ -690,9 +702,7 @@ class FusedClipAdam:
             tab[i].max_exp_avg_sq = st["max_exp_avg_sq"].data_ptr() if amsgrad else None
             tab[i].n, tab[i].group = p.numel(), gi
             total += p.numel()
-        steps = {int(st["step"]) for _, st, _ in entries}
-        if len(steps) != 1:
-            raise _lib.MuconHipError("FusedClipAdam: parameters at different step counts (torch keeps one per tensor; this kernel one per call)")
+        steps = {counts.pop() + 1}
         nbytes = lib.mucon_adam_workspace_bytes(n, total)
         dev = entries[0][0].device
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
@@ -822,6 +832,8 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     for v in range(nv):
         j = jobs[v]
         ns = int(nseg_h[v])
-        out.append(ViterbiResult(score=np.float64(score_h[v]), labels=labels_h[j.label_off: j.label_off + j.T].copy(),
+        ok = int(status_h[v]) in (_lib.VIT_OK, _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
+        out.append(ViterbiResult(score=np.float64(score_h[v]),
+                                 labels=labels_h[j.label_off: j.label_off + j.T].copy() if ok else np.empty(0, np.int32),
                                  seg_len=seg_h[j.seg_off: j.seg_off + ns].copy(), n_seg=ns, status=int(status_h[v])))
     return out

@@ -62,9 +62,14 @@ def main(argv=None):
         device = f"cuda:{torch.cuda.current_device()}"
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")     # one node: the gradient all-reduce stays on xGMI (an operator's own setting wins)
         dist.init_process_group(os.environ.get("MUCON_DIST_BACKEND", "nccl" if device.startswith("cuda") else "gloo"))
     if rank == 0:
         print(cfg.dump())
+        # the reference pins PyTorch 1.1, whose affine_grid / grid_sample behave as align_corners=True; torch >= 1.3 defaults to
+        # False.  The convention is an explicit key here (saved with config.yaml): say which one this run uses.
+        print(f"model.loss.mucon.align_corners = {bool(cfg.model.loss.mucon.get('align_corners', True))} "
+              f"(True = the reference's PyTorch 1.1 environment; a reference run on torch >= 1.3 corresponds to False)", flush=True)
     torch.manual_seed(int(cfg.system.seed))
 
     train_db, test_db = handel_dataset(cfg, train=True), handel_dataset(cfg, train=False)

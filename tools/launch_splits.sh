@@ -13,6 +13,7 @@
 #                               RCCL refuses two ranks on one GPU)
 #   BASE_PORT=29600         group g rendezvous on 127.0.0.1:BASE_PORT+g
 #   LOG_DIR=./split_logs    one log per group
+#   NCCL_IB_DISABLE         defaults to 1 here: single node, gradients travel over xGMI only (set it to 0 to override)
 # Exit code: non-zero if any group failed.
 set -u
 SPLITS=${SPLITS:-"1 2 3 4"}
@@ -20,6 +21,7 @@ GPUS_PER_GROUP=${GPUS_PER_GROUP:-2}
 DEVICES=(${DEVICES:-0 1 2 3 4 5 6 7})
 BASE_PORT=${BASE_PORT:-29600}
 LOG_DIR=${LOG_DIR:-./split_logs}
+export NCCL_IB_DISABLE=${NCCL_IB_DISABLE:-1}
 mkdir -p "$LOG_DIR"
 pids=()
 g=0
