@@ -30,6 +30,15 @@
 #ifndef TS_ABL
 #define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
 #endif
+#ifndef TS_STAMP
+#define TS_STAMP 0   // tools/ts_ablate.hip: 1 = s_memtime stamps around the phases of a tile (block 0 publishes per-wave sums; timing builds only)
+#endif
+#if TS_STAMP
+__device__ long long g_ts_stamps[8 * 8];
+#define TS_T(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define TS_T(k) do { } while (0)
+#endif
 constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 32-step G image (24,576 B)
 constexpr int TS_XT_FLOATS = 32 * 32;                   // a wave's X tile [32 time steps][32 columns] (4 KB), transposed through LDS
 constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS_XT_FLOATS * 4;   // two buffers x two images + eight X tiles: 131,072 B
@@ -289,9 +298,14 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     //   { MFMAs of step 0 | split of X step 1, first half of image mt+1 -> buffer O }
     //   { X tile <- tile mt+1 (set O), set O <- tile mt+3 requested; first half of image mt+2 requested; X (mt+1, step 0) read back }
     //   { MFMAs of step 1 | split of X (mt+1, step 0), second half of image mt+1 }
+#if TS_STAMP
+    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
     auto tile = [&](int mt, auto SET, auto OTHER) {
         constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
         (void)Q;
+        TS_T(5);
         const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n3 = min(mt + 3, last);
         const float bw = mt < last ? 1.f : 0.f;
         if (!(TS_ABL & 8)) gloadG(n1, I1{});
@@ -299,6 +313,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         if (!x_int(mt)) fixX(rawT, mt, 1);
         if (!g_int(n1)) fixG(n1, I0{});
         __builtin_amdgcn_sched_barrier(0);
+        TS_T(0);
         pin(rawT);   // (keeps the splits below in this block: without it they are duplicated into the fix-up branches, outside the weave)
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgA[u]);
@@ -308,6 +323,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         weave();
         use(nxt);   // (a use inside the phase: otherwise the split is sunk behind the branches below, out of the weave)
         __builtin_amdgcn_sched_barrier(0);
+        TS_T(1);
         stageX(OTHER);
         if (!(TS_ABL & 8)) {
             gloadG(n2, I0{});
@@ -317,6 +333,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         if (!x_int(n1)) fixX(rawT, n1, 0);
         if (!g_int(n1)) fixG(n1, I1{});
         __builtin_amdgcn_sched_barrier(0);
+        TS_T(2);
         pin(rawT);
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgB[u]);
@@ -326,13 +343,19 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         weave();
         use(cur);
         __builtin_amdgcn_sched_barrier(0);
+        TS_T(3);
         __syncthreads();
+        TS_T(4);
     };
     for (int mt = 0; mt < ntiles; mt += 2) {
         tile(mt, I0{}, I1{});
         if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
     }
 
+#if TS_STAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
+#endif
     if (active) {
         float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
 #pragma unroll

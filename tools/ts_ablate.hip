@@ -6,8 +6,18 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include "../mucon_amd/csrc/gemm_tn_split.hpp"
+#include "experiments/gemm_tn_ws.hpp"
+#ifndef USE_TW
+#define USE_TW 0   // 1: the wave-specialised kernel (gemm_tn_ws.hpp)
+#endif
+#if USE_TW
+#define LAUNCH launch_tw_batch
+#else
+#define LAUNCH launch_ts_batch
+#endif
 int g_tn_batch_ks = 2;
 int g_ts_xcd = 1;
 
@@ -39,19 +49,80 @@ int main(int argc, char **argv) {
         t.slabs = slabs; t.bias_slabs = bslabs; t.MC = MC; t.chunks_per_video = nmc; t.drop.thresh = 0; t.drop.scale = 1.f;
         tb.j[0].nkc = K / 128; tb.j[0].block0 = nmc; tb.j[0].x0_act = 0; tb.j[0].dual = 0;
     };
+    if (getenv("TS_CHECK")) {   // one launch against a float64 host product of the slabs' sum (small sizes only)
+        job();
+        CK(LAUNCH(tb, 0));
+        CK(hipDeviceSynchronize());
+        double *ref = new double[(size_t)128 * K]();
+        float *hy = new float[(size_t)M * 128], *hx = new float[(size_t)M * K], *hs = new float[(size_t)nmc * 128 * K];
+        CK(hipMemcpy(hy, Y, (size_t)M * 128 * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hx, X, (size_t)M * K * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hs, slabs, (size_t)nmc * 128 * K * 4, hipMemcpyDeviceToHost));
+        for (int t = 0; t < M; ++t)
+            for (int n = 0; n < 128; ++n) {
+                const double g = hy[(size_t)t * 128 + n];
+                for (int k = 0; k < K; ++k) ref[(size_t)n * K + k] += g * hx[(size_t)t * K + k];
+            }
+        double worst = 0, scale = 0;
+        for (size_t i = 0; i < (size_t)128 * K; ++i) {
+            double got = 0;
+            for (int c = 0; c < nmc; ++c) got += hs[(size_t)c * 128 * K + i];
+            worst = fmax(worst, fabs(got - ref[i]));
+            scale = fmax(scale, fabs(ref[i]));
+        }
+        printf("check: max abs error %.3e against max |dW| %.3e (relative %.2e)\n", worst, scale, worst / scale);
+        float hb[256];
+        CK(hipMemcpy(hb, bslabs, sizeof(hb), hipMemcpyDeviceToHost));
+        double bs = 0;
+        for (int t = 0; t < (MC < M ? MC : M); ++t) bs += hy[(size_t)t * 128 + 5];
+        printf("check: bias slab 0 channel 5: %.6f against %.6f\n", hb[5], bs);
+    }
+    const int wgs = nmc * (K / (USE_TW ? 128 : 256));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w) { job(); CK(launch_ts_batch(tb, 0)); }
+    for (int w = 0; w < 3; ++w) { job(); CK(LAUNCH(tb, 0)); }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) { job(); CK(launch_ts_batch(tb, 0)); }
+    for (int i = 0; i < iters; ++i) { job(); CK(LAUNCH(tb, 0)); }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, flop = 2.0 * M * 128.0 * K;
-    const int wgs = nmc * (K / 256);
+#if TW_STAMP
+    {   // block 0, last launch: cycles per tile spent working / waiting at the tile barrier, multipliers (waves 0-3) and stagers (4-7)
+        long long h[96];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tw_stamps), sizeof(h)));
+        const double nt = MC / 32;
+        {
+            static long long hb[4096 * 4];
+            CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_tw_blk), sizeof(hb)));
+            const int nb = wgs < 4096 ? wgs : 4096;
+            long long t0 = hb[0], t1 = hb[1];
+            for (int i = 0; i < nb; ++i) { if (hb[i * 4] < t0) t0 = hb[i * 4]; if (hb[i * 4 + 1] > t1) t1 = hb[i * 4 + 1]; }
+            double dmin = 1e30, dmax = 0, dsum = 0, smax = 0, cmin = 1e30, cmax = 0;
+            for (int i = 0; i < nb; ++i) {
+                const double d = (hb[i * 4 + 1] - hb[i * 4]) / 100.0, st = (hb[i * 4] - t0) / 100.0, ghz = hb[i * 4 + 2] / d / 1e3;
+                dmin = fmin(dmin, d); dmax = fmax(dmax, d); dsum += d; smax = fmax(smax, st); cmin = fmin(cmin, ghz); cmax = fmax(cmax, ghz);
+            }
+            printf("  blocks: span %.1f us; start skew up to %.1f us; per-block duration min %.1f / mean %.1f / max %.1f us; clock %.2f-%.2f GHz\n",
+                   (t1 - t0) / 100.0, smax, dmin, dsum / nb, dmax, cmin, cmax);
+        }
+        for (int w = 0; w < 4 + TW_NS; ++w) printf("  wave %d (%s) cycles/tile: work %.0f  barrier wait %.0f\n", w, w < 4 ? "multiplier" : "stager", h[w * 8] / nt, h[w * 8 + 1] / nt);
+    }
+#endif
+#if TS_STAMP
+    {   // per-wave cycle sums of block 0 over the last launch, per tile: pre-phase-0 | phase 0 (24 MFMAs) | pre-phase-1 | phase 1 | barrier | loop edge
+        long long h[64];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts_stamps), sizeof(h)));
+        const double nt = MC / 32;
+        for (int w = 0; w < 8; ++w)
+            printf("  wave %d cycles/tile: pre0 %.0f  ph0 %.0f  pre1 %.0f  ph1 %.0f  barrier %.0f  edge %.0f  total %.0f\n", w, h[w * 8] / nt,
+                   h[w * 8 + 1] / nt, h[w * 8 + 2] / nt, h[w * 8 + 3] / nt, h[w * 8 + 4] / nt, h[w * 8 + 5] / nt,
+                   (h[w * 8] + h[w * 8 + 1] + h[w * 8 + 2] + h[w * 8 + 3] + h[w * 8 + 4] + h[w * 8 + 5]) / nt);
+    }
+#endif
     printf("TS_ABL=%d xcd=%d M=%d K=%d MC=%d: %d workgroups x %d tiles: %.1f us per launch, %.1f TFLOP/s fp32-equivalent, %.2f us per tile\n",
            TS_ABL, g_ts_xcd, M, K, MC, wgs, MC / 32, us, flop / us * 1e-6, us / (MC / 32) / ((wgs + 255) / 256));
     return 0;
