@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 3
+#define MUCON_ABI_VERSION 4   /* 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -171,7 +171,9 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
  * Viterbi: transcript-constrained decode with a length model
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
-    int64_t lp_off;     /* float offset of this video's emissions [T][C] inside `lp`            */
+    const float *lp;    /* DEVICE pointer to this video's emissions [T][C] f32, row-major, 16-byte
+                           aligned when C is a multiple of 4 (ABI 4: one pointer per video -- a batch
+                           of videos is decoded where its emissions lie, nothing is concatenated)  */
     int64_t tr_off;     /* int32 offset of its transcript [N] inside `transcripts`              */
     int64_t p_off;      /* double offset of its length table [J][N] inside `length_tables`      */
     int64_t label_off;  /* int32 offset of its output labels [T] inside `labels`                */
@@ -193,10 +195,29 @@ size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_t N, int32_
  * jobs: DEVICE array [n_videos].  Outputs: labels, seg_len (per job offsets), n_seg[n_videos],
  * score[n_videos] (f64), status[n_videos] (MUCON_VIT_*). */
 int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C,
-                               int32_t fs, int32_t max_len, int32_t max_N, const float *lp,
+                               int32_t fs, int32_t max_len, int32_t max_N,
                                const int32_t *transcripts, const double *length_tables,
                                int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
                                int32_t *status, void *workspace, void *stream);
+
+/* The same decode with HOST-side inputs and outputs -- what the reference's call site is
+ * (src/mucon/evaluators.py:178-180: numpy in, Python lists out): emissions stay on the device,
+ * transcript and length table are host arrays, the results arrive in host arrays when the call returns
+ * (it synchronises with the work it enqueued on `stream`; everything queued before it on that stream is
+ * ordered in front of the decode).  One launch for a single short video (T / fs * C * 4 bytes of frame
+ * scores beside the chain's LDS buffers, <= 32 transcript states); inputs are read from and results
+ * written to library-owned pinned host buffers, no copy calls.  labels: video v's T labels at the sum of
+ * max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid). */
+typedef struct {
+    const float *lp;            /* DEVICE: emissions [T][C] f32 */
+    const int32_t *transcript;  /* HOST [N] */
+    const double *table;        /* HOST [J][N], J = max_len / fs */
+    int32_t T, N;
+    int32_t force_n, force_j;   /* as in mucon_viterbi_job (-1, -1: none) */
+} mucon_viterbi_video;
+int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs,
+                              int32_t max_len, double *score, int32_t *n_seg, int32_t *status,
+                              int32_t *labels, int32_t *seg_len, void *stream);
 
 /* ---- s-head sequence encoder: bidirectional LSTM --------------------------------
  * Replaces torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True) as the reference's s-head calls

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 METRICS_MAX_RUNS = 1024   # MUCON_METRICS_MAX_RUNS
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
@@ -46,10 +46,15 @@ class EncoderParams(ctypes.Structure):
 
 class ViterbiJob(ctypes.Structure):
     _fields_ = [
-        ("lp_off", ctypes.c_int64), ("tr_off", ctypes.c_int64), ("p_off", ctypes.c_int64),
+        ("lp", ctypes.c_void_p), ("tr_off", ctypes.c_int64), ("p_off", ctypes.c_int64),
         ("label_off", ctypes.c_int64), ("seg_off", ctypes.c_int64), ("ws_off", ctypes.c_int64),
         ("T", ctypes.c_int32), ("N", ctypes.c_int32), ("force_n", ctypes.c_int32), ("force_j", ctypes.c_int32),
     ]
+
+
+class ViterbiVideo(ctypes.Structure):
+    _fields_ = [("lp", ctypes.c_void_p), ("transcript", ctypes.c_void_p), ("table", ctypes.c_void_p),
+                ("T", ctypes.c_int32), ("N", ctypes.c_int32), ("force_n", ctypes.c_int32), ("force_j", ctypes.c_int32)]
 
 
 class LstmParams(ctypes.Structure):
@@ -111,7 +116,8 @@ SYMBOLS = {
     "mucon_head_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
-    "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_viterbi_decode_host": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_encoder_saved_view": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), _i32, _i32, ctypes.POINTER(ctypes.c_size_t),
                                                 ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

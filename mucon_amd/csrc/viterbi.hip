@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 
 #include "../../include/mucon_hip.h"
 
@@ -41,8 +43,7 @@ constexpr int FS_ROWS = 256;
 constexpr int FS_THREADS = 256;
 typedef float vit_f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mucon_viterbi_job *jobs, const float *lp,
-                                                                        char *ws, int C, int fs) {
+__global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mucon_viterbi_job *jobs, char *ws, int C, int fs) {
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][FS_ROWS * C]
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
     float *F = reinterpret_cast<float *>(ws + job.ws_off);
     const int n = K * fs;                       // frames that enter the decode
     const int tid = threadIdx.x;
-    const float *src = lp + job.lp_off;
+    const float *src = job.lp;
     const int chunk = FS_ROWS * C;              // floats per chunk: a contiguous range of the [T][C] array
     const int nchunks = (n + FS_ROWS - 1) / FS_ROWS;
     const long total = (long)n * C;
@@ -145,6 +146,7 @@ constexpr int FSC_STAGE = FSC_THREADS - 64;  // staging threads
 constexpr int FSC_NPER = 10;                 // tiles per staging wave per chunk: ceil(16 row blocks x 4 float4 blocks / 7)
 constexpr int FSC_MAX_LDS = 160 * 1024;
 constexpr int FSC_DEPTH = 8;                 // b128 reads in flight
+constexpr size_t VF_DYN_MAX = 160 * 1024 - 24 * 1024;   // dynamic LDS of the one-launch kernel: 160 KiB minus the DP's static arrays
 constexpr int FSC_SLACK = 8 * FSC_DEPTH;     // rows the read-ahead and the last round may run past a chunk's end
 __host__ __device__ inline int fsc_pitch(int rows) { return ((rows + FSC_SLACK + 15) & ~15) + 4; }   // = 4 mod 16, in floats
 __host__ __device__ inline int fsc_floats(int C, int fs, int cols) {                                 // dynamic LDS, in floats
@@ -152,13 +154,8 @@ __host__ __device__ inline int fsc_floats(int C, int fs, int cols) {            
     return 2 * C * fsc_pitch(cols * nq * 4) + 2 * (cols * nq + FSC_DEPTH) * 64;
 }
 template <bool W4>   // the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column
-__global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(const mucon_viterbi_job *jobs, const float *lp,
-                                                                              char *ws, int C, int fs, int cols) {
-    extern __shared__ __attribute__((aligned(16))) float fs_smem[];   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
-    const mucon_viterbi_job job = jobs[blockIdx.x];
-    const int K = job.T / fs;
-    if (K < 1) return;
-    float *F = reinterpret_cast<float *>(ws + job.ws_off);
+__device__ __forceinline__ void framescore_cols_body(const float *lp_video, float *F, const int K, const int C, const int fs, const int cols,
+                                                     float *fs_smem) {   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
     const int tid = threadIdx.x;
     const int nq = (fs + 3) >> 2;                 // b128 reads per column
     const int P = nq * 4;                         // LDS rows per column
@@ -177,7 +174,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(co
     if (tid >= 64) {
         // ---- waves 1..7: staging and the column differences ----
         const int j = tid - 64;
-        const vit_f32x4 *src4 = reinterpret_cast<const vit_f32x4 *>(lp + job.lp_off);
+        const vit_f32x4 *src4 = reinterpret_cast<const vit_f32x4 *>(lp_video);
         const int total4 = K * fs * C4;               // < 2^31: T * C / 4
         const unsigned inv_fs = (1u << 20) / fs + 1;  // x / fs == (x * inv_fs) >> 20 for x < 4096
         // One wave instruction moves a tile of 16 rows x 4 float4 (lane = 4 * row + float4): the global load reads 64
@@ -284,6 +281,15 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(co
         if (nquads & (FSC_DEPTH - 1)) run = runs[(ci & 1) * runsz + (nquads - 1) * 64 + tid];
         __syncthreads();
     }
+}
+
+template <bool W4>
+__global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(const mucon_viterbi_job *jobs, char *ws, int C, int fs, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int K = job.T / fs;
+    if (K < 1) return;
+    framescore_cols_body<W4>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem);
 }
 
 struct Cand {
@@ -426,10 +432,10 @@ __device__ __forceinline__ double dpp_f64(double v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 
-template <int G, int JG, int NW>   // NW = 1: wave 0 decodes, three more waves only help with the labels; NW = 2: two decoding waves
-__global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
-    int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
+template <int G, int JG, int NW>   // NW = 1: wave 0 decodes, the other waves only help with the labels; NW = 2: two decoding waves
+__device__ __forceinline__ void viterbi_dp_lanes_body(
+    const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, const int32_t *transcripts, const double *tables,
+    int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J) {
     constexpr bool PL_LDS = JG > 40;        // one lane per state: 2 x 67 doubles do not fit the registers, Pl goes to LDS
     constexpr int VL_CH = PL_LDS ? 8 : 32;  // columns of frame scores staged at a time (one register each while in flight)
     constexpr int NL = 64 * NW;             // decoding lanes
@@ -441,11 +447,9 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_k
     __shared__ int a[NL], pre[NL + 1];
     __shared__ double fin_score;
     __shared__ int fin_n, fin_j;
-    const mucon_viterbi_job job = jobs[blockIdx.x];
     const int T = job.T, N = job.N;
     const int K = T / fs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vid = blockIdx.x;
     if (K < 1) {  // frame_scores[fs-1] does not exist: IndexError in the reference (viterbi.py:87)
         if (tid == 0) {
             status[vid] = MUCON_VIT_INDEX_ERROR;
@@ -462,9 +466,6 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_k
         }
         return;
     }
-    const float *F = reinterpret_cast<const float *>(ws + job.ws_off);
-    const size_t f_bytes = ((size_t)K * C * sizeof(float) + 15) & ~(size_t)15;
-    uint8_t *bp = reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes);  // [K][N]
     const bool forced = job.force_n >= 0 || K < N;
     if (tid < NL) a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
     for (int j = tid; j < J; j += blockDim.x) Pl0[j] = tables[job.p_off + (size_t)j * N];
@@ -644,6 +645,49 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_k
         return;
     }
     vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs);
+}
+
+template <int G, int JG, int NW>
+__global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_kernel(
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
+    int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int K = job.T / fs;
+    const size_t f_bytes = ((size_t)(K > 0 ? K : 0) * C * sizeof(float) + 15) & ~(size_t)15;
+    viterbi_dp_lanes_body<G, JG, NW>(job, blockIdx.x, reinterpret_cast<const float *>(ws + job.ws_off),
+                                     reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes), transcripts, tables, labels, seg_len, n_seg,
+                                     score, status, C, fs, J);
+}
+
+// ONE launch for a short video (the evaluation's case: T ~ 2,000 frames, a handful of transcript states): the frame scores never
+// leave the workgroup -- phase 1 (framescore_cols_body: wave 0's float32 chain, seven staging waves) writes them to LDS, phase 2
+// (viterbi_dp_lanes_body) decodes from there.  Inputs (job, transcript, length table) are read straight from the caller's PINNED
+// host staging buffer and the results go straight into pinned host memory (no copy calls on either side: of the 0.10 ms a
+// two-launch decode of a T = 2,000 video took, half was the upload, the second launch and the synchronous download); thread 0
+// publishes `*done_flag = done_value` behind a system-scope fence, which is what the host waits for.
+template <int G, int JG, bool W4>
+__global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job *jobs, const int32_t *transcripts,
+                                                                    const double *tables, int32_t *labels, int32_t *seg_len,
+                                                                    int32_t *n_seg, double *score, int32_t *status, char *ws, int C,
+                                                                    int fs, int J, int cols, int dyn_floats, volatile int32_t *done_flag,
+                                                                    int32_t done_value) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int K = job.T / fs;
+    float *F = fs_smem + dyn_floats;                 // [K][C] behind phase 1's buffers
+    if (K >= 1) {
+        framescore_cols_body<W4>(job.lp, F, K, C, fs, cols, fs_smem);
+        __syncthreads();
+    }
+    viterbi_dp_lanes_body<G, JG, 1>(job, blockIdx.x, F, reinterpret_cast<uint8_t *>(ws + job.ws_off), transcripts, tables, labels, seg_len,
+                                    n_seg, score, status, C, fs, J);
+    if (done_flag) {
+        __threadfence_system();                      // every thread's label stores are visible to the host ...
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(const_cast<int32_t *>(done_flag), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag
+        }
+    }
 }
 
 
@@ -886,12 +930,11 @@ extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_
     return f_bytes + bp_bytes + 16;
 }
 
-extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
-                                          int32_t max_len, int32_t max_N, const float *lp,
-                                          const int32_t *transcripts, const double *length_tables,
-                                          int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
-                                          int32_t *status, void *workspace, void *stream) {
-    if (n_videos <= 0) return MUCON_OK;
+// Launches of one decode: `fused` = the one-launch kernel (short videos, <= 32 states), else frame scores + DP.
+static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs, int32_t max_len, int32_t max_N,
+                      const int32_t *transcripts, const double *length_tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
+                      double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int fused_maxK, bool cols_ok,
+                      volatile int32_t *done_flag, int32_t done_value) {
     if (fs <= 0 || max_len < fs || C <= 0 || C > 64 || max_N <= 0) {
         snprintf(g_err, sizeof(g_err), "viterbi: unsupported arguments (C=%d must be <= 64, fs=%d, max_len=%d, max_N=%d)",
                  C, fs, max_len, max_N);
@@ -910,44 +953,81 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
                  max_N, J, smem);
         VIT_FAIL(MUCON_E_ARG);
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the > 64 KB LDS opt-ins are per device: keyed by the current device
+    static int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "viterbi: hipGetDevice failed");
+        VIT_FAIL(MUCON_E_HIP);
+    }
+    if (attr_dev != dev) {
         const void *ks[4] = {reinterpret_cast<const void *>(viterbi_dp_kernel<1>), reinterpret_cast<const void *>(viterbi_dp_kernel<2>),
                              reinterpret_cast<const void *>(viterbi_dp_kernel<4>), reinterpret_cast<const void *>(viterbi_dp_kernel<8>)};
-        for (const void *kp : ks)
-            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
-                snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
-                VIT_FAIL(MUCON_E_HIP);
-            }
-        attr_set = true;
-    }
-    static bool fs_attr = false;
-    const size_t fs_smem = (size_t)2 * FS_ROWS * C * sizeof(float);
-    if (!fs_attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FS_ROWS * 64 * 4) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) != hipSuccess) {
+        bool ok = true;
+        for (const void *kp : ks) ok = ok && hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * FS_ROWS * 64 * 4) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_framescore_cols_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FSC_MAX_LDS) == hipSuccess;
+#define VF_ATTR(G, JG)                                                                                                          \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fused_kernel<G, JG, true>),                            \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, VF_DYN_MAX) == hipSuccess &&                      \
+         hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fused_kernel<G, JG, false>),                                 \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, VF_DYN_MAX) == hipSuccess
+        VF_ATTR(8, 9);
+        VF_ATTR(4, 17);
+        VF_ATTR(2, 34);
+#undef VF_ATTR
+        if (!ok) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
             VIT_FAIL(MUCON_E_HIP);
         }
-        fs_attr = true;
+        attr_dev = dev;
     }
-    if (fs <= FS_ROWS && (C & 3) == 0) {   // whole columns per chunk: the pipelined chain
+    const bool w4 = (((fs + 3) >> 2) & 3) == 0;
+    if (fused && lanes && max_N <= 32 && cols_ok) {
+        // phase 1's buffers + the frame scores [K][C] share the dynamic LDS: as many columns per chunk as fit beside them
+        const size_t f_bytes = (size_t)fused_maxK * C * sizeof(float);
+        int cols = FS_ROWS / ((fs + 3) & ~3);
+        while (cols > 1 && (size_t)fsc_floats(C, fs, cols) * 4 + f_bytes > VF_DYN_MAX) --cols;
+        if ((size_t)fsc_floats(C, fs, cols) * 4 + f_bytes <= VF_DYN_MAX) {
+            const int dyn = fsc_floats(C, fs, cols);
+            const size_t bytes = (size_t)dyn * 4 + f_bytes;
+#define VF_LAUNCH(G, JG)                                                                                                          \
+    do {                                                                                                                          \
+        if (w4) hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, true>), dim3(n_videos), dim3(FSC_THREADS), bytes, s, jobs, transcripts, \
+                                   length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J, \
+                                   cols, dyn, done_flag, done_value);                                                             \
+        else hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, false>), dim3(n_videos), dim3(FSC_THREADS), bytes, s, jobs, transcripts,  \
+                                length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J,  \
+                                cols, dyn, done_flag, done_value);                                                                \
+    } while (0)
+            if (max_N <= 8) VF_LAUNCH(8, 9);
+            else if (max_N <= 16) VF_LAUNCH(4, 17);
+            else VF_LAUNCH(2, 34);
+#undef VF_LAUNCH
+            if (hipGetLastError() != hipSuccess) {
+                snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
+                VIT_FAIL(MUCON_E_HIP);
+            }
+            return 1;   // (fused: the completion flag, if any, will be published)
+        }
+    }
+    const size_t fs_smem = (size_t)2 * FS_ROWS * C * sizeof(float);
+    if (fs <= FS_ROWS && cols_ok) {   // whole columns per chunk: the pipelined chain
         // columns padded to whole b128 reads in LDS; as many columns per chunk as 256 rows and the LDS hold
         int cols = FS_ROWS / ((fs + 3) & ~3);
         while (cols > 1 && fsc_floats(C, fs, cols) * 4 > FSC_MAX_LDS) --cols;
-        if ((((fs + 3) >> 2) & 3) == 0)
+        if (w4)
             hipLaunchKernelGGL(viterbi_framescore_cols_kernel<true>, dim3(n_videos), dim3(FSC_THREADS), (size_t)fsc_floats(C, fs, cols) * sizeof(float), s,
-                               jobs, lp, static_cast<char *>(workspace), C, fs, cols);
+                               jobs, static_cast<char *>(workspace), C, fs, cols);
         else
             hipLaunchKernelGGL(viterbi_framescore_cols_kernel<false>, dim3(n_videos), dim3(FSC_THREADS), (size_t)fsc_floats(C, fs, cols) * sizeof(float), s,
-                               jobs, lp, static_cast<char *>(workspace), C, fs, cols);
+                               jobs, static_cast<char *>(workspace), C, fs, cols);
     } else {
-        hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs, lp,
+        hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs,
                            static_cast<char *>(workspace), C, fs);
     }
     // the DP: up to 66 length slots run in the registers of one wave (<= 32 states) or two (<= 128) ...
@@ -993,5 +1073,150 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
         snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
         VIT_FAIL(MUCON_E_HIP);
     }
+    return MUCON_OK;
+}
+
+extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
+                                          int32_t max_len, int32_t max_N, const int32_t *transcripts, const double *length_tables,
+                                          int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
+                                          int32_t *status, void *workspace, void *stream) {
+    if (n_videos <= 0) return MUCON_OK;
+    // the job table lives on the device: the emission pointers cannot be inspected here, so the 16-byte loads of the pipelined
+    // frame-score kernel are only taken for class counts where every row of an aligned base is aligned (the caller keeps `lp`
+    // 16-byte aligned: include/mucon_hip.h)
+    const int rc = vit_launch(n_videos, jobs, C, fs, max_len, max_N, transcripts, length_tables, labels, seg_len, n_seg, score, status,
+                              workspace, static_cast<hipStream_t>(stream), false, 0, (C & 3) == 0, nullptr, 0);
+    return rc > 0 ? MUCON_OK : rc;
+}
+
+// ---- decode with host-side inputs and outputs (what Viterbi.decode is: numpy in, Python objects out) -------------------------
+// Library-owned, per device, grown on demand: a pinned host buffer the kernels READ the job table / transcripts / length tables from
+// (no upload call), a pinned host buffer they WRITE the results to (no download call), device scratch for frame scores and
+// back-pointers.  One host thread per process (include/mucon_hip.h), so no locking.
+namespace {
+struct VitHostState {
+    char *pin_in = nullptr, *pin_out = nullptr, *ws = nullptr;
+    size_t in_cap = 0, out_cap = 0, ws_cap = 0;
+    int32_t seq = 0;
+};
+VitHostState g_vh[16];
+
+int vh_grow(char **buf, size_t *cap, size_t need, bool pinned) {
+    if (need <= *cap) return MUCON_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return MUCON_E_HIP;     // nothing may still be using the old buffer
+    if (*buf) (void)(pinned ? hipHostFree(*buf) : hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 2 + 4096;
+    const hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void **>(buf), want, hipHostMallocMapped | hipHostMallocPortable)
+                                : hipMalloc(reinterpret_cast<void **>(buf), want);
+    if (e != hipSuccess) return MUCON_E_HIP;
+    *cap = want;
+    return MUCON_OK;
+}
+inline size_t up16(size_t n) { return (n + 15) & ~(size_t)15; }
+}  // namespace
+
+extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
+                                         double *score, int32_t *n_seg, int32_t *status, int32_t *labels, int32_t *seg_len,
+                                         void *stream) {
+    if (n_videos <= 0) return MUCON_OK;
+    if (!videos || !score || !n_seg || !status || !labels || !seg_len || fs <= 0 || max_len < fs) {
+        snprintf(g_err, sizeof(g_err), "viterbi: null argument / bad frame sampling");
+        VIT_FAIL(MUCON_E_ARG);
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+        snprintf(g_err, sizeof(g_err), "viterbi: unsupported device index");
+        VIT_FAIL(MUCON_E_HIP);
+    }
+    VitHostState &st = g_vh[dev];
+    const int J = max_len / fs;
+    size_t sum_T = 0, sum_N = 0, ws_bytes = 0;
+    int max_N = 0, max_K = 0;
+    bool aligned = (C & 3) == 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const mucon_viterbi_video &q = videos[v];
+        if (q.T < 0 || q.N <= 0 || !q.lp || !q.transcript || !q.table) {
+            snprintf(g_err, sizeof(g_err), "viterbi: video %d: T=%d N=%d or a null pointer", v, q.T, q.N);
+            VIT_FAIL(MUCON_E_ARG);
+        }
+        sum_T += (size_t)(q.T > 0 ? q.T : 1);
+        sum_N += (size_t)q.N;
+        ws_bytes += (mucon_viterbi_job_workspace_bytes(q.T, C, q.N, fs) + 255) & ~(size_t)255;
+        max_N = q.N > max_N ? q.N : max_N;
+        max_K = q.T / fs > max_K ? q.T / fs : max_K;
+        aligned = aligned && (reinterpret_cast<uintptr_t>(q.lp) & 15) == 0;   // the pipelined frame-score kernel loads 16 bytes per lane
+    }
+    // input staging: [jobs][length tables][transcripts]; output staging: [flag, 64 B][score][n_seg][status][seg_len][labels]
+    const size_t o_tab = up16(sizeof(mucon_viterbi_job) * n_videos), o_tr = o_tab + up16(sizeof(double) * J * sum_N);
+    const size_t in_bytes = o_tr + up16(sizeof(int32_t) * sum_N);
+    const size_t o_score = 64, o_nseg = o_score + up16(8 * (size_t)n_videos), o_stat = o_nseg + up16(4 * (size_t)n_videos);
+    const size_t o_seg = o_stat + up16(4 * (size_t)n_videos), o_lab = o_seg + up16(4 * sum_N), out_bytes = o_lab + up16(4 * sum_T);
+    if (vh_grow(&st.pin_in, &st.in_cap, in_bytes, true) != MUCON_OK || vh_grow(&st.pin_out, &st.out_cap, out_bytes, true) != MUCON_OK ||
+        vh_grow(&st.ws, &st.ws_cap, ws_bytes + 256, false) != MUCON_OK) {
+        snprintf(g_err, sizeof(g_err), "viterbi: staging allocation failed (%zu / %zu / %zu bytes)", in_bytes, out_bytes, ws_bytes);
+        VIT_FAIL(MUCON_E_HIP);
+    }
+    mucon_viterbi_job *jobs = reinterpret_cast<mucon_viterbi_job *>(st.pin_in);
+    double *tabs = reinterpret_cast<double *>(st.pin_in + o_tab);
+    int32_t *trs = reinterpret_cast<int32_t *>(st.pin_in + o_tr);
+    size_t tr_off = 0, lab_off = 0, ws_off = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const mucon_viterbi_video &q = videos[v];
+        mucon_viterbi_job &j = jobs[v];
+        j.lp = q.lp;
+        j.tr_off = (int64_t)tr_off;
+        j.p_off = (int64_t)tr_off * J;
+        j.label_off = (int64_t)lab_off;
+        j.seg_off = (int64_t)tr_off;
+        j.ws_off = (int64_t)ws_off;
+        j.T = q.T;
+        j.N = q.N;
+        j.force_n = q.force_n;
+        j.force_j = q.force_j;
+        memcpy(tabs + tr_off * J, q.table, sizeof(double) * (size_t)J * q.N);
+        memcpy(trs + tr_off, q.transcript, sizeof(int32_t) * (size_t)q.N);
+        tr_off += (size_t)q.N;
+        lab_off += (size_t)(q.T > 0 ? q.T : 1);
+        ws_off += (mucon_viterbi_job_workspace_bytes(q.T, C, q.N, fs) + 255) & ~(size_t)255;
+    }
+    char *din = nullptr, *dout = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&din), st.pin_in, 0) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&dout), st.pin_out, 0) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "viterbi: hipHostGetDevicePointer failed");
+        VIT_FAIL(MUCON_E_HIP);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    volatile int32_t *flag_h = reinterpret_cast<volatile int32_t *>(st.pin_out);
+    const int32_t seq = ++st.seq == 0 ? ++st.seq : st.seq;
+    // latency path: a handful of short videos in ONE launch each; throughput path: two launches whose second packs many per CU
+    const bool want_fused = n_videos == 1;
+    const int rc = vit_launch(n_videos, reinterpret_cast<const mucon_viterbi_job *>(din), C, fs, max_len, max_N,
+                              reinterpret_cast<const int32_t *>(din + o_tr), reinterpret_cast<const double *>(din + o_tab),
+                              reinterpret_cast<int32_t *>(dout + o_lab), reinterpret_cast<int32_t *>(dout + o_seg),
+                              reinterpret_cast<int32_t *>(dout + o_nseg), reinterpret_cast<double *>(dout + o_score),
+                              reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
+                              reinterpret_cast<volatile int32_t *>(dout), seq);
+    if (rc < 0) return rc;
+    bool done = false;
+    if (rc > 0) {   // the fused kernel publishes the flag: spin on it (a stream synchronisation costs several microseconds more)
+        for (long spin = 0; spin < 40000000L; ++spin) {
+            if (__atomic_load_n(const_cast<const int32_t *>(flag_h), __ATOMIC_ACQUIRE) == seq) {
+                done = true;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done && hipStreamSynchronize(s) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "viterbi: the decode failed on the device: %s", hipGetErrorString(hipGetLastError()));
+        VIT_FAIL(MUCON_E_HIP);
+    }
+    memcpy(score, st.pin_out + o_score, 8 * (size_t)n_videos);
+    memcpy(n_seg, st.pin_out + o_nseg, 4 * (size_t)n_videos);
+    memcpy(status, st.pin_out + o_stat, 4 * (size_t)n_videos);
+    memcpy(seg_len, st.pin_out + o_seg, 4 * sum_N);
+    memcpy(labels, st.pin_out + o_lab, 4 * sum_T);
     return MUCON_OK;
 }

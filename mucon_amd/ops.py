@@ -759,81 +759,57 @@ class ViterbiResult:
 def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
                          tables: Sequence[np.ndarray], fs: int, max_len: int,
                          forces: Optional[Sequence[Optional[tuple]]] = None) -> List[ViterbiResult]:
-    """Decode a batch of videos in one launch (one workgroup per video).
+    """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
 
-    lps[v]: device float32 [T_v, C] log-probs (stay on the device -- no D2H of emissions);
-    transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
-    forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved
-    degenerate outcomes of the reference)."""
+    lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
+    concatenated or copied); transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
+    forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved degenerate outcomes of the
+    reference).  The library reads the small inputs from and writes the results to its own pinned host buffers; a single
+    short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation)."""
     lib = _lib.load()
     nv = len(lps)
     if nv == 0:
         return []
-    dev = lps[0].device
     _check_dev(*lps)
     C = int(lps[0].shape[1])
     J = max_len // fs
-    jobs = (_lib.ViterbiJob * nv)()
-    lp_off = tr_off = p_off = lab_off = seg_off = ws_off = 0
-    maxN = 0
+    vids = (_lib.ViterbiVideo * nv)()
+    keep = []                      # the arrays the pointers below refer to
+    sum_T = sum_N = 0
     for v in range(nv):
-        T, N = int(lps[v].shape[0]), int(len(transcripts[v]))
-        assert tables[v].shape == (J, N) and tables[v].dtype == np.float64, (tables[v].shape, J, N)
-        assert lps[v].shape[1] == C
-        j = jobs[v]
-        j.lp_off, j.tr_off, j.p_off, j.label_off, j.seg_off, j.ws_off = lp_off, tr_off, p_off, lab_off, seg_off, ws_off
-        j.T, j.N = T, N
+        lp = lps[v]
+        if not lp.is_contiguous() or (lp.data_ptr() & 15):
+            lp = lp.contiguous()
+            if lp.data_ptr() & 15:                      # (a storage-offset view whose start is not 16-byte aligned)
+                lp = lp.clone(memory_format=torch.contiguous_format)
+        tr = np.ascontiguousarray(transcripts[v], dtype=np.int32)
+        tab = np.ascontiguousarray(tables[v], dtype=np.float64)
+        T, N = int(lp.shape[0]), int(tr.shape[0])
+        assert tab.shape == (J, N), (tab.shape, J, N)
+        assert lp.shape[1] == C
+        keep.append((lp, tr, tab))
+        q = vids[v]
+        q.lp, q.transcript, q.table = lp.data_ptr(), tr.ctypes.data, tab.ctypes.data
+        q.T, q.N = T, N
         f = forces[v] if forces is not None else None
-        j.force_n, j.force_j = (int(f[0]), int(f[1])) if f is not None else (-1, -1)
-        lp_off += T * C
-        tr_off += N
-        p_off += J * N
+        q.force_n, q.force_j = (int(f[0]), int(f[1])) if f is not None else (-1, -1)
+        sum_T += max(T, 1)
+        sum_N += N
+    score = np.empty(nv, np.float64)
+    n_seg = np.empty(nv, np.int32)
+    status = np.empty(nv, np.int32)
+    labels = np.empty(sum_T, np.int32)
+    seg = np.empty(sum_N, np.int32)
+    _lib.check(lib.mucon_viterbi_decode_host(nv, vids, C, fs, max_len, score.ctypes.data, n_seg.ctypes.data, status.ctypes.data,
+                                             labels.ctypes.data, seg.ctypes.data, _lib.current_stream_ptr()),
+               "mucon_viterbi_decode_host")
+    out, lab_off, seg_off = [], 0, 0
+    for v in range(nv):
+        T, N = vids[v].T, vids[v].N
+        ns = int(n_seg[v])
+        ok = int(status[v]) in (_lib.VIT_OK, _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
+        out.append(ViterbiResult(score=np.float64(score[v]), labels=labels[lab_off: lab_off + T] if ok else np.empty(0, np.int32),
+                                 seg_len=seg[seg_off: seg_off + ns], n_seg=ns, status=int(status[v])))
         lab_off += max(T, 1)
         seg_off += N
-        ws_off += (lib.mucon_viterbi_job_workspace_bytes(T, C, N, fs) + 255) // 256 * 256
-        maxN = max(maxN, N)
-    lp_all = lps[0].contiguous().reshape(-1) if nv == 1 else torch.cat([x.contiguous().reshape(-1) for x in lps])
-
-    def up8(n):
-        return (n + 7) // 8 * 8
-
-    # ONE host->device copy (jobs | length tables | transcripts) and ONE device->host copy
-    # (score | labels | segment lengths | n_seg | status): the decode of a short video is latency-bound
-    jobs_b = np.frombuffer(bytes(jobs), dtype=np.uint8)
-    tb_b = np.concatenate([np.ascontiguousarray(t, dtype=np.float64).reshape(-1) for t in tables]).view(np.uint8)
-    tr_b = np.concatenate([np.asarray(t, dtype=np.int32) for t in transcripts]).view(np.uint8)
-    o_jobs, o_tb = 0, up8(jobs_b.size)
-    o_tr = o_tb + up8(tb_b.size)
-    h_in = np.zeros(o_tr + up8(tr_b.size), dtype=np.uint8)
-    h_in[o_jobs: o_jobs + jobs_b.size] = jobs_b
-    h_in[o_tb: o_tb + tb_b.size] = tb_b
-    h_in[o_tr: o_tr + tr_b.size] = tr_b
-    d_in = torch.from_numpy(h_in).to(dev)
-    o_score, o_lab = 0, up8(8 * nv)
-    o_seg = o_lab + up8(4 * lab_off)
-    o_nseg = o_seg + up8(4 * seg_off)
-    o_stat = o_nseg + up8(4 * nv)
-    d_out = torch.empty(o_stat + up8(4 * nv), dtype=torch.uint8, device=dev)   # every field read below is written by the kernels
-    ws = torch.empty(max(ws_off, 256), dtype=torch.uint8, device=dev)
-    base_in, base_out = d_in.data_ptr(), d_out.data_ptr()
-    vp = ctypes.c_void_p
-    _lib.check(lib.mucon_viterbi_decode_batch(nv, vp(base_in + o_jobs), C, fs, max_len, maxN, _lib.ptr(lp_all),
-                                              vp(base_in + o_tr), vp(base_in + o_tb), vp(base_out + o_lab),
-                                              vp(base_out + o_seg), vp(base_out + o_nseg), vp(base_out + o_score),
-                                              vp(base_out + o_stat), _lib.ptr(ws), _lib.current_stream_ptr()),
-               "mucon_viterbi_decode_batch")
-    h_out = d_out.cpu().numpy()  # the result fetch synchronises
-    score_h = h_out[o_score: o_score + 8 * nv].view(np.float64)
-    labels_h = h_out[o_lab: o_lab + 4 * lab_off].view(np.int32)
-    seg_h = h_out[o_seg: o_seg + 4 * seg_off].view(np.int32)
-    nseg_h = h_out[o_nseg: o_nseg + 4 * nv].view(np.int32)
-    status_h = h_out[o_stat: o_stat + 4 * nv].view(np.int32)
-    out = []
-    for v in range(nv):
-        j = jobs[v]
-        ns = int(nseg_h[v])
-        ok = int(status_h[v]) in (_lib.VIT_OK, _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
-        out.append(ViterbiResult(score=np.float64(score_h[v]),
-                                 labels=labels_h[j.label_off: j.label_off + j.T].copy() if ok else np.empty(0, np.int32),
-                                 seg_len=seg_h[j.seg_off: j.seg_off + ns].copy(), n_seg=ns, status=int(status_h[v])))
     return out
