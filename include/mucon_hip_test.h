@@ -55,6 +55,10 @@ int mucon_profile_end(float *total_ms_host, int32_t *count_host);
  * needs more slab space make those calls fail with MUCON_E_WORKSPACE, never overrun. */
 int mucon_test_set_knob(const char *name, const char *value);
 
+/* Timing builds only (MUCON_HIPCC_FLAGS=-DFS_STAMP=1): the s_memtime sums fs_kernel's block 0 left behind, [64 variants][8 waves][8
+ * phases] (gemm_fused_split.hpp); returns MUCON_E_ARG in a normal build. */
+int mucon_test_read_stamps(long long *out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,7 @@ SYMBOLS = {
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
     "mucon_test_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "mucon_test_read_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_first_conv_split": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32,

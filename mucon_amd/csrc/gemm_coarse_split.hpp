@@ -8,7 +8,7 @@
 //   stage 1  wave w multiplies channels 32 w .. 32 w + 31 of every tap (one 32-deep step per tap) -- 48 MFMAs per tap instead of
 //            192 -- and loads exactly the activation values and weight fragments it multiplies: every weight fragment of the
 //            layer is used by ONE wave of the workgroup, once, so it goes straight from L2 into operand registers (the images of
-//            fs_pack_kernel are lane-linear: one coalesced 1 KB load per fragment), no LDS staging, no barrier in the loop;
+//            fs_pack_body are lane-linear: one coalesced 1 KB load per fragment), no LDS staging, no barrier in the loop;
 //   reduce   the four partial tiles meet in LDS (one barrier); wave w finishes channel blocks 2 w, 2 w + 1: bias / non-linearity
 //            (FWD) or residual / mask / max-pool un-routing / dropout replay (BWD) -- which are exactly the 32 channels that
 //            form 32-deep step w of stage 2's reduction, in accumulator order;
@@ -329,7 +329,7 @@ static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const u
 // rows its own workgroup just produced -- and after cs_kernel's second reduction wave w holds, in accumulator order, exactly the
 // 32 channels that are its k-slice of the next product.  ct_kernel therefore walks a LIST of products in one launch: product 0
 // reads its operand from memory (natural-order image), every later one takes the previous product's finished values from the
-// registers (accumulator-order images: a layer's W2 / W2t, and images 4 / 5 of fs_pack_kernel for the dilated convs' centre taps
+// registers (accumulator-order images: a layer's W2 / W2t, and images 4 / 5 of fs_pack_body for the dilated convs' centre taps
 // and last_conv).  Every intermediate the backward pass or the weight gradients need is still written.
 //   forward   layers L-2, L-1 and last_conv:  W1c -> ReLU -> W2, dropout, +x -> W1c -> ReLU -> W2, dropout, +x -> ReLU -> W_last
 //             (3 launches -> 1; reference temporal.py:43-53, :144-145)

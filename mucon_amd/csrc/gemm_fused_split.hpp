@@ -16,7 +16,7 @@
 //     exchange between waves -- the stage-1 epilogue (bias, non-linearity / residual, mask, dropout replay) runs on the
 //     registers, which are then split and fed back.  Only the k order inside a 32-step differs (accumulator order:
 //     n = 16 (j >> 2) + 4 g + (j & 3)); the W2 image is packed in that order.
-//   * only the weights go through LDS: pre-split fragment-ordered images written by fs_pack_kernel ([k-step][plane 3]
+//   * only the weights go through LDS: pre-split fragment-ordered images written by fs_pack_body ([k-step][plane 3]
 //     [channel block 8][lane 64][8 bf16]: conflict-free ds_read_b128), 64-deep tiles (48 KB), double buffered, one barrier per
 //     tile; the eight tiles of both stages (6 x W1, 2 x W2) form one sequence, so W2 is in flight while stage 1 ends.
 // One workgroup = 8 waves = 128 time steps; the waves only share the weight tiles.  16x16x32 rather than 32x32x16: a wave's
@@ -37,6 +37,16 @@ constexpr int FS_LAYER_ELEMS = 2 * FS_IMG_K384 + 4 * FS_IMG_K128;   // W1f, W1b,
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+#ifndef FS_STAMP
+#define FS_STAMP 0   // timing builds (MUCON_HIPCC_FLAGS=-DFS_STAMP=1): s_memtime sums per phase, block 0 of every variant -> mucon_test_read_stamps
+#endif
+#if FS_STAMP
+__device__ long long g_fs_stamps[64 * 8 * 8];   // [variant: BWD * 32 + POOL * 4 + ONE * 2 + (NW == 8)][wave][phase]
+#define FS_T(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define FS_T(k) do { } while (0)
+#endif
+
 // ---- weight images ---------------------------------------------------------------------------------------------------
 // Fragment (k-step q, channel block nb, lane (r, g)): the 8 k of channel n = 16 nb + r that lane group g feeds the MFMA:
 //   natural order      k32 = 8 g + j                      (stage 1: the lane loads 8 consecutive channels of its row)
@@ -51,9 +61,8 @@ struct FsPackArgs {
     uint16_t *img;            // [slot][FS_LAYER_ELEMS]
     int nl;
 };
-__global__ __launch_bounds__(256) void fs_pack_kernel(const FsPackArgs a) {
-    const int slot = blockIdx.y;
-    const int f = blockIdx.x * 256 + threadIdx.x;   // fragment index over the six matrices: 6144 + 6144 + 2048 + 2048 + 2048 + 2048
+// (a device function: pack_all_kernel of mucon_hip.hip runs it in the same launch as pack_weights' blocks)
+__device__ __forceinline__ void fs_pack_body(const FsPackArgs &a, const int slot, const int f) {   // f: fragment index over the six matrices: 6144 + 6144 + 2048 + 2048 + 2048 + 2048
     if (f >= 20480) return;
     const bool last = slot == a.nl;
     if (last && (f < 12288 || f >= 18432)) return;
@@ -110,6 +119,10 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     const long vbase = (long)b * p.Trows;
     const float *Ab = p.A + vbase * 128 + 8 * g;
 
+#if FS_STAMP
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 prologue | 1 step 0 of a tile | 2 step 1 | 3 barrier | 4 epilogue 1 | 5 stage 2 | 6 epilogue 2
+    long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
     f32x4 ra[2][4];       // two k-tiles of this lane's activation values in flight: [set][2 steps x 2 halves]
     bool rok[2] = {true, true};
     u32x4 rws[2][NQ];     // this thread's share of the next TWO W tiles (a tile is requested two tiles before it is multiplied)
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     storeW(0, I0{});
     Planes cur = convertA(ra[0][0], ra[0][1], rok[0]);
     __syncthreads();
+    FS_T(0);
     auto tile1 = [&](int S, int buf, auto SET, auto OTHER) {
         constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
         if (S + 2 < (ONE ? 6 : 8)) gloadW(S + 2, SET);   // tiles 6, 7: W2
@@ -240,6 +254,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         weave(std::false_type{});
         use(nxt);
         __builtin_amdgcn_sched_barrier(0);
+        FS_T(1);
         gloadA(min(S + 2, 5), SET);          // the tail re-loads the last tile; nobody uses it
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 1, nxt);
@@ -249,7 +264,9 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         use(cur);
         __builtin_amdgcn_sched_barrier(0);
         if (S == 4) prefetch1();             // the stage-1 epilogue's operands travel under the last tile
+        FS_T(2);
         __syncthreads();
+        FS_T(3);
     };
     for (int S = 0; S < 6; S += 2) {
         tile1(S, 0, I0{}, I1{});
@@ -314,6 +331,13 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         }
     }
 
+    FS_T(4);
+#if FS_STAMP
+    if constexpr (ONE) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+            for (int k = 0; k < 8; ++k) g_fs_stamps[((BWD * 32 + POOL * 4 + ONE * 2 + (NW == 8)) * 8 + wave) * 8 + k] = st_acc[k];
+    }
+#endif
     if constexpr (ONE) return;
 
     // ---------------------------------------------------------------- stage 2: two tiles of W2, operand(s) from the registers
@@ -404,6 +428,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     weave2(std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
 
+    FS_T(5);
     // ---------------------------------------------------------------- stage-2 epilogue
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
@@ -438,6 +463,11 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
             }
         }
     }
+#if FS_STAMP
+    FS_T(6);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+        for (int k = 0; k < 8; ++k) g_fs_stamps[((BWD * 32 + POOL * 4 + ONE * 2 + (NW == 8)) * 8 + wave) * 8 + k] = st_acc[k];
+#endif
 }
 
 template <bool BWD, int POOL, bool ONE, int NW>

@@ -70,7 +70,7 @@ int g_nt_split = 1;                    // ... and layer 0's dilated-conv data gr
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
-int g_tn_batch_target = 128;  // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups
+int g_tn_batch_target = 64;   // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups (r3: 128 -> 64 halves the layer jobs' slabs: the slab reduction 20 -> 12 us, the launch itself unchanged)
 int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
 int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; MUCON_FUSED_SPLIT=0: f32 MFMA)
 long g_fs_rows = 16384;       // ... from this many rows in the batch (MUCON_FUSED_SPLIT_ROWS)
@@ -426,6 +426,14 @@ void prof_mark(int slot, bool stop, hipStream_t s) {
     if (stop) ++g_prof.n[slot];
 }
 
+// every weight re-layout of a forward pass in one launch: rows [0, ypack) of the grid are pack_weights' blocks (small_kernels.hpp),
+// the rows behind them fs_pack's (gemm_fused_split.hpp: 20,480 fragments per layer slot = 20 blocks of 1,024 threads)
+__global__ __launch_bounds__(PACK_THREADS) void pack_all_kernel(const PackArgs a, const FsPackArgs f, const int ypack) {
+    __shared__ float lds[PACK_LDS_FLOATS];
+    if ((int)blockIdx.y < ypack) pack_weights_body(a, lds);
+    else if (blockIdx.x < 20) fs_pack_body(f, blockIdx.y - ypack, blockIdx.x * PACK_THREADS + threadIdx.x);
+}
+
 __global__ void dropout_mask_kernel(uint8_t *mask, long n, DropCfg d) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
         mask[e] = drop_mul(d, (uint32_t)e) != 0.f ? 1 : 0;
@@ -586,6 +594,18 @@ int mucon_test_set_knob(const char *name, const char *value) {
     return MUCON_OK;
 }
 const char *mucon_last_error(void) { return g_err; }
+int mucon_test_read_stamps(long long *out, int32_t n) {
+#if FS_STAMP
+    if (!out || n < 64 * 8 * 8) return fail(MUCON_E_ARG, "read_stamps: buffer of 64 * 8 * 8 values needed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fs_stamps), sizeof(long long) * 64 * 8 * 8));
+    return MUCON_OK;
+#else
+    (void)out;
+    (void)n;
+    return fail(MUCON_E_ARG, "read_stamps: not a timing build (MUCON_HIPCC_FLAGS=-DFS_STAMP=1)");
+#endif
+}
 
 int32_t mucon_encoder_out_length(const mucon_encoder_cfg *cfg) {
     if (validate(cfg) != MUCON_OK) return -1;
@@ -673,18 +693,19 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
     const bool split_dgrad0 = g_nt_split && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(32, L + (split_dgrad0 ? 3 : (split_first ? 2 : 1))), dim3(PACK_THREADS), 0, s, pa);
-    HIPCHK(hipGetLastError());
-    {   // split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp (a layer's images sit at its own slot)
+    {   // ... and, in the SAME launch, the split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp
+        // (a layer's images sit at its own slot): two launches were 8 + 7 us at the head of every forward pass
+        const int ypack = L + (split_dgrad0 ? 3 : (split_first ? 2 : 1));
+        FsPackArgs fa;
+        memset(&fa, 0, sizeof(fa));
         int lo = -1, hi = -1;
         for (int l = 0; l < L; ++l)
             if (cs_on() || fs_level(cfg, pl, l)) {
                 if (lo < 0) lo = l;
                 hi = l;
             }
+        int yfs = 0;
         if (lo >= 0) {
-            FsPackArgs fa;
-            memset(&fa, 0, sizeof(fa));
             fa.nl = hi - lo + 1;
             for (int l = lo; l <= hi; ++l) {
                 fa.dil_w[l - lo] = prm->dil_w[l];
@@ -692,9 +713,10 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
             fa.last_w = (cs_on() && hi == L - 1) ? prm->last_w : nullptr;
             fa.img = reinterpret_cast<uint16_t *>(ws + pl.Wfs) + (long)lo * FS_LAYER_ELEMS;
-            hipLaunchKernelGGL(fs_pack_kernel, dim3(80, fa.nl + (fa.last_w ? 1 : 0)), dim3(256), 0, s, fa);
-            HIPCHK(hipGetLastError());
+            yfs = fa.nl + (fa.last_w ? 1 : 0);
         }
+        hipLaunchKernelGGL(pack_all_kernel, dim3(32, ypack + yfs), dim3(PACK_THREADS), 0, s, pa, fa, ypack);
+        HIPCHK(hipGetLastError());
     }
 
     // first_conv + non-linearity (temporal.py:133); the tape is consumed row-major, no permute

@@ -46,8 +46,7 @@ __device__ __forceinline__ void pack_image_tile(const float *tile, uint16_t *img
     }
 }
 
-__global__ __launch_bounds__(PACK_THREADS) void pack_weights_kernel(const PackArgs a) {
-    __shared__ float lds[PACK_LDS_FLOATS];
+__device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds) {
     const int y = blockIdx.y, x = blockIdx.x, tid = threadIdx.x;
     if (y <= a.L) {
         if (x >= 4) return;
