@@ -269,10 +269,12 @@ def end_to_end_bench(dev, steps=40):
             "reference_readme_it_per_s": [14.67, 16.23]}
 
 
-def eval_bench(dev, n_videos=16):
+def eval_bench(dev, n_videos=32):
     """Evaluation scope: MuConEvaluator.evaluate() per test video = eval-mode forward (greedy s-head decode, at most 8
-    words here), predict, Viterbi decode on the device-resident log-probs, and the reference's full metric set on the host
-    (reference src/mucon/evaluators.py:121-257).  Random-init weights; the EOS logit is biased down so that the greedy
+    words here), predict, Viterbi decode on the device-resident log-probs, and the reference's full metric set
+    (reference src/mucon/evaluators.py:121-257) -- batched: one chunk of 32 videos = every forward enqueued, ONE copy of the
+    transcripts back, ONE Viterbi launch, ONE metrics launch (MoF / IoD / IoU / edit / F1 on the device); the record equals the
+    one-video-at-a-time path's bit for bit (tests/test_gpu_eval_batched.py).  Random-init weights; the EOS logit is biased down so that the greedy
     decode emits a transcript (an untrained s-head emits EOS first, on which the reference's evaluator fails as well)."""
     from mucon_amd import synth
     from mucon_amd.config import get_cfg_defaults, update_config
@@ -318,7 +320,8 @@ def eval_bench(dev, n_videos=16):
     dt = (time.perf_counter() - t0) / len(db)
     return {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3),
             "config": f"MuConEvaluator.evaluate(): {n_videos} videos, T={T}: eval forward + greedy decode (8 words) + predict + "
-                      f"Viterbi (fs=30) + MoF/IoD/IoU/edit/F1 for y-, s- and Viterbi segmentations; tapes resident in HBM"}
+                      f"Viterbi (fs=30) + MoF/IoD/IoU/edit/F1 for y-, s- and Viterbi segmentations; tapes resident in HBM; batched "
+                      f"(chunks of {ev.chunk_videos} videos: pooled round trips, one Viterbi launch, device metrics)"}
 
 
 def main():

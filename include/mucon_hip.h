@@ -149,6 +149,19 @@ int mucon_metrics_overlap(int32_t n_videos, const int64_t *offsets, const int32_
                           const int32_t *ignore_ids, int32_t n_ignore, int64_t *mof, int32_t *n_runs, int32_t *run_label,
                           double *iod, double *iou, void *stream);
 
+/* The whole per-video record of the reference's evaluator for a list of (target, prediction) pairs in ONE launch: the counters
+ * above plus the segmental edit distance and F1 counts (reference src/core/metrics/mstcn_code.py:6-81, fully_supervised.py:9-94).
+ *   mof [n_pairs][4]                  correct, total over all frames; correct, total over the frames whose target is not ignored
+ *   n_runs, run_label, iod, iou       as above
+ *   seg [n_pairs][1 + 3 * 4]          unit-cost Levenshtein distance between the two run-label sequences, then (tp, fp, fn) of the
+ *                                     segmental F1 at thresholds[0 .. n_thresholds) (n_thresholds <= 4): every predicted run claims,
+ *                                     in order, the target run numpy's argmax over (1.0 * inter / union) * (labels equal) names
+ * Integers and single float64 quotients only: the host classes' float results follow from them bit for bit. */
+int mucon_metrics_segmental(int32_t n_pairs, const int64_t *offsets, const int32_t *targets, const int32_t *predictions,
+                            const int32_t *ignore_ids, int32_t n_ignore, const double *thresholds, int32_t n_thresholds,
+                            int64_t *mof, int32_t *n_runs, int32_t *run_label, double *iod, double *iou, int32_t *seg,
+                            void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * y-head: nearest upsample Tz -> Tf, 1x1 conv H -> C, log-softmax over C
  * ---------------------------------------------------------------------------------------- */

@@ -108,6 +108,7 @@ SYMBOLS = {
     "mucon_linear_fwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_linear_bwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_metrics_overlap": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_metrics_segmental": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_conv128_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mucon_conv128_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mucon_conv128_dgrad": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -67,3 +67,67 @@ def add_to_metrics(counters: dict, mof: MoFAccuracyMetric = None, iod: IoDMetric
         iod.values.append(counters["iod"])
     if iou is not None:
         iou.values.append(counters["iou"])
+
+
+def segmental_counters(targets: Sequence[torch.Tensor], predictions: Sequence[torch.Tensor], ignore_ids: Iterable[int] = (),
+                       overlaps: Sequence[float] = (0.1, 0.25, 0.5)) -> List[dict]:
+    """One launch (mucon_metrics_segmental) for a list of (target, prediction) pairs of device int tensors: per pair everything
+    the evaluator's metric objects accumulate --
+      correct / total, correct_nbg / total_nbg      MoFAccuracyMetric() / MoFAccuracyMetric(ignore_ids)
+      iod, iou, iod_nbg, iou_nbg                     IoDMetric / IoUMetric without and with ignore_ids
+      edit                                           Edit().add's score        f1: [(tp, fp, fn)] per overlap threshold (F1Score)
+    with the values the host classes compute from the same labellings, bit for bit."""
+    from ... import _lib
+    lib = _lib.load()
+    n = len(targets)
+    if n == 0:
+        return []
+    dev = targets[0].device
+    assert all(t.is_cuda and p.is_cuda and t.shape == p.shape and t.dim() == 1 for t, p in zip(targets, predictions))
+    assert len(overlaps) <= 4
+    lens = [int(t.shape[0]) for t in targets]
+    off = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int64)).to(dev, non_blocking=True)
+    tg = torch.cat([t.to(torch.int32) for t in targets]).contiguous()
+    pr = torch.cat([p.to(torch.int32) for p in predictions]).contiguous()
+    ign = sorted(int(i) for i in (ignore_ids or ()))
+    ign_d = torch.tensor(ign, dtype=torch.int32).to(dev) if ign else None
+    thr_d = torch.tensor(list(overlaps), dtype=torch.float64).to(dev)
+    R = _lib.METRICS_MAX_RUNS
+    # the small per-pair records share one buffer (one copy back): mof int64 [n][4] | n_runs int32 [n][3] | seg int32 [n][13]
+    small = torch.zeros(n * (32 + 12 + 52), dtype=torch.uint8, device=dev)
+    mof = small[: 32 * n].view(torch.int64).view(n, 4)
+    n_runs = small[32 * n: 44 * n].view(torch.int32).view(n, 3)
+    seg = small[44 * n:].view(torch.int32).view(n, 13)
+    run_label = torch.empty((n, R), dtype=torch.int32, device=dev)
+    iod = torch.empty((n, R), dtype=torch.float64, device=dev)
+    iou = torch.empty((n, R), dtype=torch.float64, device=dev)
+    _lib.check(lib.mucon_metrics_segmental(n, _lib.ptr(off), _lib.ptr(tg), _lib.ptr(pr), _lib.ptr(ign_d), len(ign), _lib.ptr(thr_d),
+                                           len(overlaps), _lib.ptr(mof), _lib.ptr(n_runs), _lib.ptr(run_label), _lib.ptr(iod),
+                                           _lib.ptr(iou), _lib.ptr(seg), _lib.current_stream_ptr()), "mucon_metrics_segmental")
+    small_h = small.cpu().numpy()                      # (synchronises)
+    mof_h = small_h[: 32 * n].view(np.int64).reshape(n, 4)
+    runs_h = small_h[32 * n: 44 * n].view(np.int32).reshape(n, 3)
+    seg_h = small_h[44 * n:].view(np.int32).reshape(n, 13)
+    if int(runs_h[:, :2].max()) > R:
+        raise ValueError(f"a labelling with more than {R} segments: use the host metrics for it")
+    nmax = max(int(runs_h[:, 0].max()), 1)
+    per_run = torch.cat([iod[:, :nmax], iou[:, :nmax], run_label[:, :nmax].to(torch.float64)], dim=1).cpu().numpy()   # labels are exact in f64
+    iod_h, iou_h, lab_h = per_run[:, :nmax], per_run[:, nmax: 2 * nmax], per_run[:, 2 * nmax:].astype(np.int64)
+    out = []
+    for v in range(n):
+        nt, npred, kept_pred = int(runs_h[v, 0]), int(runs_h[v, 1]), int(runs_h[v, 2])
+        res = {"correct": int(mof_h[v, 0]), "total": int(mof_h[v, 1]), "correct_nbg": int(mof_h[v, 2]), "total_nbg": int(mof_h[v, 3])}
+        keep_nbg = ~np.isin(lab_h[v, :nt], ign) if ign else np.ones(nt, dtype=bool)
+        for suffix, keep, kp in (("", np.ones(nt, dtype=bool), npred), ("_nbg", keep_nbg, kept_pred)):
+            for name, vals in (("iod", iod_h), ("iou", iou_h)):
+                if lens[v] == 0 or not keep.any():
+                    res[name + suffix] = float("nan")
+                elif kp == 0:
+                    res[name + suffix] = 0.0
+                else:
+                    res[name + suffix] = float(np.maximum(vals[v, :nt][keep], 0.0).mean())
+        with np.errstate(all="ignore"):
+            res["edit"] = float((1 - np.float64(float(seg_h[v, 0])) / max(npred, nt)) * 100)
+        res["f1"] = [(float(seg_h[v, 1 + 3 * s]), float(seg_h[v, 2 + 3 * s]), float(seg_h[v, 3 + 3 * s])) for s in range(len(overlaps))]
+        out.append(res)
+    return out

@@ -134,23 +134,41 @@ class Viterbi(object):
 
     # ------------------------------------------------------------------------------ decode
     def decode_batch(self, log_frame_probs: Sequence, transcripts: Sequence[Sequence[int]],
-                     length_models: Sequence) -> List[tuple]:
+                     length_models: Sequence, return_exceptions: bool = False) -> List[tuple]:
         """Decode several videos in one kernel launch (one workgroup per video).  Each result is
-        what decode() returns.  Not in the reference (it decodes one video at a time)."""
+        what decode() returns.  Not in the reference (it decodes one video at a time).
+
+        return_exceptions: a video the reference's decode raises for (ShortSequenceError, NoHypothesisError) yields that
+        exception object in its place instead of ending the whole batch (the batched evaluation skips such videos one by one)."""
         import torch
         from ... import _lib, ops
 
         fs = self.frame_sampling
         if len(log_frame_probs) and all(isinstance(lp, torch.Tensor) and not lp.is_cuda for lp in log_frame_probs):
             # cfg.system.device = "cpu" (reference core/config.py:16): the plumbing path, mucon_amd/cpu_plumbing.py
-            return [self._decode_host(lp, tr, lm) for lp, tr, lm in zip(log_frame_probs, transcripts, length_models)]
-        lps, trs, tabs, forces = [], [], [], []
+            out = []
+            for lp, tr, lm in zip(log_frame_probs, transcripts, length_models):
+                try:
+                    out.append(self._decode_host(lp, tr, lm))
+                except (ShortSequenceError, NoHypothesisError) as e:
+                    if not return_exceptions:
+                        raise
+                    out.append(e)
+            return out
+        lps, trs, tabs, forces, slots = [], [], [], [], []
+        out: List = [None] * len(log_frame_probs)
         max_len = None
-        for lp, tr, lm in zip(log_frame_probs, transcripts, length_models):
+        for i, (lp, tr, lm) in enumerate(zip(log_frame_probs, transcripts, length_models)):
             if isinstance(lp, np.ndarray):
                 lp = torch.from_numpy(np.ascontiguousarray(lp, dtype=np.float32)).cuda()
             v = Viterbi(SingleTranscriptGrammar(tr, lp.shape[1]), lm, fs, self.max_hypotheses)
-            t, P, force = v._prepare(int(lp.shape[0]))
+            try:
+                t, P, force = v._prepare(int(lp.shape[0]))
+            except (ShortSequenceError, NoHypothesisError) as e:
+                if not return_exceptions:
+                    raise
+                out[i] = e
+                continue
             ml = int(lm.max_length())
             if max_len is not None and ml != max_len:
                 raise ValueError("all length models of a batch must share max_length()")
@@ -159,15 +177,21 @@ class Viterbi(object):
             trs.append(t)
             tabs.append(P)
             forces.append(force)
-        res = ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces)
-        out = []
-        for r, t in zip(res, trs):
+            slots.append(i)
+        res = ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces) if lps else []
+        for i, r, t in zip(slots, res, trs):
+            err = None
             if r.status == _lib.VIT_INDEX_ERROR:
-                raise ShortSequenceError("frame_sampling exceeds the sequence length")
-            if r.status == _lib.VIT_NO_HYPOTHESIS:
-                raise NoHypothesisError("'NoneType' object has no attribute 'label'")
+                err = ShortSequenceError("frame_sampling exceeds the sequence length")
+            elif r.status == _lib.VIT_NO_HYPOTHESIS:
+                err = NoHypothesisError("'NoneType' object has no attribute 'label'")
+            if err is not None:
+                if not return_exceptions:
+                    raise err
+                out[i] = err
+                continue
             segs = [Viterbi.Segment(int(t[s]), int(r.seg_len[s])) for s in range(r.n_seg)]
-            out.append((r.score, r.labels.tolist(), segs))
+            out[i] = (r.score, r.labels.tolist(), segs)
         return out
 
     def _decode_host(self, lp, transcript, length_model):

@@ -33,9 +33,15 @@ def mean_lengths_from_s_head(predicted_relative_lengths: np.ndarray, transcript:
 
 
 def make_same_size_interpolate(prediction: np.ndarray, target_len: int) -> np.ndarray:
-    """Nearest-neighbour resize of a label array (reference core/utils.py:34-47)."""
-    p = torch.tensor(np.asarray(prediction)[None, None]).float()
-    return torch.nn.functional.interpolate(p, size=target_len, mode="nearest")[0, 0].long().numpy()
+    """Nearest-neighbour resize of a label array (reference core/utils.py:34-47: F.interpolate(mode="nearest") on the float
+    copy).  torch's rule, in ITS arithmetic: source index = min(floor(i * scale), L - 1) with scale = float32(L) / float32(n)
+    and the product in float32 -- restated in NumPy (a torch CPU call costs 4x as much per video); equality with
+    F.interpolate over thousands of (L, n) pairs is tests/test_cpu_plumbing.py::test_nearest_resize_equals_torch."""
+    p = np.asarray(prediction)
+    L, n = int(p.shape[0]), int(target_len)
+    scale = np.float32(L) / np.float32(n)
+    idx = np.minimum(np.floor(np.arange(n, dtype=np.float32) * scale).astype(np.int64), L - 1)
+    return p[idx].astype(np.int64)
 
 
 def create_segmentation_from_segments(actions: np.ndarray, lengths: np.ndarray, n_frames: int) -> np.ndarray:
@@ -160,6 +166,134 @@ class MuConEvaluator:
             warnings.simplefilter("ignore")       # the mean of an empty list (no video evaluated) is nan, as upstream
             return {k: self.metrics[k].summary() for k in RESULT_FIELDS}
 
+    # ------------------------------------------------------------------------------------------ batched evaluation
+    def _evaluate_chunk(self, idxs):
+        """A chunk of test videos with the host round trips of batch_eval_calculation pooled: every forward is enqueued first
+        (MuCon.forward_deferred: the number of decoded words stays on the device), ONE copy fetches the transcripts of the chunk,
+        ONE launch decodes all its videos (Viterbi.decode_batch), ONE launch scores all its labellings (mucon_metrics_segmental:
+        MoF / IoD / IoU / edit / F1 for the y-head, the s-head and the Viterbi segmentations).  Feeds the same metric objects
+        and per-video lists, in dataset order, with the same values as the per-video path (tests/test_gpu_eval_batched.py)."""
+        from ..core.metrics.device import segmental_counters
+        dev, model, C = self.device, self.model, self.test_db.get_num_classes()
+        vids = []
+        for i in idxs:
+            batch = self.test_db[i].to(dev)
+            vids.append({"i": i, "batch": batch, "out": model.forward_deferred(batch)})
+        # -- sync 1: how many words every video decoded, and which
+        S = model.max_decoding_steps
+        n_steps = torch.cat([v["out"]["n_steps"] for v in vids]).cpu().numpy()
+        alive = []
+        for v, n in zip(vids, n_steps):
+            n = int(n)
+            if n < 2:        # EOS as the first word: the reference dies in torch.stack([]) (models.py:351)
+                self.skipped += 1
+                continue
+            v["n"] = n
+            lens = v["out"]["lengths"][:n - 1]
+            e = torch.exp(lens - lens.max())                   # MuCon.predict's softmax, op for op
+            v["rel_d"] = e / e.sum()
+            v["words_d"] = v["out"]["transcript"][:n].argmax(dim=1)
+            v["y_d"] = v["out"]["logp"].argmax(dim=1)
+            alive.append(v)
+        if not alive:
+            return
+        # -- sync 2: words, relative lengths, y-head labels and ground truth of the chunk in one copy each
+        words = torch.cat([v["words_d"] for v in alive]).cpu().numpy()
+        rels = torch.cat([v["rel_d"] for v in alive]).cpu().numpy()
+        ys = torch.cat([v["y_d"] for v in alive]).cpu().numpy()
+        gts = torch.cat([v["batch"].gt_label.reshape(-1) for v in alive]).cpu().numpy()
+        wo = ro = yo = go = 0
+        for v in alive:
+            n, Tf, Tg = v["n"], int(v["out"]["logp"].shape[0]), int(v["batch"].gt_label.numel())
+            v["transcript"] = words[wo: wo + n].tolist()
+            v["rel"] = rels[ro: ro + n - 1].copy()
+            v["y_pred"] = ys[yo: yo + Tf]
+            v["target"] = gts[go: go + Tg]
+            wo, ro, yo, go = wo + n, ro + n - 1, yo + Tf, go + Tg
+        tts = torch.cat([v["batch"].transcript.reshape(-1) for v in alive]).cpu().numpy()
+        to = 0
+        for v in alive:
+            k = int(v["batch"].transcript.numel())
+            v["target_transcript"] = tts[to: to + k].tolist()
+            to += k
+        # -- Viterbi: one launch for the chunk (the emissions stay where the y-head wrote them)
+        if self.enable_viterbi:
+            lms = []
+            for v in alive:
+                s_tr = v["transcript"][:-1]
+                lengths = mean_lengths_from_s_head(v["rel"], s_tr, int(v["out"]["logp"].shape[0]), C)
+                with np.errstate(all="ignore"):
+                    lms.append(PoissonModel(lengths))
+            res = self.vi_decoder.decode_batch([v["out"]["logp"] for v in alive], [v["transcript"][:-1] for v in alive], lms,
+                                               return_exceptions=True)
+            kept = []
+            for v, r in zip(alive, res):
+                if isinstance(r, Exception):
+                    self.skipped += 1
+                    continue
+                v["vit"] = r
+                kept.append(v)
+            alive = kept
+            if not alive:
+                return
+        # -- the three labellings per video at the ground truth's length, scored in one launch
+        preds, tgts = [], []
+        for v in alive:
+            s_tr, Tf, target = v["transcript"][:-1], int(v["out"]["logp"].shape[0]), v["target"]
+            s_pred = create_segmentation_from_segments(np.array(s_tr), v["rel"], Tf)
+            v["s_same"] = make_same_size_interpolate(s_pred, len(target))
+            v["y_same"] = v["y_pred"] if len(v["y_pred"]) == len(target) else make_same_size_interpolate(v["y_pred"], len(target))
+            heads = [v["y_same"], v["s_same"]]
+            if self.enable_viterbi:
+                vl = np.asarray(v["vit"][1])
+                v["vit_same"] = vl if len(vl) == len(target) else make_same_size_interpolate(vl, len(target))
+                heads.append(v["vit_same"])
+            for h in heads:
+                preds.append(np.asarray(h, dtype=np.int32))
+                tgts.append(v["batch"].gt_label.reshape(-1))
+        nh = 3 if self.enable_viterbi else 2
+        flat = torch.from_numpy(np.concatenate(preds)).to(dev)
+        pred_d, off = [], 0
+        for p in preds:
+            pred_d.append(flat[off: off + len(p)])
+            off += len(p)
+        bg = self.metrics["y_mof_nbg"].ignore_ids
+        cnt = segmental_counters(tgts, pred_d, bg, self.metrics["y_f1_score"].overlaps)
+        # -- feed the metric objects, video by video in dataset order (what batch_eval_calculation does with the host classes)
+        m = self.metrics
+        for k, v in enumerate(alive):
+            s_tr = v["transcript"][:-1]
+            m["s_mat_score"].add(target_transcript=v["target_transcript"], predicted_transcript=s_tr)
+            m["s_len_diff"].add(target_transcript=v["target_transcript"], predicted_transcript=s_tr)
+            for hi, head in enumerate(("y", "s", "vit")[:nh]):
+                c = cnt[k * nh + hi]
+                m[f"{head}_mof"].correct += c["correct"]
+                m[f"{head}_mof"].total += c["total"]
+                m[f"{head}_mof_nbg"].correct += c["correct_nbg"]
+                m[f"{head}_mof_nbg"].total += c["total_nbg"]
+                m[f"{head}_iod"].values.append(c["iod"])
+                m[f"{head}_iou"].values.append(c["iou"])
+                if head != "y":
+                    m[f"{head}_iod_nbg"].values.append(c["iod_nbg"])
+                    m[f"{head}_iou_nbg"].values.append(c["iou_nbg"])
+                m[f"{head}_edit_score"].values.append(c["edit"])
+                f1 = m[f"{head}_f1_score"]
+                for s_, (tp, fp, fn) in enumerate(c["f1"]):
+                    f1.tp[s_] += tp
+                    f1.fp[s_] += fp
+                    f1.fn[s_] += fn
+            self.vit_segs.append(v["vit_same"] if self.enable_viterbi else v["s_same"])
+            self.y_segs.append(v["y_same"])
+            self.s_segs.append(v["s_same"])
+            self.s_lens.append(v["rel"])
+            self.s_transcript.append(s_tr)
+            self.target_segs.append(v["target"])
+            self.target_transcripts.append(v["target_transcript"])
+            self._evaluated.append(v["i"])
+
+    batched = True          # pooled host round trips + device metrics for device-resident test videos (False: one video at a time)
+    chunk_videos = 32
+
     @torch.no_grad()
     def evaluate(self, rank: int = 0, world_size: int = 1):
         """Test videos sharded over ranks; every metric's accumulator is a few scalars, all-reduced as one vector."""
@@ -170,7 +304,14 @@ class MuConEvaluator:
         self._reset_lists()
         self.skipped = 0
         self._evaluated = []     # dataset indices of the videos that made it into the lists
-        for i in range(rank, len(self.test_db), world_size):
+        mine = list(range(rank, len(self.test_db), world_size))
+        use_chunks = (self.batched and str(self.device).startswith("cuda") and hasattr(self.model, "can_defer_eval")
+                      and len(mine) > 0 and self.model.can_defer_eval(self.test_db[mine[0]].to(self.device)))
+        if use_chunks:
+            for c0 in range(0, len(mine), self.chunk_videos):
+                self._evaluate_chunk(mine[c0: c0 + self.chunk_videos])
+            mine = []
+        for i in mine:
             batch = self.test_db[i].to(self.device)
             try:
                 forward_out = self.model.forward(batch)

@@ -298,6 +298,35 @@ class MuCon(nn.Module):
         loss = MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2], smoothing_loss=parts[3])
         return loss, fo
 
+    def can_defer_eval(self, batch: Batch) -> bool:
+        """The evaluation forward without host round trips exists for the all-HIP configuration (device tensors, the native LSTM and
+        decoder at the reference's sizes, one video per batch); everything else takes forward() / predict()."""
+        enc_len = batch.feats.shape[1]
+        for i in range(len(self.cfg.model.ft.stages)):
+            if self.cfg.model.ft.pooling and i in self.cfg.model.ft.pooling_layers:
+                enc_len //= 2
+        lstm, d = self.fs_encoder_lstm, self.fs_decoder_lstm
+        return (not self.training and not self.teacher_forcing and batch.feats.is_cuda and batch.feats.shape[0] == 1
+                and isinstance(self.ft, WaveNetBlock) and self.native_lstm and self.native_decoder
+                and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
+                and d.input_size == 128 and d.hidden_size == 128 and d.num_layers == 1 and self.num_classes + 1 <= 128
+                and self.fs_decoder_embedding.embedding_dim == 128 and (2 if lstm.bidirectional else 1) * lstm.hidden_size <= 256
+                and 1 <= enc_len <= 4096)
+
+    @torch.no_grad()
+    def forward_deferred(self, batch: Batch) -> dict:
+        """forward() of the evaluation (eval mode, greedy decoding with the EOS stop: reference models.py:319-358 as
+        evaluators.py:316-318 drives it) as the same launches, but nothing is read back: the number of decoded words stays on
+        the device.  -> {"logp" [T x M] log-softmaxed y-head output, "segmentation" [T x M] logits, "transcript" [S x (M+1)]
+        log-probs of all S = max_decoding_steps rows (rows >= n_steps unwritten), "lengths" [S], "n_steps" int32 [1]}."""
+        Tf = batch.feats.shape[1]
+        temporal_encoded = self.temporal_modeling_forward(input=batch.feats)
+        enc_out, h_n, c_n = self._sequence_encoder(temporal_encoded)
+        tlogp, lens, n_steps = ops.decoder_forward_deferred(enc_out[0], h_n, c_n, batch.transcript_tf_input, self._decoder_param_list(),
+                                                            self.max_decoding_steps, self.EOS_token_id)
+        segmentation, logp = self._segmentation_and_logp(temporal_encoded, Tf)
+        return {"logp": logp, "segmentation": segmentation, "transcript": tlogp, "lengths": lens, "n_steps": n_steps}
+
     def predict(self, batch: Batch, forward_out: MuConForwardOut) -> MuConPredictOut:
         if self.teacher_forcing:
             transcript = batch.transcript_tf_target.detach().cpu().numpy().tolist()

@@ -473,6 +473,41 @@ def decoder_forward(memory: torch.Tensor, h_n: torch.Tensor, c_n: torch.Tensor, 
                             (int(max_steps), bool(teacher_forcing), bool(stop_on_eos), int(eos)), *params)
 
 
+@torch.no_grad()
+def decoder_forward_deferred(memory: torch.Tensor, h_n: torch.Tensor, c_n: torch.Tensor, tf_input: torch.Tensor,
+                             params: Sequence[torch.Tensor], max_steps: int, eos: int):
+    """Greedy decoding with the EOS stop (evaluation: no teacher forcing, no dropout) WITHOUT the host round trip: the same
+    launch as decoder_forward(..., teacher_forcing=False, stop_on_eos=True), but the step count stays on the device.
+    Returns (logp [max_steps, NC], lengths [max_steps], n_steps int32 [1]); rows from n_steps on are unwritten.  A batched
+    evaluation fetches the step counts of many videos in one copy (mucon_amd/mucon/evaluators.py)."""
+    lib = _lib.load()
+    if len(params) != len(_lib.DECODER_PARAM_FIELDS):
+        raise ValueError(f"decoder_forward_deferred: expected {len(_lib.DECODER_PARAM_FIELDS)} parameter tensors, got {len(params)}")
+    memory, hn, cn = memory.contiguous(), h_n.reshape(-1).contiguous(), c_n.reshape(-1).contiguous()
+    params = [w.contiguous() for w in params]
+    _check_dev(memory, hn, cn, *params)
+    if not tf_input.is_cuda:
+        raise _lib.MuconHipError("mucon_amd ops need device tensors: there is no CPU fallback")
+    tf_input = tf_input.contiguous().to(torch.int64)
+    if tf_input.numel() < 1:
+        raise ValueError("decoder_forward_deferred: tf_input needs the start token")
+    Tz, ME = memory.shape
+    cfg = _lib.DecoderCfg(Tz=Tz, ME=ME, D=params[7].shape[0], NC=params[17].shape[0], n_emb=params[8].shape[0],
+                          max_steps=int(max_steps), teacher_forcing=0, stop_on_eos=1, eos=int(eos))
+    nbytes = lib.mucon_decoder_workspace_bytes(ctypes.byref(cfg))
+    if nbytes == 0:
+        _lib.check(_lib.E_ARG, "mucon_decoder_workspace_bytes")
+    dev = memory.device
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    logp = torch.empty((int(max_steps), cfg.NC), dtype=torch.float32, device=dev)
+    lengths = torch.empty(int(max_steps), dtype=torch.float32, device=dev)
+    n_steps = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.mucon_decoder_fwd(ctypes.byref(cfg), ctypes.byref(_decoder_params(params)), _lib.ptr(memory), _lib.ptr(hn),
+                                     _lib.ptr(cn), _lib.ptr(tf_input), None, _lib.ptr(logp), _lib.ptr(lengths),
+                                     _lib.ptr(n_steps), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()), "mucon_decoder_fwd")
+    return logp, lengths, n_steps
+
+
 # --------------------------------------------------------------------------------------- losses
 @dataclass
 class LossSpec:

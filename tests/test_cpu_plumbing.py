@@ -126,3 +126,16 @@ def test_device_tensors_never_reach_the_plumbing(monkeypatch):
     v = Viterbi(SingleTranscriptGrammar(tr.tolist(), C), PoissonModel(np.full(C, T / 3)), frame_sampling=30)
     _, labels, _ = v.decode(model.predict(batch, out).segmentation_logits.detach())
     assert len(labels) == T
+
+
+def test_nearest_resize_equals_torch():
+    """make_same_size_interpolate (NumPy) against what the reference calls, F.interpolate(mode="nearest") (core/utils.py:34-47)."""
+    from mucon_amd.mucon.evaluators import make_same_size_interpolate
+    rng = np.random.default_rng(0)
+    for it in range(1500):
+        L, n = int(rng.integers(1, 12000)), int(rng.integers(1, 12000))
+        if it % 5 == 0:
+            n = max(1, L + int(rng.integers(-3, 4)))
+        x = rng.integers(0, 48, L)
+        want = torch.nn.functional.interpolate(torch.tensor(x[None, None]).float(), size=n, mode="nearest")[0, 0].long().numpy()
+        np.testing.assert_array_equal(make_same_size_interpolate(x, n), want)

@@ -1,0 +1,101 @@
+"""GPU: the batched evaluation (pooled host round trips, ONE Viterbi launch and ONE metrics launch per chunk of videos:
+MuConEvaluator._evaluate_chunk, mucon_metrics_segmental) against the one-video-at-a-time path of reference
+src/mucon/evaluators.py:121-257 -- the result record and the saved per-video lists must be EQUAL, not close -- and the device
+counters against the host metric classes (reference src/core/metrics/*) on random labellings."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _labelling(rng, T, n_classes, mean_run):
+    out = []
+    while len(out) < T:
+        out += [int(rng.integers(0, n_classes))] * int(max(1, rng.poisson(mean_run)))
+    return np.asarray(out[:T], dtype=np.int64)
+
+
+@pytest.mark.parametrize("ignore", [(), (0,), (0, 3)])
+def test_segmental_counters_equal_the_host_metrics(ignore):
+    from mucon_amd.core.metrics import Edit, F1Score, IoDMetric, IoUMetric, MoFAccuracyMetric
+    from mucon_amd.core.metrics.device import segmental_counters
+
+    rng = np.random.default_rng(11 + len(ignore))
+    pairs = []
+    for T, ncls, run in ((1, 3, 1), (37, 2, 1), (400, 6, 25), (2000, 48, 120), (2000, 5, 3), (3000, 48, 400), (513, 4, 2), (256, 1, 9)):
+        pairs.append((_labelling(rng, T, ncls, run), _labelling(rng, T, ncls, run)))
+    pairs.append((pairs[3][0], pairs[3][0].copy()))                      # identical labellings
+    pairs.append((np.zeros(300, np.int64), _labelling(rng, 300, 4, 20)))  # an all-background target
+    got = segmental_counters([torch.from_numpy(t).cuda() for t, _ in pairs], [torch.from_numpy(p).cuda() for _, p in pairs], ignore)
+    for (t, p), g in zip(pairs, got):
+        mof, mof_i = MoFAccuracyMetric(), MoFAccuracyMetric(ignore_ids=ignore)
+        mof.add(t, p), mof_i.add(t, p)
+        assert (g["correct"], g["total"], g["correct_nbg"], g["total_nbg"]) == (mof.correct, mof.total, mof_i.correct, mof_i.total)
+        with np.errstate(all="ignore"):
+            for key, metric in (("iod", IoDMetric()), ("iou", IoUMetric()), ("iod_nbg", IoDMetric(ignore_ids=ignore)),
+                                ("iou_nbg", IoUMetric(ignore_ids=ignore))):
+                want = metric.add(targets=t, predictions=p)
+                assert (np.isnan(want) and np.isnan(g[key])) or np.float64(want).tobytes() == np.float64(g[key]).tobytes(), (key, want, g[key])
+            want = Edit().add(targets=t, predictions=p)
+            assert np.float64(want).tobytes() == np.float64(g["edit"]).tobytes(), (want, g["edit"])
+        f1 = F1Score()
+        f1.add(targets=t, predictions=p)
+        assert [x[0] for x in g["f1"]] == f1.tp and [x[1] for x in g["f1"]] == f1.fp and [x[2] for x in g["f1"]] == f1.fn
+
+
+class _Videos:
+    background_class_ids = [0]
+
+    def __init__(self, n, C, dev, seed):
+        from mucon_amd import synth
+        from mucon_amd.core.datasets import Batch
+        rng = np.random.default_rng(seed)
+        self.items = []
+        for v in range(n):
+            T, N = int(rng.integers(150, 900)), int(rng.integers(2, 7))
+            tr = synth.transcript(100 + v, N, C, allow_repeats=False)
+            self.items.append(Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(200 + v, T, tr)),
+                                    transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
+                                    transcript_tf_target=torch.tensor(tr.tolist() + [C]), video_name=f"v{v}").to(dev))
+        self.C = C
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def get_num_classes(self):
+        return self.C
+
+
+@pytest.mark.parametrize("eos_bias, viterbi", [(-20.0, True), (-0.5, True), (0.3, True), (-20.0, False)])
+def test_batched_evaluation_equals_the_per_video_path(eos_bias, viterbi):
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.evaluators import RESULT_FIELDS, MuConEvaluator
+    from mucon_amd.mucon.models import create_model
+
+    dev, C = "cuda:0", 48
+    cfg = update_config(get_cfg_defaults(), [], [])
+    torch.manual_seed(3)
+    model = create_model(cfg, C, 9, 2048).to(dev)
+    with torch.no_grad():
+        model.fs_decoder_transcript[2].bias[C] = eos_bias      # how soon the untrained s-head says EOS (first word: the video is skipped)
+    db = _Videos(11, C, dev, seed=5)
+    records = []
+    for batched in (False, True):
+        ev = MuConEvaluator(cfg, db, model, dev)
+        ev.batched, ev.chunk_videos = batched, 4                # 11 videos: chunks of 4, 4, 3
+        ev.viterbi_mode(viterbi)
+        res = ev.evaluate()
+        records.append((res, ev.to_save, ev.skipped, list(ev._evaluated)))
+    (ra, sa, ka, ea), (rb, sb, kb, eb) = records
+    assert ka == kb and ea == eb
+    for k in RESULT_FIELDS:
+        a, b = np.asarray(ra[k], dtype=np.float64), np.asarray(rb[k], dtype=np.float64)
+        assert a.shape == b.shape and all((np.isnan(x) and np.isnan(y)) or x.tobytes() == y.tobytes() for x, y in zip(a.ravel(), b.ravel())), (k, ra[k], rb[k])
+    for name in sa:
+        assert len(sa[name]) == len(sb[name]), name
+        for x, y in zip(sa[name], sb[name]):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
