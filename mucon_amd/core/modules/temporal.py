@@ -135,11 +135,15 @@ class NoFt(nn.Module):
     def forward_time_major(self, tape: Tensor) -> Tensor:
         """[B, T, Cin] row-major -> [B, T, out_dims] on the tape as it lies in memory: first_conv's kernels without the
         non-linearity (ops.linear_forward: f32 MFMA, split-bf16 from 8,192 frames; weight gradient = first_conv's job).
-        Shapes those kernels are not built for (out_dims != 128, Cin not a multiple of 128) and CPU tensors (the CPU test of
-        the module surface) take one torch GEMM."""
-        if tape.is_cuda and self.out_dims == 128 and self.in_chnnels % 128 == 0 and tape.dtype == torch.float32:
+        Device tensors of a shape those kernels are not built for (out_dims != 128, Cin not a multiple of 128) RAISE; host
+        tensors (cfg.system.device = "cpu": plumbing, and the CPU test of the module surface) take one torch GEMM."""
+        if tape.is_cuda:
+            if not (self.out_dims == 128 and self.in_chnnels % 128 == 0 and tape.dtype == torch.float32):
+                # no silent library-op path for device tensors: the kernels are what this package is
+                raise NotImplementedError(f"NoFt on the HIP path needs out_dims = 128, in_channels a multiple of 128 and float32 "
+                                          f"(got {self.in_chnnels} -> {self.out_dims}, {tape.dtype})")
             return ops.linear_forward(tape, self.last_conv.weight, self.last_conv.bias)
-        return torch.matmul(tape, self.last_conv.weight[:, :, 0].t()) + self.last_conv.bias
+        return torch.matmul(tape, self.last_conv.weight[:, :, 0].t()) + self.last_conv.bias      # host tensors: cfg.system.device = "cpu" plumbing
 
     def forward(self, x: Tensor) -> Tensor:
         """Reference signature: [B, Cin, T] -> [B, out_dims, T]."""
@@ -185,11 +189,16 @@ class MSTCNPPFirstStage(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         """[B, Cin, T] -> [B, output_dim, Tz].  On the GPU with the reference's sizes (128 feature maps, Cin a multiple of 128): the
-        hand-written kernels (a permuted view of a row-major [B, T, Cin] tensor is consumed without a copy); other sizes and CPU
-        tensors (the CPU test of the module surface): library ops."""
-        if self._hip_ok(x):
+        hand-written kernels (a permuted view of a row-major [B, T, Cin] tensor is consumed without a copy); device tensors of other
+        sizes RAISE; host tensors (cfg.system.device = "cpu" plumbing, the CPU test of the module surface): library ops."""
+        if x.is_cuda:
+            if not self._hip_ok(x):
+                # no silent library-op path for device tensors: the kernels are what this package is
+                raise NotImplementedError(f"MSTCNPPFirstStage on the HIP path needs 128 feature maps, an input width that is a multiple of "
+                                          f"128 and float32 (got {self.conv_1x1_in.in_channels} -> {self.conv_1x1_in.out_channels} -> "
+                                          f"{self.conv_out.out_channels}, {x.dtype})")
             return self.forward_time_major(x.permute(0, 2, 1)).permute(0, 2, 1)
-        f = self.conv_1x1_in(x)
+        f = self.conv_1x1_in(x)                          # host tensors: cfg.system.device = "cpu" plumbing
         for i, (far, near, fuse) in enumerate(zip(self.conv_dilated_1, self.conv_dilated_2, self.conv_fusion)):
             both = torch.cat((far(f), near(f)), dim=1)
             f = f + self.dropout(torch.relu(fuse(both)))

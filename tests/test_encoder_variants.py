@@ -178,3 +178,20 @@ def test_model_with_hidden_64_trains():
     with torch.no_grad():
         enc = model.temporal_modeling_forward(make_batch(640, 5).to("cuda").feats)
     assert tuple(enc.shape) == (1, 40, 64)
+
+
+@pytest.mark.gpu
+def test_unsupported_device_shapes_raise_instead_of_falling_back():
+    """A device tensor never takes library ops silently: shapes the kernels are not built for raise (host tensors keep the
+    cfg.system.device = "cpu" plumbing path); an input that wants a gradient is refused too (the HIP path produces none)."""
+    from mucon_amd import _lib
+    from mucon_amd.core.modules.temporal import MSTCNPPFirstStage, NoFt
+    with pytest.raises(NotImplementedError):
+        NoFt(in_chnnels=100, out_dims=128).cuda()(torch.randn(1, 100, 64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        NoFt(in_chnnels=256, out_dims=64).cuda()(torch.randn(1, 256, 64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        MSTCNPPFirstStage(num_layers=3, num_f_maps=64, input_dim=256, output_dim=64, pooling_layers=()).cuda()(torch.randn(1, 256, 64, device="cuda"))
+    assert NoFt(in_chnnels=100, out_dims=128)(torch.randn(1, 100, 64)).shape == (1, 128, 64)      # host tensors: plumbing
+    with pytest.raises(_lib.MuconHipError):
+        NoFt(in_chnnels=256, out_dims=128).cuda()(torch.randn(1, 256, 64, device="cuda", requires_grad=True))
