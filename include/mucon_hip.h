@@ -124,6 +124,21 @@ int mucon_linear_bwd(int32_t B, int32_t T, int32_t D, const float *tape, const f
 size_t mucon_conv128_workspace_bytes(int32_t B, int32_t T, int32_t taps);
 int mucon_conv128_fwd(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *x, const float *w_fwd, const float *b,
                       float *y, void *stream);
+/* The tail of an MS-TCN++ layer (reference src/core/modules/temporal.py:196-201) as ONE launch:
+ *   y = [max_pool1d(2)] ( f + dropout( relu( conv_fusion(cat(a, b)) ) ) )
+ * a, b [B][T][128]: the two dilated convolutions' outputs; w = conv_fusion.weight [128][256] as nn.Conv1d stores it ([out][in][1]);
+ * bias [128] or NULL; f [B][T][128] the layer input (residual).  Dropout is counter-based (seed, element index), active when
+ * training != 0.  pool != 0: y is [B][T/2][128] and y_pre receives the un-pooled rows [B][T][128] (the backward's arg-max).
+ * x_act (NULL, or [B][T][128]) receives the branch value dropout(relu(.)) before the residual is added: x > 0 marks the elements
+ * whose gradient passes (mucon_mstcn_tail_bwd). */
+int mucon_mstcn_fuse_fwd(int32_t B, int32_t T, const float *a, const float *b, const float *w, const float *bias, const float *f,
+                         float p_drop, uint64_t seed, int32_t training, int32_t pool, float *y, float *y_pre, float *x_act,
+                         void *stream);
+/* Its backward up to the fusion convolution's output u: d_sum [B][T][128] = the gradient w.r.t. the un-pooled sum f + x (d_y routed
+ * to the arg-max row of each pair when pooled; this is also the residual path's gradient w.r.t. f), d_u = d_sum * scale where
+ * x_act > 0, else 0 (scale = 1 / (1 - p) in training, 1 otherwise).  The convolutions' own gradients are mucon_conv128_dgrad / _wgrad. */
+int mucon_mstcn_tail_bwd(int32_t B, int32_t T, int32_t pool, const float *d_y, const float *y_pre, const float *x_act, float scale,
+                         float *d_sum, float *d_u, void *stream);
 int mucon_conv128_dgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *w_bwd, float *d_x,
                         void *stream);
 int mucon_conv128_wgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *x, float *d_w,

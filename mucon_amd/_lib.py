@@ -111,6 +111,8 @@ SYMBOLS = {
     "mucon_metrics_segmental": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_conv128_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mucon_conv128_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mucon_mstcn_fuse_fwd": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_uint64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mucon_mstcn_tail_bwd": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "mucon_conv128_dgrad": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mucon_conv128_wgrad": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_head_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -172,19 +172,18 @@ class MSTCNPPFirstStage(nn.Module):
 
     def forward_time_major(self, tape: Tensor) -> Tensor:
         """[B, T, Cin] row-major -> [B, Tz, output_dim] on the encoder's kernels through the C ABI: conv_1x1_in = first_conv without
-        its non-linearity (mucon_linear_fwd), every 128-channel convolution = mucon_conv128_fwd / _dgrad / _wgrad (f32 MFMA);
-        conv_fusion over the concatenation = the sum of two 1x1 convolutions over its halves.  ReLU, dropout, residual and the
-        max-pooling are element-wise torch ops on the time-major rows."""
+        its non-linearity (mucon_linear_fwd), the two dilated convolutions = mucon_conv128_fwd / _dgrad / _wgrad (f32 MFMA), and the
+        layer's tail -- conv_fusion over the concatenation (a two-source 1x1 convolution), ReLU, dropout, residual, max-pooling --
+        ONE launch (mucon_mstcn_fuse_fwd): three launches per layer, no torch glue in the forward."""
         f = ops.linear_forward(tape, self.conv_1x1_in.weight, self.conv_1x1_in.bias)
         for i, (far, near, fuse) in enumerate(zip(self.conv_dilated_1, self.conv_dilated_2, self.conv_fusion)):
             a = ops.conv128_forward(f, far.weight, far.bias, far.dilation[0])
             b = ops.conv128_forward(f, near.weight, near.bias, near.dilation[0])
-            u = ops.conv128_forward(a, fuse.weight[:, :128], fuse.bias, 1) + ops.conv128_forward(b, fuse.weight[:, 128:], None, 1)
-            f = f + self.dropout(torch.relu(u))
-            if i in self.pooling_layers:
-                B, T, Cc = f.shape
-                pairs = f[:, :2 * (T // 2)].reshape(B, T // 2, 2, Cc)
-                f = torch.where(pairs[:, :, 1] > pairs[:, :, 0], pairs[:, :, 1], pairs[:, :, 0])   # max_pool1d: the first wins a tie
+            # conv_fusion over cat(a, b), ReLU, Dropout, the residual and the x2 max-pooling: ONE launch (mucon_mstcn_fuse_fwd).  The
+            # dropout is the kernels' counter-based one, keyed by a seed drawn from torch's generator per layer call.
+            drop_on = self.training and self.dropout.p > 0
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_on else 0
+            f = ops.mstcn_fuse_forward(a, b, f, fuse.weight, fuse.bias, float(self.dropout.p), seed, drop_on, i in self.pooling_layers)
         return ops.conv128_forward(f, self.conv_out.weight, self.conv_out.bias, 1)
 
     def forward(self, x: Tensor) -> Tensor:

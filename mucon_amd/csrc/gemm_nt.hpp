@@ -45,6 +45,10 @@ struct NtParams {
     float *out_pre;     // POOL 1: un-pooled rows [B][Trows][128], kept for the max-pool backward
     const float *ypre;  // POOL 3: the forward's un-pooled rows [B][Tfine][128] (arg-max routing of the max-pool backward)
     int Tfine;          // POOL 3 / 4: rows per video of the un-pooled level; out is [B][Tfine][128]
+    long tap_shift;     // floats added to A per tap index: tap k reads A + k * tap_shift (0 = one source; a two-input 1x1 convolution over
+                        // the concatenation [a; b] is taps = 2, tap_step = 0, tap_shift = b - a: mucon_mstcn_fuse_fwd)
+    float *out_act;     // EPI_RES, when non-null: the branch value after bias / act / dropout, BEFORE the residual is added
+                        // ([B][Trows][128]; what its backward needs: x > 0 <=> the element passed both the ReLU and the dropout)
     const float *res;   // EPI_RES : [B][Trows][128] added after bias/act/dropout
     const float *mask;  // EPI_MASK: [B][Trows][128]; result *= act'(mask) (skipped when null)
     float slope;        // 0 = ReLU, 0.01 = leaky ReLU
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
             const int ts = t + off;
             const bool ok = (t < p.Trows) && (ts >= 0) && (ts < p.Ta);
             const int tc = ts < 0 ? 0 : (ts >= p.Ta ? p.Ta - 1 : ts);
-            ra[S][q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tc * p.lda + kk + lc4);
+            ra[S][q] = *reinterpret_cast<const f32x4 *>(Ab + (long)tap * p.tap_shift + (long)tc * p.lda + kk + lc4);
             rt[S][q] = ok ? t : -1;
         }
     };
@@ -318,7 +322,10 @@ __global__ __launch_bounds__(64 * NW) void nt_gemm_kernel(const NtParams p) {
                     if (EPI_DROP) {
                         if (p.drop.thresh) x *= drop_mul(p.drop, (uint32_t)g);
                     }
-                    if (EPI_RES) x += rres[reg];
+                    if (EPI_RES) {
+                        if (p.out_act && (FULL || t < p.Trows)) p.out_act[g] = x;
+                        x += rres[reg];
+                    }
                     if (EPI_MASK) {
                         if (use_mask) x *= act_grad(rmask[reg], p.slope);
                     }

@@ -1413,6 +1413,38 @@ int mucon_conv128_fwd(int32_t B, int32_t T, int32_t taps, int32_t dilation, cons
     return MUCON_OK;
 }
 
+int mucon_mstcn_fuse_fwd(int32_t B, int32_t T, const float *a, const float *b, const float *w, const float *bias, const float *f,
+                         float p_drop, uint64_t seed, int32_t training, int32_t pool, float *y, float *y_pre, float *x_act,
+                         void *stream) {
+    if (B < 1 || T < 1 || (pool && T < 2)) return fail(MUCON_E_ARG, "mstcn_fuse: B=%d T=%d pool=%d", B, T, pool);
+    if (!a || !b || !w || !f || !y || (pool && !y_pre)) return fail(MUCON_E_ARG, "null pointer argument");
+    if (p_drop < 0.f || p_drop >= 1.f) return fail(MUCON_E_ARG, "mstcn_fuse: dropout probability %g", (double)p_drop);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the 1x1 convolution over the concatenation [a; b] = two "taps" that differ in their source, not in their row
+    NtParams p = nt_base(a, (long)T * 128, 128, T, T, 2, 0, 128, w, bias, y, 0.f);   // slope 0: ReLU
+    p.tap_shift = b - a;
+    p.ldw = 256;
+    p.res = f;
+    p.out_act = x_act;
+    p.out_pre = y_pre;
+    p.drop = make_drop(seed, 0, p_drop, training != 0);
+    if (pool) HIPCHK((launch_nt<false, false, true, true, true, false, 1>(p, B, s)));
+    else HIPCHK((launch_nt<false, false, true, true, true, false, 0>(p, B, s)));
+    return MUCON_OK;
+}
+
+int mucon_mstcn_tail_bwd(int32_t B, int32_t T, int32_t pool, const float *d_y, const float *y_pre, const float *x_act, float scale,
+                         float *d_sum, float *d_u, void *stream) {
+    if (B < 1 || T < 1) return fail(MUCON_E_ARG, "mstcn_tail_bwd: B=%d T=%d", B, T);
+    if (!d_y || !x_act || !d_sum || !d_u || (pool && !y_pre)) return fail(MUCON_E_ARG, "null pointer argument");
+    const long n4 = (long)B * T * 32;
+    const int blocks = (int)std::min<long>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(mstcn_tail_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_y, y_pre, x_act, d_sum, d_u, B, T,
+                       pool ? 1 : 0, scale);
+    HIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
 int mucon_conv128_dgrad(int32_t B, int32_t T, int32_t taps, int32_t dilation, const float *g, const float *w_bwd, float *d_x,
                         void *stream) {
     if (B < 1 || T < 1 || (taps != 1 && taps != 3) || dilation < 0) return fail(MUCON_E_ARG, "conv128: B=%d T=%d taps=%d dilation=%d", B, T, taps, dilation);

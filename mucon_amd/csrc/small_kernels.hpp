@@ -111,6 +111,44 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds)
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward of an MS-TCN++ layer's tail  y = pool(f + dropout(relu(u)))  (reference temporal.py:196-201) in one pass:
+//   dyd[t] = the gradient w.r.t. the un-pooled sum: dy[t / 2] on the arg-max row of the forward pair (first wins ties, as
+//            torch's max_pool1d backward) when pooled, dy[t] otherwise; an odd trailing row gets 0;
+//   gu[t]  = dyd[t] * scale where the branch value x = dropout(relu(u)) is positive (the element passed the ReLU and was
+//            kept by the dropout, whose factor is `scale`), else 0 -- the gradient w.r.t. u, the fusion convolution's output.
+// ------------------------------------------------------------------------------------------
+__global__ void mstcn_tail_bwd_kernel(const float *dy, const float *ypre, const float *xact, float *dyd, float *gu, int B, int Trows,
+                                      int pooled, float scale) {
+    const long n4 = (long)B * Trows * 32;  // float4 elements
+    const int Th = Trows >> 1;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e & 31);
+        const long bt = e >> 5;
+        const int b = (int)(bt / Trows), t = (int)(bt - (long)b * Trows);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (!pooled) {
+            g = *reinterpret_cast<const f32x4 *>(dy + e * 4);
+        } else if ((t >> 1) < Th) {
+            const int tp = t >> 1;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dy + ((long)b * Th + tp) * 128 + c4 * 4);
+            const f32x4 y0 = *reinterpret_cast<const f32x4 *>(ypre + ((long)b * Trows + 2 * tp) * 128 + c4 * 4);
+            const f32x4 y1 = *reinterpret_cast<const f32x4 *>(ypre + ((long)b * Trows + 2 * tp + 1) * 128 + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool second = y1[k] > y0[k];
+                g[k] = ((t & 1) == (second ? 1 : 0)) ? d[k] : 0.f;
+            }
+        }
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(xact + e * 4);
+        f32x4 u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = x[k] > 0.f ? g[k] * scale : 0.f;
+        *reinterpret_cast<f32x4 *>(dyd + e * 4) = g;
+        *reinterpret_cast<f32x4 *>(gu + e * 4) = u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward of F.max_pool1d(k=2) / avg_pool1d(k=2)*2 (temporal.py:137-142):
 //   dyd[t] = dy[t/2] if t is the arg-max of its pair (first wins ties), or for sum pooling always;
 //   an odd trailing step gets 0.    ypre: un-pooled forward rows.

@@ -260,6 +260,69 @@ class _Conv128Fn(torch.autograd.Function):
         return d_x, d_w, d_b, None
 
 
+class _MstcnFuseFn(torch.autograd.Function):
+    """The tail of an MS-TCN++ layer (reference core/modules/temporal.py:196-201) as one launch:
+    y = [max_pool1d(2)](f + dropout(relu(conv_fusion(cat(a, b))))) -- mucon_mstcn_fuse_fwd; its backward is one element-wise
+    launch (mucon_mstcn_tail_bwd: un-pooling + the ReLU / dropout mask) and the convolution gradients of mucon_conv128_*."""
+
+    @staticmethod
+    def forward(ctx, a, b, f, w, bias, p_drop, seed, training, pool):
+        lib = _lib.load()
+        _check_dev(a, b, f, w, bias)
+        a, b, f = a.contiguous(), b.contiguous(), f.contiguous()
+        w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
+        B, T, Cc = a.shape
+        assert Cc == 128 and tuple(w2.shape) == (128, 256) and a.shape == b.shape == f.shape
+        dev = a.device
+        y = torch.empty((B, T // 2 if pool else T, 128), dtype=torch.float32, device=dev)
+        y_pre = torch.empty_like(a) if pool else None
+        need_bwd = any(ctx.needs_input_grad[:5]) if hasattr(ctx, "needs_input_grad") else False
+        x_act = torch.empty_like(a) if need_bwd else None
+        _lib.check(lib.mucon_mstcn_fuse_fwd(B, T, _lib.ptr(a), _lib.ptr(b), _lib.ptr(w2), _lib.ptr(bias.contiguous()) if bias is not None else None,
+                                            _lib.ptr(f), float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, int(bool(training)), int(bool(pool)),
+                                            _lib.ptr(y), _lib.ptr(y_pre), _lib.ptr(x_act), _lib.current_stream_ptr()), "mucon_mstcn_fuse_fwd")
+        ctx.dims = (B, T, bool(pool), (1.0 / (1.0 - p_drop)) if (training and p_drop > 0) else 1.0, bias is not None)
+        ctx.save_for_backward(a, b, w2, y_pre, x_act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b, w2, y_pre, x_act = ctx.saved_tensors
+        B, T, pool, scale, has_b = ctx.dims
+        g = g.contiguous()
+        d_sum, d_u = torch.empty_like(a), torch.empty_like(a)
+        st = _lib.current_stream_ptr()
+        _lib.check(lib.mucon_mstcn_tail_bwd(B, T, int(pool), _lib.ptr(g), _lib.ptr(y_pre), _lib.ptr(x_act), float(scale), _lib.ptr(d_sum),
+                                            _lib.ptr(d_u), st), "mucon_mstcn_tail_bwd")
+        d_a = d_b = d_w = d_bias = None
+        wa, wb = w2[:, :128], w2[:, 128:]
+        if ctx.needs_input_grad[0]:
+            d_a = torch.empty_like(a)      # d a = d_u . W_a: a 1x1 "data gradient" whose operand is W_a as [in][out]
+            _lib.check(lib.mucon_conv128_dgrad(B, T, 1, 0, _lib.ptr(d_u), _lib.ptr(wa.t().contiguous()), _lib.ptr(d_a), st), "mucon_conv128_dgrad")
+        if ctx.needs_input_grad[1]:
+            d_b = torch.empty_like(b)
+            _lib.check(lib.mucon_conv128_dgrad(B, T, 1, 0, _lib.ptr(d_u), _lib.ptr(wb.t().contiguous()), _lib.ptr(d_b), st), "mucon_conv128_dgrad")
+        if ctx.needs_input_grad[3] or (has_b and ctx.needs_input_grad[4]):
+            nbytes = lib.mucon_conv128_workspace_bytes(B, T, 1)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+            d_w = torch.empty((128, 256, 1), dtype=torch.float32, device=a.device)
+            halves = torch.empty((2, 128, 128), dtype=torch.float32, device=a.device)
+            d_bias = torch.empty(128, dtype=torch.float32, device=a.device) if has_b else None
+            for k, src in enumerate((a, b)):
+                _lib.check(lib.mucon_conv128_wgrad(B, T, 1, 0, _lib.ptr(d_u), _lib.ptr(src), _lib.ptr(halves[k]),
+                                                   _lib.ptr(d_bias) if (has_b and k == 0) else None, _lib.ptr(ws), nbytes, st),
+                           "mucon_conv128_wgrad")
+            d_w[:, :128, 0], d_w[:, 128:, 0] = halves[0], halves[1]
+        return d_a, d_b, (d_sum if ctx.needs_input_grad[2] else None), d_w, d_bias, None, None, None, None
+
+
+def mstcn_fuse_forward(a: torch.Tensor, b: torch.Tensor, f: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                       p_drop: float, seed: int, training: bool, pool: bool) -> torch.Tensor:
+    """a, b, f [B,T,128] time-major; weight = conv_fusion.weight [128,256,1] -> [B, T or T//2, 128]."""
+    return _MstcnFuseFn.apply(a, b, f, weight, bias, float(p_drop), int(seed), bool(training), bool(pool))
+
+
 def conv128_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1) -> torch.Tensor:
     """x [B,T,128] time-major -> [B,T,128]; weight [128,128,1|3] (nn.Conv1d layout), zero padding = dilation."""
     return _Conv128Fn.apply(x, weight, bias, dilation)

@@ -195,3 +195,35 @@ def test_unsupported_device_shapes_raise_instead_of_falling_back():
     assert NoFt(in_chnnels=100, out_dims=128)(torch.randn(1, 100, 64)).shape == (1, 128, 64)      # host tensors: plumbing
     with pytest.raises(_lib.MuconHipError):
         NoFt(in_chnnels=256, out_dims=128).cuda()(torch.randn(1, 256, 64, device="cuda", requires_grad=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool, training, T", [(False, False, 130), (True, False, 203), (True, True, 96), (False, True, 257)])
+def test_mstcn_fused_tail_against_float64(pool, training, T):
+    """ops.mstcn_fuse_forward (one launch: conv_fusion over cat(a, b), ReLU, dropout, residual, max-pool -- reference
+    temporal.py:196-201) against the same expression in float64 on the host, the kernel's counter-based dropout mask replayed in
+    numpy; output and the gradients of all five inputs."""
+    from helpers import dropout_keep_np
+    from mucon_amd import ops
+    B, p, seed = 2, 0.5, 0x1234567890ABCDEF
+    g = torch.Generator().manual_seed(21)
+    a, b, f = (torch.randn(B, T, 128, generator=g).cuda().requires_grad_() for _ in range(3))
+    w = (torch.randn(128, 256, 1, generator=g) * 0.06).cuda().requires_grad_()
+    bias = torch.randn(128, generator=g).cuda().requires_grad_()
+    u = torch.randn(B, T // 2 if pool else T, 128, generator=g)
+    y = ops.mstcn_fuse_forward(a, b, f, w, bias, p, seed, training, pool)
+    (y * u.cuda()).sum().backward()
+    ad, bd, fd, wd, biasd = (t.detach().double().cpu().requires_grad_() for t in (a, b, f, w, bias))
+    pre = torch.nn.functional.conv1d(torch.cat((ad, bd), dim=2).permute(0, 2, 1), wd, biasd).permute(0, 2, 1)
+    x = torch.relu(pre)
+    if training:
+        keep = torch.from_numpy(dropout_keep_np(B * T * 128, seed, 0, p).reshape(B, T, 128))
+        x = x * keep.double() / (1 - p)
+    s = fd + x
+    ref = torch.nn.functional.max_pool1d(s.permute(0, 2, 1), 2).permute(0, 2, 1) if pool else s
+    (ref * u.double()).sum().backward()
+    # elements whose pre-activation is within float32 noise of the ReLU's kink may fall on either side: exclude nothing, bound loosely
+    assert float((y.detach().double().cpu() - ref.detach()).abs().max()) <= 5e-5 * float(ref.detach().abs().max())
+    for name, got, want in (("a", a.grad, ad.grad), ("b", b.grad, bd.grad), ("f", f.grad, fd.grad), ("w", w.grad, wd.grad), ("bias", bias.grad, biasd.grad)):
+        err = float((got.double().cpu() - want).norm()) / (float(want.norm()) + 1e-30)
+        assert err <= 2e-4, (name, err)
