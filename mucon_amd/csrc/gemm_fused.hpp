@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "dispatch.hpp"
 #include "gemm_nt.hpp"
 
 constexpr int FUSED_HS = 132;  // padded row length of the intermediate tile (floats): 132 mod 64 = 4 -> conflict-free b128 reads
@@ -447,14 +448,12 @@ static hipError_t launch_fused_cfg(const FusedParams &p, int B, hipStream_t s) {
     return hipGetLastError();
 }
 
-extern int g_fused_bm;  // 0 = automatic (tuning hook: MUCON_FUSED_BM = 32 / 64)
-extern int g_fused_ks;  // k-split of the BM = 32 variant: 1 (default) or 2 (tuning hook: MUCON_FUSED_KS)
 template <bool BWD, int POOL>
 static hipError_t launch_fused(const FusedParams &p, int B, hipStream_t s) {
-    int bm = g_fused_bm ? g_fused_bm : (((long)B * p.Trows >= 512L * 64) ? 64 : ((long)B * p.Trows < g_nt_bm16_rows ? 16 : 32));
+    int bm = kFusedBm ? kFusedBm : (((long)B * p.Trows >= 512L * 64) ? 64 : ((long)B * p.Trows < g_nt_bm16_rows ? 16 : 32));
     if (bm == 64) return launch_fused_cfg<1, 2, 1, BWD, POOL>(p, B, s);
     if (bm == 16) return launch_fused_cfg<1, 1, 1, BWD, POOL, 16>(p, B, s);
     if constexpr (!(BWD && POOL >= 3))
-        if (g_fused_ks == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
+        if (kFusedKs == 2) return launch_fused_cfg<1, 1, 2, BWD, POOL>(p, B, s);
     return launch_fused_cfg<1, 1, 1, BWD, POOL>(p, B, s);
 }

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "dispatch.hpp"
 #include "gemm_fused.hpp"
 
 constexpr int FS_WSTEP = 3 * 128 * 32;          // bf16 elements of one 32-deep step of a [128][K] image: [plane 3][block 8][lane 64][8]
@@ -485,10 +486,9 @@ static hipError_t launch_fs_cfg(const FusedParams &p, const uint16_t *W1img, con
 }
 // 128 rows per workgroup (8 waves) where that gives at least one workgroup per CU, 64 rows (4 waves, one per SIMD) below:
 // the T/2 level and every pooled boundary (whose stage 1 runs on the coarse level's rows) would leave half of the chip idle
-extern int g_fs_nw;   // 0 = automatic, 4 / 8 forced (MUCON_FUSED_SPLIT_NW)
 template <bool BWD, int POOL, bool ONE = false>
 static hipError_t launch_fs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
-    const int nw = g_fs_nw ? g_fs_nw : ((long)B * ((p.Trows + 127) / 128) >= 256 ? 8 : 4);
+    const int nw = kFsNw ? kFsNw : ((long)B * ((p.Trows + 127) / 128) >= 256 ? 8 : 4);
     if (nw == 8) return launch_fs_cfg<BWD, POOL, ONE, 8>(p, W1img, W2img, B, s);
     return launch_fs_cfg<BWD, POOL, ONE, 4>(p, W1img, W2img, B, s);
 }

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "dispatch.hpp"
 
 constexpr int NT_BK = 32;
 constexpr int NT_LDS = 36;  // padded row length (floats)
@@ -404,7 +405,6 @@ __global__ __launch_bounds__(256) void first_conv_combine_kernel(const NtParams 
 // Tile height by problem size: keep >= ~2 workgroups per CU in flight where the level allows it; below ~one workgroup
 // per CU at BM = 32 the launch is latency-bound and 16-row tiles (twice the workgroups, half the MFMA chain) are faster.
 extern int g_nt_force_bm;  // 0 = automatic (tuning hook: MUCON_NT_BM)
-extern int g_first_conv_8w;   // first_conv forward as 128-row, 8-wave workgroups (MUCON_FIRST_CONV_8W)
 extern long g_nt_bm16_rows;  // levels with fewer rows in the batch than this use BM = 16 (MUCON_NT_BM16_ROWS; 0 = never)
 static inline int nt_pick_bm(int B, int Trows) {
     if (g_nt_force_bm) return g_nt_force_bm;
@@ -417,7 +417,7 @@ static inline int nt_pick_bm(int B, int Trows) {
 
 template <bool PRO_ACT, bool PRO_DROP, bool EPI_ACT, bool EPI_DROP, bool EPI_RES, bool EPI_MASK, int POOL, int TAG = 0>
 static hipError_t launch_nt(const NtParams &p, int B, hipStream_t s) {
-    if ((TAG == 1 || g_first_conv_8w == 2) && g_first_conv_8w && POOL < 3 && (long)B * p.Trows >= 512L * 64)   // 128 rows x 8 waves
+    if ((TAG == 1 || kFirstConv8w == 2) && kFirstConv8w && POOL < 3 && (long)B * p.Trows >= 512L * 64)   // 128 rows x 8 waves
         return launch_nt_cfg<1, 4, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG, 32, 8>(p, B, s);
     switch (nt_pick_bm(B, p.Trows)) {
         case 128: return launch_nt_cfg<2, 2, PRO_ACT, PRO_DROP, EPI_ACT, EPI_DROP, EPI_RES, EPI_MASK, POOL, TAG>(p, B, s);

@@ -14,6 +14,7 @@
 // needed: the MFMA operand read is ds_read_b32 with 32 consecutive lanes on consecutive floats).
 #pragma once
 #include "common.hpp"
+#include "dispatch.hpp"
 
 constexpr int TN_SMEM_BYTES = 2 * 2 * 32 * 128 * 4;  // Y and X tiles, double buffered = 64 KiB
 
@@ -236,7 +237,6 @@ __global__ __launch_bounds__(256 * KS) void tn_batched_kernel(const TnBatch tb) 
     else if (job.x0_act) tn_body<true, false, KS>(job.p, kc, mc, smem);
     else tn_body<false, false, KS>(job.p, kc, mc, smem);
 }
-extern int g_tn_batch_ks;   // waves per workgroup of the batched launch: 1 -> 4 waves, 2 -> 8 waves (k-split)  (MUCON_TN_BATCH_KS)
 static hipError_t launch_tn_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
     static bool attr_set = false;
@@ -259,7 +259,7 @@ static hipError_t launch_tn_batch(TnBatch &tb, hipStream_t s) {
         blocks += lb.j[i].nkc * (tb.j[tb.njobs - 1 - i].block0);   // block0 carried the time-chunk count while queued
     }
     lb.nblocks = blocks;
-    if (g_tn_batch_ks == 2) hipLaunchKernelGGL(tn_batched_kernel<2>, dim3(blocks), dim3(512), TN_SMEM_BYTES, s, lb);
+    if (kTnBatchKs == 2) hipLaunchKernelGGL(tn_batched_kernel<2>, dim3(blocks), dim3(512), TN_SMEM_BYTES, s, lb);
     else hipLaunchKernelGGL(tn_batched_kernel<1>, dim3(blocks), dim3(256), TN_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "dispatch.hpp"
 #include "gemm_tn.hpp"
 
 #ifndef TS_ABL
@@ -415,7 +416,6 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
     else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
 }
 
-extern int g_ts_xcd;   // XCD-aware block order of the batched launch (MUCON_TS_XCD)
 static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
     static bool attr_set = false;
@@ -435,10 +435,10 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
         lb.j[i].block0 = blocks;
         lb.j[i].nmc = src.block0;                     // block0 carried the time-chunk count while queued
         blocks += ((src.nkc + 1) / 2) * src.block0;
-        if (g_ts_xcd) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
+        if (kTsXcdOrder) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
     }
     lb.nblocks = blocks;
-    lb.xcd_order = g_ts_xcd;
+    lb.xcd_order = kTsXcdOrder;
     hipLaunchKernelGGL(ts_batched_kernel, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();

@@ -13,32 +13,21 @@
 #include "../../include/mucon_hip.h"
 #include "../../include/mucon_hip_test.h"
 #include "common.hpp"
+#include "dispatch.hpp"
 #include "gemm_nt.hpp"
 #include "gemm_fused.hpp"
 #include "gemm_tn.hpp"
 #include "gemm_split.hpp"
+#include "gemm_split_ws.hpp"
 #include "gemm_tn_split.hpp"
 #include "gemm_fused_split.hpp"
 #include "gemm_coarse_split.hpp"
 #include "small_kernels.hpp"
 
-int g_ts_xcd = 1;             // the split weight-gradient launch keeps the workgroups that share gradient rows on one XCD (MUCON_TS_XCD=0: plain order)
 int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
-int g_fs_nw = 0;              // waves per workgroup of the split-bf16 two-stage kernels: 0 = by level size, 4 / 8 forced (MUCON_FUSED_SPLIT_NW)
-int g_tn_batch_ks = 2;   // 8-wave workgroups in the batched weight-gradient launch (gemm_tn.hpp; MUCON_TN_BATCH_KS=1: 4 waves)
-int g_first_conv_8w = 1;   // 1: first_conv forward as 128-row 8-wave workgroups; 2: every full-resolution NT launch; 0: off
 int g_nt_force_bm = 0;
-// weight gradients: 2 = ONE launch for every layer's and first_conv's after the data-gradient chain; 1 = the layers' in one
-// launch, first_conv's in its own; 0 = one launch per layer (coarse levels on the side stream)  (MUCON_TN_BATCH)
-int g_tn_batch = 2;
-int g_tn_ks = 0;  // weight-gradient k-split: 0 = automatic (2 for the layer launches, 1 for first_conv), 1 / 2 forced (MUCON_TN_KS)
-int g_pool_fuse = 1;   // fused launch across pooled boundaries in the backward (MUCON_POOL_FUSE=0: NT launch pair)
-int g_no_unpool_fuse = 0;  // MUCON_UNPOOL_FUSE=0: separate unpool_kernel pass (tuning / regression hook)
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
-int g_fused_bm = 0;
-int g_fused_ks = 1;  // 2 = in-workgroup k-split for the BM = 32 variant (measured: not faster; changes the summation order)
 int g_no_fuse = 0;  // the fused two-stage layer kernels (gemm_fused.hpp); MUCON_FUSE=0 runs two launches per layer
-long g_fuse_max_rows = 1L << 40;  // ... and only for levels with at most this many rows in the batch (MUCON_FUSE_MAXROWS)
 
 
 namespace {
@@ -62,23 +51,19 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
-int g_tn_target = 256;  // tuning hook: MUCON_TN_TARGET
-int g_tn_mc_cap = 2048;       // longest time chunk of a weight-gradient workgroup (MUCON_TN_MC_CAP)
 int g_first_conv_ksplit = 1;           // first_conv of small launches in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
 long g_first_conv_ksplit_rows = 6144;  // ... up to this many frames per launch (MUCON_FIRST_CONV_KSPLIT_ROWS; measured: 65 -> 47 us at 5,000, even at 8,000)
-int g_nt_split = 1;                    // ... and layer 0's dilated-conv data gradient (MUCON_NT_SPLIT)
+int g_first_conv_ws = 1;               // ... by the wave-specialised kernel (gemm_split_ws.hpp; MUCON_FIRST_CONV_WS=0: gemm_split.hpp, every wave loads, splits and multiplies)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
-int g_reduce_lanes = 4;        // slab lanes per workgroup of the slab reduction: 1/2/4/8/16 (MUCON_REDUCE_LANES)
-int g_tn_batch_target = 64;   // per job inside the batched launch (MUCON_TN_BATCH_TARGET): fewer, longer workgroups (r3: 128 -> 64 halves the layer jobs' slabs: the slab reduction 20 -> 12 us, the launch itself unchanged)
 int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
 int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; MUCON_FUSED_SPLIT=0: f32 MFMA)
 long g_fs_rows = 16384;       // ... from this many rows in the batch (MUCON_FUSED_SPLIT_ROWS)
 int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
 int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false) {
-    const int target = batched ? g_tn_batch_target : g_tn_target;
-    const int cap = split ? g_ts_mc_cap : g_tn_mc_cap;
+    const int target = batched ? kTnBatchTarget : kTnTarget;
+    const int cap = split ? g_ts_mc_cap : kTnMcCap;
     long want = ((long)B * Trows * kchunks + target - 1) / target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
@@ -203,47 +188,8 @@ static bool tail_chain_ok(const mucon_encoder_cfg *cfg, const Plan &pl, const mu
     if (!g_tail_chain || !cs_on() || L < 2) return false;
     for (int l = L - 2; l < L; ++l)
         if (cfg->pool_after[l] || cfg->dilation[l] < pl.Tl[l] || fs_level(cfg, pl, l) || !prm->dil_b[l] || !prm->pw_b[l]) return false;
-    return prm->last_b && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows;
+    return prm->last_b && (long)B * pl.Tl[L - 1] <= kFuseMaxRows;
 }
-
-// Second stream for the weight-gradient launches (they hang off the data-gradient chain and are not on its
-// critical path; the coarse levels leave most CUs idle).  Created on first use; MUCON_NO_OVERLAP=1 disables it.
-struct SideStream {
-    bool init = false, enabled = true;
-    hipStream_t s = nullptr;
-    hipEvent_t ev[2 * MUCON_MAX_LAYERS + 8];
-    int next = 0;
-    int ensure() {
-        if (init) return MUCON_OK;
-        const char *e = getenv("MUCON_NO_OVERLAP");
-        enabled = !(e && atoi(e) != 0);
-        if (enabled) {
-            HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            for (auto &x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-        }
-        init = true;
-        return MUCON_OK;
-    }
-    hipEvent_t fresh() {
-        hipEvent_t x = ev[next];
-        next = (next + 1) % (int)(sizeof(ev) / sizeof(ev[0]));
-        return x;
-    }
-    // side stream continues after everything enqueued so far on `from`
-    int fork(hipStream_t from) {
-        hipEvent_t x = fresh();
-        HIPCHK(hipEventRecord(x, from));
-        HIPCHK(hipStreamWaitEvent(s, x, 0));
-        return MUCON_OK;
-    }
-    // `to` continues after everything enqueued so far on the side stream
-    int join(hipStream_t to) {
-        hipEvent_t x = fresh();
-        HIPCHK(hipEventRecord(x, s));
-        HIPCHK(hipStreamWaitEvent(to, x, 0));
-        return MUCON_OK;
-    }
-} g_side;
 
 // Collects the slab reductions of one backward pass; run() sums them all in one launch.
 struct Reducer {
@@ -282,7 +228,7 @@ struct Reducer {
         // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
         // ... and a pass whose jobs have one or two slabs (a batch-1 step: every time chunk is the whole video) is a copy:
         // one wave per workgroup, no exchange
-        switch (rb.nblocks <= 128 ? 16 : (max_slabs <= 2 ? 1 : g_reduce_lanes)) {
+        switch (rb.nblocks <= 128 ? 16 : (max_slabs <= 2 ? 1 : kReduceLanes)) {
             case 1: hipLaunchKernelGGL(reduce_batch_kernel<1>, dim3(rb.nblocks), dim3(64), 0, stream, rb); break;
             case 2: hipLaunchKernelGGL(reduce_batch_kernel<2>, dim3(rb.nblocks), dim3(128), 0, stream, rb); break;
             case 4: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
@@ -365,7 +311,7 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     } else {
     if (prof_slot >= 0) prof_mark(prof_slot, false, s);
     // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
-    const bool ks2 = g_tn_ks == 2 || (g_tn_ks == 0 && dual);
+    const bool ks2 = kTnKs == 2 || (kTnKs == 0 && dual);
     if (dual) {
         if (ks2) HIPCHK((launch_tn<false, true, 2>(t, pl.B, s)));
         else HIPCHK((launch_tn<false, true, 1>(t, pl.B, s)));
@@ -457,26 +403,6 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_nt_force_bm = atoi(e);
         return true;
     }
-    if (!strcmp(name, "MUCON_FUSED_BM")) {
-        if (e) g_fused_bm = atoi(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TN_BATCH")) {
-        if (e) g_tn_batch = atoi(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TN_BATCH_KS")) {
-        if (e) g_tn_batch_ks = atoi(e) == 2 ? 2 : 1;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TN_MC_CAP")) {
-        if (e && atoi(e) >= 128) g_tn_mc_cap = atoi(e) / 32 * 32;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TN_BATCH_TARGET")) {
-        if (e && atoi(e) > 0) g_tn_batch_target = atoi(e);
-        return true;
-    }
     if (!strcmp(name, "MUCON_FUSED_SPLIT")) {
         g_fs = atoi(e) ? 1 : 0;
         return true;
@@ -489,28 +415,20 @@ static bool apply_knob(const char *name, const char *e) {
         g_cs = atoi(e) ? 1 : 0;
         return true;
     }
-    if (!strcmp(name, "MUCON_FUSED_SPLIT_NW")) {
-        g_fs_nw = (atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
-        return true;
-    }
     if (!strcmp(name, "MUCON_FUSED_SPLIT_ROWS")) {
         g_fs_rows = atol(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_XCD")) {
-        g_ts_xcd = atoi(e) ? 1 : 0;
         return true;
     }
     if (!strcmp(name, "MUCON_TN_SPLIT")) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
     }
-    if (!strcmp(name, "MUCON_TS_MC_CAP")) {
-        if (e && atoi(e) >= 128) g_ts_mc_cap = atoi(e) / 32 * 32;
+    if (!strcmp(name, "MUCON_FIRST_CONV_WS")) {
+        if (e) g_first_conv_ws = atoi(e) ? 1 : 0;
         return true;
     }
-    if (!strcmp(name, "MUCON_TN_KS")) {
-        if (e) g_tn_ks = atoi(e);
+    if (!strcmp(name, "MUCON_TS_MC_CAP")) {
+        if (e && atoi(e) >= 128) g_ts_mc_cap = atoi(e) / 32 * 32;
         return true;
     }
     if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT")) {
@@ -525,53 +443,21 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_first_conv_ksplit_rows = atol(e);
         return true;
     }
-    if (!strcmp(name, "MUCON_NT_SPLIT")) {
-        if (e) g_nt_split = atoi(e) ? 1 : 0;
-        return true;
-    }
     if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT_ROWS")) {
         if (e) g_first_conv_split_rows = atol(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_REDUCE_LANES")) {
-        if (e) g_reduce_lanes = atoi(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FIRST_CONV_8W")) {
-        if (e) g_first_conv_8w = atoi(e);
         return true;
     }
     if (!strcmp(name, "MUCON_NT_BM16_ROWS")) {
         if (e) g_nt_bm16_rows = atol(e);
         return true;
     }
-    if (!strcmp(name, "MUCON_POOL_FUSE")) {
-        if (e) g_pool_fuse = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_UNPOOL_FUSE")) {
-        if (e) g_no_unpool_fuse = atoi(e) ? 0 : 1;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FUSED_KS")) {
-        if (e) g_fused_ks = atoi(e) == 2 ? 2 : 1;
-        return true;
-    }
     if (!strcmp(name, "MUCON_FUSE")) {
         if (e) g_no_fuse = atoi(e) ? 0 : 1;
         return true;
     }
-    if (!strcmp(name, "MUCON_FUSE_MAXROWS")) {
-        if (e) g_fuse_max_rows = atol(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TN_TARGET")) {
-        if (e && atoi(e) > 0) g_tn_target = atoi(e);
-        return true;
-    }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_NW", "MUCON_TS_XCD", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_FUSED_BM", "MUCON_TN_BATCH", "MUCON_TN_BATCH_KS", "MUCON_TN_MC_CAP", "MUCON_TN_BATCH_TARGET", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_TN_KS", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_NT_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_REDUCE_LANES", "MUCON_FIRST_CONV_8W", "MUCON_NT_BM16_ROWS", "MUCON_POOL_FUSE", "MUCON_UNPOOL_FUSE", "MUCON_FUSED_KS", "MUCON_FUSE", "MUCON_FUSE_MAXROWS", "MUCON_TN_TARGET"};
+static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_FIRST_CONV_WS", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -691,7 +577,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     pa.first_w = prm->first_w;
     pa.first_planes = split_first ? reinterpret_cast<uint16_t *>(ws + pl.W0s) : nullptr;
     // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
-    const bool split_dgrad0 = g_nt_split && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
+    const bool split_dgrad0 = kNtSplitDgrad0 && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
     {   // ... and, in the SAME launch, the split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp
         // (a layer's images sit at its own slot): two launches were 8 + 7 us at the head of every forward pass
@@ -725,7 +611,8 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
         if (split_first) {
-            HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+            if (g_first_conv_ws) HIPCHK((launch_nt_ws<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+            else HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
         } else if (g_first_conv_ksplit && (long)B * pl.T <= g_first_conv_ksplit_rows && pl.D % 256 == 0 && prm->first_b) {
             // few rows: every workgroup would walk all D/32 k-tiles alone (64 dependent steps, 38 us at T = 2000).  Four k-chunks
             // in grid.z, partial sums in level-0 buffers that are idle during the forward, one ordered combine pass.
@@ -777,7 +664,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             tail_done = true;
             break;
         }
-        if (!g_no_fuse && (long)B * Tl <= g_fuse_max_rows) {
+        if (!g_no_fuse && (long)B * Tl <= kFuseMaxRows) {
             // one launch per residual layer: dilated_conv + non-linearity (temporal.py:48-49), then conv_1x1,
             // dropout, residual (:50-52) and the pooling of WaveNetBlock (:137-142); h crosses through LDS
             FusedParams f;
@@ -846,7 +733,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     if (!tail_done) {   // non-linearity + last_conv (temporal.py:144-145)
         const int Tz = pl.Tz;
-        if (cs_on() && prm->last_b && !g_no_fuse && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
+        if (cs_on() && prm->last_b && !g_no_fuse && (long)B * pl.Tl[L - 1] <= kFuseMaxRows) {
             FusedParams f;
             memset(&f, 0, sizeof(f));
             f.Trows = Tz;
@@ -898,16 +785,12 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     const int B = pl.B, L = pl.L, Tz = pl.Tz;
     DropCfg nodrop = make_drop(0, 0, 0.f, false);
 
-    rc = g_side.ensure();
-    if (rc != MUCON_OK) return rc;
-    const bool overlap = g_side.enabled;
-    hipStream_t sw = overlap ? g_side.s : s;   // stream of the weight-gradient launches
     Reducer red(s);
     size_t arena = 0, barena = 0;
     float *gz = ws + pl.gz;
     TnBatch tnb;
     tnb.njobs = 0;
-    TnBatch *batch = g_tn_batch ? &tnb : nullptr;   // queue the layer weight gradients for one launch after the chain
+    TnBatch *batch = &tnb;   // every weight gradient of the pass is queued for ONE launch after the data-gradient chain
 
     {   // GroupNorm / ReLU / Dropout backward -> dz
         GnBwdArgs g;
@@ -946,8 +829,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     bool have_dpre = false;  // dpre[l] already produced by the previous (fused) launch
     bool tail_chained = false;  // ... and so are g[L-1] and dpre[L-2]: layer L-1's data gradient ran inside the chained launch
     bool unpooled_by_producer = false;  // dyd[l] (un-pooled gradient) already written by the launch that produced g[l+1]
-    {   // last_conv backward: weight gradient queued (or on the side stream), data gradient on the chain
-        if (!batch && overlap && (rc = g_side.fork(s)) != MUCON_OK) return rc;
+    {   // last_conv backward: weight gradient queued, data gradient on the chain
         WgradArgs a;
         memset(&a, 0, sizeof(a));
         a.Y0 = gz;
@@ -961,7 +843,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.out_w0 = gr->last_w;
         a.out_b0 = gr->last_b;
         a.drop = nodrop;
-        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, sw, -1, batch);
+        rc = wgrad(pl, ws, arena, barena, Tz, a, slope, red, s, -1, batch);
         if (rc != MUCON_OK) return rc;
         if (tail_chain_ok(cfg, pl, prm, B)) {
             // last_conv's and layer L-1's data gradients (both row-local) as ONE launch: g[L], dpre[L-1], g[L-1], dpre[L-2]
@@ -986,7 +868,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             HIPCHK(launch_ct<true>(c, B, s));
             have_dpre = true;
             tail_chained = true;
-        } else if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= g_fuse_max_rows) {
+        } else if (!g_no_fuse && !cfg->pool_after[L - 1] && (long)B * pl.Tl[L - 1] <= kFuseMaxRows) {
             FusedParams f;
             memset(&f, 0, sizeof(f));
             f.Trows = Tz;
@@ -1035,11 +917,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             p.drop = dl;
             HIPCHK((launch_nt<false, true, false, false, false, true, 0>(p, B, s)));
         }
-        {   // all four parameter gradients of the layer in one launch -- off the critical path (second stream) at the
-            // coarse levels, where neither this launch nor the data-gradient chain fills the chip; at the fine
-            // levels both do, and running them side by side only makes them thrash
-            const bool side = !batch && overlap && (long)B * Tl < 512L * 64;
-            if (side && (rc = g_side.fork(s)) != MUCON_OK) return rc;
+        {   // all four parameter gradients of the layer: one job of the batched launch
             WgradArgs a;
             memset(&a, 0, sizeof(a));
             a.Y0 = dpre;
@@ -1058,7 +936,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             a.out_w1 = gr->pw_w[l];
             a.out_b1 = gr->pw_b[l];
             a.drop = dl;
-            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, side ? sw : s, -1, batch);
+            rc = wgrad(pl, ws, arena, barena, Tl, a, slope, red, s, -1, batch);
             if (rc != MUCON_OK) return rc;
         }
         if (tail_chained && l == L - 1) {
@@ -1067,7 +945,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             const bool centre_only = cfg->dilation[l] >= Tl;
             const float *W1b = ws + pl.W1b + (size_t)l * 49152 + (centre_only ? 128 : 0);
             have_dpre = false;
-            if (!g_no_fuse && l >= 1 && !cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= g_fuse_max_rows) {
+            if (!g_no_fuse && l >= 1 && !cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= kFuseMaxRows) {
                 FusedParams f;
                 memset(&f, 0, sizeof(f));
                 f.Trows = Tl;
@@ -1086,7 +964,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                     else HIPCHK((launch_cs<true, 0, 3>(f, w1, w2, B, s)));
                 } else HIPCHK((launch_fused<true, 0>(f, B, s)));
                 have_dpre = true;
-            } else if (!g_no_fuse && g_pool_fuse && l >= 1 && cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= g_fuse_max_rows) {
+            } else if (!g_no_fuse && kPoolFuse && l >= 1 && cfg->pool_after[l - 1] && (long)B * pl.Tl[l] <= kFuseMaxRows) {
                 // pooled boundary: dilated-conv data gradient on this (coarse) level, max-pool backward in its epilogue,
                 // layer l-1's conv_1x1 backward on the 2 x rows of the finer level -- one launch instead of two
                 FusedParams f;
@@ -1124,7 +1002,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                 p.ldw = 384;
                 p.res = dyd;
                 p.mask = (l == 0) ? ws + pl.x[0] : nullptr;  // through first_conv's non-linearity
-                if (l >= 1 && cfg->pool_after[l - 1] && !g_no_unpool_fuse) {
+                if (l >= 1 && cfg->pool_after[l - 1] && kUnpoolFuse) {
                     // layer l-1 was pooled: this launch's epilogue scatters the gradient straight onto the un-pooled
                     // rows of level l-1 (the max-pool backward), instead of a separate pass over that level
                     p.out = ws + pl.dyd[l - 1];
@@ -1163,7 +1041,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                     const uint16_t *w1 = fs_img(ws, pl, 0, 1) + (centre_only ? 4 * FS_WSTEP : 0);
                     if (centre_only) HIPCHK((launch_cs<true, 0, 1, true>(f, w1, nullptr, B, s)));
                     else HIPCHK((launch_cs<true, 0, 3, true>(f, w1, nullptr, B, s)));
-                } else if (l == 0 && !centre_only && g_nt_split && (long)B * Tl >= g_first_conv_split_rows) {
+                } else if (l == 0 && !centre_only && kNtSplitDgrad0 && (long)B * Tl >= g_first_conv_split_rows) {
                     // bf16 MFMA on exactly split operands (gemm_split.hpp); the W1b image was written by the forward's pack_weights
                     HIPCHK((launch_nt_split<false, true, true, true>(p, reinterpret_cast<const uint16_t *>(ws + pl.Wd0s), B, s)));
                 } else {
@@ -1172,7 +1050,6 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
-    if (batch && g_tn_batch < 2) HIPCHK(g_tn_split ? launch_ts_batch(tnb, s) : launch_tn_batch(tnb, s));   // every layer's weight gradients: one launch, fine levels first
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
@@ -1186,15 +1063,14 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         a.out_w0 = gr->first_w;
         a.out_b0 = gr->first_b;
         a.drop = nodrop;
-        rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1, g_tn_batch >= 2 ? batch : nullptr);
+        rc = wgrad(pl, ws, arena, barena, pl.T, a, slope, red, s, 1, batch);
         if (rc != MUCON_OK) return rc;
     }
-    if (batch && g_tn_batch >= 2) {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
+    {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
         prof_mark(1, false, s);
         HIPCHK(g_tn_split ? launch_ts_batch(tnb, s) : launch_tn_batch(tnb, s));
         prof_mark(1, true, s);
     }
-    if (!batch && overlap && (rc = g_side.join(s)) != MUCON_OK) return rc;
     HIPCHK(red.run());
     return MUCON_OK;
 }
@@ -1583,7 +1459,10 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
     hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
     HIPCHK(hipGetLastError());
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
-    auto go = [&]() { return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s); };
+    auto go = [&]() {
+        if (g_first_conv_ws) return relu ? launch_nt_ws<true>(p, P, B, s) : launch_nt_ws<false>(p, P, B, s);
+        return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s);
+    };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

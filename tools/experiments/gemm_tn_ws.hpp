@@ -364,7 +364,6 @@ __global__ __launch_bounds__(256 + 64 * NS) void tw_batched_kernel(const TnBatch
     else tw_body<false, false, NS>(job.p, kc, mc, job.dual != 0, tw_smem);
 }
 
-extern int g_ts_xcd;   // XCD-aware block order of the batched launch (MUCON_TS_XCD)
 #ifndef TW_NS
 #define TW_NS 8
 #endif
@@ -390,10 +389,10 @@ static hipError_t launch_tw_batch(TnBatch &tb, hipStream_t s) {
         lb.j[i].block0 = blocks;
         lb.j[i].nmc = src.block0;                     // block0 carried the time-chunk count while queued
         blocks += src.nkc * src.block0;
-        if (g_ts_xcd) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
+        if (kTsXcdOrder) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
     }
     lb.nblocks = blocks;
-    lb.xcd_order = g_ts_xcd;
+    lb.xcd_order = kTsXcdOrder;
     hipLaunchKernelGGL(tw_batched_kernel<TW_NS>, dim3(blocks), dim3(256 + 64 * TW_NS), TW_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();

@@ -18,8 +18,6 @@
 #else
 #define LAUNCH launch_ts_batch
 #endif
-int g_tn_batch_ks = 2;
-int g_ts_xcd = 1;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -31,7 +29,6 @@ __global__ void fill(float *p, long n, uint32_t seed) {
 int main(int argc, char **argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32768, K = argc > 2 ? atoi(argv[2]) : 2048;
     const int MC = argc > 3 ? atoi(argv[3]) : 2048, iters = argc > 4 ? atoi(argv[4]) : 20;
-    if (argc > 5) g_ts_xcd = atoi(argv[5]);
     float *Y, *X, *slabs, *bslabs;
     const int nmc = (M + MC - 1) / MC;
     CK(hipMalloc(&Y, (size_t)M * 128 * 4));
@@ -124,6 +121,6 @@ int main(int argc, char **argv) {
     }
 #endif
     printf("TS_ABL=%d xcd=%d M=%d K=%d MC=%d: %d workgroups x %d tiles: %.1f us per launch, %.1f TFLOP/s fp32-equivalent, %.2f us per tile\n",
-           TS_ABL, g_ts_xcd, M, K, MC, wgs, MC / 32, us, flop / us * 1e-6, us / (MC / 32) / ((wgs + 255) / 256));
+           TS_ABL, kTsXcdOrder, M, K, MC, wgs, MC / 32, us, flop / us * 1e-6, us / (MC / 32) / ((wgs + 255) / 256));
     return 0;
 }
