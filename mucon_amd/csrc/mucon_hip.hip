@@ -18,7 +18,6 @@
 #include "gemm_fused.hpp"
 #include "gemm_tn.hpp"
 #include "gemm_split.hpp"
-#include "gemm_split_ws.hpp"
 #include "gemm_tn_split.hpp"
 #include "gemm_fused_split.hpp"
 #include "gemm_coarse_split.hpp"
@@ -53,7 +52,6 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
 int g_first_conv_ksplit = 1;           // first_conv of small launches in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
 long g_first_conv_ksplit_rows = 6144;  // ... up to this many frames per launch (MUCON_FIRST_CONV_KSPLIT_ROWS; measured: 65 -> 47 us at 5,000, even at 8,000)
-int g_first_conv_ws = 1;               // ... by the wave-specialised kernel (gemm_split_ws.hpp; MUCON_FIRST_CONV_WS=0: gemm_split.hpp, every wave loads, splits and multiplies)
 int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
@@ -423,10 +421,6 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
     }
-    if (!strcmp(name, "MUCON_FIRST_CONV_WS")) {
-        if (e) g_first_conv_ws = atoi(e) ? 1 : 0;
-        return true;
-    }
     if (!strcmp(name, "MUCON_TS_MC_CAP")) {
         if (e && atoi(e) >= 128) g_ts_mc_cap = atoi(e) / 32 * 32;
         return true;
@@ -457,7 +451,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_FIRST_CONV_WS", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -611,8 +605,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                              ws + pl.x[0], slope);
         prof_mark(0, false, s);
         if (split_first) {
-            if (g_first_conv_ws) HIPCHK((launch_nt_ws<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
-            else HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
+            HIPCHK((launch_nt_split<true>(p, reinterpret_cast<const uint16_t *>(ws + pl.W0s), B, s)));
         } else if (g_first_conv_ksplit && (long)B * pl.T <= g_first_conv_ksplit_rows && pl.D % 256 == 0 && prm->first_b) {
             // few rows: every workgroup would walk all D/32 k-tiles alone (64 dependent steps, 38 us at T = 2000).  Four k-chunks
             // in grid.z, partial sums in level-0 buffers that are idle during the forward, one ordered combine pass.
@@ -1459,10 +1452,7 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
     hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
     HIPCHK(hipGetLastError());
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
-    auto go = [&]() {
-        if (g_first_conv_ws) return relu ? launch_nt_ws<true>(p, P, B, s) : launch_nt_ws<false>(p, P, B, s);
-        return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s);
-    };
+    auto go = [&]() { return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s); };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

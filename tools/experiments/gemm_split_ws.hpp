@@ -1,3 +1,10 @@
+// EXPERIMENT (round 3), not part of the product: measured against gemm_split.hpp's kernel and left out -- DESIGN.md "What did not pay".
+// Correct (tests/test_gpu_split.py while it was wired in), but 112-115 us per launch against 91: with the tape ALSO going through LDS
+// (staged by dedicated waves) the four multiplier waves read 60 fragments per 32-deep tile each; reads (960 LDS cycles) + the stagers'
+// stores (600) fill the LDS pipe for longer than the tile's 1,536 MFMA cycles -- in-kernel stamps: stagers 2,900 cycles per tile,
+// multipliers 2,050 + 1,000 waiting, whatever the prefetch depth.  The product kernel keeps the tape in registers (each element
+// belongs to one wave) and sends only the weight image through LDS: that asymmetry is what the exact split needs (three planes per
+// operand = three times a plain bf16 GEMM's LDS traffic per MFMA).
 // first_conv forward (temporal.py:133: relu(W x + b), 2048 -> 128 channels over every frame of the tape) on the bf16 MFMA with
 // exactly split fp32 operands -- the arithmetic of gemm_split.hpp (x = hi + mid + lo, six of the nine partial products, fp32
 // accumulate) -- WAVE-SPECIALISED.
@@ -16,10 +23,11 @@
 // The matrix pipe and the vector pipe of a SIMD are separate; the stager's ~120 instructions per tile run in the gaps of its
 // partner's 48 MFMAs (1,536 cycles).  One barrier per 32-deep tile keeps the roles in step.
 #pragma once
+#include <stdio.h>
 #include <type_traits>
 
-#include "common.hpp"
-#include "gemm_nt.hpp"
+#include "../../mucon_amd/csrc/common.hpp"
+#include "../../mucon_amd/csrc/gemm_nt.hpp"
 
 constexpr int SW_ABLK = 128 * 8 + 16;                  // bf16 elements of one (step, plane, half) block of the A image: 128 frames x 8
                                                        // slots, + 32 B (the eight blocks a wave's stores hit land on different banks)
@@ -43,6 +51,15 @@ __global__ __launch_bounds__(512) void nt_ws_kernel(const NtParams p, const uint
     const int t0 = blockIdx.x * 128;
     const int ntiles = p.Kc >> 5;                      // 32-deep tiles (Kc is a multiple of 128)
     const int last = ntiles - 1;
+#if SW_STAMP
+    long long st_work = 0, st_wait = 0, st_prev = __builtin_amdgcn_s_memtime();
+    const long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#define SW_TS(acc) do { const long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - st_prev; st_prev = t_; } while (0)
+#define SW_REPORT(role) do { if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0) printf("nt_ws wave %d (" role "): cycles per tile: work %lld  barrier wait %lld  | %lld tiles, %.2f GHz\n", wave, st_work / ntiles, st_wait / ntiles, (long long)ntiles, (double)(st_work + st_wait) / ((double)(__builtin_amdgcn_s_memrealtime() - st_r0) * 10.0)); } while (0)
+#else
+#define SW_TS(acc) do { } while (0)
+#define SW_REPORT(role) do { } while (0)
+#endif
 
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------------------ stagers
@@ -59,10 +76,11 @@ __global__ __launch_bounds__(512) void nt_ws_kernel(const NtParams p, const uint
             a_dst[i] = (uint32_t)(((s * 3) * 2 + h) * SW_ABLK + row * 8 + 4 * half);
         }
         const uint16_t *w_src = Wimg + st * 8;
-        f32x4 ra[2][4];
-        u32x4 rw[2][6];
+        f32x4 ra[3][4];     // three register sets: a tile's loads are issued three intervals before it is split (one interval is
+        u32x4 rw[3][6];     // shorter than an HBM round trip under load: with two sets the stagers' period WAS that round trip)
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
         auto gload = [&](int tile, auto SET) {
             constexpr int Q = decltype(SET)::value;
 #pragma unroll
@@ -86,24 +104,38 @@ __global__ __launch_bounds__(512) void nt_ws_kernel(const NtParams p, const uint
 #pragma unroll
             for (int q = 0; q < 6; ++q) *reinterpret_cast<u32x4 *>(img + SW_AIMG + st * 8 + q * 2048) = rw[Q][q];
         };
-        // prologue: tiles 0 and 1 staged, tile 2 in flight
+        // prologue: tiles 0 and 1 staged; tiles 2, 3, 4 in flight (sets 2, 0, 1)
         gload(0, I0{});
         gload(min(1, last), I1{});
+        gload(min(2, last), I2{});
         stage(0, I0{});
-        gload(min(2, last), I0{});
+        gload(min(3, last), I0{});
         if (ntiles > 1) stage(1, I1{});
+        gload(min(4, last), I1{});
         __syncthreads();
-        // interval mt: the multipliers are on tile mt (and fetch the head of tile mt + 1); tile mt + 2 is written, tile mt + 3 requested
-        for (int mt = 0; mt < ntiles; mt += 2) {
-            gload(min(mt + 3, last), I1{});
-            if (mt + 2 < ntiles) stage(mt + 2, I0{});
+        // interval mt: the multipliers are on tile mt (and fetch the head of tile mt + 1); tile mt + 2 is written, tile mt + 5 requested
+        for (int mt = 0; mt < ntiles; mt += 3) {
+            if (mt + 2 < ntiles) stage(mt + 2, I2{});
+            gload(min(mt + 5, last), I2{});
+            SW_TS(st_work);
             __syncthreads();
+            SW_TS(st_wait);
             if (mt + 1 < ntiles) {
-                gload(min(mt + 4, last), I0{});
-                if (mt + 3 < ntiles) stage(mt + 3, I1{});
+                if (mt + 3 < ntiles) stage(mt + 3, I0{});
+                gload(min(mt + 6, last), I0{});
+                SW_TS(st_work);
                 __syncthreads();
+                SW_TS(st_wait);
+            }
+            if (mt + 2 < ntiles) {
+                if (mt + 4 < ntiles) stage(mt + 4, I1{});
+                gload(min(mt + 7, last), I1{});
+                SW_TS(st_work);
+                __syncthreads();
+                SW_TS(st_wait);
             }
         }
+        SW_REPORT("stager");
         return;
     }
 
@@ -177,8 +209,11 @@ __global__ __launch_bounds__(512) void nt_ws_kernel(const NtParams p, const uint
         __builtin_amdgcn_sched_barrier(0);
         mm(acc[3], A1, W3);
         __builtin_amdgcn_sched_barrier(0);
+        SW_TS(st_work);
         __builtin_amdgcn_s_barrier();   // no fence: the reads in flight are of tile mt + 1, which nobody writes before the next barrier
+        SW_TS(st_wait);
     }
+    SW_REPORT("multiplier");
     // epilogue: bias, non-linearity, store (C layout: column = lane & 31, row of register e = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
     const long vbase = (long)b * p.Trows;
     const bool full = t0 + 128 <= p.Trows;
