@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun):  bash tools/profile_round.sh r02
+# Run ON THE GPU BOX (through gpurun):  bash tools/profile_round.sh r03
 # Produces the rocprofv3 summaries that profiles/ keeps for this round: kernel-trace stats of the default
 # bench command, and two PMC passes (FETCH_SIZE, WRITE_SIZE) of a short bench run.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 rm -rf $OUT && mkdir -p $OUT

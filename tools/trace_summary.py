@@ -6,14 +6,14 @@ f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 hp = [r for r in rows if 'viterbi' not in r['Kernel_Name']]
-# a hot-path bench step starts at a pack_weights launch followed by the first conv of a B > 1 batch (grid y = B);
+# a hot-path bench step starts at the weight re-layout launch (pack_all_kernel; pack_weights before r3) followed by the first conv of a B > 1 batch (grid y = B);
 # bench.py's end-to-end leg (batch 1) is summarised separately by tools/e2e_trace_summary.py
 def first_conv_after(i):      # the launch behind the weight re-packing (pack_weights, fs_pack)
     j = i + 1
     while j < len(hp) and 'pack' in hp[j]['Kernel_Name']:
         j += 1
     return hp[j] if j < len(hp) else None
-idx = [i for i, r in enumerate(hp) if 'pack_weights' in r['Kernel_Name'] and first_conv_after(i) is not None
+idx = [i for i, r in enumerate(hp) if ('pack_all' in r['Kernel_Name'] or 'pack_weights' in r['Kernel_Name']) and first_conv_after(i) is not None
        and int(first_conv_after(i)['Grid_Size_Y']) > 1]
 def wall(a, b):
     return max(int(r['End_Timestamp']) for r in hp[a:b]) - int(hp[a]['Start_Timestamp'])
