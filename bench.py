@@ -211,7 +211,7 @@ def viterbi_bench(dev, C=48):
     out["cpu_oracle_ms_per_video"] = round(best * 1e3, 3)
     out["cpu_oracle_all_cores_ms_per_video"] = round(_cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, 4 * cores, cores), 4)
     out["config"] = (f"ms_per_video_single/batch64/batch256 and cpu_oracle_*: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
-                     f"(K=546 columns, 64x66 hypotheses); every GPU timing includes the upload of the job table and the result D2H; "
+                     f"(K=546 columns, 64x66 hypotheses); every GPU timing is the whole ops.viterbi_decode_batch call: job table / transcripts / length tables read by the kernels from pinned host memory, results written there (no copy calls); "
                      f"cpu_oracle_all_cores_*: {cores} threads, one video each, {cores} physical cores")
     out["algorithmic_bytes_per_video"] = T * C * 4 + T * 4
     out["algorithmic_bytes_per_video_T2000_N6"] = bytes_small

@@ -22,6 +22,7 @@ constexpr int kReduceLanes = 4;         // slab lanes per workgroup of the batch
 constexpr int kFirstConv8w = 1;         // first_conv forward on the f32 MFMA: 128-row tiles with 8 waves (0.160 -> 0.153 ms)
 constexpr int kFusedBm = 0;             // f32 two-stage kernel: 0 = tile height by level size
 constexpr int kFusedKs = 1;             // ... without the in-workgroup k-split (measured: not faster; changes the summation order)
+constexpr int kCsRb2Workgroups = 256;   // coarse kernel: 32 rows per workgroup where 16-row workgroups would number more than this (one per CU)
 constexpr int kFsNw = 0;                // split two-stage kernel: 0 = 8 waves where that gives >= 256 workgroups, else 4
 constexpr long kFuseMaxRows = 1L << 40; // the two-stage kernels take every level (no row limit)
 constexpr int kNtSplitDgrad0 = 1;       // layer 0's dilated-conv data gradient on gemm_split.hpp (50.6 -> 39.8 us)

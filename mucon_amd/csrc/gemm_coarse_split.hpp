@@ -306,13 +306,15 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
         }
 }
 
-// Rows per workgroup: 16.  (32 -- two row blocks sharing every weight fragment, half the L2 -> register weight traffic -- is
-// built and tested, MUCON_COARSE_RB=2, and measured slower at every level: 0.832 vs 0.802 ms per step at B=8 x T=4096, 1.17 vs
-// 1.11 ms per video at batch 1.  What a launch costs is the latency of its chain, not the weight bytes.)
-extern int g_cs_rb;   // 0 / 1 = 16 rows, 2 = 32 rows (MUCON_COARSE_RB)
+// Rows per workgroup: 16, or 32 (two row blocks sharing every weight fragment in registers: half the L2 -> register weight traffic per
+// row) where 16-row workgroups would be MORE than one per CU.  r2 measured 32 rows at every level: slower (0.832 vs 0.802 ms per step;
+// at <= 256 workgroups a launch costs the latency of its chain, not its weight bytes).  r3: at B = 8 x T = 4096 the T/4 level is 512
+// workgroups of 16 rows, two per CU, and IS bound by the 786 KB of fragments its CU streams (15-21 us per launch against 9.6 at T/8):
+// 32 rows there and 16 elsewhere is -11.5 us per step (0.7855 -> 0.774 ms, same box, twice).
+extern int g_cs_rb;   // 0 = by level size (above), 1 = 16 rows, 2 = 32 rows (MUCON_COARSE_RB; tests force both)
 template <bool BWD, int POOL, int TAPS, bool ONE = false, bool PRO_ACT = false>
 static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
-    const int rb = g_cs_rb == 2 ? 2 : 1;
+    const int rb = g_cs_rb ? g_cs_rb : ((long)B * ((p.Trows + 15) / 16) > kCsRb2Workgroups ? 2 : 1);
     if (rb == 2) {
         dim3 grid((p.Trows + 31) / 32, B);
         hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img);

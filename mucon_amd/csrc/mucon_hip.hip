@@ -56,7 +56,9 @@ int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, o
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
 int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; MUCON_FUSED_SPLIT=0: f32 MFMA)
-long g_fs_rows = 16384;       // ... from this many rows in the batch (MUCON_FUSED_SPLIT_ROWS)
+long g_fs_rows = 32768;       // ... from this many rows in the batch = one 128-row workgroup per CU (MUCON_FUSED_SPLIT_ROWS).  r3: 16,384 -> 32,768: at
+                              // B = 8 x T = 4096 the T/2 level (16,384 rows: 256 workgroups of 64 rows on the 4-wave variant) is 3.7 us per step
+                              // faster on the coarse kernel's 32-row workgroups (512 of them, two per CU)
 int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
 int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
 inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false) {

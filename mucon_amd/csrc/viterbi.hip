@@ -1108,7 +1108,7 @@ int vh_grow(char **buf, size_t *cap, size_t need, bool pinned) {
     *buf = nullptr;
     *cap = 0;
     const size_t want = need + need / 2 + 4096;
-    const hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void **>(buf), want, hipHostMallocMapped | hipHostMallocPortable)
+    const hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void **>(buf), want, hipHostMallocMapped | hipHostMallocCoherent)   // fine-grained: the kernels' stores (results, completion flag) are visible to the host while the launch runs
                                 : hipMalloc(reinterpret_cast<void **>(buf), want);
     if (e != hipSuccess) return MUCON_E_HIP;
     *cap = want;
