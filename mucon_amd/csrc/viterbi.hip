@@ -32,6 +32,21 @@
 
 namespace {
 
+#ifndef VIT_STAMP
+#define VIT_STAMP 0
+#endif
+#if VIT_STAMP   // timing builds (MUCON_HIPCC_FLAGS=-DVIT_STAMP=1, tools/vit_stamps.py): s_memtime of thread 0 of block 0 at the phase edges
+__device__ long long g_vit_stamps[16];
+#define VSTAMP(i)                                                                    \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_vit_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define VSTAMP(i) \
+    do {          \
+    } while (0)
+#endif
+
 constexpr int VIT_THREADS = 1024;
 constexpr int VIT_FCHUNK = 16;  // columns of frame scores staged in LDS at a time
 
@@ -146,12 +161,22 @@ constexpr int FSC_STAGE = FSC_THREADS - 64;  // staging threads
 constexpr int FSC_NPER = 10;                 // tiles per staging wave per chunk: ceil(16 row blocks x 4 float4 blocks / 7)
 constexpr int FSC_MAX_LDS = 160 * 1024;
 constexpr int FSC_DEPTH = 8;                 // b128 reads in flight
+constexpr int FSC_SETS = 3;                  // register sets of staged global loads (chunks in flight)
 constexpr size_t VF_DYN_MAX = 160 * 1024 - 24 * 1024;   // dynamic LDS of the one-launch kernel: 160 KiB minus the DP's static arrays
+constexpr size_t VL_BP_LDS_MAX = 96 * 1024;             // dynamic LDS of the register DP kernels: back-pointers [K][N] of a latency call
 constexpr int FSC_SLACK = 8 * FSC_DEPTH;     // rows the read-ahead and the last round may run past a chunk's end
 __host__ __device__ inline int fsc_pitch(int rows) { return ((rows + FSC_SLACK + 15) & ~15) + 4; }   // = 4 mod 16, in floats
 __host__ __device__ inline int fsc_floats(int C, int fs, int cols) {                                 // dynamic LDS, in floats
     const int nq = (fs + 3) >> 2;
     return 2 * C * fsc_pitch(cols * nq * 4) + 2 * (cols * nq + FSC_DEPTH) * 64;
+}
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- in
+// the staging waves that is the read-ahead just issued (one HBM latency per chunk: what paced the chain until r3), in the chain
+// wave of the one-launch kernel the length scores on their way from pinned host memory.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 template <bool W4>   // the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column
 __device__ __forceinline__ void framescore_cols_body(const float *lp_video, float *F, const int K, const int C, const int fs, const int cols,
@@ -166,15 +191,20 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
     const int C4 = C >> 2;
     const int chunk4 = cols * fs * C4;            // float4 per chunk in memory (contiguous: whole columns)
     const int nchunks = (K + cols - 1) / cols;
-    {
+    const int nch3 = (nchunks + FSC_SETS - 1) / FSC_SETS * FSC_SETS;
+    // the padding rows of both buffers: -0.0f (every thread its share)
+    VSTAMP(12);
+    auto zero_fill = [&]() {
         vit_f32x4 *z = reinterpret_cast<vit_f32x4 *>(fs_smem);
         for (int i = tid; i < bufsz / 2; i += FSC_THREADS) z[i] = vit_f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
-    }
-    __syncthreads();
+    };
     if (tid >= 64) {
         // ---- waves 1..7: staging and the column differences ----
         const int j = tid - 64;
-        const vit_f32x4 *src4 = reinterpret_cast<const vit_f32x4 *>(lp_video);
+        // (global address space spelled out: through the generic pointer of the job record these were FLAT loads, which count
+        // against the LDS wait counter as well -- every LDS wait of the staging waves then waited for the read-ahead)
+        typedef const __attribute__((address_space(1))) vit_f32x4 *gptr4;
+        const gptr4 src4 = (gptr4)(reinterpret_cast<const vit_f32x4 *>(lp_video));
         const int total4 = K * fs * C4;               // < 2^31: T * C / 4
         const unsigned inv_fs = (1u << 20) / fs + 1;  // x / fs == (x * inv_fs) >> 20 for x < 4096
         // One wave instruction moves a tile of 16 rows x 4 float4 (lane = 4 * row + float4): the global load reads 64
@@ -183,25 +213,28 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
         // twelve float4 of a row land on two banks, and the conflicts stall the chain's own reads.
         const int wv = j >> 6, l = j & 63;
         const int ncb = (C4 + 3) >> 2;                // tiles across the classes
+        const int inv_ncb = 65536 / ncb + 1;
         int dsto[FSC_NPER], srco[FSC_NPER];           // LDS word / chunk-relative float4 of this thread's u-th element; -1 = none
 #pragma unroll
         for (int u = 0; u < FSC_NPER; ++u) {
-            const int t = u * (FSC_STAGE / 64) + wv;
-            const int rb = t / ncb, cb = t - rb * ncb;
+            const int t = u * (FSC_STAGE / 64) + wv;                       // < 70
+            const int rb = (t * inv_ncb) >> 16, cb = t - rb * ncb;         // t / ncb (ncb <= 4: exact); a division is ~30 instructions,
+                                                                          // and this set-up is in front of the first load
             const int row = rb * 16 + (l >> 2), c4 = cb * 4 + (l & 3);
             const int col = (int)(((unsigned)row * inv_fs) >> 20);
             const bool on = row < cols * fs && c4 < C4;
             dsto[u] = on ? 4 * c4 * pitch + row + col * (P - fs) : -1;
             srco[u] = row * C4 + c4;
         }
-        vit_f32x4 r[FSC_NPER];
-        auto gload = [&](int ci) {
+        // Three register sets: the loads of chunk ci + 3 are issued when chunk ci's set has been stored, so a load has three
+        // chunk times (3 x ~0.7 us of chain) to return -- with one set the chain ran at one HBM latency (~1.4 us) per chunk.
+        vit_f32x4 rs[FSC_SETS][FSC_NPER];
+        auto gload = [&](int ci, vit_f32x4 (&r)[FSC_NPER]) {
             const int base4 = ci * chunk4;
 #pragma unroll
-            for (int u = 0; u < FSC_NPER; ++u)
-                if (dsto[u] >= 0) r[u] = src4[min(base4 + srco[u], total4 - 1)];
+            for (int u = 0; u < FSC_NPER; ++u) r[u] = src4[min(base4 + srco[u], total4 - 1)];   // (unconditional: the clamp keeps idle threads inside the video, and a branch per load serialises them)
         };
-        auto sstore = [&](int ci) {
+        auto sstore = [&](int ci, const vit_f32x4 (&r)[FSC_NPER]) {
             float *dst = fs_smem + (ci & 1) * bufsz;
             const int left4 = total4 - ci * chunk4;   // the last chunk may be short: keep the clamped re-loads out
 #pragma unroll
@@ -232,54 +265,89 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
             }
             if (j < 64) carry = rn[(cols * nq - 1) * 64 + j];   // (a short last chunk has no successor)
         };
-        gload(0);
-        sstore(0);
-        if (nchunks > 1) gload(1);
-        __syncthreads();
-        for (int ci = 0; ci < nchunks; ++ci) {
-            if (ci + 1 < nchunks) sstore(ci + 1);
-            if (ci + 2 < nchunks) gload(ci + 2);
-            if (ci > 0) diffs(ci - 1);
-            __syncthreads();
+        // Every load below is issued on every path (past the video's end the clamp re-reads its last float4): the wait in front of a
+        // set's stores counts the loads issued after it, and LLVM takes the smallest count over all paths that reach it.  For the
+        // same reason both sides run the chunk loop to a multiple of three (the extra rounds find nothing to do).
+        gload(0, rs[0]);
+        gload(1, rs[1]);
+        gload(2, rs[2]);
+        zero_fill();                                  // (behind the first loads: they are in flight meanwhile)
+        lds_barrier();
+        sstore(0, rs[0]);
+        gload(3, rs[0]);
+        lds_barrier();
+        for (int c0 = 0; c0 < nch3; c0 += FSC_SETS) {
+#pragma unroll
+            for (int u3 = 0; u3 < FSC_SETS; ++u3) {      // chunk ci + 1 lives in set (ci + 1) % 3 = (u3 + 1) % 3
+                const int ci = c0 + u3;
+                vit_f32x4(&r)[FSC_NPER] = rs[(u3 + 1) % FSC_SETS];
+                sstore(ci + 1, r);                        // (behind the last chunk: left4 <= 0, nothing is stored)
+                gload(ci + 1 + FSC_SETS, r);
+                if (ci > 0) diffs(ci - 1);
+                lds_barrier();
+            }
         }
-        diffs(nchunks - 1);
+        if (nch3 == nchunks) diffs(nchunks - 1);
         return;
     }
     // ---- wave 0: the chain ----
     const int lane_c = tid < C ? tid : C - 1;
     float run = -0.0f;
+    zero_fill();
+    lds_barrier();
+    VSTAMP(13);
     __builtin_amdgcn_s_setprio(3);                 // the chain goes first on the SIMD it shares with a staging wave
-    __syncthreads();
-    for (int ci = 0; ci < nchunks; ++ci) {
+    lds_barrier();
+    VSTAMP(14);
+    for (int ci = 0; ci < nch3; ++ci) {
         const vit_f32x4 *q = reinterpret_cast<const vit_f32x4 *>(fs_smem + (ci & 1) * bufsz + lane_c * pitch);
         float *w = runs + (ci & 1) * runsz + tid;
         const int nquads = min(cols, K - ci * cols) * nq;
-        auto addq = [&](vit_f32x4 v, float *o, bool keep) {
-            run = run + v.x;                       // sequential float32 chain
-            run = run + v.y;
-            run = run + v.z;
-            run = run + v.w;
-            if (keep) *o = run;
-        };
+#if VIT_STAMP
+        const long long tl0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         // eight reads in flight (an LDS read that waves 1..7 are writing into takes ~150 cycles to return, a read's four adds
-        // ~27); the sched_barriers keep each re-load right behind the adds that free its registers.  The last round may add up
-        // to seven reads too many: their sums land in the slack of `runs` and `run` is restored from the last real one.
+        // ~27); the sched_barriers keep each re-load right behind the adds that free its registers (placing the re-load BETWEEN the
+        // dependent adds was measured: 16.4 instead of 11.5 cycles per row -- back-to-back dependent adds are the fast path).  The last
+        // round may add up to seven reads too many: their sums land in the slack of `runs`, `run` is restored from the last real one.
         vit_f32x4 qr[FSC_DEPTH];
+        // (issued in the loop's own order: the wait counter is in-order, and the count LLVM puts in front of read u's adds is the
+        // smaller of what the prologue and the loop edge allow -- with the prologue's reads reordered it waited for a read issued
+        // three groups earlier instead of eight: 11.8 instead of 7.5 cycles per row)
 #pragma unroll
-        for (int u = 0; u < FSC_DEPTH; ++u) qr[u] = q[u];
+        for (int u = 0; u < FSC_DEPTH; ++u) {
+            qr[u] = q[u];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         for (int s = 0; s < nquads; s += FSC_DEPTH) {
             q += FSC_DEPTH;
 #pragma unroll
             for (int u = 0; u < FSC_DEPTH; ++u) {
                 __builtin_amdgcn_sched_barrier(0);
-                addq(qr[u], w + u * 64, !W4 || (u & 3) == 3);
+                const vit_f32x4 v = qr[u];
+                run = run + v.x;                   // sequential float32 chain
+                run = run + v.y;
+                run = run + v.z;
+                run = run + v.w;
+                if (!W4 || (u & 3) == 3) w[u * 64] = run;
                 qr[u] = q[u];                      // behind the chunk's end: slack rows
             }
             __builtin_amdgcn_sched_barrier(0);
             w += FSC_DEPTH * 64;
         }
-        if (nquads & (FSC_DEPTH - 1)) run = runs[(ci & 1) * runsz + (nquads - 1) * 64 + tid];
-        __syncthreads();
+        if (nquads > 0 && (nquads & (FSC_DEPTH - 1))) run = runs[(ci & 1) * runsz + (nquads - 1) * 64 + tid];
+#if VIT_STAMP
+        const long long tb0 = (long long)__builtin_amdgcn_s_memtime();
+        lds_barrier();
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            const long long tb1 = (long long)__builtin_amdgcn_s_memtime();
+            if (ci == 0) g_vit_stamps[10] = 0, g_vit_stamps[11] = 0;
+            g_vit_stamps[10] += tb0 - tl0;     // adds of the chunk
+            g_vit_stamps[11] += tb1 - tb0;     // waiting for the stagers
+        }
+#else
+        lds_barrier();
+#endif
     }
 }
 
@@ -289,7 +357,9 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(co
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
     if (K < 1) return;
+    VSTAMP(8);
     framescore_cols_body<W4>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem);
+    VSTAMP(9);
 }
 
 struct Cand {
@@ -354,7 +424,8 @@ __device__ __forceinline__ double add_frame(double s, float f, int n) {
 // segments into per-frame labels.  `pre` is an LDS scratch of N + 1 ints, `a` the transcript in LDS.
 __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job &job, int vid, int fin_n, int fin_j, double fin_score,
                                                          bool forced, const uint8_t *bp, const int *a, int *pre, int32_t *labels,
-                                                         int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int fs) {
+                                                         int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int fs,
+                                                         const uint8_t *bp_l = nullptr, const bool bp_lds = false) {   // bp_lds: the back-pointers are in bp_l (LDS), bp is unused
     const int T = job.T, N = job.N, K = T / fs;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     // traceback
@@ -363,22 +434,27 @@ __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job
     if (tid == 0) {
         int n = fin_n, j = fin_j, k = K - 1;
         int32_t *sl = seg_len + job.seg_off;
+        // (the outputs may live in pinned host memory: nothing written there is read back -- the lengths also go to `pre`)
         for (int s = nseg - 1; s >= 0; --s) {
-            sl[s] = (j + 1) * fs;
+            const int len = (j + 1) * fs;
+            pre[s + 1] = len;
+            sl[s] = s == nseg - 1 ? len + missing : len;   // leftover frames are added to the last segment's length
             const int k0 = k - j;
             if (n > 0) {
-                j = bp[(size_t)k0 * N + n];
+                // (a dependent chain of N reads: ~100 cycles each from LDS, ~1,500 from memory.  The volatile access keeps LLVM from merging
+                // the two loads into one of a selected pointer: clang 22's inliner pass crashes on that form)
+                j = bp_lds ? (int)*(volatile const __attribute__((address_space(3))) uint8_t *)(bp_l + k0 * N + n) : (int)bp[(size_t)k0 * N + n];
                 k = k0 - 1;
                 --n;
             }
         }
         int acc = 0;
-        for (int s = 0; s < nseg; ++s) {
+        for (int s = 0; s < nseg; ++s) {                   // pre[s] = frames in front of segment s
+            const int len = pre[s + 1];
             pre[s] = acc;
-            acc += sl[s];
+            acc += len;
         }
         pre[nseg] = acc;
-        sl[nseg - 1] += missing;  // leftover frames are added to the last segment's length
         for (int s = nseg; s < N; ++s) sl[s] = 0;
         n_seg[vid] = nseg;
         score[vid] = fin_score;
@@ -405,45 +481,76 @@ __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job
     }
 }
 
-// Phase 2, transcripts of up to 64 states and J <= 66 length slots (every shipped configuration: max_len 2000, fs 30): ONE wave
-// runs the whole DP with the hypothesis scores in REGISTERS, no barrier and no LDS round trip per column.
+// Phase 2, J <= 66 length slots (every shipped configuration: max_len 2000, fs 30) and up to 128 transcript states: the whole DP
+// runs with the hypothesis scores in REGISTERS -- one wave (<= 32 states: no barrier, no LDS round trip per column) or two / four
+// waves (one barrier per column for the hand-over across the wave boundaries).
 //
-// Lane n * G + g owns state n's hypotheses with length index j in [g * JG, (g + 1) * JG) -- G = 8, 4, 2, 1 lanes per state
-// for N <= 8, 16, 32, 64.  Indexing by LENGTH instead of by entry column turns "every hypothesis grows by one column" into
-// S[j] = S[j-1] + f with a different destination register (the shift costs nothing; across a lane boundary it is one DPP
-// row_shr), and makes every table index a compile-time constant: the length scores Pl[n][j] sit in registers too.  Dead
-// hypotheses hold -inf (-inf + f stays -inf: emissions are log-probabilities), so the column has no liveness test:
+// Lane n * G + g owns state n's hypotheses with length index j in [g * JG, (g + 1) * JG) -- G = 8, 4, 2 lanes per state.
+// Indexing by LENGTH instead of by entry column turns "every hypothesis grows by one column" into S[j] = S[j-1] + f with a
+// different destination register (the shift costs nothing; across a lane boundary it is one DPP row_shr), and makes every table
+// index a compile-time constant: the length scores Pl[n][j] sit in registers too.  Dead hypotheses hold -inf (-inf + f stays
+// -inf: emissions are log-probabilities), so the column has no liveness test:
 //     S[j]  = S[j-1] + f                         stay in state n (viterbi.py:96-104); slot J only feeds the candidates
 //     cand  = S[j] + Pl[n][j-1]                   leave state n after (old) length index j-1 (viterbi.py:105-121)
 //     (v,j) = arg max, the larger j among equals   HypDict.update's `<=` (viterbi.py:27) -> enters state n + 1 at index 0
-// The arg max is a compare-and-select per slot, then log2(G) DPP steps; one ds_bpermute hands it to the next state's lane.
+// What one column costs is its DEPENDENT chain, entry -> S[1] -> candidate -> maximum -> next state's entry, so (r3) the arg max
+// is taken apart: the VALUE is a max tree over the lane's candidates with the one that hangs on the fresh entry (slot 1) joined
+// last, three DPP butterflies inside the state's lane group, and a DPP hand-over to the next state's lanes (row_shr:G inside a
+// 16-lane row, row_bcast:15 across rows: after the butterflies every lane of a group holds the maximum) -- no LDS instruction
+// on the chain; the INDEX (largest slot whose candidate equals the maximum -- the reference's tie rule) is computed behind it
+// and only feeds the back-pointer store.  (r2 walked a compare-and-select chain over the slots and handed over by ds_bpermute:
+// 1,150 cycles per column at G = 8, now ~ 1/3.)
 // If every candidate is -inf the reference still picks the longest LIVE one: that index is the closed form min(J, k-n) - 1.
 // The reference's `+ 0.0` on every candidate only turns -0.0 into +0.0; comparisons do not see the sign of zero, so it is
 // applied once, to the winner.  State 0 holds a single hypothesis (entered at column 0) whose score is float32 + float32
 // (NumPy promotion, see add_frame): a scalar side chain, its one candidate enters state 1 directly.
-// ~6 instructions per slot and column: 0.2 us per column at N <= 8, 0.8 us at N = 64 (the LDS kernel below: 0.9 and 4 us).
-constexpr int VL_THREADS = 256;   // wave 0 decodes; waves 1..3 wait at the barrier and help to expand the labels
-template <int CTRL>
+constexpr int VL_THREADS = 256;   // NW = 1: wave 0 decodes; waves 1..3 wait at the barrier and help to expand the labels
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_f64(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
-                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false));
 }
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+// max of two non-NaN doubles, one of them fresh from a DPP move: fmax() would first canonicalise the moved value (LLVM cannot know
+// it is no signalling NaN) -- one more v_max_f64 on the column's dependent chain.  The trailing s_nop covers the two wait states a
+// DPP read of the result needs (the hazard recogniser does not look into inline assembly).
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the value lane - G holds (G = 2, 4, 8; every lane of a G-group holds the same): row_shr:G inside a 16-lane row, lane 15 of the
+// row below for a row's first group.  Row 0's first group keeps its own value (its source is another wave, or nothing).
+template <int G>
+__device__ __forceinline__ double hand_up_f64(double v, int lane) {
+    const double a = dpp_f64<0x110 + G>(v), b = dpp_f64<0x142, 0xE>(v);   // row_shr:G | row_bcast:15 into rows 1..3
+    return (lane & 15) >= G ? a : b;
+}
+template <int G>
+__device__ __forceinline__ int hand_up_i32(int v, int lane) {
+    const int a = dpp_i32<0x110 + G>(v), b = dpp_i32<0x142, 0xE>(v);
+    return (lane & 15) >= G ? a : b;
+}
 
-template <int G, int JG, int NW>   // NW = 1: wave 0 decodes, the other waves only help with the labels; NW = 2: two decoding waves
+struct VitNoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid` runs between the loads that do not depend on the frame scores (length scores, transcript: from pinned host memory in the
+// one-launch kernel, ~2 us away) and their first use: the one-launch kernel puts phase 1 there.  bp_lds: the back-pointers go to bp_l (LDS) instead of bp.
+template <int G, int JG, int NW, typename Mid>   // NW decoding waves (1: wave 0 decodes, the workgroup's other waves only help with the labels)
 __device__ __forceinline__ void viterbi_dp_lanes_body(
-    const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, const int32_t *transcripts, const double *tables,
-    int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J) {
-    constexpr bool PL_LDS = JG > 40;        // one lane per state: 2 x 67 doubles do not fit the registers, Pl goes to LDS
-    constexpr int VL_CH = PL_LDS ? 8 : 32;  // columns of frame scores staged at a time (one register each while in flight)
-    constexpr int NL = 64 * NW;             // decoding lanes
-    __shared__ double PlL[PL_LDS ? JG : 1][NL];   // [slot][lane]: immediate offsets, no bank conflict
-    __shared__ float Fb[2][VL_CH][NL];      // frame scores of the lanes' own labels, two chunks
-    __shared__ double xch_v[2];             // NW = 2: wave 0's last state hands its best candidate to wave 1's first
-    __shared__ int xch_j[2];
-    __shared__ double Pl0[128];             // state 0's length scores (runtime index: its hypothesis has j = column)
+    const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, uint8_t *bp_l, const bool bp_lds, const int32_t *transcripts,
+    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
+    Mid mid) {
+    static_assert(G * JG >= 67 && (G == 2 || G == 4 || G == 8), "slots 0..66 over the G lanes of a state");
+    constexpr int VL_CH = NW >= 4 ? 16 : 32;  // columns of frame scores staged at a time (one register each while in flight)
+    constexpr int NL = 64 * NW;               // decoding lanes
+    __shared__ float Fb[2][VL_CH][NL];        // frame scores of the lanes' own labels, two chunks
+    __shared__ double xch_v[2][NW];           // NW > 1: a wave's last state hands its best candidate to the next wave's first
+    __shared__ int xch_j[2][NW];
+    __shared__ double Pl0[128];               // state 0's length scores (runtime index: its hypothesis has j = column)
     __shared__ int a[NL], pre[NL + 1];
     __shared__ double fin_score;
     __shared__ int fin_n, fin_j;
@@ -467,25 +574,37 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         return;
     }
     const bool forced = job.force_n >= 0 || K < N;
-    if (tid < NL) a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
-    for (int j = tid; j < J; j += blockDim.x) Pl0[j] = tables[job.p_off + (size_t)j * N];
-    __syncthreads();
-
+    const int n = tid / G, g = tid - n * G;              // this lane's state and slot group (decoding lanes: tid < NL)
+    const bool state_on = tid < NL && n >= 1 && n < N;
+    const double NEG = -INFINITY;
+    // length scores against the slot index s = j + 1 (the candidate of slot s uses the OLD length index s - 1); state 0's go to LDS
+    double PlS[JG], pl0r[2] = {0.0, 0.0};
+    int a_own = 0, an = 0;
     if (tid < NL) {
-        const int n = tid / G, g = tid - n * G;          // this lane's state and slot group
-        const int an = a[n < N ? n : 0];
-        const bool state_on = n >= 1 && n < N;
-        const double NEG = -INFINITY;
-        // length scores against the slot index s = j + 1 (the candidate of slot s uses the OLD length index s - 1)
-        double PlS[JG], S[JG];   // (PlS unused, and optimised away, when PL_LDS)
+        a_own = tid < N ? transcripts[job.tr_off + tid] : 0;
+        an = transcripts[job.tr_off + (n < N ? n : 0)];
 #pragma unroll
         for (int i = 0; i < JG; ++i) {
             const int sidx = g * JG + i;
-            const double pl = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
-            if constexpr (PL_LDS) PlL[i][tid] = pl;
-            else PlS[i] = pl;
-            S[i] = NEG;
+            PlS[i] = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * NL < J) pl0r[u] = tables[job.p_off + (size_t)(tid + u * NL) * N];
+    }
+    mid();
+    if (tid < NL) {
+        a[tid] = a_own;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * NL < J) Pl0[tid + u * NL] = pl0r[u];
+    }
+    if constexpr (NW > 1) __syncthreads();               // (NW = 1: Pl0 is wave 0's own; `a` is read behind the barrier below)
+
+    if (tid < NL) {
+        double S[JG];
+#pragma unroll
+        for (int i = 0; i < JG; ++i) S[i] = NEG;
         // frame scores: chunk q in Fb[q & 1]; the loads of chunk q + 1 are issued at the start of chunk q
         float fq[VL_CH];
         auto fetch = [&](int q) {
@@ -499,13 +618,15 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
 #pragma unroll
             for (int u = 0; u < VL_CH; ++u) Fb[q & 1][u][tid] = fq[u];
         };
+        VSTAMP(2);
         fetch(0);
         stash(0);
-        // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32
+        VSTAMP(3);
+        // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32.  (State 0 is lane 0 of wave 0; the other
+        // waves carry a side chain of their own first lane's scores that nothing reads.)
         float s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Fb[0][0][tid])));
         const int nchunks = (K + VL_CH - 1) / VL_CH;
-        // The entry a column produces is first read by the NEXT column's S[1] = S[0] + f, so it stays pending across the
-        // loop edge: its ds_bpermute returns behind the shifts of the other slots instead of in front of an idle wave.
+        // The entry a column produces is first read by the NEXT column's S[1] = S[0] + f, so it stays pending across the loop edge.
         double e_v = NEG;                                                // pending entry of this lane's state (g == 0)
         for (int q = 0; q < nchunks; ++q) {
             if (q + 1 < nchunks) fetch(q + 1);
@@ -531,55 +652,45 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
                 s0 = t0;
                 S[1] = (g == 0 ? e_v : S[0]) + fd;
                 S[0] = g == 0 ? NEG : in + fd;
-                // the best candidate of this lane's slots; equal scores: the later (longer) one
-                double vb = NEG;
-                int ib = 0;
-                constexpr int PLD = 6;                                  // LDS reads of Pl in flight (PL_LDS)
-                double plq[PL_LDS ? JG : 1];
-                if constexpr (PL_LDS) {
+                // candidates; the maximum of the lane's, slot 1 (behind the fresh entry) last
+                double c[JG];
 #pragma unroll
-                    for (int i = 0; i < PLD; ++i) plq[i] = PlL[i][tid];
-                }
+                for (int i = 0; i < JG; ++i) c[i] = S[i] + PlS[i];
+                double t[JG];
+                t[0] = c[0];
 #pragma unroll
-                for (int i = 0; i < JG; ++i) {
-                    double pl;
-                    if constexpr (PL_LDS) {
-                        if (i + PLD < JG) plq[i + PLD] = PlL[i + PLD][tid];
-                        pl = plq[i];
-                    } else {
-                        pl = PlS[i];
-                    }
-                    const double c = S[i] + pl;
-                    const bool take = c >= vb;
-                    vb = take ? c : vb;
-                    ib = take ? i : ib;
-                    // (keeps each compare next to its three selects: left alone, the scheduler runs the index chain slots behind
-                    // the score chain and spills the masks in between)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // ... of the state: the maximum, then the largest index among the lanes that hold it
-                double vm = vb;
-                if (G >= 2) vm = fmax(vm, dpp_f64<0xB1>(vm));           // quad_perm [1,0,3,2]
-                if (G >= 4) vm = fmax(vm, dpp_f64<0x4E>(vm));           // quad_perm [2,3,0,1]
-                if (G >= 8) vm = fmax(vm, dpp_f64<0x141>(vm));          // row_half_mirror
-                int jm = vb == vm ? g * JG + ib - 1 : -1;
-                if (G >= 2) jm = max(jm, dpp_i32<0xB1>(jm));
+                for (int i = 1; i < JG - 1; ++i) t[i] = c[i + 1];
+#pragma unroll
+                for (int st = 1; st < JG - 1; st *= 2)
+#pragma unroll
+                    for (int i = 0; i + st < JG - 1; i += 2 * st) t[i] = fmax(t[i], t[i + st]);
+                double vm = fmax(t[0], c[1]);
+                // ... of the state: butterflies inside the lane group, every lane ends up with the maximum
+                vm = max_f64_raw(vm, dpp_f64<0xB1>(vm));                // quad_perm [1,0,3,2]
+                if (G >= 4) vm = max_f64_raw(vm, dpp_f64<0x4E>(vm));    // quad_perm [2,3,0,1]
+                if (G >= 8) vm = max_f64_raw(vm, dpp_f64<0x141>(vm));   // row_half_mirror
+                // hand over to the next state's lanes; state 1 takes state 0's candidate
+                const double vout = vm + 0.0;
+                double vin = hand_up_f64<G>(vout, lane);
+                // the index, behind the chain: the largest slot whose candidate is the maximum
+                int mi = -128;
+#pragma unroll
+                for (int i = 0; i < JG; ++i) mi = max(mi, c[i] == vm ? i : -128);
+                int jm = g * JG - 1 + mi;                               // (< 0 in lanes that do not hold the maximum)
+                jm = max(jm, dpp_i32<0xB1>(jm));
                 if (G >= 4) jm = max(jm, dpp_i32<0x4E>(jm));
                 if (G >= 8) jm = max(jm, dpp_i32<0x141>(jm));
                 if (vm == NEG) jm = min(J, k - n) - 1;                  // all -inf: the longest live hypothesis
-                vm = vm + 0.0;
-                // hand over to the next state (lane - G); state 1 takes state 0's candidate
-                double vin = __shfl_up(vm, G);
-                int jin = __shfl_up(jm, G);
-                if constexpr (NW == 2) {                                 // across the wave boundary: through LDS, one barrier per column
-                    if (tid == 63) {
-                        xch_v[k & 1] = vm;
-                        xch_j[k & 1] = jm;
+                int jin = hand_up_i32<G>(jm, lane);
+                if constexpr (NW > 1) {                                  // across a wave boundary: through LDS, one barrier per column
+                    if (lane == 63) {
+                        xch_v[k & 1][wave] = vout;
+                        xch_j[k & 1][wave] = jm;
                     }
                     __syncthreads();
-                    if (wave == 1 && lane < G) {
-                        vin = xch_v[k & 1];
-                        jin = xch_j[k & 1];
+                    if (wave >= 1 && lane < G) {
+                        vin = xch_v[k & 1][wave - 1];
+                        jin = xch_j[k & 1][wave - 1];
                     }
                 }
                 if (n == 1) {
@@ -588,13 +699,18 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
                 }
                 const bool enter = state_on && k >= n && k <= J * n;
                 e_v = enter ? vin : NEG;
-                if (g == 0 && enter) bp[(size_t)k * N + n] = (uint8_t)jin;
+                if (g == 0 && enter) {
+                    if (bp_lds) bp_l[k * N + n] = (uint8_t)jin;
+                    else bp[(size_t)k * N + n] = (uint8_t)jin;
+                }
             }
             if (q + 1 < nchunks) stash(q + 1);
         }
         if (g == 0) S[0] = e_v;                                          // the last column's entries
+        VSTAMP(4);
 
         // finalize_decoding (viterbi.py:125-138)
+        const double pl_up = dpp_f64<0x101>(PlS[0]);                     // row_shl:1 -- the next lane's first length score
         if (forced) {
             // Degenerate outcomes of the reference, see viterbi_dp_kernel
             if (tid == 0) {
@@ -618,9 +734,9 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
 #pragma unroll
                 for (int i = 0; i < JG; ++i) {
                     const int j = g * JG + i;
-                    // Pl[nf][j] = the candidates' table one slot up (the one-lane-per-state variant keeps it in LDS)
-                    const double pl = PL_LDS ? PlL[PL_LDS ? min(i + 1, JG - 1) : 0][tid]
-                                             : tables[job.p_off + (size_t)min(j, J - 1) * N + nf];
+                    // Pl[nf][j] is the candidates' table one slot up: the next register, the next lane's first for the lane's last slot
+                    // (j beyond J - 1 is not live: whatever arrives there is not used)
+                    const double pl = i + 1 < JG ? PlS[i + 1 < JG ? i + 1 : 0] : pl_up;
                     Cand d;
                     d.v = (S[i] + pl) + 0.0;
                     d.j = j;
@@ -636,6 +752,7 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         }
     }
     __syncthreads();
+    VSTAMP(5);
     if (fin_j < 0) {  // no comparable final hypothesis (NaN scores): traceback is None in the reference
         if (tid == 0) {
             status[vid] = MUCON_VIT_NO_HYPOTHESIS;
@@ -644,19 +761,27 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         }
         return;
     }
-    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs);
+    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs, bp_l, bp_lds);
+    VSTAMP(6);
 }
 
 template <int G, int JG, int NW>
-__global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_kernel(
+__global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lanes_kernel(
     const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
-    int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
+    int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J, int bp_lds_bytes,
+    volatile int32_t *done_flag, int32_t done_value) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vl_bp[];   // [K][N] back-pointers when they fit (bp_lds_bytes of them)
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
     const size_t f_bytes = ((size_t)(K > 0 ? K : 0) * C * sizeof(float) + 15) & ~(size_t)15;
     viterbi_dp_lanes_body<G, JG, NW>(job, blockIdx.x, reinterpret_cast<const float *>(ws + job.ws_off),
-                                     reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes), transcripts, tables, labels, seg_len, n_seg,
-                                     score, status, C, fs, J);
+                                     reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes), vl_bp, K > 0 && K * job.N <= bp_lds_bytes, transcripts, tables, labels, seg_len,
+                                     n_seg, score, status, C, fs, J, VitNoMid());
+    if (done_flag) {                                 // (one video per call: see viterbi_fused_kernel)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(const_cast<int32_t *>(done_flag), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ONE launch for a short video (the evaluation's case: T ~ 2,000 frames, a handful of transcript states): the frame scores never
@@ -666,24 +791,26 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 128) void viterbi_dp_lanes_k
 // two-launch decode of a T = 2,000 video took, half was the upload, the second launch and the synchronous download); thread 0
 // publishes `*done_flag = done_value` behind a system-scope fence, which is what the host waits for.
 template <int G, int JG, bool W4>
-__global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job *jobs, const int32_t *transcripts,
+__global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job job, const int32_t *transcripts,
                                                                     const double *tables, int32_t *labels, int32_t *seg_len,
-                                                                    int32_t *n_seg, double *score, int32_t *status, char *ws, int C,
+                                                                    int32_t *n_seg, double *score, int32_t *status, int C,
                                                                     int fs, int J, int cols, int dyn_floats, volatile int32_t *done_flag,
                                                                     int32_t done_value) {
+    // (the job travels as a kernel argument: read from the pinned table it was one more PCIe round trip in front of everything)
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
-    float *F = fs_smem + dyn_floats;                 // [K][C] behind phase 1's buffers
-    if (K >= 1) {
+    float *F = fs_smem + dyn_floats;                 // [K][C] behind phase 1's buffers, then the back-pointers [K][N]
+    uint8_t *bp_l = reinterpret_cast<uint8_t *>(F + (K > 0 ? K : 0) * C);
+    VSTAMP(0);
+    viterbi_dp_lanes_body<G, JG, 1>(job, 0, F, nullptr, bp_l, true, transcripts, tables, labels, seg_len, n_seg, score, status, C, fs, J, [&] {
         framescore_cols_body<W4>(job.lp, F, K, C, fs, cols, fs_smem);
-        __syncthreads();
-    }
-    viterbi_dp_lanes_body<G, JG, 1>(job, blockIdx.x, F, reinterpret_cast<uint8_t *>(ws + job.ws_off), transcripts, tables, labels, seg_len,
-                                    n_seg, score, status, C, fs, J);
+        lds_barrier();                               // (F is in LDS; the staging waves' surplus read-ahead may still be in flight)
+        VSTAMP(1);
+    });
     if (done_flag) {
         __threadfence_system();                      // every thread's label stores are visible to the host ...
         __syncthreads();
+        VSTAMP(7);
         if (threadIdx.x == 0) {
             __hip_atomic_store(const_cast<int32_t *>(done_flag), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag
         }
@@ -923,6 +1050,13 @@ void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_l
         return (code);                    \
     } while (0)
 
+#if VIT_STAMP
+extern "C" int mucon_test_vit_stamps(long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return MUCON_E_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vit_stamps), sizeof(long long) * 16) == hipSuccess ? MUCON_OK : MUCON_E_HIP;
+}
+#endif
+
 extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_t N, int32_t fs) {
     const size_t K = fs > 0 ? (size_t)(T / fs) : 0;
     const size_t f_bytes = (K * (size_t)C * sizeof(float) + 15) & ~(size_t)15;
@@ -933,8 +1067,10 @@ extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_
 // Launches of one decode: `fused` = the one-launch kernel (short videos, <= 32 states), else frame scores + DP.
 static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs, int32_t max_len, int32_t max_N,
                       const int32_t *transcripts, const double *length_tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
-                      double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int fused_maxK, bool cols_ok,
-                      volatile int32_t *done_flag, int32_t done_value) {
+                      double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int max_K, bool cols_ok,
+                      volatile int32_t *done_flag, int32_t done_value, const mucon_viterbi_job *host_jobs) {
+    // host_jobs: the job table where the host can read it (the one-launch kernel takes its job as a kernel argument), or nullptr;
+    // max_K: the longest video's column count when the caller knows it (LDS sizing of the latency paths), else 0
     if (fs <= 0 || max_len < fs || C <= 0 || C > 64 || max_N <= 0) {
         snprintf(g_err, sizeof(g_err), "viterbi: unsupported arguments (C=%d must be <= 64, fs=%d, max_len=%d, max_N=%d)",
                  C, fs, max_len, max_N);
@@ -978,8 +1114,17 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
                              hipFuncAttributeMaxDynamicSharedMemorySize, VF_DYN_MAX) == hipSuccess
         VF_ATTR(8, 9);
         VF_ATTR(4, 17);
-        VF_ATTR(2, 34);
 #undef VF_ATTR
+#define VL_ATTR(G, JG, NW)                                                                                                      \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_dp_lanes_kernel<G, JG, NW>),                           \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, VL_BP_LDS_MAX) == hipSuccess
+        VL_ATTR(8, 9, 1);
+        VL_ATTR(4, 17, 1);
+        VL_ATTR(2, 34, 1);
+        VL_ATTR(4, 17, 2);
+        VL_ATTR(4, 17, 4);
+        VL_ATTR(2, 34, 4);
+#undef VL_ATTR
         if (!ok) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
             VIT_FAIL(MUCON_E_HIP);
@@ -987,9 +1132,9 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         attr_dev = dev;
     }
     const bool w4 = (((fs + 3) >> 2) & 3) == 0;
-    if (fused && lanes && max_N <= 32 && cols_ok) {
-        // phase 1's buffers + the frame scores [K][C] share the dynamic LDS: as many columns per chunk as fit beside them
-        const size_t f_bytes = (size_t)fused_maxK * C * sizeof(float);
+    if (fused && lanes && max_N <= 16 && cols_ok && host_jobs && n_videos == 1) {   // (34 slots per lane + the staging waves' registers do not fit 256 VGPRs)
+        // phase 1's buffers + the frame scores [K][C] + the back-pointers [K][N] share the dynamic LDS: as many columns per chunk as fit beside them
+        const size_t f_bytes = (((size_t)max_K * C * sizeof(float) + (size_t)max_K * max_N) + 15) & ~(size_t)15;
         int cols = FS_ROWS / ((fs + 3) & ~3);
         while (cols > 1 && (size_t)fsc_floats(C, fs, cols) * 4 + f_bytes > VF_DYN_MAX) --cols;
         if ((size_t)fsc_floats(C, fs, cols) * 4 + f_bytes <= VF_DYN_MAX) {
@@ -997,16 +1142,13 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
             const size_t bytes = (size_t)dyn * 4 + f_bytes;
 #define VF_LAUNCH(G, JG)                                                                                                          \
     do {                                                                                                                          \
-        if (w4) hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, true>), dim3(n_videos), dim3(FSC_THREADS), bytes, s, jobs, transcripts, \
-                                   length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J, \
-                                   cols, dyn, done_flag, done_value);                                                             \
-        else hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, false>), dim3(n_videos), dim3(FSC_THREADS), bytes, s, jobs, transcripts,  \
-                                length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, fs, J,  \
-                                cols, dyn, done_flag, done_value);                                                                \
+        if (w4) hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, true>), dim3(1), dim3(FSC_THREADS), bytes, s, host_jobs[0], transcripts, \
+                                   length_tables, labels, seg_len, n_seg, score, status, C, fs, J, cols, dyn, done_flag, done_value); \
+        else hipLaunchKernelGGL((viterbi_fused_kernel<G, JG, false>), dim3(1), dim3(FSC_THREADS), bytes, s, host_jobs[0], transcripts,  \
+                                length_tables, labels, seg_len, n_seg, score, status, C, fs, J, cols, dyn, done_flag, done_value);   \
     } while (0)
             if (max_N <= 8) VF_LAUNCH(8, 9);
-            else if (max_N <= 16) VF_LAUNCH(4, 17);
-            else VF_LAUNCH(2, 34);
+            else VF_LAUNCH(4, 17);
 #undef VF_LAUNCH
             if (hipGetLastError() != hipSuccess) {
                 snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
@@ -1032,21 +1174,27 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
     }
     // the DP: up to 66 length slots run in the registers of one wave (<= 32 states) or two (<= 128) ...
 #define VL_LAUNCH(G, JG, NW)                                                                                          \
-    hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG, NW>), dim3(n_videos), dim3(NW == 1 ? VL_THREADS : 128), 0, s, jobs, \
+    hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG, NW>), dim3(n_videos), dim3(NW == 1 ? VL_THREADS : 64 * NW), bp_lds, s, jobs, \
                        transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, \
-                       fs, J)
+                       fs, J, (int)bp_lds, flag1, done_value)
     if (lanes) {
+        // latency calls (a few videos whose sizes the caller knows): back-pointers in LDS -- the traceback is a chain of N dependent
+        // reads; throughput calls leave the LDS to more workgroups per CU.  One video: the kernel publishes the completion flag.
+        const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
+        const size_t bp_lds = (max_K > 0 && n_videos <= 8 && bp_need <= VL_BP_LDS_MAX) ? bp_need : 0;
+        volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
         if (max_N <= 8) VL_LAUNCH(8, 9, 1);
         else if (max_N <= 16) VL_LAUNCH(4, 17, 1);
-        else if (max_N <= 32) VL_LAUNCH(2, 34, 1);
-        else if (max_N <= 64) VL_LAUNCH(2, 34, 2);
-        else VL_LAUNCH(1, 67, 2);
+        else if (max_N <= 32 && g_vit_lanes != 2) VL_LAUNCH(2, 34, 1);
+        else if (max_N <= 32) VL_LAUNCH(4, 17, 2);
+        else if (max_N <= 64) VL_LAUNCH(4, 17, 4);
+        else VL_LAUNCH(2, 34, 4);
 #undef VL_LAUNCH
         if (hipGetLastError() != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
             VIT_FAIL(MUCON_E_HIP);
         }
-        return MUCON_OK;
+        return flag1 ? 1 : MUCON_OK;
     }
     // ... longer transcripts or more slots: one wave per state, the column in LDS
     const int spw = (max_N + 15) / 16;   // transcript states per wave
@@ -1085,7 +1233,7 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     // frame-score kernel are only taken for class counts where every row of an aligned base is aligned (the caller keeps `lp`
     // 16-byte aligned: include/mucon_hip.h)
     const int rc = vit_launch(n_videos, jobs, C, fs, max_len, max_N, transcripts, length_tables, labels, seg_len, n_seg, score, status,
-                              workspace, static_cast<hipStream_t>(stream), false, 0, (C & 3) == 0, nullptr, 0);
+                              workspace, static_cast<hipStream_t>(stream), false, 0, (C & 3) == 0, nullptr, 0, nullptr);
     return rc > 0 ? MUCON_OK : rc;
 }
 
@@ -1197,10 +1345,10 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
                               reinterpret_cast<int32_t *>(dout + o_lab), reinterpret_cast<int32_t *>(dout + o_seg),
                               reinterpret_cast<int32_t *>(dout + o_nseg), reinterpret_cast<double *>(dout + o_score),
                               reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
-                              reinterpret_cast<volatile int32_t *>(dout), seq);
+                              reinterpret_cast<volatile int32_t *>(dout), seq, jobs);
     if (rc < 0) return rc;
     bool done = false;
-    if (rc > 0) {   // the fused kernel publishes the flag: spin on it (a stream synchronisation costs several microseconds more)
+    if (rc > 0) {   // a one-video call's last kernel publishes the flag: spin on it (a stream synchronisation costs several microseconds more)
         for (long spin = 0; spin < 40000000L; ++spin) {
             if (__atomic_load_n(const_cast<const int32_t *>(flag_h), __ATOMIC_ACQUIRE) == seq) {
                 done = true;
