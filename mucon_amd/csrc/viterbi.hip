@@ -11,16 +11,16 @@
 // reaches the maximum length.  Which slots are alive is a closed form of (n, k0, k):
 // entries into state n >= 1 exist for n <= k0 <= J*n, state 0 is entered at k0 = 0 only.
 //
-//   phase 1  viterbi_framescore_kernel: one wave per video, one lane per class: the sequential
-//            float32 cumsum of the emissions (np.cumsum, viterbi.py:51) and its fs-strided
-//            differences (frame_score, viterbi.py:68-72) -> F[K][C].
-//   phase 2  viterbi_dp_kernel: one workgroup per video, one wave per transcript state (looping
-//            when N > 16), lanes = length slots (lane and lane+64).  The previous time column
-//            S_old[N][J] (f64) lives in LDS, double buffered, one barrier per column.  The wave of
-//            state m also evaluates the "advance" candidates of state m-1 (a max-reduction with
-//            the reference's tie rule: `<=` in HypDict.update keeps the LAST, i.e. longest, of
-//            equal candidates) so entries need no second barrier.  Back-pointers go to HBM
-//            scratch; thread 0 walks them (viterbi.py:140-158) and all threads expand labels.
+// Kernels (dispatch: vit_launch below):
+//   phase 1  viterbi_framescore_cols_kernel -- the sequential float32 cumsum of the emissions (np.cumsum, viterbi.py:51) and its
+//            fs-strided differences (frame_score, viterbi.py:68-72) -> F[K][C]: one wave adds (lane = class), seven stage the
+//            emissions through LDS three chunks ahead.  (viterbi_framescore_kernel: the plain version for unaligned inputs / fs > 256.)
+//   phase 2  viterbi_dp_lanes_kernel -- J <= 66 slots, N <= 128 states: hypothesis scores in registers, lanes = (state, slot group),
+//            length-indexed slots, DPP reductions and hand-over (VitLanes).  viterbi_dp_kernel: the general LDS version (one wave per
+//            transcript state, lanes = length slots, the column double buffered in LDS), also the tests' second implementation.
+//   both     viterbi_fused_kernel -- one short video in one launch, phase 2 running under phase 1 in the same workgroup.
+//   Back-pointers: one byte per (column, state), LDS for latency calls, HBM scratch otherwise; thread 0 walks them
+//   (viterbi.py:140-158) and all threads expand the labels.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -157,12 +157,11 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
 //   * waves 1..7 do the rest: global float4 -> four transposed LDS words one chunk ahead of the chain (the global loads two
 //     chunks ahead), and the fs-strided differences of the previous chunk's running sums -> F.
 constexpr int FSC_THREADS = 512;
-constexpr int FSC_STAGE = FSC_THREADS - 64;  // staging threads
-constexpr int FSC_NPER = 10;                 // tiles per staging wave per chunk: ceil(16 row blocks x 4 float4 blocks / 7)
 constexpr int FSC_MAX_LDS = 160 * 1024;
 constexpr int FSC_DEPTH = 8;                 // b128 reads in flight
 constexpr int FSC_SETS = 3;                  // register sets of staged global loads (chunks in flight)
-constexpr size_t VF_DYN_MAX = 160 * 1024 - 24 * 1024;   // dynamic LDS of the one-launch kernel: 160 KiB minus the DP's static arrays
+constexpr size_t VF_DYN_MAX = 160 * 1024 - 8 * 1024;    // dynamic LDS of the one-launch kernel: 160 KiB minus its static arrays
+constexpr int VF_MAX_K = 640;                           // columns of a video the one-launch kernel takes
 constexpr size_t VL_BP_LDS_MAX = 96 * 1024;             // dynamic LDS of the register DP kernels: back-pointers [K][N] of a latency call
 constexpr int FSC_SLACK = 8 * FSC_DEPTH;     // rows the read-ahead and the last round may run past a chunk's end
 __host__ __device__ inline int fsc_pitch(int rows) { return ((rows + FSC_SLACK + 15) & ~15) + 4; }   // = 4 mod 16, in floats
@@ -178,9 +177,19 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-template <bool W4>   // the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column
+struct FscNoDp {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
+// W4: the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column.
+// NSTG staging waves: 7 -- waves 1..7 stage; 6 -- wave 1 is the one-launch kernel's DECODING wave instead: once per round, between
+// the same barriers, it runs dp(k_lo, k_hi) on the columns whose frame scores the round before made visible (two rounds behind the
+// chain: phase 2 runs UNDER phase 1 instead of after it).
+template <bool W4, int NSTG, typename Dp>
 __device__ __forceinline__ void framescore_cols_body(const float *lp_video, float *F, const int K, const int C, const int fs, const int cols,
-                                                     float *fs_smem) {   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
+                                                     float *fs_smem, Dp dp) {   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
+    constexpr int STG0 = FSC_THREADS - 64 * NSTG;     // first staging thread
+    constexpr int NSTAGE = 64 * NSTG;                 // staging threads
+    constexpr int NPER = (64 + NSTG - 1) / NSTG;      // tiles per staging wave per chunk: 16 row blocks x 4 float4 blocks over the waves
     const int tid = threadIdx.x;
     const int nq = (fs + 3) >> 2;                 // b128 reads per column
     const int P = nq * 4;                         // LDS rows per column
@@ -191,16 +200,17 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
     const int C4 = C >> 2;
     const int chunk4 = cols * fs * C4;            // float4 per chunk in memory (contiguous: whole columns)
     const int nchunks = (K + cols - 1) / cols;
-    const int nch3 = (nchunks + FSC_SETS - 1) / FSC_SETS * FSC_SETS;
+    // rounds: chunk c is added in round c, differenced in round c + 1, decoded in round c + 2; a multiple of three (see below)
+    const int nch3 = (nchunks + (NSTG == 6 ? 2 : 1) + FSC_SETS - 1) / FSC_SETS * FSC_SETS;
     // the padding rows of both buffers: -0.0f (every thread its share)
     VSTAMP(12);
     auto zero_fill = [&]() {
         vit_f32x4 *z = reinterpret_cast<vit_f32x4 *>(fs_smem);
         for (int i = tid; i < bufsz / 2; i += FSC_THREADS) z[i] = vit_f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
     };
-    if (tid >= 64) {
-        // ---- waves 1..7: staging and the column differences ----
-        const int j = tid - 64;
+    if (tid >= STG0) {
+        // ---- the staging waves: global -> LDS, and the column differences ----
+        const int j = tid - STG0;
         // (global address space spelled out: through the generic pointer of the job record these were FLAT loads, which count
         // against the LDS wait counter as well -- every LDS wait of the staging waves then waited for the read-ahead)
         typedef const __attribute__((address_space(1))) vit_f32x4 *gptr4;
@@ -214,10 +224,10 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
         const int wv = j >> 6, l = j & 63;
         const int ncb = (C4 + 3) >> 2;                // tiles across the classes
         const int inv_ncb = 65536 / ncb + 1;
-        int dsto[FSC_NPER], srco[FSC_NPER];           // LDS word / chunk-relative float4 of this thread's u-th element; -1 = none
+        int dsto[NPER], srco[NPER];                   // LDS word / chunk-relative float4 of this thread's u-th element; -1 = none
 #pragma unroll
-        for (int u = 0; u < FSC_NPER; ++u) {
-            const int t = u * (FSC_STAGE / 64) + wv;                       // < 70
+        for (int u = 0; u < NPER; ++u) {
+            const int t = u * NSTG + wv;                                   // < 72
             const int rb = (t * inv_ncb) >> 16, cb = t - rb * ncb;         // t / ncb (ncb <= 4: exact); a division is ~30 instructions,
                                                                           // and this set-up is in front of the first load
             const int row = rb * 16 + (l >> 2), c4 = cb * 4 + (l & 3);
@@ -228,17 +238,17 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
         }
         // Three register sets: the loads of chunk ci + 3 are issued when chunk ci's set has been stored, so a load has three
         // chunk times (3 x ~0.7 us of chain) to return -- with one set the chain ran at one HBM latency (~1.4 us) per chunk.
-        vit_f32x4 rs[FSC_SETS][FSC_NPER];
-        auto gload = [&](int ci, vit_f32x4 (&r)[FSC_NPER]) {
+        vit_f32x4 rs[FSC_SETS][NPER];
+        auto gload = [&](int ci, vit_f32x4 (&r)[NPER]) {
             const int base4 = ci * chunk4;
 #pragma unroll
-            for (int u = 0; u < FSC_NPER; ++u) r[u] = src4[min(base4 + srco[u], total4 - 1)];   // (unconditional: the clamp keeps idle threads inside the video, and a branch per load serialises them)
+            for (int u = 0; u < NPER; ++u) r[u] = src4[min(base4 + srco[u], total4 - 1)];   // (unconditional: the clamp keeps idle threads inside the video, and a branch per load serialises them)
         };
-        auto sstore = [&](int ci, const vit_f32x4 (&r)[FSC_NPER]) {
+        auto sstore = [&](int ci, const vit_f32x4 (&r)[NPER]) {
             float *dst = fs_smem + (ci & 1) * bufsz;
             const int left4 = total4 - ci * chunk4;   // the last chunk may be short: keep the clamped re-loads out
 #pragma unroll
-            for (int u = 0; u < FSC_NPER; ++u)
+            for (int u = 0; u < NPER; ++u)
                 if (dsto[u] >= 0 && srco[u] < left4) {
                     float *d = dst + dsto[u];
                     d[0] = r[u].x;
@@ -254,7 +264,7 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
         auto diffs = [&](int ci) {
             const float *rn = runs + (ci & 1) * runsz;
             const int ncols = min(cols, K - ci * cols);
-            for (int i = j; i < ncols * 64; i += FSC_STAGE) {
+            for (int i = j; i < ncols * 64; i += NSTAGE) {
                 const int kc = i >> 6, c = i & 63;
                 if (c < C) {
                     const float hi = rn[((kc + 1) * nq - 1) * 64 + c];
@@ -269,25 +279,37 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
         // set's stores counts the loads issued after it, and LLVM takes the smallest count over all paths that reach it.  For the
         // same reason both sides run the chunk loop to a multiple of three (the extra rounds find nothing to do).
         gload(0, rs[0]);
+        zero_fill();                                  // (behind the first chunk's loads: they are in flight meanwhile.  All three sets in
+        lds_barrier();                                // front of it kept the waves at the load queue for ~3,000 cycles)
+        sstore(0, rs[0]);                             // (the chain starts on chunk 0 while the next three are fetched)
+        lds_barrier();
         gload(1, rs[1]);
         gload(2, rs[2]);
-        zero_fill();                                  // (behind the first loads: they are in flight meanwhile)
-        lds_barrier();
-        sstore(0, rs[0]);
         gload(3, rs[0]);
-        lds_barrier();
         for (int c0 = 0; c0 < nch3; c0 += FSC_SETS) {
 #pragma unroll
             for (int u3 = 0; u3 < FSC_SETS; ++u3) {      // chunk ci + 1 lives in set (ci + 1) % 3 = (u3 + 1) % 3
                 const int ci = c0 + u3;
-                vit_f32x4(&r)[FSC_NPER] = rs[(u3 + 1) % FSC_SETS];
+                vit_f32x4(&r)[NPER] = rs[(u3 + 1) % FSC_SETS];
                 sstore(ci + 1, r);                        // (behind the last chunk: left4 <= 0, nothing is stored)
                 gload(ci + 1 + FSC_SETS, r);
                 if (ci > 0) diffs(ci - 1);
                 lds_barrier();
             }
         }
-        if (nch3 == nchunks) diffs(nchunks - 1);
+        return;
+    }
+    if (NSTG == 6 && tid >= 64) {
+        // ---- wave 1: the decoding wave (one-launch kernel) ----
+        __builtin_amdgcn_s_setprio(2);               // in front of the staging wave it shares a SIMD with
+        zero_fill();
+        lds_barrier();
+        lds_barrier();
+        for (int r = 0; r < nch3; ++r) {
+            const int c = r - 2;
+            if (c >= 0 && c < nchunks) dp(c * cols, min(K, (c + 1) * cols));
+            lds_barrier();
+        }
         return;
     }
     // ---- wave 0: the chain ----
@@ -358,7 +380,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(co
     const int K = job.T / fs;
     if (K < 1) return;
     VSTAMP(8);
-    framescore_cols_body<W4>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem);
+    framescore_cols_body<W4, 7>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem, FscNoDp());
     VSTAMP(9);
 }
 
@@ -461,31 +483,22 @@ __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job
         status[vid] = forced ? MUCON_VIT_TRUNCATED : MUCON_VIT_OK;
     }
     __syncthreads();
-    // ... and labelled, at the START of the video, with the last segment's label
+    // ... and labelled, at the START of the video, with the last segment's label.  Segment by segment (a wave-uniform loop, the
+    // threads stride over the segment's frames): a binary search per frame cost ~6 dependent LDS reads for every label.
     int32_t *lab = labels + job.label_off;
-    for (int t = tid; t < T; t += nthreads) {
-        int l;
-        if (t < missing) {
-            l = a[nseg - 1];
-        } else {
-            const int u = t - missing;
-            int lo = 0, hi = nseg - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (pre[mid] <= u) lo = mid;
-                else hi = mid - 1;
-            }
-            l = a[lo];
-        }
-        lab[t] = l;
+    for (int t = tid; t < missing; t += nthreads) lab[t] = a[nseg - 1];
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int t0 = missing + pre[sg], t1 = missing + pre[sg + 1], l = a[sg];
+        for (int t = t0 + tid; t < t1; t += nthreads) lab[t] = l;
     }
+    for (int t = missing + pre[nseg] + tid; t < T; t += nthreads) lab[t] = a[nseg - 1];   // (nothing, when the segments cover the columns)
 }
 
 // Phase 2, J <= 66 length slots (every shipped configuration: max_len 2000, fs 30) and up to 128 transcript states: the whole DP
-// runs with the hypothesis scores in REGISTERS -- one wave (<= 32 states: no barrier, no LDS round trip per column) or two / four
+// runs with the hypothesis scores in REGISTERS -- one wave (<= 16 states: no barrier, no LDS round trip per column) or four / eight
 // waves (one barrier per column for the hand-over across the wave boundaries).
 //
-// Lane n * G + g owns state n's hypotheses with length index j in [g * JG, (g + 1) * JG) -- G = 8, 4, 2 lanes per state.
+// Lane n * G + g owns state n's hypotheses with length index j in [g * JG, (g + 1) * JG) -- G = 8 or 4 lanes per state.
 // Indexing by LENGTH instead of by entry column turns "every hypothesis grows by one column" into S[j] = S[j-1] + f with a
 // different destination register (the shift costs nothing; across a lane boundary it is one DPP row_shr), and makes every table
 // index a compile-time constant: the length scores Pl[n][j] sit in registers too.  Dead hypotheses hold -inf (-inf + f stays
@@ -499,7 +512,8 @@ __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job
 // 16-lane row, row_bcast:15 across rows: after the butterflies every lane of a group holds the maximum) -- no LDS instruction
 // on the chain; the INDEX (largest slot whose candidate equals the maximum -- the reference's tie rule) is computed behind it
 // and only feeds the back-pointer store.  (r2 walked a compare-and-select chain over the slots and handed over by ds_bpermute:
-// 1,150 cycles per column at G = 8, now ~ 1/3.)
+// 1,150 cycles per column at G = 8; now ~ 165 -> ~ 100 instructions and ~ 700 cycles: one wave issues an instruction every 5-7
+// cycles whatever the dependences -- what a column costs is its instruction count.)
 // If every candidate is -inf the reference still picks the longest LIVE one: that index is the closed form min(J, k-n) - 1.
 // The reference's `+ 0.0` on every candidate only turns -0.0 into +0.0; comparisons do not see the sign of zero, so it is
 // applied once, to the winner.  State 0 holds a single hypothesis (entered at column 0) whose score is float32 + float32
@@ -511,46 +525,195 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false),
                             __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false));
 }
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+// butterflies (every lane has a valid source): no `old` operand to keep alive, and an integer max takes the DPP operand itself
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_all(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32_all(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 // max of two non-NaN doubles, one of them fresh from a DPP move: fmax() would first canonicalise the moved value (LLVM cannot know
-// it is no signalling NaN) -- one more v_max_f64 on the column's dependent chain.  The trailing s_nop covers the two wait states a
-// DPP read of the result needs (the hazard recogniser does not look into inline assembly).
+// it is no signalling NaN) -- one more v_max_f64 on the column's dependent chain.  (The hazard recogniser treats the statement's
+// result as a vector write: it puts the two wait states a DPP read needs behind it itself -- checked in the listing.)
 __device__ __forceinline__ double max_f64_raw(double a, double b) {
     double r;
-    asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// the value lane - G holds (G = 2, 4, 8; every lane of a G-group holds the same): row_shr:G inside a 16-lane row, lane 15 of the
-// row below for a row's first group.  Row 0's first group keeps its own value (its source is another wave, or nothing).
+// the value lane - G holds (G = 4, 8; every lane of a G-group holds the same): row_shr:G inside a 16-lane row, lane 15 of the
+// row below for a row's first group (bank masks steer the two moves into the same register: no select).  Row 0's first group keeps
+// its own value (its source is another wave, or nothing).
 template <int G>
-__device__ __forceinline__ double hand_up_f64(double v, int lane) {
-    const double a = dpp_f64<0x110 + G>(v), b = dpp_f64<0x142, 0xE>(v);   // row_shr:G | row_bcast:15 into rows 1..3
-    return (lane & 15) >= G ? a : b;
+__device__ __forceinline__ int hand_up_i32(int v) {
+    constexpr int LOW = G == 8 ? 0x3 : 0x1;                                           // the banks (4 lanes each) of a row's first G lanes
+    const int a = __builtin_amdgcn_update_dpp(v, v, 0x110 + G, 0xF, 0xF & ~LOW, false);   // row_shr:G into the lanes >= G
+    return __builtin_amdgcn_update_dpp(a, v, 0x142, 0xE, LOW, false);                    // row_bcast:15 into the first G of rows 1..3
 }
 template <int G>
-__device__ __forceinline__ int hand_up_i32(int v, int lane) {
-    const int a = dpp_i32<0x110 + G>(v), b = dpp_i32<0x142, 0xE>(v);
-    return (lane & 15) >= G ? a : b;
+__device__ __forceinline__ double hand_up_f64(double v) {
+    return __hiloint2double(hand_up_i32<G>(__double2hiint(v)), hand_up_i32<G>(__double2loint(v)));
 }
 
-struct VitNoMid {
-    __device__ __forceinline__ void operator()() const {}
+// The decoding lanes' registers and one column of the DP (see the comment above).  Lane dl = n * G + g of the NW decoding waves.
+template <int G, int JG>
+struct VitLanes {
+    static_assert(G * JG >= 67 && (G == 4 || G == 8), "slots 0..66 over the G lanes of a state");
+    double S[JG];     // hypothesis scores by slot; S[0] of a state's first lane (g == 0): the entry the last column produced
+    double PlS[JG];   // length scores against the slot index s = j + 1 (the candidate of slot s uses the OLD length index s - 1)
+    double zmask;     // state 0's candidate + zmask: the reference's `+ 0.0` in state 1's first lane, -inf everywhere else
+    float s0;         // state 0: one hypothesis, a float32 chain
+    int n, g, lane;
+    int lo_s, R;      // this lane stores a back-pointer at column k <=> (unsigned)(k - lo_s) <= R   (g == 0 and n <= k <= J n)
+    bool is_n1;       // a lane of state 1 (its entry comes from state 0's side chain, not from the hand-over)
+
+    // the loads that do not depend on the frame scores (issued early; `dl` = decoding lane index)
+    __device__ __forceinline__ void load(const mucon_viterbi_job &job, const double *tables, const int dl, const int J) {
+        const int N = job.N;
+        n = dl / G;
+        g = dl - n * G;
+        lane = dl & 63;
+        const bool state_on = n >= 1 && n < N;
+        const double NEG = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < JG; ++i) {
+            const int sidx = g * JG + i;
+            PlS[i] = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
+            S[i] = NEG;
+        }
+        zmask = (state_on && n == 1 && g == 0) ? 0.0 : NEG;
+        lo_s = (state_on && g == 0) ? n : 0x40000000;
+        R = (J - 1) * n;
+        is_n1 = n == 1;
+        s0 = 0.f;
+
+    }
+    // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32.  (State 0 is lane 0 of wave 0; the other
+    // waves carry a side chain of their own first lane's scores that nothing reads.)
+    __device__ __forceinline__ void init(const float f_col0) { s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f_col0))); }
+
+    // Column k >= 1, first half: everything up to the state's best candidate.  f = frame score of this lane's label, pl0 = state 0's
+    // length score at the old length index k - 1 (-inf from J on).  -> vout: the winner (+ 0.0), handed to the next state's lanes
+    // in vin; jm / jin: its length index likewise.
+    __device__ __forceinline__ void col_a(const int k, const float f, const double pl0, const int J, double &vout, double &vin, int &jm,
+                                          int &jin, double &alt) {
+        const double fd = (double)f;
+        // every hypothesis grows by one column (viterbi.py:96-104); across a lane boundary: row_shr:1 from the slot group below
+        const double in = dpp_f64<0x111>(S[JG - 1]);
+#pragma unroll
+        for (int i = JG - 1; i >= 1; --i) S[i] = S[i - 1] + fd;
+        S[0] = in + fd;                                   // (g == 0: overwritten by col_b; its candidate below is -inf whatever this is)
+        // state 0's float32 chain and its candidate for state 1: ((s + f) + P) + 0.0
+        const float f0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f)));
+        const float t0 = s0 + f0;
+        s0 = t0;
+        const double a1 = ((double)t0 + pl0) + zmask;     // state 1's first lane: its entry; -inf elsewhere
+        alt = g == 0 ? a1 : S[0];                         // what S[0] becomes where no entry arrives through the hand-over
+        // candidates; the maximum of the lane's, slot 1 (behind the fresh entry) last
+        double c[JG];
+#pragma unroll
+        for (int i = 0; i < JG; ++i) c[i] = S[i] + PlS[i];
+        double t[JG];
+        t[0] = c[0];
+#pragma unroll
+        for (int i = 1; i < JG - 1; ++i) t[i] = c[i + 1];
+#pragma unroll
+        for (int st = 1; st < JG - 1; st *= 2)
+#pragma unroll
+            for (int i = 0; i + st < JG - 1; i += 2 * st) t[i] = fmax(t[i], t[i + st]);
+        double vm = fmax(t[0], c[1]);
+        // ... of the state: butterflies inside the lane group, every lane ends up with the maximum
+        vm = max_f64_raw(vm, dpp_f64_all<0xB1>(vm));                // quad_perm [1,0,3,2]
+        if (G >= 4) vm = max_f64_raw(vm, dpp_f64_all<0x4E>(vm));    // quad_perm [2,3,0,1]
+        if (G >= 8) vm = max_f64_raw(vm, dpp_f64_all<0x141>(vm));   // row_half_mirror
+        vout = vm + 0.0;
+        vin = hand_up_f64<G>(vout);
+        // the index, behind the chain: the largest slot whose candidate is the maximum (HypDict.update's `<=`, viterbi.py:27).
+        // (Taking it one column late, next to the next column's value chain, was measured: the copies of the kept candidates cost
+        // more than the stalls they fill.)
+        const double NEG = -INFINITY;
+        int m3[3] = {-128, -128, -128};                             // three short select chains instead of one long one
+#pragma unroll
+        for (int i = 0; i < JG; ++i) m3[i % 3] = max(m3[i % 3], c[i] == vm ? i : -128);
+        jm = g * JG - 1 + max(max(m3[0], m3[1]), m3[2]);            // (< 0 in lanes that do not hold the maximum)
+        jm = max(jm, dpp_i32_all<0xB1>(jm));
+        if (G >= 4) jm = max(jm, dpp_i32_all<0x4E>(jm));
+        if (G >= 8) jm = max(jm, dpp_i32_all<0x141>(jm));
+        // all -inf: the reference still picks the longest live hypothesis.  (State 0's lanes always take this path, and for them it
+        // is k - 1 while state 1 can be entered: exactly the length index of state 0's one hypothesis -- state 1 needs no special case.)
+        if (vm == NEG) jm = min(J - 1, k - n - 1);
+        jin = hand_up_i32<G>(jm);
+    }
+    // second half: the entry arrives (vin / jin: from the hand-over, or across the wave boundary).  -> whether this lane stores jin
+    __device__ __forceinline__ bool col_b(const int k, const double vin, const double alt) {
+        const bool store = (unsigned)(k - lo_s) <= (unsigned)R;     // g == 0 and state n can be entered at column k
+        const bool take = store && !is_n1;
+        S[0] = take ? vin : alt;
+        return store;
+    }
 };
-// `mid` runs between the loads that do not depend on the frame scores (length scores, transcript: from pinned host memory in the
-// one-launch kernel, ~2 us away) and their first use: the one-launch kernel puts phase 1 there.  bp_lds: the back-pointers go to bp_l (LDS) instead of bp.
-template <int G, int JG, int NW, typename Mid>   // NW decoding waves (1: wave 0 decodes, the workgroup's other waves only help with the labels)
+
+// finalize_decoding (viterbi.py:125-138) on the decoding lanes: the best final hypothesis -> *fin_n / *fin_j / *fin_score (LDS)
+template <int G, int JG>
+__device__ __forceinline__ void vit_lanes_finalize(const VitLanes<G, JG> &L, const mucon_viterbi_job &job, const int K, const int J,
+                                                   const bool forced, const double *Pl0, const int wave, int *fin_n, int *fin_j,
+                                                   double *fin_score) {
+    const int N = job.N, n = L.n, g = L.g;
+    const double NEG = -INFINITY;
+    const double pl_up = dpp_f64<0x101>(L.PlS[0]);                   // row_shl:1 -- the next lane's first length score
+    if (forced) {
+        // Degenerate outcomes of the reference, see viterbi_dp_kernel
+        if (L.lane == 0 && wave == 0) {
+            *fin_n = job.force_n >= 0 ? job.force_n : K - 1;
+            *fin_j = job.force_n >= 0 ? job.force_j : 0;
+            *fin_score = -INFINITY;
+        }
+        return;
+    }
+    const int nf = N - 1, c = K - 1;
+    Cand best;
+    best.v = NEG;
+    best.j = -1;
+    if (nf == 0) {
+        if (c < J) {
+            best.v = ((double)L.s0 + Pl0[c]) + 0.0;
+            best.j = c;
+        }
+    } else if (n == nf) {
+        // live length indices at the last column: entered at k0 = c - j with nf <= k0 <= J nf, and j < J
+        const int j_lo = max(0, c - J * nf), j_hi = min(J - 1, c - nf);
+#pragma unroll
+        for (int i = 0; i < JG; ++i) {
+            const int j = g * JG + i;
+            // Pl[nf][j] is the candidates' table one slot up: the next register, the next lane's first for the lane's last slot
+            // (j beyond J - 1 is not live: whatever arrives there is not used)
+            const double pl = i + 1 < JG ? L.PlS[i + 1 < JG ? i + 1 : 0] : pl_up;
+            Cand d;
+            d.v = (L.S[i] + pl) + 0.0;
+            d.j = j;
+            if (j >= j_lo && j <= j_hi) best = better(best, d);
+        }
+    }
+    best = wave_best(best);
+    if (L.lane == 0 && wave == (nf * G) / 64) {                       // the wave that holds the last state
+        *fin_n = nf;
+        *fin_j = best.j;
+        *fin_score = best.v;
+    }
+}
+
+// The two-launch DP: frame scores from memory (phase 1 wrote them), NW decoding waves (1: wave 0 decodes, the workgroup's other
+// waves only help with the labels).  bp_lds: the back-pointers go to bp_l (LDS) instead of bp.
+template <int G, int JG, int NW>
 __device__ __forceinline__ void viterbi_dp_lanes_body(
     const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, uint8_t *bp_l, const bool bp_lds, const int32_t *transcripts,
-    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
-    Mid mid) {
-    static_assert(G * JG >= 67 && (G == 2 || G == 4 || G == 8), "slots 0..66 over the G lanes of a state");
-    constexpr int VL_CH = NW >= 4 ? 16 : 32;  // columns of frame scores staged at a time (one register each while in flight)
+    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J) {
+    constexpr int VL_CH = NW >= 8 ? 8 : (NW >= 4 ? 16 : 32);  // columns of frame scores staged at a time (one register each while in flight)
     constexpr int NL = 64 * NW;               // decoding lanes
-    __shared__ float Fb[2][VL_CH][NL];        // frame scores of the lanes' own labels, two chunks
+    __shared__ float Fb[2 * VL_CH + 1][NL];   // frame scores of the lanes' own labels, two chunks (+ a row the read-ahead may touch)
     __shared__ double xch_v[2][NW];           // NW > 1: a wave's last state hands its best candidate to the next wave's first
     __shared__ int xch_j[2][NW];
-    __shared__ double Pl0[128];               // state 0's length scores (runtime index: its hypothesis has j = column)
+    __shared__ double Pl0[128];               // state 0's length scores (runtime index: its hypothesis has j = column), -inf from J on
     __shared__ int a[NL], pre[NL + 1];
     __shared__ double fin_score;
     __shared__ int fin_n, fin_j;
@@ -574,38 +737,21 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         return;
     }
     const bool forced = job.force_n >= 0 || K < N;
-    const int n = tid / G, g = tid - n * G;              // this lane's state and slot group (decoding lanes: tid < NL)
-    const bool state_on = tid < NL && n >= 1 && n < N;
     const double NEG = -INFINITY;
-    // length scores against the slot index s = j + 1 (the candidate of slot s uses the OLD length index s - 1); state 0's go to LDS
-    double PlS[JG], pl0r[2] = {0.0, 0.0};
-    int a_own = 0, an = 0;
+    VitLanes<G, JG> L;
     if (tid < NL) {
-        a_own = tid < N ? transcripts[job.tr_off + tid] : 0;
-        an = transcripts[job.tr_off + (n < N ? n : 0)];
-#pragma unroll
-        for (int i = 0; i < JG; ++i) {
-            const int sidx = g * JG + i;
-            PlS[i] = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
-        }
+        L.load(job, tables, tid, J);
+        a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            if (tid + u * NL < J) pl0r[u] = tables[job.p_off + (size_t)(tid + u * NL) * N];
+            if (tid + u * NL < 128) Pl0[tid + u * NL] = tid + u * NL < J ? tables[job.p_off + (size_t)(tid + u * NL) * N] : NEG;
     }
-    mid();
-    if (tid < NL) {
-        a[tid] = a_own;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (tid + u * NL < J) Pl0[tid + u * NL] = pl0r[u];
-    }
-    if constexpr (NW > 1) __syncthreads();               // (NW = 1: Pl0 is wave 0's own; `a` is read behind the barrier below)
+    __syncthreads();
 
     if (tid < NL) {
-        double S[JG];
-#pragma unroll
-        for (int i = 0; i < JG; ++i) S[i] = NEG;
-        // frame scores: chunk q in Fb[q & 1]; the loads of chunk q + 1 are issued at the start of chunk q
+        const int n = L.n;
+        const int an = a[n < N ? n : 0];
+        // frame scores: chunk q in Fb[(q & 1) * VL_CH ..]; the loads of chunk q + 1 are issued at the start of chunk q
         float fq[VL_CH];
         auto fetch = [&](int q) {
 #pragma unroll
@@ -616,73 +762,32 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         };
         auto stash = [&](int q) {
 #pragma unroll
-            for (int u = 0; u < VL_CH; ++u) Fb[q & 1][u][tid] = fq[u];
+            for (int u = 0; u < VL_CH; ++u) Fb[(q & 1) * VL_CH + u][tid] = fq[u];
         };
         VSTAMP(2);
         fetch(0);
         stash(0);
         VSTAMP(3);
-        // init_decoding (viterbi.py:81-90): score = 0.0 + frame_score(fs-1, a_0), float32.  (State 0 is lane 0 of wave 0; the other
-        // waves carry a side chain of their own first lane's scores that nothing reads.)
-        float s0 = 0.0f + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Fb[0][0][tid])));
+        L.init(Fb[0][tid]);
         const int nchunks = (K + VL_CH - 1) / VL_CH;
-        // The entry a column produces is first read by the NEXT column's S[1] = S[0] + f, so it stays pending across the loop edge.
-        double e_v = NEG;                                                // pending entry of this lane's state (g == 0)
         for (int q = 0; q < nchunks; ++q) {
             if (q + 1 < nchunks) fetch(q + 1);
             const int k_lo = q == 0 ? 1 : q * VL_CH, k_hi = min(K, (q + 1) * VL_CH);
-            const float *fcol = &Fb[q & 1][0][tid];
-            float f_nx = fcol[(k_lo & (VL_CH - 1)) * NL];
-            double pl0_nx = Pl0[min(k_lo - 1, J - 1)];
+            const float *fp = &Fb[(q & 1) * VL_CH + (k_lo & (VL_CH - 1))][tid];
+            float f_nx = fp[0];
+            double pl0_nx = Pl0[min(k_lo - 1, 127)];
             for (int k = k_lo; k < k_hi; ++k) {
-                const int c_old = k - 1;
                 const float f = f_nx;
                 const double pl0 = pl0_nx;
-                f_nx = fcol[(min(k + 1, k_hi - 1) & (VL_CH - 1)) * NL];   // the next column's reads overlap this column
-                pl0_nx = Pl0[min(k, J - 1)];
-                const double fd = (double)f;
-                // every hypothesis grows by one column
-                const double in = dpp_f64<0x111>(S[JG - 1]);            // row_shr:1 -- from the slot group below
-#pragma unroll
-                for (int i = JG - 1; i >= 2; --i) S[i] = S[i - 1] + fd;
-                // state 0: one hypothesis, float32 chain; its candidate for state 1
-                const float f0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f)));
-                const float t0 = s0 + f0;
-                const double cand01 = c_old < J ? (double)t0 + pl0 : NEG;
-                s0 = t0;
-                S[1] = (g == 0 ? e_v : S[0]) + fd;
-                S[0] = g == 0 ? NEG : in + fd;
-                // candidates; the maximum of the lane's, slot 1 (behind the fresh entry) last
-                double c[JG];
-#pragma unroll
-                for (int i = 0; i < JG; ++i) c[i] = S[i] + PlS[i];
-                double t[JG];
-                t[0] = c[0];
-#pragma unroll
-                for (int i = 1; i < JG - 1; ++i) t[i] = c[i + 1];
-#pragma unroll
-                for (int st = 1; st < JG - 1; st *= 2)
-#pragma unroll
-                    for (int i = 0; i + st < JG - 1; i += 2 * st) t[i] = fmax(t[i], t[i + st]);
-                double vm = fmax(t[0], c[1]);
-                // ... of the state: butterflies inside the lane group, every lane ends up with the maximum
-                vm = max_f64_raw(vm, dpp_f64<0xB1>(vm));                // quad_perm [1,0,3,2]
-                if (G >= 4) vm = max_f64_raw(vm, dpp_f64<0x4E>(vm));    // quad_perm [2,3,0,1]
-                if (G >= 8) vm = max_f64_raw(vm, dpp_f64<0x141>(vm));   // row_half_mirror
-                // hand over to the next state's lanes; state 1 takes state 0's candidate
-                const double vout = vm + 0.0;
-                double vin = hand_up_f64<G>(vout, lane);
-                // the index, behind the chain: the largest slot whose candidate is the maximum
-                int mi = -128;
-#pragma unroll
-                for (int i = 0; i < JG; ++i) mi = max(mi, c[i] == vm ? i : -128);
-                int jm = g * JG - 1 + mi;                               // (< 0 in lanes that do not hold the maximum)
-                jm = max(jm, dpp_i32<0xB1>(jm));
-                if (G >= 4) jm = max(jm, dpp_i32<0x4E>(jm));
-                if (G >= 8) jm = max(jm, dpp_i32<0x141>(jm));
-                if (vm == NEG) jm = min(J, k - n) - 1;                  // all -inf: the longest live hypothesis
-                int jin = hand_up_i32<G>(jm, lane);
-                if constexpr (NW > 1) {                                  // across a wave boundary: through LDS, one barrier per column
+                fp += NL;
+                f_nx = fp[0];                                            // the next column's reads overlap this column (behind a chunk's
+                pl0_nx = Pl0[min(k, 127)];                               // end: a value nothing uses)
+                double vout, vin, alt;
+                int jm, jin;
+                L.col_a(k, f, pl0, J, vout, vin, jm, jin, alt);
+                if constexpr (NW > 1) {
+                    // Across a wave boundary: through LDS, one barrier per column.  (A mailbox per column that only the next wave polls,
+                    // so that the waves run skewed and none waits for all, was measured: the polling reads cost more than the barrier.)
                     if (lane == 63) {
                         xch_v[k & 1][wave] = vout;
                         xch_j[k & 1][wave] = jm;
@@ -693,63 +798,15 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
                         jin = xch_j[k & 1][wave - 1];
                     }
                 }
-                if (n == 1) {
-                    vin = cand01 + 0.0;
-                    jin = c_old;
-                }
-                const bool enter = state_on && k >= n && k <= J * n;
-                e_v = enter ? vin : NEG;
-                if (g == 0 && enter) {
+                if (L.col_b(k, vin, alt)) {
                     if (bp_lds) bp_l[k * N + n] = (uint8_t)jin;
                     else bp[(size_t)k * N + n] = (uint8_t)jin;
                 }
             }
             if (q + 1 < nchunks) stash(q + 1);
         }
-        if (g == 0) S[0] = e_v;                                          // the last column's entries
         VSTAMP(4);
-
-        // finalize_decoding (viterbi.py:125-138)
-        const double pl_up = dpp_f64<0x101>(PlS[0]);                     // row_shl:1 -- the next lane's first length score
-        if (forced) {
-            // Degenerate outcomes of the reference, see viterbi_dp_kernel
-            if (tid == 0) {
-                fin_n = job.force_n >= 0 ? job.force_n : K - 1;
-                fin_j = job.force_n >= 0 ? job.force_j : 0;
-                fin_score = -INFINITY;
-            }
-        } else {
-            const int nf = N - 1, c = K - 1;
-            Cand best;
-            best.v = NEG;
-            best.j = -1;
-            if (nf == 0) {
-                if (c < J) {
-                    best.v = ((double)s0 + Pl0[c]) + 0.0;
-                    best.j = c;
-                }
-            } else if (n == nf) {
-                // live length indices at the last column: entered at k0 = c - j with nf <= k0 <= J nf, and j < J
-                const int j_lo = max(0, c - J * nf), j_hi = min(J - 1, c - nf);
-#pragma unroll
-                for (int i = 0; i < JG; ++i) {
-                    const int j = g * JG + i;
-                    // Pl[nf][j] is the candidates' table one slot up: the next register, the next lane's first for the lane's last slot
-                    // (j beyond J - 1 is not live: whatever arrives there is not used)
-                    const double pl = i + 1 < JG ? PlS[i + 1 < JG ? i + 1 : 0] : pl_up;
-                    Cand d;
-                    d.v = (S[i] + pl) + 0.0;
-                    d.j = j;
-                    if (j >= j_lo && j <= j_hi) best = better(best, d);
-                }
-            }
-            best = wave_best(best);
-            if (lane == 0 && wave == (nf * G) / 64) {                     // the wave that holds the last state
-                fin_n = nf;
-                fin_j = best.j;
-                fin_score = best.v;
-            }
-        }
+        vit_lanes_finalize<G, JG>(L, job, K, J, forced, Pl0, wave, &fin_n, &fin_j, &fin_score);
     }
     __syncthreads();
     VSTAMP(5);
@@ -776,7 +833,7 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lan
     const size_t f_bytes = ((size_t)(K > 0 ? K : 0) * C * sizeof(float) + 15) & ~(size_t)15;
     viterbi_dp_lanes_body<G, JG, NW>(job, blockIdx.x, reinterpret_cast<const float *>(ws + job.ws_off),
                                      reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes), vl_bp, K > 0 && K * job.N <= bp_lds_bytes, transcripts, tables, labels, seg_len,
-                                     n_seg, score, status, C, fs, J, VitNoMid());
+                                     n_seg, score, status, C, fs, J);
     if (done_flag) {                                 // (one video per call: see viterbi_fused_kernel)
         __threadfence_system();
         __syncthreads();
@@ -784,12 +841,13 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lan
     }
 }
 
-// ONE launch for a short video (the evaluation's case: T ~ 2,000 frames, a handful of transcript states): the frame scores never
-// leave the workgroup -- phase 1 (framescore_cols_body: wave 0's float32 chain, seven staging waves) writes them to LDS, phase 2
-// (viterbi_dp_lanes_body) decodes from there.  Inputs (job, transcript, length table) are read straight from the caller's PINNED
-// host staging buffer and the results go straight into pinned host memory (no copy calls on either side: of the 0.10 ms a
-// two-launch decode of a T = 2,000 video took, half was the upload, the second launch and the synchronous download); thread 0
-// publishes `*done_flag = done_value` behind a system-scope fence, which is what the host waits for.
+// ONE launch for a short video (the evaluation's case: T ~ 2,000 frames, up to 16 transcript states): the frame scores never leave
+// the workgroup, and phase 2 runs UNDER phase 1 -- wave 0 adds (framescore_cols_body's float32 chain), waves 2..7 stage and take the
+// column differences into LDS, wave 1 decodes the columns two rounds behind the chain (VitLanes), back-pointers in LDS.  The job
+// record is a kernel argument; transcript and length scores are read straight from the caller's PINNED host staging buffer by the
+// decoding wave before it does anything else; the results go straight into pinned host memory (no copy calls on either side);
+// thread 0 publishes `*done_flag = done_value` behind a system-scope fence, which is what the host waits for.
+// (r2, two launches + copies: 0.100 ms for T = 2,000 / N = 6; r3: 0.050 ms.)
 template <int G, int JG, bool W4>
 __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job job, const int32_t *transcripts,
                                                                     const double *tables, int32_t *labels, int32_t *seg_len,
@@ -798,15 +856,78 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_
                                                                     int32_t done_value) {
     // (the job travels as a kernel argument: read from the pinned table it was one more PCIe round trip in front of everything)
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    const int K = job.T / fs;
+    __shared__ double Pl0[VF_MAX_K];                 // state 0's length scores by column, -inf from J on
+    __shared__ int a[64], pre[65];
+    __shared__ double fin_score;
+    __shared__ int fin_n, fin_j;
+    const int T = job.T, N = job.N, K = T / fs;
+    const int tid = threadIdx.x, vid = 0;
     float *F = fs_smem + dyn_floats;                 // [K][C] behind phase 1's buffers, then the back-pointers [K][N]
     uint8_t *bp_l = reinterpret_cast<uint8_t *>(F + (K > 0 ? K : 0) * C);
     VSTAMP(0);
-    viterbi_dp_lanes_body<G, JG, 1>(job, 0, F, nullptr, bp_l, true, transcripts, tables, labels, seg_len, n_seg, score, status, C, fs, J, [&] {
-        framescore_cols_body<W4>(job.lp, F, K, C, fs, cols, fs_smem);
-        lds_barrier();                               // (F is in LDS; the staging waves' surplus read-ahead may still be in flight)
+    bool early = false;
+    if (K < 1) {  // frame_scores[fs-1] does not exist: IndexError in the reference (viterbi.py:87)
+        if (tid == 0) status[vid] = MUCON_VIT_INDEX_ERROR;
+        early = true;
+    } else if (job.force_n < 0 && K > J * N) {  // every hypothesis has outlived max_length: empty set
+        if (tid == 0) status[vid] = MUCON_VIT_NO_HYPOTHESIS;
+        early = true;
+    }
+    if (early) {
+        if (tid == 0) {
+            n_seg[vid] = 0;
+            score[vid] = -INFINITY;
+        }
+    } else {
+        const bool forced = job.force_n >= 0 || K < N;
+        // wave 1 decodes: its loads from pinned host memory (~2 us away) are issued in front of everything else it does
+        // (they stay in registers until its first round: an LDS store would have it wait for them in front of the first barrier)
+        VitLanes<G, JG> L;
+        const int dl = tid - 64;
+        int an = 0, a_own = 0;
+        double pl0r[2] = {0.0, 0.0};
+        if (tid >= 64 && tid < 128) {
+            L.load(job, tables, dl, J);
+            an = transcripts[job.tr_off + (L.n < N ? L.n : 0)];
+            a_own = dl < N ? transcripts[job.tr_off + dl] : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) pl0r[u] = dl + 64 * u < J ? tables[job.p_off + (size_t)(dl + 64 * u) * N] : -INFINITY;
+        }
+        framescore_cols_body<W4, 6>(job.lp, F, K, C, fs, cols, fs_smem, [&](const int k_lo, const int k_hi) {
+            int k = k_lo;
+            if (k_lo == 0) {                             // the first round: the prefetched values, then init_decoding on column 0
+                a[dl] = a_own;
+                Pl0[dl] = pl0r[0];
+                Pl0[dl + 64] = pl0r[1];
+                for (int j = dl + 128; j < K; j += 64) Pl0[j] = -INFINITY;
+                L.init(F[an]);
+                k = 1;
+            }
+            const float *fp = F + k * C + an;
+            const double *pp = Pl0 + (k - 1);
+            for (; k < k_hi; ++k, fp += C, ++pp) {
+                double vout, vin, alt;
+                int jm, jin;
+                L.col_a(k, *fp, *pp, J, vout, vin, jm, jin, alt);
+                if (L.col_b(k, vin, alt)) bp_l[k * N + L.n] = (uint8_t)jin;
+            }
+        });
         VSTAMP(1);
-    });
+        if (tid >= 64 && tid < 128) vit_lanes_finalize<G, JG>(L, job, K, J, forced, Pl0, 0, &fin_n, &fin_j, &fin_score);
+        __syncthreads();
+        VSTAMP(5);
+        if (fin_j < 0) {  // no comparable final hypothesis (NaN scores): traceback is None in the reference
+            if (tid == 0) {
+                status[vid] = MUCON_VIT_NO_HYPOTHESIS;
+                n_seg[vid] = 0;
+                score[vid] = -INFINITY;
+            }
+        } else {
+            vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, nullptr, a, pre, labels, seg_len, n_seg, score, status, fs,
+                                     bp_l, true);
+        }
+        VSTAMP(6);
+    }
     if (done_flag) {
         __threadfence_system();                      // every thread's label stores are visible to the host ...
         __syncthreads();
@@ -1064,7 +1185,7 @@ extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_
     return f_bytes + bp_bytes + 16;
 }
 
-// Launches of one decode: `fused` = the one-launch kernel (short videos, <= 32 states), else frame scores + DP.
+// Launches of one decode: `fused` = the one-launch kernel (one short video, <= 16 states), else frame scores + DP.
 static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs, int32_t max_len, int32_t max_N,
                       const int32_t *transcripts, const double *length_tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
                       double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int max_K, bool cols_ok,
@@ -1120,10 +1241,9 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
                                    hipFuncAttributeMaxDynamicSharedMemorySize, VL_BP_LDS_MAX) == hipSuccess
         VL_ATTR(8, 9, 1);
         VL_ATTR(4, 17, 1);
-        VL_ATTR(2, 34, 1);
-        VL_ATTR(4, 17, 2);
+        VL_ATTR(8, 9, 4);
         VL_ATTR(4, 17, 4);
-        VL_ATTR(2, 34, 4);
+        VL_ATTR(4, 17, 8);
 #undef VL_ATTR
         if (!ok) {
             snprintf(g_err, sizeof(g_err), "viterbi: hipFuncSetAttribute failed");
@@ -1132,7 +1252,7 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         attr_dev = dev;
     }
     const bool w4 = (((fs + 3) >> 2) & 3) == 0;
-    if (fused && lanes && max_N <= 16 && cols_ok && host_jobs && n_videos == 1) {   // (34 slots per lane + the staging waves' registers do not fit 256 VGPRs)
+    if (fused && lanes && max_N <= 16 && max_K <= VF_MAX_K && cols_ok && host_jobs && n_videos == 1) {
         // phase 1's buffers + the frame scores [K][C] + the back-pointers [K][N] share the dynamic LDS: as many columns per chunk as fit beside them
         const size_t f_bytes = (((size_t)max_K * C * sizeof(float) + (size_t)max_K * max_N) + 15) & ~(size_t)15;
         int cols = FS_ROWS / ((fs + 3) & ~3);
@@ -1172,7 +1292,7 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs,
                            static_cast<char *>(workspace), C, fs);
     }
-    // the DP: up to 66 length slots run in the registers of one wave (<= 32 states) or two (<= 128) ...
+    // the DP: up to 66 length slots run in the registers of one wave (<= 16 states), four (<= 64) or eight (<= 128) ...
 #define VL_LAUNCH(G, JG, NW)                                                                                          \
     hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG, NW>), dim3(n_videos), dim3(NW == 1 ? VL_THREADS : 64 * NW), bp_lds, s, jobs, \
                        transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, \
@@ -1183,12 +1303,13 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
         const size_t bp_lds = (max_K > 0 && n_videos <= 8 && bp_need <= VL_BP_LDS_MAX) ? bp_need : 0;
         volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
+        // lanes per state x waves, by measurement (single T = 4,000 .. 16,384 decodes): more lanes per state shorten the per-lane
+        // slot loop, more waves pay a barrier per column, and past four waves two share a SIMD
         if (max_N <= 8) VL_LAUNCH(8, 9, 1);
         else if (max_N <= 16) VL_LAUNCH(4, 17, 1);
-        else if (max_N <= 32 && g_vit_lanes != 2) VL_LAUNCH(2, 34, 1);
-        else if (max_N <= 32) VL_LAUNCH(4, 17, 2);
+        else if (max_N <= 32) VL_LAUNCH(8, 9, 4);
         else if (max_N <= 64) VL_LAUNCH(4, 17, 4);
-        else VL_LAUNCH(2, 34, 4);
+        else VL_LAUNCH(4, 17, 8);
 #undef VL_LAUNCH
         if (hipGetLastError() != hipSuccess) {
             snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");

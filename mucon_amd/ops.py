@@ -845,6 +845,10 @@ def run_backward(fn, ctx, *grads):
 
 
 # --------------------------------------------------------------------------------------- viterbi
+_VITERBI_VIDEO_DTYPE = np.dtype([("lp", np.uint64), ("transcript", np.uint64), ("table", np.uint64), ("T", np.int32), ("N", np.int32),
+                                 ("force_n", np.int32), ("force_j", np.int32)])   # = _lib.ViterbiVideo = mucon_viterbi_video
+
+
 @dataclass
 class ViterbiResult:
     score: np.float64
@@ -854,23 +858,9 @@ class ViterbiResult:
     status: int
 
 
-def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
-                         tables: Sequence[np.ndarray], fs: int, max_len: int,
-                         forces: Optional[Sequence[Optional[tuple]]] = None) -> List[ViterbiResult]:
-    """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
-
-    lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
-    concatenated or copied); transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
-    forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved degenerate outcomes of the
-    reference).  The library reads the small inputs from and writes the results to its own pinned host buffers; a single
-    short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation)."""
-    lib = _lib.load()
+def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J):
+    """viterbi_decode_batch for a handful of videos (the latency path: NumPy's record-array set-up costs more than it saves here)."""
     nv = len(lps)
-    if nv == 0:
-        return []
-    _check_dev(*lps)
-    C = int(lps[0].shape[1])
-    J = max_len // fs
     vids = (_lib.ViterbiVideo * nv)()
     keep = []                      # the arrays the pointers below refer to
     sum_T = sum_N = 0
@@ -883,8 +873,8 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
         tr = np.ascontiguousarray(transcripts[v], dtype=np.int32)
         tab = np.ascontiguousarray(tables[v], dtype=np.float64)
         T, N = int(lp.shape[0]), int(tr.shape[0])
-        assert tab.shape == (J, N), (tab.shape, J, N)
-        assert lp.shape[1] == C
+        if tab.shape != (J, N) or lp.shape[1] != C:
+            raise ValueError(f"video {v}: length table {tab.shape} (expected {(J, N)}) / {lp.shape[1]} classes (expected {C})")
         keep.append((lp, tr, tab))
         q = vids[v]
         q.lp, q.transcript, q.table = lp.data_ptr(), tr.ctypes.data, tab.ctypes.data
@@ -910,4 +900,75 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
                                  seg_len=seg[seg_off: seg_off + ns], n_seg=ns, status=int(status[v])))
         lab_off += max(T, 1)
         seg_off += N
+    return out
+
+
+def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
+                         tables: Sequence[np.ndarray], fs: int, max_len: int,
+                         forces: Optional[Sequence[Optional[tuple]]] = None) -> List[ViterbiResult]:
+    """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
+
+    lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
+    concatenated or copied); transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
+    forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved degenerate outcomes of the
+    reference).  The library reads the small inputs from and writes the results to its own pinned host buffers; a single
+    short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation)."""
+    lib = _lib.load()
+    nv = len(lps)
+    if nv == 0:
+        return []
+    _check_dev(*lps)
+    C = int(lps[0].shape[1])
+    J = max_len // fs
+    # the per-video records as one NumPy record array in mucon_viterbi_video's layout, filled column by column (a ctypes structure
+    # per video cost ~4 us of Python each: more than the decode itself at 256 videos in flight)
+    if nv <= 4:
+        return _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J)
+    rec = np.empty(nv, dtype=_VITERBI_VIDEO_DTYPE)
+    keep = []                      # the arrays the pointers below refer to
+    p_lp, p_tr, p_tab, Ts, Ns = [], [], [], [], []
+    for v in range(nv):
+        lp = lps[v]
+        if not lp.is_contiguous() or (lp.data_ptr() & 15):
+            lp = lp.contiguous()
+            if lp.data_ptr() & 15:                      # (a storage-offset view whose start is not 16-byte aligned)
+                lp = lp.clone(memory_format=torch.contiguous_format)
+        tr, tab = transcripts[v], tables[v]
+        if not (type(tr) is np.ndarray and tr.dtype == np.int32 and tr.flags.c_contiguous):
+            tr = np.ascontiguousarray(tr, dtype=np.int32)
+        if not (type(tab) is np.ndarray and tab.dtype == np.float64 and tab.flags.c_contiguous):
+            tab = np.ascontiguousarray(tab, dtype=np.float64)
+        T, N = lp.shape[0], tr.shape[0]
+        if tab.shape != (J, N) or lp.shape[1] != C:
+            raise ValueError(f"video {v}: length table {tab.shape} (expected {(J, N)}) / {lp.shape[1]} classes (expected {C})")
+        keep.append((lp, tr, tab))
+        p_lp.append(lp.data_ptr())
+        p_tr.append(tr.__array_interface__["data"][0])
+        p_tab.append(tab.__array_interface__["data"][0])
+        Ts.append(T)
+        Ns.append(N)
+    rec["lp"], rec["transcript"], rec["table"], rec["T"], rec["N"] = p_lp, p_tr, p_tab, Ts, Ns
+    if forces is None:
+        rec["force_n"] = rec["force_j"] = -1
+    else:
+        rec["force_n"] = [int(f[0]) if f is not None else -1 for f in forces]
+        rec["force_j"] = [int(f[1]) if f is not None else -1 for f in forces]
+    lab_off = np.concatenate(([0], np.cumsum(np.maximum(rec["T"], 1))))
+    seg_off = np.concatenate(([0], np.cumsum(rec["N"])))
+    score = np.empty(nv, np.float64)
+    n_seg = np.empty(nv, np.int32)
+    status = np.empty(nv, np.int32)
+    labels = np.empty(int(lab_off[-1]), np.int32)
+    seg = np.empty(int(seg_off[-1]), np.int32)
+    _lib.check(lib.mucon_viterbi_decode_host(nv, rec.ctypes.data_as(ctypes.POINTER(_lib.ViterbiVideo)), C, fs, max_len, score.ctypes.data,
+                                             n_seg.ctypes.data, status.ctypes.data, labels.ctypes.data, seg.ctypes.data,
+                                             _lib.current_stream_ptr()),
+               "mucon_viterbi_decode_host")
+    out = []
+    ok = (status == _lib.VIT_OK) | (status == _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
+    lab_off, seg_off, ns_l, st_l, ok_l = lab_off.tolist(), seg_off.tolist(), n_seg.tolist(), status.tolist(), ok.tolist()
+    empty = np.empty(0, np.int32)
+    for v in range(nv):
+        out.append(ViterbiResult(score[v], labels[lab_off[v]: lab_off[v] + Ts[v]] if ok_l[v] else empty,
+                                 seg[seg_off[v]: seg_off[v] + ns_l[v]], ns_l[v], st_l[v]))
     return out

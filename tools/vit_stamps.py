@@ -24,6 +24,6 @@ for (T, N) in ((2000, 6), (2000, 12), (4096, 8), (16384, 64), (16384, 30)):
     print(f"   chain wave since kernel start: body entry {s[12]-base}, zero fill done {s[13]-base}, first chunk staged {s[14]-base}")
     print(f"   chain wave: adds {s[10]} cycles ({s[10]/T:.1f} per row), barrier waits {s[11]}; before the chain's first chunk: {(s[1]-s[0] if N <= 16 else s[9]-s[8]) - s[10] - s[11]}")
     if N <= 16:
-        print(f"T={T} N={N} fused: chain {s[1]-s[0]} | dp setup {s[3]-s[1]} | columns {s[4]-s[3]} ({(s[4]-s[3])/max(K-1,1):.1f} per column) | finalize {s[5]-s[4]} | labels {s[6]-s[5]} | fence {s[7]-s[6]}   [core cycles]")
+        print(f"T={T} N={N} one launch: phases 1 + 2 overlapped {s[1]-s[0]} ({(s[1]-s[0])/K:.0f} per column) | finalize {s[5]-s[1]} | labels {s[6]-s[5]} | fence {s[7]-s[6]}   [core cycles]")
     else:
         print(f"T={T} N={N} two launches: chain {s[9]-s[8]} | gap {s[2]-s[9]} | dp setup {s[3]-s[2]} | columns {s[4]-s[3]} ({(s[4]-s[3])/max(K-1,1):.1f} per column) | finalize {s[5]-s[4]} | labels {s[6]-s[5]}   [core cycles]")
