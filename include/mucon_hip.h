@@ -232,9 +232,10 @@ int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, 
  * (src/mucon/evaluators.py:178-180: numpy in, Python lists out): emissions stay on the device,
  * transcript and length table are host arrays, the results arrive in host arrays when the call returns
  * (it synchronises with the work it enqueued on `stream`; everything queued before it on that stream is
- * ordered in front of the decode).  One launch for a single short video (T / fs * C * 4 bytes of frame
- * scores beside the chain's LDS buffers, <= 32 transcript states); inputs are read from and results
- * written to library-owned pinned host buffers, no copy calls.  labels: video v's T labels at the sum of
+ * ordered in front of the decode).  One launch for a single short video (<= 16 transcript states, <= 640
+ * columns, T / fs * (C * 4 + N) bytes of frame scores and back-pointers beside the chain's LDS buffers: the
+ * DP runs under the frame-score chain); inputs are read from and results written to library-owned pinned
+ * host buffers, no copy calls.  labels: video v's T labels at the sum of
  * max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid). */
 typedef struct {
     const float *lp;            /* DEVICE: emissions [T][C] f32 */
