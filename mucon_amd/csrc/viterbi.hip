@@ -161,6 +161,7 @@ constexpr int FSC_MAX_LDS = 160 * 1024;
 constexpr int FSC_DEPTH = 8;                 // b128 reads in flight
 constexpr int FSC_SETS = 3;                  // register sets of staged global loads (chunks in flight)
 constexpr size_t VF_DYN_MAX = 160 * 1024 - 8 * 1024;    // dynamic LDS of the one-launch kernel: 160 KiB minus its static arrays
+constexpr size_t VP_DYN_MAX = 160 * 1024 - 40 * 1024;   // dynamic LDS of the pair kernel: 160 KiB minus the decoding role's static arrays
 constexpr int VF_MAX_K = 640;                           // columns of a video the one-launch kernel takes
 constexpr size_t VL_BP_LDS_MAX = 96 * 1024;             // dynamic LDS of the register DP kernels: back-pointers [K][N] of a latency call
 constexpr int FSC_SLACK = 8 * FSC_DEPTH;     // rows the read-ahead and the last round may run past a chunk's end
@@ -181,10 +182,12 @@ struct FscNoDp {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
 // W4: the column length in reads is a multiple of four (fs = 29..32, the default 30): only every fourth sum can end a column.
-// NSTG staging waves: 7 -- waves 1..7 stage; 6 -- wave 1 is the one-launch kernel's DECODING wave instead: once per round, between
-// the same barriers, it runs dp(k_lo, k_hi) on the columns whose frame scores the round before made visible (two rounds behind the
-// chain: phase 2 runs UNDER phase 1 instead of after it).
-template <bool W4, int NSTG, typename Dp>
+// NSTG staging waves: 7 -- waves 1..7 stage; 6 -- wave 1 has a job of its own, once per round between the same barriers:
+//   PUB = false  the one-launch kernel's DECODING wave: dp(k_lo, k_hi) on the columns whose frame scores the round before made
+//                visible (two rounds behind the chain: phase 2 runs UNDER phase 1 instead of after it);
+//   PUB = true   the pair kernel's PUBLISHING wave: it takes the column differences itself (it has no loads in flight, so its
+//                release fence waits for nothing but its own stores) and then calls dp(0, columns done) -- which publishes the count.
+template <bool W4, int NSTG, bool PUB, typename Dp>
 __device__ __forceinline__ void framescore_cols_body(const float *lp_video, float *F, const int K, const int C, const int fs, const int cols,
                                                      float *fs_smem, Dp dp) {   // [2][C][pitch] rows, then [2][cols * nq + 8][64] sums
     constexpr int STG0 = FSC_THREADS - 64 * NSTG;     // first staging thread
@@ -201,7 +204,25 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
     const int chunk4 = cols * fs * C4;            // float4 per chunk in memory (contiguous: whole columns)
     const int nchunks = (K + cols - 1) / cols;
     // rounds: chunk c is added in round c, differenced in round c + 1, decoded in round c + 2; a multiple of three (see below)
-    const int nch3 = (nchunks + (NSTG == 6 ? 2 : 1) + FSC_SETS - 1) / FSC_SETS * FSC_SETS;
+    const int nch3 = (nchunks + (NSTG == 6 && !PUB ? 2 : 1) + FSC_SETS - 1) / FSC_SETS * FSC_SETS;
+    // F[k][c] = run(end of column k) - run(end of column k - 1) for the columns of chunk ci (frame_score, viterbi.py:68-72), by
+    // the `nthr` threads j.  Runs while wave 0 fills the OTHER sums buffer, so the end of the chunk before travels in a register
+    // (threads j < 64 own column 0 of every chunk).
+    float carry = 0.f;
+    auto diffs = [&](const int ci, const int j, const int nthr) {
+        const float *rn = runs + (ci & 1) * runsz;
+        const int ncols = min(cols, K - ci * cols);
+        for (int i = j; i < ncols * 64; i += nthr) {
+            const int kc = i >> 6, c = i & 63;
+            if (c < C) {
+                const float hi = rn[((kc + 1) * nq - 1) * 64 + c];
+                const float lo = kc > 0 ? rn[(kc * nq - 1) * 64 + c] : carry;
+                const int k = ci * cols + kc;
+                F[(long)k * C + c] = k == 0 ? hi : hi - lo;
+            }
+        }
+        if (j < 64) carry = rn[(cols * nq - 1) * 64 + j];   // (a short last chunk has no successor)
+    };
     // the padding rows of both buffers: -0.0f (every thread its share)
     VSTAMP(12);
     auto zero_fill = [&]() {
@@ -257,24 +278,6 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
                     d[3 * pitch] = r[u].w;
                 }
         };
-        // F[k][c] = run(end of column k) - run(end of column k - 1) for the columns of chunk ci (frame_score, viterbi.py:68-72).
-        // Runs while wave 0 fills the OTHER sums buffer, so the end of the chunk before travels in a register (threads j < 64
-        // own column 0 of every chunk).
-        float carry = 0.f;
-        auto diffs = [&](int ci) {
-            const float *rn = runs + (ci & 1) * runsz;
-            const int ncols = min(cols, K - ci * cols);
-            for (int i = j; i < ncols * 64; i += NSTAGE) {
-                const int kc = i >> 6, c = i & 63;
-                if (c < C) {
-                    const float hi = rn[((kc + 1) * nq - 1) * 64 + c];
-                    const float lo = kc > 0 ? rn[(kc * nq - 1) * 64 + c] : carry;
-                    const int k = ci * cols + kc;
-                    F[(long)k * C + c] = k == 0 ? hi : hi - lo;
-                }
-            }
-            if (j < 64) carry = rn[(cols * nq - 1) * 64 + j];   // (a short last chunk has no successor)
-        };
         // Every load below is issued on every path (past the video's end the clamp re-reads its last float4): the wait in front of a
         // set's stores counts the loads issued after it, and LLVM takes the smallest count over all paths that reach it.  For the
         // same reason both sides run the chunk loop to a multiple of three (the extra rounds find nothing to do).
@@ -293,21 +296,28 @@ __device__ __forceinline__ void framescore_cols_body(const float *lp_video, floa
                 vit_f32x4(&r)[NPER] = rs[(u3 + 1) % FSC_SETS];
                 sstore(ci + 1, r);                        // (behind the last chunk: left4 <= 0, nothing is stored)
                 gload(ci + 1 + FSC_SETS, r);
-                if (ci > 0) diffs(ci - 1);
+                if (!PUB && ci > 0) diffs(ci - 1, j, NSTAGE);
                 lds_barrier();
             }
         }
         return;
     }
     if (NSTG == 6 && tid >= 64) {
-        // ---- wave 1: the decoding wave (one-launch kernel) ----
+        // ---- wave 1: the decoding wave (one-launch kernel) / the publishing wave (pair kernel) ----
         __builtin_amdgcn_s_setprio(2);               // in front of the staging wave it shares a SIMD with
         zero_fill();
         lds_barrier();
         lds_barrier();
         for (int r = 0; r < nch3; ++r) {
-            const int c = r - 2;
-            if (c >= 0 && c < nchunks) dp(c * cols, min(K, (c + 1) * cols));
+            if constexpr (PUB) {
+                if (r > 0 && r <= nchunks) {
+                    diffs(r - 1, tid - 64, 64);
+                    dp(0, min(K, r * cols));
+                }
+            } else {
+                const int c = r - 2;
+                if (c >= 0 && c < nchunks) dp(c * cols, min(K, (c + 1) * cols));
+            }
             lds_barrier();
         }
         return;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_framescore_cols_kernel(co
     const int K = job.T / fs;
     if (K < 1) return;
     VSTAMP(8);
-    framescore_cols_body<W4, 7>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem, FscNoDp());
+    framescore_cols_body<W4, 7, false>(job.lp, reinterpret_cast<float *>(ws + job.ws_off), K, C, fs, cols, fs_smem, FscNoDp());
     VSTAMP(9);
 }
 
@@ -447,9 +457,10 @@ __device__ __forceinline__ double add_frame(double s, float f, int n) {
 __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job &job, int vid, int fin_n, int fin_j, double fin_score,
                                                          bool forced, const uint8_t *bp, const int *a, int *pre, int32_t *labels,
                                                          int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int fs,
-                                                         const uint8_t *bp_l = nullptr, const bool bp_lds = false) {   // bp_lds: the back-pointers are in bp_l (LDS), bp is unused
+                                                         const uint8_t *bp_l = nullptr, const bool bp_lds = false,
+                                                         const int live_threads = 0) {   // bp_lds: the back-pointers are in bp_l (LDS), bp is unused; live_threads: the threads that got here, if not all
     const int T = job.T, N = job.N, K = T / fs;
-    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int tid = threadIdx.x, nthreads = live_threads ? live_threads : (int)blockDim.x;
     // traceback
     const int nseg = fin_n + 1;
     const int missing = T - K * fs;
@@ -707,7 +718,10 @@ __device__ __forceinline__ void vit_lanes_finalize(const VitLanes<G, JG> &L, con
 template <int G, int JG, int NW>
 __device__ __forceinline__ void viterbi_dp_lanes_body(
     const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, uint8_t *bp_l, const bool bp_lds, const int32_t *transcripts,
-    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J) {
+    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
+    const int32_t *progress = nullptr, const int32_t seq = 0, const int live_threads = 0) {
+    // progress != nullptr (pair kernel): the frame scores are being written by another workgroup, which publishes
+    // (seq << 16 | columns done) there; live_threads: the workgroup's threads that run this body (the others have left)
     constexpr int VL_CH = NW >= 8 ? 8 : (NW >= 4 ? 16 : 32);  // columns of frame scores staged at a time (one register each while in flight)
     constexpr int NL = 64 * NW;               // decoding lanes
     __shared__ float Fb[2 * VL_CH + 1][NL];   // frame scores of the lanes' own labels, two chunks (+ a row the read-ahead may touch)
@@ -754,6 +768,14 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         // frame scores: chunk q in Fb[(q & 1) * VL_CH ..]; the loads of chunk q + 1 are issued at the start of chunk q
         float fq[VL_CH];
         auto fetch = [&](int q) {
+            if (progress) {                                              // (the adding workgroup runs ~3x ahead of the decode: a wait at the start only)
+                const int need = min(K, (q + 1) * VL_CH);
+                for (;;) {
+                    const int v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 16) == seq && (v & 0xFFFF) >= need) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < VL_CH; ++u) {
                 const int col = q * VL_CH + u;
@@ -818,7 +840,8 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         }
         return;
     }
-    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs, bp_l, bp_lds);
+    vit_traceback_and_labels(job, vid, fin_n, fin_j, fin_score, forced, bp, a, pre, labels, seg_len, n_seg, score, status, fs, bp_l, bp_lds,
+                             live_threads);
     VSTAMP(6);
 }
 
@@ -835,6 +858,43 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lan
                                      reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes), vl_bp, K > 0 && K * job.N <= bp_lds_bytes, transcripts, tables, labels, seg_len,
                                      n_seg, score, status, C, fs, J);
     if (done_flag) {                                 // (one video per call: see viterbi_fused_kernel)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(const_cast<int32_t *>(done_flag), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// A few longer videos (or more transcript states than the one-launch kernel takes): phase 1 and phase 2 as TWO WORKGROUPS of one
+// launch, blockIdx.y = 0 adds (framescore_cols_body, wave 1 publishing "columns done" behind a release fence), blockIdx.y = 1 decodes
+// (viterbi_dp_lanes_body, waiting on that count before each chunk of frame scores it fetches).  The decode is the longer of the two
+// (~1,200 against ~350 cycles per column), so after the first chunk it never waits: the call costs the decode, not the sum
+// (T = 16,384 / N = 64: 0.44 -> 0.34 ms).  For latency calls (vit_launch: <= 8 videos).
+template <int G, int JG, int NW, bool W4>
+__global__ __launch_bounds__(FSC_THREADS) void viterbi_pair_kernel(
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
+    double *score, int32_t *status, char *ws, int C, int fs, int J, int cols, int bp_lds_bytes, volatile int32_t *done_flag,
+    int32_t done_value, int32_t seq) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    const mucon_viterbi_job job = jobs[blockIdx.x];
+    const int K = job.T / fs;
+    const size_t f_bytes = ((size_t)(K > 0 ? K : 0) * C * sizeof(float) + 15) & ~(size_t)15;
+    const size_t bp_bytes = ((size_t)(K > 0 ? K : 0) * job.N + 15) & ~(size_t)15;
+    float *F = reinterpret_cast<float *>(ws + job.ws_off);
+    int32_t *progress = reinterpret_cast<int32_t *>(ws + job.ws_off + f_bytes + bp_bytes);   // (the 16 spare bytes of mucon_viterbi_job_workspace_bytes)
+    if (blockIdx.y == 0) {
+        if (K < 1) return;
+        framescore_cols_body<W4, 6, true>(job.lp, F, K, C, fs, cols, fs_smem, [&](int, const int done) {
+            __threadfence();                             // this wave's frame-score stores are visible on the device ...
+            if (threadIdx.x == 64) __hip_atomic_store(progress, (seq << 16) | done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
+        });
+        return;
+    }
+    constexpr int LIVE = NW == 1 ? VL_THREADS : 64 * NW;
+    if ((int)threadIdx.x >= LIVE) return;                // (a finished wave no longer counts at the workgroup's barriers)
+    viterbi_dp_lanes_body<G, JG, NW>(job, blockIdx.x, F, reinterpret_cast<uint8_t *>(ws + job.ws_off + f_bytes),
+                                     reinterpret_cast<uint8_t *>(fs_smem), K > 0 && K * job.N <= bp_lds_bytes, transcripts, tables, labels,
+                                     seg_len, n_seg, score, status, C, fs, J, progress, seq, LIVE);
+    if (done_flag) {                                     // (one video per call: see viterbi_fused_kernel)
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(const_cast<int32_t *>(done_flag), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -893,7 +953,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_
 #pragma unroll
             for (int u = 0; u < 2; ++u) pl0r[u] = dl + 64 * u < J ? tables[job.p_off + (size_t)(dl + 64 * u) * N] : -INFINITY;
         }
-        framescore_cols_body<W4, 6>(job.lp, F, K, C, fs, cols, fs_smem, [&](const int k_lo, const int k_hi) {
+        framescore_cols_body<W4, 6, false>(job.lp, F, K, C, fs, cols, fs_smem, [&](const int k_lo, const int k_hi) {
             int k = k_lo;
             if (k_lo == 0) {                             // the first round: the prefetched values, then init_decoding on column 0
                 a[dl] = a_own;
@@ -1236,6 +1296,17 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         VF_ATTR(8, 9);
         VF_ATTR(4, 17);
 #undef VF_ATTR
+#define VP_ATTR(G, JG, NW)                                                                                                      \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_pair_kernel<G, JG, NW, true>),                         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, VP_DYN_MAX) == hipSuccess &&                      \
+         hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_pair_kernel<G, JG, NW, false>),                              \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, VP_DYN_MAX) == hipSuccess
+        VP_ATTR(8, 9, 1);
+        VP_ATTR(4, 17, 1);
+        VP_ATTR(8, 9, 4);
+        VP_ATTR(4, 17, 4);
+        VP_ATTR(4, 17, 8);
+#undef VP_ATTR
 #define VL_ATTR(G, JG, NW)                                                                                                      \
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_dp_lanes_kernel<G, JG, NW>),                           \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, VL_BP_LDS_MAX) == hipSuccess
@@ -1275,6 +1346,41 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
                 VIT_FAIL(MUCON_E_HIP);
             }
             return 1;   // (fused: the completion flag, if any, will be published)
+        }
+    }
+    // a few videos of known size: both phases as two workgroups of ONE launch, the decode running beside the chain (viterbi_pair_kernel)
+    // (latency calls only: measured at 64 videos per call the pair is slower than two launches -- 17.0 against 15.3 us per video at
+    // T = 16,384: every workgroup then holds the chain's 112 KB of LDS.  Any number would be SAFE: workgroups are dispatched in
+    // order, every adding workgroup before any decoding one, and the adding ones wait for nothing.)
+    if (lanes && cols_ok && fs <= FS_ROWS && max_K > 0 && max_K <= 0xFFFF && n_videos <= 8 && done_flag) {
+        int cols = FS_ROWS / ((fs + 3) & ~3);
+        while (cols > 1 && (size_t)fsc_floats(C, fs, cols) * 4 > VP_DYN_MAX) --cols;
+        const size_t fsc_bytes = (size_t)fsc_floats(C, fs, cols) * 4;
+        if (fsc_bytes <= VP_DYN_MAX) {
+            const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
+            const size_t bp_lds = bp_need <= fsc_bytes ? bp_need : 0;      // (the decoding workgroup uses the same dynamic LDS for them)
+            volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
+            const int32_t seq = done_value & 0x7FFF;
+#define VP_LAUNCH(G, JG, NW)                                                                                                        \
+    do {                                                                                                                            \
+        if (w4) hipLaunchKernelGGL((viterbi_pair_kernel<G, JG, NW, true>), dim3(n_videos, 2), dim3(FSC_THREADS), fsc_bytes, s, jobs,  \
+                                   transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), \
+                                   C, fs, J, cols, (int)bp_lds, flag1, done_value, seq);                                             \
+        else hipLaunchKernelGGL((viterbi_pair_kernel<G, JG, NW, false>), dim3(n_videos, 2), dim3(FSC_THREADS), fsc_bytes, s, jobs,    \
+                                transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace),   \
+                                C, fs, J, cols, (int)bp_lds, flag1, done_value, seq);                                                \
+    } while (0)
+            if (max_N <= 8) VP_LAUNCH(8, 9, 1);
+            else if (max_N <= 16) VP_LAUNCH(4, 17, 1);
+            else if (max_N <= 32) VP_LAUNCH(8, 9, 4);
+            else if (max_N <= 64) VP_LAUNCH(4, 17, 4);
+            else VP_LAUNCH(4, 17, 8);
+#undef VP_LAUNCH
+            if (hipGetLastError() != hipSuccess) {
+                snprintf(g_err, sizeof(g_err), "viterbi: kernel launch failed");
+                VIT_FAIL(MUCON_E_HIP);
+            }
+            return flag1 ? 1 : MUCON_OK;
         }
     }
     const size_t fs_smem = (size_t)2 * FS_ROWS * C * sizeof(float);
