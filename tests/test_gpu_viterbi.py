@@ -110,6 +110,33 @@ def test_batched_launch_many_videos():
         _check(g, *w)
 
 
+@pytest.mark.parametrize("nv,n_hi,t_hi", [(2, 6, 3000), (3, 16, 6000), (5, 40, 9000), (8, 90, 12000), (1, 14, 30000), (2, 3, 700)])
+def test_latency_calls_a_few_ragged_videos(nv, n_hi, t_hi):
+    """Calls of 1..8 videos take the one-launch kernel (one video, <= 16 states, <= 640 columns) or the pair kernel (both phases as two
+    workgroups of one launch, the decode behind the published column count; back-pointers in LDS): ragged lengths and transcript
+    sizes -- the launch's lane layout is the largest transcript's -- against the oracle, repeated (the scratch, and with it the
+    published count of the call before, is reused)."""
+    from mucon_amd.core.viterbi import PoissonModel, Viterbi
+    for rep in range(3):
+        lps, trs, lms, wants = [], [], [], []
+        for i in range(nv):
+            seed = 7000 + 100 * rep + 10 * i + nv
+            T = 90 + int(synth.integers(seed, 1, 0, t_hi)[0])
+            N = 1 + int(synth.integers(seed + 1, 1, 0, n_hi)[0]) if i else n_hi
+            N = max(min(N, T // 30), -(-(T // 30) // 66))  # 1 <= N <= K, and K <= 66 N so that hypotheses survive
+            tr = synth.transcript(seed + 2, N, C)
+            lp = synth.emissions(seed + 3, T, C, labels=synth.segment_labels(seed + 4, T, tr))
+            mu = np.ones(C)
+            mu[np.unique(tr)] = float(T) / N
+            wants.append(oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN))
+            lps.append(torch.from_numpy(lp).cuda())
+            trs.append([int(x) for x in tr])
+            lms.append(PoissonModel(mu))
+        got = Viterbi(None, None, frame_sampling=FS).decode_batch(lps, trs, lms)
+        for g, w in zip(got, wants):
+            _check(g, *w)
+
+
 def test_baseline_config5_long_video():
     """BASELINE config 5: T = 16384, 64-state transcript (K = 546 columns, 64 x 66 hypotheses)."""
     from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
