@@ -92,6 +92,15 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
     auto convert = [&](f32x4 v0, f32x4 v1, bool ok) {
         u32x4 hh, mm, ll;
         uint32_t a, bb, c;
+#ifdef S2_ABL_NOSPLIT    // (timing ablation: the operands without the split arithmetic)
+        {
+            Planes P0;
+            P0.pl[0] = __builtin_bit_cast(bf16x8, v0);
+            P0.pl[1] = __builtin_bit_cast(bf16x8, v1);
+            P0.pl[2] = __builtin_bit_cast(bf16x8, v0);
+            return P0;
+        }
+#endif
         if (TAPS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -124,7 +133,19 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
+            for (int pl = 0; pl < 3; ++pl) {
+#ifdef S2_ABL_NOW        // (timing ablation, tools/abl_first_conv.sh -- wrong results: no fragment reads)
+                w[nb][pl] = A.pl[pl];
+                continue;
+#endif
+                w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
+            }
+#ifdef S2_ABL_NOMFMA     // (timing ablation: one MFMA per column block instead of six; the condition keeps the loads and the split alive)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.pl[0], w[nb][0], acc[nb], 0, 0, 0);
+        if (w[0][1][0] == 12345 && w[1][2][0] == 777 && A.pl[1][0] == 3 && A.pl[2][0] == 5) acc[0][0] += 1.f;
+        return;
+#endif
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.pl[1], w[nb][1], acc[nb], 0, 0, 0);
@@ -162,7 +183,9 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef S2_ABL_NOA       // (timing ablation: the tape is loaded for the first two k-tiles only)
         gloadA(min(S + 2, nS - 1), SET);   // the tail re-loads the last tile; nobody uses it
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 2 * g + 1, nxt);
         cur = convert(ra[O][0], ra[O][1], rok[O]);
