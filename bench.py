@@ -225,7 +225,7 @@ def viterbi_roofline(v):
         gbs = nbytes / (ms * 1e-3) / 1e9
         return {"ms_per_video": ms, "achieved": round(gbs, 3), "frac": round(gbs / PEAK_HBM_GBS, 6)}
     b5, b2 = v["algorithmic_bytes_per_video"], v["algorithmic_bytes_per_video_T2000_N6"]
-    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": "viterbi_framescore_cols_kernel + viterbi_dp_lanes_kernel",
+    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": "single video: viterbi_fused_kernel (T=2000/N=6: one launch, the DP under the frame-score chain) / viterbi_pair_kernel (config 5: both phases as two workgroups of one launch); batches: viterbi_framescore_cols_kernel + viterbi_dp_lanes_kernel",
             "config5_T16384_N64": {"algorithmic_bytes_per_video": b5, "single": leg(v["ms_per_video_single"], b5),
                                    "batch256": leg(v["ms_per_video_batch256"], b5)},
             "T2000_N6": {"algorithmic_bytes_per_video": b2, "single": leg(v["ms_per_video_T2000_N6_single"], b2),
