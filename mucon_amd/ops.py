@@ -958,7 +958,9 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     score = np.empty(nv, np.float64)
     n_seg = np.empty(nv, np.int32)
     status = np.empty(nv, np.int32)
-    labels = np.empty(int(lab_off[-1]), np.int32)
+    # the labels in PINNED host memory (torch's caching host allocator): the kernels then write them in place, no staging copy;
+    # the per-video arrays handed back are views of it
+    labels = torch.empty(int(lab_off[-1]), dtype=torch.int32, pin_memory=True).numpy()
     seg = np.empty(int(seg_off[-1]), np.int32)
     _lib.check(lib.mucon_viterbi_decode_host(nv, rec.ctypes.data_as(ctypes.POINTER(_lib.ViterbiVideo)), C, fs, max_len, score.ctypes.data,
                                              n_seg.ctypes.data, status.ctypes.data, labels.ctypes.data, seg.ctypes.data,
