@@ -236,7 +236,9 @@ int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, 
  * columns, T / fs * (C * 4 + N) bytes of frame scores and back-pointers beside the chain's LDS buffers: the
  * DP runs under the frame-score chain); inputs are read from and results written to library-owned pinned
  * host buffers, no copy calls.  labels: video v's T labels at the sum of
- * max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid). */
+ * max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid).
+ * If `labels` is itself pinned host memory (hipHostMalloc / torch pin_memory) and the call has >= 8 videos, the
+ * kernels write it in place (no staging copy of the largest output). */
 typedef struct {
     const float *lp;            /* DEVICE: emissions [T][C] f32 */
     const int32_t *transcript;  /* HOST [N] */
