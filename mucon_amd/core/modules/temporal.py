@@ -65,10 +65,17 @@ class WaveNetBlock(nn.Module):
 
     def ordered_parameters(self) -> List[Tensor]:
         """[first_w, first_b, (dil_w, dil_b, pw_w, pw_b) per layer, last_w, last_b] -- ops.param_names order."""
+        # (cached: 50 attribute walks through nn.Module.__getattr__ per forward; nn.Module keeps its Parameter OBJECTS across .to(),
+        # load_state_dict() and optimizer steps -- the first one's identity is checked in case a caller replaced them)
+        cache = self.__dict__.get("_ordered_params")
+        if cache is not None and cache[0] is self.first_conv.weight:
+            return cache
         out = [self.first_conv.weight, self.first_conv.bias]
         for l in self.layers:
             out += [l.dilated_conv.weight, l.dilated_conv.bias, l.conv_1x1.weight, l.conv_1x1.bias]
-        return out + [self.last_conv.weight, self.last_conv.bias]
+        out += [self.last_conv.weight, self.last_conv.bias]
+        self.__dict__["_ordered_params"] = out
+        return out
 
     def forward_time_major(self, tape: Tensor, gn_weight: Tensor, gn_bias: Tensor, spec: ops.EncoderSpec,
                            seed: int = 0) -> Tensor:

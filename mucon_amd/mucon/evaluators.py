@@ -167,7 +167,7 @@ class MuConEvaluator:
             return {k: self.metrics[k].summary() for k in RESULT_FIELDS}
 
     # ------------------------------------------------------------------------------------------ batched evaluation
-    forward_streams = 2          # streams the forwards of a chunk alternate between (0: all on the current stream); measured 0 / 2 / 4 / 8: 0.70 / 0.62 / 0.64-0.90 / 0.62-0.78 ms per video -- the chunk is bound by the host's enqueue rate, two streams take the GPU-side gaps out
+    forward_streams = 4          # streams the forwards of a chunk rotate over (0: all on the current stream).  One forward is ~0.18 ms of host time to enqueue and ~0.36 ms of GPU time on a stream of its own (batch-1 launches, persistent LSTM / decoder kernels on one or two CUs): measured 0 / 2 / 4 streams: 0.68 / 0.51-0.52 / 0.51-0.52 ms per video (tools/eval_repeat.py)
 
     def _forward_streams(self, dev):
         if self.forward_streams <= 0:
@@ -177,6 +177,20 @@ class MuConEvaluator:
         return self._fw_streams
 
     def _evaluate_chunk(self, idxs):
+        """_evaluate_chunk_on(idxs, ...) with the chunk's forwards rotating over self.forward_streams side streams.  What they allocate
+        is read on the current stream until the chunk is done; it is handed back to the side streams' pools only after those
+        streams have been made to wait for the current one (no per-tensor record_stream: its deferred frees made the caching
+        allocator grow the pools with hipMalloc for the first passes -- 1.2-1.6 ms per video instead of 0.55)."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        streams = self._forward_streams(dev)
+        try:
+            self._evaluate_chunk_on(idxs, cur, streams)
+        finally:
+            for st in streams:
+                st.wait_stream(cur)
+
+    def _evaluate_chunk_on(self, idxs, cur, streams):
         """A chunk of test videos with the host round trips of batch_eval_calculation pooled: every forward is enqueued first
         (MuCon.forward_deferred: the number of decoded words stays on the device), ONE copy fetches the transcripts of the chunk,
         ONE launch decodes all its videos (Viterbi.decode_batch), ONE launch scores all its labellings (mucon_metrics_segmental:
@@ -187,8 +201,6 @@ class MuConEvaluator:
         vids = []
         # the forwards of a chunk are independent chains of small launches (batch 1: a persistent LSTM / decoder kernel occupies one
         # or two CUs): round-robin over a few streams they overlap on the chip; the current stream waits for all of them below
-        cur = torch.cuda.current_stream(dev)
-        streams = self._forward_streams(dev)
         if streams:
             start = cur.record_event()
             for st in streams:
@@ -198,9 +210,6 @@ class MuConEvaluator:
                 with torch.cuda.stream(streams[k % len(streams)]):
                     batch = self.test_db[i].to(dev)
                     out = model.forward_deferred(batch)
-                for t in list(out.values()) + [batch.feats, batch.gt_label, batch.transcript]:
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(cur)          # (allocated on a side stream, read on the current one from here on)
             else:
                 batch = self.test_db[i].to(dev)
                 out = model.forward_deferred(batch)

@@ -374,7 +374,15 @@ class MuCon(nn.Module):
         return transcripts, lengths
 
     def _decoder_param_list(self):
-        """The 23 tensors of _lib.DECODER_PARAM_FIELDS, in that order."""
+        """The 23 tensors of _lib.DECODER_PARAM_FIELDS, in that order (cached like WaveNetBlock.ordered_parameters)."""
+        cache = self.__dict__.get("_decoder_params_cache")
+        if cache is not None and cache[0] is self.fs_encoder_hidden_out.weight:
+            return cache
+        cache = self._decoder_param_list_uncached()
+        self.__dict__["_decoder_params_cache"] = cache
+        return cache
+
+    def _decoder_param_list_uncached(self):
         return [self.fs_encoder_hidden_out.weight, self.fs_encoder_hidden_out.bias, self.fs_encoder_cn_out.weight,
                 self.fs_encoder_cn_out.bias, self.fs_decoder_attention_W1, self.fs_decoder_attention_l2.weight,
                 self.fs_decoder_attention_l2.bias, self.fs_decoder_attention_V, self.fs_decoder_embedding.weight,
