@@ -244,8 +244,9 @@ class MuCon(nn.Module):
         """forward + loss + backward of one video as a straight line of kernel launches: the same autograd Functions
         (same C entry points, same arithmetic) called directly in dependency order, gradients assigned to `.grad`.
         Equivalent to `loss = self.loss(batch, self.forward(batch)); loss.main.backward()` (tests/test_gpu_fused_step.py);
-        what it saves is the autograd graph walk: ~40 nodes with a Python round trip each -- half of the step's host time,
-        and the step is host-bound."""
+        what it saves is the autograd graph walk: ~40 nodes with a Python round trip each -- half of the step's host time.
+        (Since r3 the step is bound by its ~50 launches on the GPU, 0.82 ms; the y-head's four launches on a side stream beside
+        the s-head's persistent kernels were measured: 0.85-0.91 ms -- the stream hand-offs cost more than the ~30 us they hide.)"""
         F_ = ops
         lc = self.cfg.model.loss
         feats = batch.feats
