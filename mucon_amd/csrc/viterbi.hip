@@ -170,9 +170,10 @@ __host__ __device__ inline int fsc_floats(int C, int fs, int cols) {            
     const int nq = (fs + 3) >> 2;
     return 2 * C * fsc_pitch(cols * nq * 4) + 2 * (cols * nq + FSC_DEPTH) * 64;
 }
-// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- in
-// the staging waves that is the read-ahead just issued (one HBM latency per chunk: what paced the chain until r3), in the chain
-// wave of the one-launch kernel the length scores on their way from pinned host memory.
+// Workgroup barrier for LDS traffic only (release / acquire on the LDS address space: s_waitcnt lgkmcnt(0) + s_barrier).  It never
+// waits for global loads or stores in flight -- the staging waves' read-ahead, the decoding wave's length scores on their way from
+// pinned host memory.  (What paced the chain until r3 were the staging waves' FLAT loads -- see gptr4 below -- which count against
+// lgkmcnt as well: every barrier waited for the read-ahead just issued, one HBM latency per chunk.)
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
