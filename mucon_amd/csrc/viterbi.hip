@@ -66,7 +66,11 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
     float *F = reinterpret_cast<float *>(ws + job.ws_off);
     const int n = K * fs;                       // frames that enter the decode
     const int tid = threadIdx.x;
-    const float *src = job.lp;
+    // (global address space spelled out: through the job record's generic pointer these are FLAT loads, which count against the
+    // LDS wait counter as well -- see framescore_cols_body)
+    typedef const __attribute__((address_space(1))) float *gptr1;
+    typedef const __attribute__((address_space(1))) vit_f32x4 *gptr4v;
+    const gptr1 src = (gptr1)job.lp;
     const int chunk = FS_ROWS * C;              // floats per chunk: a contiguous range of the [T][C] array
     const int nchunks = (n + FS_ROWS - 1) / FS_ROWS;
     const long total = (long)n * C;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(FS_THREADS) void viterbi_framescore_kernel(const mu
             if (u < nper) {
                 long e = base4 + u * FS_THREADS + tid;
                 e = e < last4 ? e : last4;
-                r[u] = reinterpret_cast<const vit_f32x4 *>(src)[e];
+                r[u] = ((gptr4v)src)[e];
             }
     };
     auto sstore = [&](int buf) {
