@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the MuCon temporal hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) this process IS one rank.  Started bare (`python bench.py --gpus N`, WORLD_SIZE unset) it
+is the LAUNCHER: before anything touches the GPU it starts N fresh child processes of itself with those variables set (rendezvous
+on 127.0.0.1, a free port), waits for them, lets rank 0's single JSON line through on stdout and exits non-zero if any child did.
+The launcher never initialises the GPU and never replaces itself (no exec).
 
 Metric (BASELINE.json): frames/sec of encoder + y-head forward+backward on Breakfast-I3D-shaped
 tapes (T x 2048), plus Viterbi ms/video as extra fields.  One step = one pass of the hot path over
@@ -324,14 +330,98 @@ def eval_bench(dev, n_videos=32):
                       f"(chunks of {ev.chunk_videos} videos: pooled round trips, one Viterbi launch, device metrics)"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started bare: N child processes of this script, one rank each (the variables torch.distributed.run
+    would set), rendezvous on 127.0.0.1.  Rank 0 inherits stdout (its one JSON line is the launcher's), the other ranks' stdout
+    goes to stderr.  Returns the exit code: 0 only if every rank returned 0.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's buffer exchange between the ranks needs it
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    codes = [0] * n
+    pending = set(range(n))
+    while pending:                         # a rank that dies takes the others down (they would wait in a collective for ever)
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                codes[r] = rc
+                pending.discard(r)
+                if rc != 0:
+                    for q in pending:
+                        procs[q].terminate()
+        time.sleep(0.05)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py launcher: ranks exited non-zero: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def stub_main(args, rank, world):
+    """MUCON_BENCH_STUB=1 -- the launcher's and the timing protocol's self-test on a box without GPUs (tests/test_bench_launcher.py):
+    the same rendezvous, warm-up, (barrier + K steps + barrier) regions, max over ranks and ONE JSON line from rank 0, with a step that
+    is one gloo all-reduce of a small host buffer.  No number in its line means anything and the line says so."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.full((1024,), float(rank + 1))
+
+    def step(i):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.mul_(1.0 / world)
+
+    for i in range(args.warmup):
+        step(i)
+    regions = []
+    for r in range(args.repeats):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        dist.barrier()
+        regions.append(time.perf_counter() - t0)
+    t = torch.tensor(regions, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    regions = t.tolist()
+    elapsed = sorted(regions)[len(regions) // 2]
+    if rank == 0:
+        B, T = args.batch, args.frames
+        out = {"metric": "STUB: launcher / timing-protocol self-test, no GPU work (MUCON_BENCH_STUB=1)", "value": round(world * B * T * args.steps / elapsed, 1),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+               "config": {"workload": "stub", "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
+               "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
+               "rccl": {"world": world, "backend": dist.get_backend(), "bytes_per_step": int(buf.numel() * 4), "collectives_per_step": 1}}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))        # the launcher: N children of this script, nothing on the GPU here
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MUCON_BENCH_STUB") == "1":
+        return stub_main(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

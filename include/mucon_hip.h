@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 4   /* 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 5   /* 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -204,7 +204,8 @@ typedef struct {
                            of videos is decoded where its emissions lie, nothing is concatenated)  */
     int64_t tr_off;     /* int32 offset of its transcript [N] inside `transcripts`              */
     int64_t p_off;      /* double offset of its length table [J][N] inside `length_tables`      */
-    int64_t label_off;  /* int32 offset of its output labels [T] inside `labels`                */
+    int64_t label_off;  /* ELEMENT offset of its output labels [T] inside `labels` (int32 or uint8
+                           elements, by label_format; unused with MUCON_VIT_LABELS_NONE)          */
     int64_t seg_off;    /* int32 offset of its output segment lengths [N] inside `seg_len`      */
     int64_t ws_off;     /* byte offset of its scratch inside `workspace` (16-byte aligned)      */
     int32_t T, N;
@@ -215,18 +216,36 @@ typedef struct {
 /* scratch bytes one video needs (frame scores [K][C] f32 + back-pointers [K][N] u8, aligned) */
 size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_t N, int32_t fs);
 
+/* The form the per-frame labels leave the decode in (ABI 5).  The decode's result proper is the segmentation
+ * (seg_len[N], n_seg) -- the reference's traceback (src/core/viterbi/viterbi.py:140-158) builds its `labels` list from exactly
+ * that: `T - K*fs` leftover frames with the LAST segment's label at the start of the video, then every segment's label
+ * `length` times (the leftover frames are included in the last segment's length, :154-157).
+ *   I32   int32 [T] per video: the reference's list of ints, 4 T bytes
+ *   U8    uint8 [T] per video (C <= 64 is an ABI limit): a quarter of the bytes
+ *   NONE  nothing is written, `labels` may be NULL: the caller expands (transcript, seg_len, n_seg, T, fs) itself when it needs
+ *         per-frame labels (mucon_amd/ops.py: ViterbiResult.labels does it on first access) */
+#define MUCON_VIT_LABELS_I32 0
+#define MUCON_VIT_LABELS_U8 1
+#define MUCON_VIT_LABELS_NONE 2
+
+/* mucon_viterbi_decode_host: calls of up to this many videos are latency calls (one launch per call, results through the library's
+ * pinned staging buffer); from this many on, a `labels` array that is itself pinned host memory is written in place. */
+#define MUCON_VIT_LATENCY_VIDEOS 8
+
 /* Replaces Viterbi.decode (reference src/core/viterbi/viterbi.py:49-158) with
  * SingleTranscriptGrammar (src/core/viterbi/grammar.py:196-217) and an f64 length table
  * P[j][n] = length_model.score((j+1)*fs, a_n), J = max_len / fs rows
  * (PoissonModel, src/core/viterbi/length_model.py:76-80), as driven by
  * src/mucon/evaluators.py:147-180.  One workgroup per video; bit-exact (score, labels, segments).
- * jobs: DEVICE array [n_videos].  Outputs: labels, seg_len (per job offsets), n_seg[n_videos],
- * score[n_videos] (f64), status[n_videos] (MUCON_VIT_*). */
+ * jobs: DEVICE array [n_videos].  Outputs (all DEVICE memory; the call is asynchronous on `stream`): labels in
+ * `label_format` (MUCON_VIT_LABELS_*), seg_len (per job offsets), n_seg[n_videos], score[n_videos] (f64),
+ * status[n_videos] (MUCON_VIT_*).  Always the throughput schedule: one frame-score launch + one DP launch for the
+ * whole batch, back-pointers in `workspace`. */
 int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C,
                                int32_t fs, int32_t max_len, int32_t max_N,
                                const int32_t *transcripts, const double *length_tables,
-                               int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
-                               int32_t *status, void *workspace, void *stream);
+                               void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg,
+                               double *score, int32_t *status, void *workspace, void *stream);
 
 /* The same decode with HOST-side inputs and outputs -- what the reference's call site is
  * (src/mucon/evaluators.py:178-180: numpy in, Python lists out): emissions stay on the device,
@@ -235,10 +254,10 @@ int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, 
  * ordered in front of the decode).  One launch for a single short video (<= 16 transcript states, <= 640
  * columns, T / fs * (C * 4 + N) bytes of frame scores and back-pointers beside the chain's LDS buffers: the
  * DP runs under the frame-score chain); inputs are read from and results written to library-owned pinned
- * host buffers, no copy calls.  labels: video v's T labels at the sum of
- * max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid).
- * If `labels` is itself pinned host memory (hipHostMalloc / torch pin_memory) and the call has >= 8 videos, the
- * kernels write it in place (no staging copy of the largest output). */
+ * host buffers, no copy calls.  labels (in `label_format`; NULL with MUCON_VIT_LABELS_NONE): video v's T labels at the
+ * ELEMENT offset sum of max(T, 1) of the videos before it; seg_len: its N entries at the sum of N before it (n_seg[v] valid).
+ * If `labels` is itself pinned host memory (hipHostMalloc / torch pin_memory) and the call has >= MUCON_VIT_LATENCY_VIDEOS
+ * videos, the kernels write it in place (no staging copy of the largest output). */
 typedef struct {
     const float *lp;            /* DEVICE: emissions [T][C] f32 */
     const int32_t *transcript;  /* HOST [N] */
@@ -248,7 +267,7 @@ typedef struct {
 } mucon_viterbi_video;
 int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs,
                               int32_t max_len, double *score, int32_t *n_seg, int32_t *status,
-                              int32_t *labels, int32_t *seg_len, void *stream);
+                              void *labels, int32_t label_format, int32_t *seg_len, void *stream);
 
 /* ---- s-head sequence encoder: bidirectional LSTM --------------------------------
  * Replaces torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True) as the reference's s-head calls

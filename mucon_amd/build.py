@@ -18,6 +18,32 @@ SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shea
 DEPS = ["common.hpp", "dispatch.hpp", "gemm_nt.hpp", "gemm_split.hpp", "gemm_tn.hpp", "gemm_tn_split.hpp", "gemm_fused_split.hpp", "gemm_coarse_split.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "decoder.hpp", "loss.hpp", "optim.hpp", "../../include/mucon_hip.h", "../../include/mucon_hip_test.h"]
 
 
+def _obj(src):
+    return os.path.join(HERE, "build", src.replace(".hip", ".o"))
+
+
+def _deps_of(src):
+    """Files the object of `src` was compiled from (hipcc -MMD wrote them next to it); None: unknown, rebuild."""
+    d = _obj(src) + ".d"
+    if not os.path.exists(d) or not os.path.exists(_obj(src)):
+        return None
+    toks = open(d).read().replace("\\\n", " ").split()
+    return [t for t in toks[1:] if os.path.exists(t)] or None
+
+
+def _flags_tag(extra):
+    return " ".join(extra + os.environ.get("MUCON_HIPCC_FLAGS", "").split())
+
+
+def _tu_stale(src, extra):
+    deps = _deps_of(src)
+    tag = _obj(src) + ".flags"
+    if deps is None or not os.path.exists(tag) or open(tag).read() != _flags_tag(extra):
+        return True
+    t = os.path.getmtime(_obj(src))
+    return any(os.path.getmtime(f) > t for f in deps + [os.path.join(CSRC, src)])
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -27,24 +53,29 @@ def _stale():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the translation units whose sources (or compile flags) changed since their object was built, then link.
+    force: every translation unit."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = []
     procs = []
     for src, extra in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+        obj = _obj(src)
+        objs.append(obj)
+        if not force and not _tu_stale(src, extra):
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-MMD", "-MF", obj + ".d",
                "-c", os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("MUCON_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, p in procs:
+        procs.append((cmd, subprocess.Popen(cmd), obj, extra))
+    for cmd, p, obj, extra in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        with open(obj + ".flags", "w") as f:
+            f.write(_flags_tag(extra))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -76,7 +76,10 @@ def segmental_counters(targets: Sequence[torch.Tensor], predictions: Sequence[to
       correct / total, correct_nbg / total_nbg      MoFAccuracyMetric() / MoFAccuracyMetric(ignore_ids)
       iod, iou, iod_nbg, iou_nbg                     IoDMetric / IoUMetric without and with ignore_ids
       edit                                           Edit().add's score        f1: [(tp, fp, fn)] per overlap threshold (F1Score)
-    with the values the host classes compute from the same labellings, bit for bit."""
+    with the values the host classes compute from the same labellings, bit for bit.
+    A pair in which either labelling has more than METRICS_MAX_RUNS (1,024) runs -- a noisy y-head labelling of a long video --
+    is beyond the kernel's LDS tables: its record is {"over_limit": True} and nothing else, and the caller scores that pair with
+    the host metric objects (MuConEvaluator._evaluate_chunk_on does)."""
     from ... import _lib
     lib = _lib.load()
     n = len(targets)
@@ -108,13 +111,15 @@ def segmental_counters(targets: Sequence[torch.Tensor], predictions: Sequence[to
     mof_h = small_h[: 32 * n].view(np.int64).reshape(n, 4)
     runs_h = small_h[32 * n: 44 * n].view(np.int32).reshape(n, 3)
     seg_h = small_h[44 * n:].view(np.int32).reshape(n, 13)
-    if int(runs_h[:, :2].max()) > R:
-        raise ValueError(f"a labelling with more than {R} segments: use the host metrics for it")
-    nmax = max(int(runs_h[:, 0].max()), 1)
+    over = (runs_h[:, :2] > R).any(axis=1)
+    nmax = max(int(np.minimum(runs_h[:, 0], R).max()), 1)
     per_run = torch.cat([iod[:, :nmax], iou[:, :nmax], run_label[:, :nmax].to(torch.float64)], dim=1).cpu().numpy()   # labels are exact in f64
     iod_h, iou_h, lab_h = per_run[:, :nmax], per_run[:, nmax: 2 * nmax], per_run[:, 2 * nmax:].astype(np.int64)
     out = []
     for v in range(n):
+        if over[v]:
+            out.append({"over_limit": True})
+            continue
         nt, npred, kept_pred = int(runs_h[v, 0]), int(runs_h[v, 1]), int(runs_h[v, 2])
         res = {"correct": int(mof_h[v, 0]), "total": int(mof_h[v, 1]), "correct_nbg": int(mof_h[v, 2]), "total_nbg": int(mof_h[v, 3])}
         keep_nbg = ~np.isin(lab_h[v, :nt], ign) if ign else np.ones(nt, dtype=bool)

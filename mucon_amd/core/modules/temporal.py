@@ -65,16 +65,22 @@ class WaveNetBlock(nn.Module):
 
     def ordered_parameters(self) -> List[Tensor]:
         """[first_w, first_b, (dil_w, dil_b, pw_w, pw_b) per layer, last_w, last_b] -- ops.param_names order."""
-        # (cached: 50 attribute walks through nn.Module.__getattr__ per forward; nn.Module keeps its Parameter OBJECTS across .to(),
-        # load_state_dict() and optimizer steps -- the first one's identity is checked in case a caller replaced them)
+        # (cached: 50 attribute walks through nn.Module.__getattr__ per forward.  nn.Module keeps its Parameter OBJECTS across .to(),
+        # load_state_dict() and optimizer steps; a caller that REPLACES one -- `layer.conv_1x1.weight = nn.Parameter(...)`, a pruning or
+        # weight-norm re-parametrisation -- changes the module's _parameters dict, so every entry's identity is checked against the
+        # dict it came from: 50 dict look-ups, still a fraction of the attribute walks)
         cache = self.__dict__.get("_ordered_params")
-        if cache is not None and cache[0] is self.first_conv.weight:
-            return cache
-        out = [self.first_conv.weight, self.first_conv.bias]
-        for l in self.layers:
-            out += [l.dilated_conv.weight, l.dilated_conv.bias, l.conv_1x1.weight, l.conv_1x1.bias]
-        out += [self.last_conv.weight, self.last_conv.bias]
+        if cache is not None:
+            owners = self.__dict__["_ordered_param_owners"]
+            if all(o[k] is t for (o, k), t in zip(owners, cache)):
+                return cache
+        mods = [self.first_conv] + [m for l in self.layers for m in (l.dilated_conv, l.conv_1x1)] + [self.last_conv]
+        out, owners = [], []
+        for m in mods:
+            out += [m.weight, m.bias]
+            owners += [(m._parameters, "weight"), (m._parameters, "bias")]
         self.__dict__["_ordered_params"] = out
+        self.__dict__["_ordered_param_owners"] = owners
         return out
 
     def forward_time_major(self, tape: Tensor, gn_weight: Tensor, gn_bias: Tensor, spec: ops.EncoderSpec,

@@ -457,10 +457,36 @@ __device__ __forceinline__ double add_frame(double s, float f, int n) {
     return n == 0 ? (double)t32 : t64;
 }
 
+// Where the per-frame labels go and in which form (include/mucon_hip.h: MUCON_VIT_LABELS_*).  The decode's own result is the
+// segmentation (seg_len, n_seg); the per-frame labels are its expansion -- 4 T bytes as the reference's ints, T bytes as uint8
+// (C <= 64), or nothing at all when the caller expands the segments itself: at 256 videos of T = 16,384 in flight the int32 labels
+// were 16.8 MB crossing PCIe, longer than the decode (r3 profiles).
+struct VitLabels {
+    void *p;
+    int fmt;
+};
+__device__ __forceinline__ void vit_fill_i32(int32_t *lab, const int t0, const int t1, const int l, const int tid, const int nthreads) {
+    for (int t = t0 + tid; t < t1; t += nthreads) lab[t] = l;
+}
+// uint8 labels: 16-byte stores over the aligned interior of a run (a wave writes 1 KB per instruction), byte stores at its two ends
+__device__ __forceinline__ void vit_fill_u8(uint8_t *lab, const int t0, const int t1, const int l, const int tid, const int nthreads) {
+    if (t1 <= t0) return;
+    const int mis = (int)(reinterpret_cast<uintptr_t>(lab + t0) & 15);
+    const int head = min(t1 - t0, (16 - mis) & 15);
+    if (tid < head) lab[t0 + tid] = (uint8_t)l;
+    const int a0 = t0 + head, nvec = (t1 - a0) >> 4;
+    const unsigned w = (unsigned)(l & 0xFF) * 0x01010101u;
+    const uint4 v = make_uint4(w, w, w, w);
+    uint4 *dst = reinterpret_cast<uint4 *>(lab + a0);
+    for (int i = tid; i < nvec; i += nthreads) dst[i] = v;
+    const int b0 = a0 + (nvec << 4);
+    if (b0 + tid < t1) lab[b0 + tid] = (uint8_t)l;
+}
+
 // The tail both DP kernels share: thread 0 walks the back-pointers (viterbi.py:140-158), then the workgroup expands the
 // segments into per-frame labels.  `pre` is an LDS scratch of N + 1 ints, `a` the transcript in LDS.
 __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job &job, int vid, int fin_n, int fin_j, double fin_score,
-                                                         bool forced, const uint8_t *bp, const int *a, int *pre, int32_t *labels,
+                                                         bool forced, const uint8_t *bp, const int *a, int *pre, const VitLabels labels,
                                                          int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int fs,
                                                          const uint8_t *bp_l = nullptr, const bool bp_lds = false,
                                                          const int live_threads = 0) {   // bp_lds: the back-pointers are in bp_l (LDS), bp is unused; live_threads: the threads that got here, if not all
@@ -501,13 +527,18 @@ __device__ __forceinline__ void vit_traceback_and_labels(const mucon_viterbi_job
     __syncthreads();
     // ... and labelled, at the START of the video, with the last segment's label.  Segment by segment (a wave-uniform loop, the
     // threads stride over the segment's frames): a binary search per frame cost ~6 dependent LDS reads for every label.
-    int32_t *lab = labels + job.label_off;
-    for (int t = tid; t < missing; t += nthreads) lab[t] = a[nseg - 1];
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int t0 = missing + pre[sg], t1 = missing + pre[sg + 1], l = a[sg];
-        for (int t = t0 + tid; t < t1; t += nthreads) lab[t] = l;
+    if (labels.fmt == MUCON_VIT_LABELS_NONE) return;           // the caller expands (transcript, seg_len) itself
+    if (labels.fmt == MUCON_VIT_LABELS_U8) {
+        uint8_t *lab = static_cast<uint8_t *>(labels.p) + job.label_off;
+        vit_fill_u8(lab, 0, missing, a[nseg - 1], tid, nthreads);
+        for (int sg = 0; sg < nseg; ++sg) vit_fill_u8(lab, missing + pre[sg], missing + pre[sg + 1], a[sg], tid, nthreads);
+        vit_fill_u8(lab, missing + pre[nseg], T, a[nseg - 1], tid, nthreads);
+        return;
     }
-    for (int t = missing + pre[nseg] + tid; t < T; t += nthreads) lab[t] = a[nseg - 1];   // (nothing, when the segments cover the columns)
+    int32_t *lab = static_cast<int32_t *>(labels.p) + job.label_off;
+    vit_fill_i32(lab, 0, missing, a[nseg - 1], tid, nthreads);
+    for (int sg = 0; sg < nseg; ++sg) vit_fill_i32(lab, missing + pre[sg], missing + pre[sg + 1], a[sg], tid, nthreads);
+    vit_fill_i32(lab, missing + pre[nseg], T, a[nseg - 1], tid, nthreads);   // (nothing, when the segments cover the columns)
 }
 
 // Phase 2, J <= 66 length slots (every shipped configuration: max_len 2000, fs 30) and up to 128 transcript states: the whole DP
@@ -723,10 +754,10 @@ __device__ __forceinline__ void vit_lanes_finalize(const VitLanes<G, JG> &L, con
 template <int G, int JG, int NW>
 __device__ __forceinline__ void viterbi_dp_lanes_body(
     const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, uint8_t *bp_l, const bool bp_lds, const int32_t *transcripts,
-    const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
-    const int32_t *progress = nullptr, const int32_t seq = 0, const int live_threads = 0) {
+    const double *tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
+    const unsigned long long *progress = nullptr, const uint32_t seq = 0, const int live_threads = 0) {
     // progress != nullptr (pair kernel): the frame scores are being written by another workgroup, which publishes
-    // (seq << 16 | columns done) there; live_threads: the workgroup's threads that run this body (the others have left)
+    // (seq << 32 | columns done) there; live_threads: the workgroup's threads that run this body (the others have left)
     constexpr int VL_CH = NW >= 8 ? 8 : (NW >= 4 ? 16 : 32);  // columns of frame scores staged at a time (one register each while in flight)
     constexpr int NL = 64 * NW;               // decoding lanes
     __shared__ float Fb[2 * VL_CH + 1][NL];   // frame scores of the lanes' own labels, two chunks (+ a row the read-ahead may touch)
@@ -776,8 +807,8 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
             if (progress) {                                              // (the adding workgroup runs ~3x ahead of the decode: a wait at the start only)
                 const int need = min(K, (q + 1) * VL_CH);
                 for (;;) {
-                    const int v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((v >> 16) == seq && (v & 0xFFFF) >= need) break;
+                    const unsigned long long v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) == seq && (int)(uint32_t)v >= need) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
@@ -852,7 +883,7 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
 
 template <int G, int JG, int NW>
 __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lanes_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J, int bp_lds_bytes,
     volatile int32_t *done_flag, int32_t done_value) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vl_bp[];   // [K][N] back-pointers when they fit (bp_lds_bytes of them)
@@ -876,21 +907,22 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lan
 // (T = 16,384 / N = 64: 0.44 -> 0.34 ms).  For latency calls (vit_launch: <= 8 videos).
 template <int G, int JG, int NW, bool W4>
 __global__ __launch_bounds__(FSC_THREADS) void viterbi_pair_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
     double *score, int32_t *status, char *ws, int C, int fs, int J, int cols, int bp_lds_bytes, volatile int32_t *done_flag,
-    int32_t done_value, int32_t seq) {
+    int32_t done_value, unsigned long long *progress_words, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     const mucon_viterbi_job job = jobs[blockIdx.x];
     const int K = job.T / fs;
     const size_t f_bytes = ((size_t)(K > 0 ? K : 0) * C * sizeof(float) + 15) & ~(size_t)15;
-    const size_t bp_bytes = ((size_t)(K > 0 ? K : 0) * job.N + 15) & ~(size_t)15;
     float *F = reinterpret_cast<float *>(ws + job.ws_off);
-    int32_t *progress = reinterpret_cast<int32_t *>(ws + job.ws_off + f_bytes + bp_bytes);   // (the 16 spare bytes of mucon_viterbi_job_workspace_bytes)
+    // one 64-bit word per video, 64 bytes apart, in a buffer of the library's own that holds nothing else and starts as zeros: the
+    // tag (a call counter that never repeats within 2^32 calls) cannot be met by stale scratch of an earlier call of another shape
+    unsigned long long *progress = progress_words + 8 * blockIdx.x;
     if (blockIdx.y == 0) {
         if (K < 1) return;
         framescore_cols_body<W4, 6, true>(job.lp, F, K, C, fs, cols, fs_smem, [&](int, const int done) {
             __threadfence();                             // this wave's frame-score stores are visible on the device ...
-            if (threadIdx.x == 64) __hip_atomic_store(progress, (seq << 16) | done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
+            if (threadIdx.x == 64) __hip_atomic_store(progress, ((unsigned long long)seq << 32) | (unsigned)done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
         });
         return;
     }
@@ -915,7 +947,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_pair_kernel(
 // (r2, two launches + copies: 0.100 ms for T = 2,000 / N = 6; r3: 0.050 ms.)
 template <int G, int JG, bool W4>
 __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job job, const int32_t *transcripts,
-                                                                    const double *tables, int32_t *labels, int32_t *seg_len,
+                                                                    const double *tables, const VitLabels labels, int32_t *seg_len,
                                                                     int32_t *n_seg, double *score, int32_t *status, int C,
                                                                     int fs, int J, int cols, int dyn_floats, volatile int32_t *done_flag,
                                                                     int32_t done_value) {
@@ -1009,7 +1041,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_
 // DPP reductions, then the writes -- so that the LDS and DPP latencies of the states overlap instead of adding up.
 template <int SPW>
 __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, int32_t *labels,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mucon_viterbi_job job = jobs[blockIdx.x];
@@ -1228,6 +1260,10 @@ thread_local char g_err[256];
 }  // namespace
 
 int g_vit_lanes = 1;   // MUCON_VIT_LANES=0: always the one-wave-per-state LDS kernel (tests)
+// Calls of up to this many videos are LATENCY calls (pair kernel, back-pointers in LDS, results through the library's own pinned
+// staging buffer); larger ones are throughput calls (two launches, many videos per CU, a pinned caller array written in place).
+// include/mucon_hip.h states the same number as MUCON_VIT_LATENCY_VIDEOS; mucon_amd/ops.py reads it from _lib.
+constexpr int kVitLatencyVideos = MUCON_VIT_LATENCY_VIDEOS;
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 #define VIT_FAIL(code)                    \
@@ -1252,9 +1288,10 @@ extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_
 
 // Launches of one decode: `fused` = the one-launch kernel (one short video, <= 16 states), else frame scores + DP.
 static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs, int32_t max_len, int32_t max_N,
-                      const int32_t *transcripts, const double *length_tables, int32_t *labels, int32_t *seg_len, int32_t *n_seg,
+                      const int32_t *transcripts, const double *length_tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
                       double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int max_K, bool cols_ok,
-                      volatile int32_t *done_flag, int32_t done_value, const mucon_viterbi_job *host_jobs) {
+                      volatile int32_t *done_flag, int32_t done_value, const mucon_viterbi_job *host_jobs,
+                      unsigned long long *progress_words = nullptr) {
     // host_jobs: the job table where the host can read it (the one-launch kernel takes its job as a kernel argument), or nullptr;
     // max_K: the longest video's column count when the caller knows it (LDS sizing of the latency paths), else 0
     if (fs <= 0 || max_len < fs || C <= 0 || C > 64 || max_N <= 0) {
@@ -1357,7 +1394,7 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
     // (latency calls only: measured at 64 videos per call the pair is slower than two launches -- 17.0 against 15.3 us per video at
     // T = 16,384: every workgroup then holds the chain's 112 KB of LDS.  Any number would be SAFE: workgroups are dispatched in
     // order, every adding workgroup before any decoding one, and the adding ones wait for nothing.)
-    if (lanes && cols_ok && fs <= FS_ROWS && max_K > 0 && max_K <= 0xFFFF && n_videos <= 8 && done_flag) {
+    if (lanes && cols_ok && fs <= FS_ROWS && max_K > 0 && n_videos <= kVitLatencyVideos && done_flag && progress_words) {
         int cols = FS_ROWS / ((fs + 3) & ~3);
         while (cols > 1 && (size_t)fsc_floats(C, fs, cols) * 4 > VP_DYN_MAX) --cols;
         const size_t fsc_bytes = (size_t)fsc_floats(C, fs, cols) * 4;
@@ -1365,15 +1402,15 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
             const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
             const size_t bp_lds = bp_need <= fsc_bytes ? bp_need : 0;      // (the decoding workgroup uses the same dynamic LDS for them)
             volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
-            const int32_t seq = done_value & 0x7FFF;
+            const uint32_t seq = (uint32_t)done_value;
 #define VP_LAUNCH(G, JG, NW)                                                                                                        \
     do {                                                                                                                            \
         if (w4) hipLaunchKernelGGL((viterbi_pair_kernel<G, JG, NW, true>), dim3(n_videos, 2), dim3(FSC_THREADS), fsc_bytes, s, jobs,  \
                                    transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), \
-                                   C, fs, J, cols, (int)bp_lds, flag1, done_value, seq);                                             \
+                                   C, fs, J, cols, (int)bp_lds, flag1, done_value, progress_words, seq);                             \
         else hipLaunchKernelGGL((viterbi_pair_kernel<G, JG, NW, false>), dim3(n_videos, 2), dim3(FSC_THREADS), fsc_bytes, s, jobs,    \
                                 transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace),   \
-                                C, fs, J, cols, (int)bp_lds, flag1, done_value, seq);                                                \
+                                C, fs, J, cols, (int)bp_lds, flag1, done_value, progress_words, seq);                                \
     } while (0)
             if (max_N <= 8) VP_LAUNCH(8, 9, 1);
             else if (max_N <= 16) VP_LAUNCH(4, 17, 1);
@@ -1412,7 +1449,7 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         // latency calls (a few videos whose sizes the caller knows): back-pointers in LDS -- the traceback is a chain of N dependent
         // reads; throughput calls leave the LDS to more workgroups per CU.  One video: the kernel publishes the completion flag.
         const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
-        const size_t bp_lds = (max_K > 0 && n_videos <= 8 && bp_need <= VL_BP_LDS_MAX) ? bp_need : 0;
+        const size_t bp_lds = (max_K > 0 && n_videos <= kVitLatencyVideos && bp_need <= VL_BP_LDS_MAX) ? bp_need : 0;
         volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
         // lanes per state x waves, by measurement (single T = 4,000 .. 16,384 decodes): more lanes per state shorten the per-lane
         // slot loop, more waves pay a barrier per column, and past four waves two share a SIMD
@@ -1458,13 +1495,17 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
 
 extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
                                           int32_t max_len, int32_t max_N, const int32_t *transcripts, const double *length_tables,
-                                          int32_t *labels, int32_t *seg_len, int32_t *n_seg, double *score,
+                                          void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg, double *score,
                                           int32_t *status, void *workspace, void *stream) {
     if (n_videos <= 0) return MUCON_OK;
+    if (label_format < MUCON_VIT_LABELS_I32 || label_format > MUCON_VIT_LABELS_NONE || (!labels && label_format != MUCON_VIT_LABELS_NONE)) {
+        snprintf(g_err, sizeof(g_err), "viterbi: label_format %d / labels %s", label_format, labels ? "given" : "NULL");
+        VIT_FAIL(MUCON_E_ARG);
+    }
     // the job table lives on the device: the emission pointers cannot be inspected here, so the 16-byte loads of the pipelined
     // frame-score kernel are only taken for class counts where every row of an aligned base is aligned (the caller keeps `lp`
     // 16-byte aligned: include/mucon_hip.h)
-    const int rc = vit_launch(n_videos, jobs, C, fs, max_len, max_N, transcripts, length_tables, labels, seg_len, n_seg, score, status,
+    const int rc = vit_launch(n_videos, jobs, C, fs, max_len, max_N, transcripts, length_tables, VitLabels{labels, label_format}, seg_len, n_seg, score, status,
                               workspace, static_cast<hipStream_t>(stream), false, 0, (C & 3) == 0, nullptr, 0, nullptr);
     return rc > 0 ? MUCON_OK : rc;
 }
@@ -1476,6 +1517,7 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
 namespace {
 struct VitHostState {
     char *pin_in = nullptr, *pin_out = nullptr, *ws = nullptr;
+    unsigned long long *progress = nullptr;   // the pair kernel's "columns done" words: kVitLatencyVideos x 64 bytes, zeroed once, nothing else
     size_t in_cap = 0, out_cap = 0, ws_cap = 0;
     int32_t seq = 0;
 };
@@ -1498,10 +1540,15 @@ inline size_t up16(size_t n) { return (n + 15) & ~(size_t)15; }
 }  // namespace
 
 extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
-                                         double *score, int32_t *n_seg, int32_t *status, int32_t *labels, int32_t *seg_len,
-                                         void *stream) {
+                                         double *score, int32_t *n_seg, int32_t *status, void *labels, int32_t label_format,
+                                         int32_t *seg_len, void *stream) {
     if (n_videos <= 0) return MUCON_OK;
-    if (!videos || !score || !n_seg || !status || !labels || !seg_len || fs <= 0 || max_len < fs) {
+    if (label_format < MUCON_VIT_LABELS_I32 || label_format > MUCON_VIT_LABELS_NONE) {
+        snprintf(g_err, sizeof(g_err), "viterbi: label_format %d", label_format);
+        VIT_FAIL(MUCON_E_ARG);
+    }
+    const size_t lab_elem = label_format == MUCON_VIT_LABELS_I32 ? 4 : (label_format == MUCON_VIT_LABELS_U8 ? 1 : 0);
+    if (!videos || !score || !n_seg || !status || (!labels && lab_elem) || !seg_len || fs <= 0 || max_len < fs) {
         snprintf(g_err, sizeof(g_err), "viterbi: null argument / bad frame sampling");
         VIT_FAIL(MUCON_E_ARG);
     }
@@ -1534,20 +1581,28 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     const size_t o_score = 64, o_nseg = o_score + up16(8 * (size_t)n_videos), o_stat = o_nseg + up16(4 * (size_t)n_videos);
     // `labels` is by far the largest output (4 T bytes per video).  When the caller's array is itself pinned host memory the kernels
     // write it directly (no staging copy: at 256 videos of T = 16,384 the copy out of the staging buffer was ~1 ms of a 2.6 ms call).
-    int32_t *labels_dev = nullptr;
-    if (n_videos >= 8) {
+    void *labels_dev = nullptr;
+    if (n_videos >= kVitLatencyVideos && lab_elem) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, labels) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
-            labels_dev = static_cast<int32_t *>(at.devicePointer);
+            labels_dev = at.devicePointer;
         else
             (void)hipGetLastError();   // (an ordinary host pointer: the query fails, and leaves that error behind)
     }
     const size_t o_seg = o_stat + up16(4 * (size_t)n_videos), o_lab = o_seg + up16(4 * sum_N),
-                 out_bytes = o_lab + (labels_dev ? 0 : up16(4 * sum_T));
+                 out_bytes = o_lab + (labels_dev ? 0 : up16(lab_elem * sum_T));
     if (vh_grow(&st.pin_in, &st.in_cap, in_bytes, true) != MUCON_OK || vh_grow(&st.pin_out, &st.out_cap, out_bytes, true) != MUCON_OK ||
         vh_grow(&st.ws, &st.ws_cap, ws_bytes + 256, false) != MUCON_OK) {
         snprintf(g_err, sizeof(g_err), "viterbi: staging allocation failed (%zu / %zu / %zu bytes)", in_bytes, out_bytes, ws_bytes);
         VIT_FAIL(MUCON_E_HIP);
+    }
+    if (!st.progress) {
+        if (hipMalloc(reinterpret_cast<void **>(&st.progress), 64 * (size_t)kVitLatencyVideos) != hipSuccess ||
+            hipMemset(st.progress, 0, 64 * (size_t)kVitLatencyVideos) != hipSuccess) {   // (synchronous on the null stream: done before any launch below)
+            st.progress = nullptr;
+            snprintf(g_err, sizeof(g_err), "viterbi: allocation of the progress words failed");
+            VIT_FAIL(MUCON_E_HIP);
+        }
     }
     mucon_viterbi_job *jobs = reinterpret_cast<mucon_viterbi_job *>(st.pin_in);
     double *tabs = reinterpret_cast<double *>(st.pin_in + o_tab);
@@ -1585,10 +1640,10 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     const bool want_fused = n_videos == 1;
     const int rc = vit_launch(n_videos, reinterpret_cast<const mucon_viterbi_job *>(din), C, fs, max_len, max_N,
                               reinterpret_cast<const int32_t *>(din + o_tr), reinterpret_cast<const double *>(din + o_tab),
-                              labels_dev ? labels_dev : reinterpret_cast<int32_t *>(dout + o_lab), reinterpret_cast<int32_t *>(dout + o_seg),
+                              VitLabels{labels_dev ? labels_dev : static_cast<void *>(dout + o_lab), label_format}, reinterpret_cast<int32_t *>(dout + o_seg),
                               reinterpret_cast<int32_t *>(dout + o_nseg), reinterpret_cast<double *>(dout + o_score),
                               reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
-                              reinterpret_cast<volatile int32_t *>(dout), seq, jobs);
+                              reinterpret_cast<volatile int32_t *>(dout), seq, jobs, st.progress);
     if (rc < 0) return rc;
     bool done = false;
     if (rc > 0) {   // a one-video call's last kernel publishes the flag: spin on it (a stream synchronisation costs several microseconds more)
@@ -1608,6 +1663,6 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     memcpy(n_seg, st.pin_out + o_nseg, 4 * (size_t)n_videos);
     memcpy(status, st.pin_out + o_stat, 4 * (size_t)n_videos);
     memcpy(seg_len, st.pin_out + o_seg, 4 * sum_N);
-    if (!labels_dev) memcpy(labels, st.pin_out + o_lab, 4 * sum_T);
+    if (!labels_dev && lab_elem) memcpy(labels, st.pin_out + o_lab, lab_elem * sum_T);
     return MUCON_OK;
 }

@@ -12,7 +12,7 @@ What runs where
 """
 import math
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -299,15 +299,17 @@ class MuCon(nn.Module):
         loss = MuConLoss(main=main, transcript_loss=parts[0], length_loss=parts[1], mucon_loss=parts[2], smoothing_loss=parts[3])
         return loss, fo
 
-    def can_defer_eval(self, batch: Batch) -> bool:
+    def can_defer_eval(self, batch: Batch, on_device: Optional[bool] = None) -> bool:
         """The evaluation forward without host round trips exists for the all-HIP configuration (device tensors, the native LSTM and
-        decoder at the reference's sizes, one video per batch); everything else takes forward() / predict()."""
+        decoder at the reference's sizes, one video per batch); everything else takes forward() / predict().  Depends on the VIDEO
+        (its encoded length): callers ask per video.  on_device: the answer for this batch once it has been moved to the GPU."""
         enc_len = batch.feats.shape[1]
+        is_cuda = batch.feats.is_cuda if on_device is None else on_device
         for i in range(len(self.cfg.model.ft.stages)):
             if self.cfg.model.ft.pooling and i in self.cfg.model.ft.pooling_layers:
                 enc_len //= 2
         lstm, d = self.fs_encoder_lstm, self.fs_decoder_lstm
-        return (not self.training and not self.teacher_forcing and batch.feats.is_cuda and batch.feats.shape[0] == 1
+        return (not self.training and not self.teacher_forcing and is_cuda and batch.feats.shape[0] == 1
                 and isinstance(self.ft, WaveNetBlock) and self.native_lstm and self.native_decoder
                 and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
                 and d.input_size == 128 and d.hidden_size == 128 and d.num_layers == 1 and self.num_classes + 1 <= 128
@@ -375,23 +377,30 @@ class MuCon(nn.Module):
         return transcripts, lengths
 
     def _decoder_param_list(self):
-        """The 23 tensors of _lib.DECODER_PARAM_FIELDS, in that order (cached like WaveNetBlock.ordered_parameters)."""
+        """The 23 tensors of _lib.DECODER_PARAM_FIELDS, in that order (cached like WaveNetBlock.ordered_parameters: every entry's
+        identity is checked against the _parameters dict it came from, so a replaced Parameter object is noticed)."""
         cache = self.__dict__.get("_decoder_params_cache")
-        if cache is not None and cache[0] is self.fs_encoder_hidden_out.weight:
-            return cache
-        cache = self._decoder_param_list_uncached()
+        if cache is not None:
+            owners = self.__dict__["_decoder_param_owners"]
+            if all(o[k] is t for (o, k), t in zip(owners, cache)):
+                return cache
+        owners = [(m._parameters, k) for m, k in self._decoder_param_sites()]
+        cache = [o[k] for o, k in owners]
         self.__dict__["_decoder_params_cache"] = cache
+        self.__dict__["_decoder_param_owners"] = owners
         return cache
 
-    def _decoder_param_list_uncached(self):
-        return [self.fs_encoder_hidden_out.weight, self.fs_encoder_hidden_out.bias, self.fs_encoder_cn_out.weight,
-                self.fs_encoder_cn_out.bias, self.fs_decoder_attention_W1, self.fs_decoder_attention_l2.weight,
-                self.fs_decoder_attention_l2.bias, self.fs_decoder_attention_V, self.fs_decoder_embedding.weight,
-                self.fs_decoder_attn_combine.weight, self.fs_decoder_attn_combine.bias, *self.fs_decoder_lstm.parameters(),
-                self.fs_decoder_transcript[0].weight, self.fs_decoder_transcript[0].bias,
-                self.fs_decoder_transcript[2].weight, self.fs_decoder_transcript[2].bias,
-                self.fs_decoder_length[0].weight, self.fs_decoder_length[0].bias,
-                self.fs_decoder_length[2].weight, self.fs_decoder_length[2].bias]
+    def _decoder_param_sites(self):
+        """(module, parameter name) per entry of _lib.DECODER_PARAM_FIELDS."""
+        lstm = self.fs_decoder_lstm
+        sites = [(self.fs_encoder_hidden_out, "weight"), (self.fs_encoder_hidden_out, "bias"), (self.fs_encoder_cn_out, "weight"),
+                 (self.fs_encoder_cn_out, "bias"), (self, "fs_decoder_attention_W1"), (self.fs_decoder_attention_l2, "weight"),
+                 (self.fs_decoder_attention_l2, "bias"), (self, "fs_decoder_attention_V"), (self.fs_decoder_embedding, "weight"),
+                 (self.fs_decoder_attn_combine, "weight"), (self.fs_decoder_attn_combine, "bias")]
+        sites += [(lstm, n) for n, _ in lstm.named_parameters()]
+        for m in (self.fs_decoder_transcript[0], self.fs_decoder_transcript[2], self.fs_decoder_length[0], self.fs_decoder_length[2]):
+            sites += [(m, "weight"), (m, "bias")]
+        return sites
 
     def _native_decoder_ok(self, enc_out: Tensor) -> bool:
         d = self.fs_decoder_lstm

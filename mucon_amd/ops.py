@@ -869,18 +869,69 @@ def run_backward(fn, ctx, *grads):
 # --------------------------------------------------------------------------------------- viterbi
 _VITERBI_VIDEO_DTYPE = np.dtype([("lp", np.uint64), ("transcript", np.uint64), ("table", np.uint64), ("T", np.int32), ("N", np.int32),
                                  ("force_n", np.int32), ("force_j", np.int32)])   # = _lib.ViterbiVideo = mucon_viterbi_video
+_VITERBI_JOB_DTYPE = np.dtype([("lp", np.uint64), ("tr_off", np.int64), ("p_off", np.int64), ("label_off", np.int64), ("seg_off", np.int64),
+                               ("ws_off", np.int64), ("T", np.int32), ("N", np.int32), ("force_n", np.int32), ("force_j", np.int32)])   # = mucon_viterbi_job
+_VIT_FEW = 4                                   # up to this many videos the per-video ctypes set-up is cheaper than NumPy's record arrays
+_VIT_LABEL_FORMATS = {"int32": _lib.VIT_LABELS_I32, "uint8": _lib.VIT_LABELS_U8, "lazy": _lib.VIT_LABELS_NONE}
+_EMPTY_I32 = np.empty(0, np.int32)
 
 
-@dataclass
+def expand_labels(transcript: np.ndarray, seg_len: np.ndarray, n_seg: int, T: int, fs: int) -> np.ndarray:
+    """Per-frame labels int32 [T] of a decoded segmentation -- the reference's traceback (src/core/viterbi/viterbi.py:140-158):
+    the `T - K*fs` leftover frames carry the LAST segment's label and sit at the START of the video (their count is included in
+    the last segment's length, :154-157), then every segment's label `length` times.  The same expansion the kernels perform
+    for the int32 / uint8 label formats (csrc/viterbi.hip: vit_traceback_and_labels)."""
+    if n_seg <= 0:
+        return _EMPTY_I32
+    missing = T - (T // fs) * fs
+    lens = np.array(seg_len[:n_seg], dtype=np.int64)
+    lens[-1] -= missing
+    tr = np.asarray(transcript[:n_seg], dtype=np.int32)
+    body = np.repeat(tr, lens)
+    rest = T - missing - body.shape[0]
+    if missing == 0 and rest == 0:
+        return body
+    last = tr[n_seg - 1]
+    return np.concatenate((np.full(missing, last, np.int32), body, np.full(max(rest, 0), last, np.int32)))
+
+
 class ViterbiResult:
-    score: np.float64
-    labels: np.ndarray      # int32 [T]
-    seg_len: np.ndarray     # int32 [S]
-    n_seg: int
-    status: int
+    """One video's decode: score (np.float64), seg_len int32 [n_seg], n_seg, status (MUCON_VIT_*) and `labels` int32 [T].
+    With the "lazy" label format the kernels write no per-frame labels at all; `labels` is then expanded from the segmentation
+    on first access (expand_labels) and cached."""
+    __slots__ = ("score", "seg_len", "n_seg", "status", "_labels", "_lazy")
+
+    def __init__(self, score, labels, seg_len, n_seg, status, lazy=None):
+        self.score, self.seg_len, self.n_seg, self.status = score, seg_len, n_seg, status
+        self._labels, self._lazy = labels, lazy          # lazy = (transcript, T, fs) when the labels were not written
+
+    @property
+    def labels(self) -> np.ndarray:
+        if self._labels is None:
+            tr, T, fs = self._lazy
+            self._labels = expand_labels(tr, self.seg_len, self.n_seg, T, fs)
+        elif self._labels.dtype != np.int32:              # the uint8 format: widened on first access
+            self._labels = self._labels.astype(np.int32)
+        return self._labels
+
+    @property
+    def labels_raw(self) -> Optional[np.ndarray]:
+        """The array the kernels wrote (int32 or uint8 [T]), None with the lazy format."""
+        return self._labels
+
+    def __repr__(self):
+        return f"ViterbiResult(score={self.score!r}, n_seg={self.n_seg}, status={self.status})"
 
 
-def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J):
+def _aligned_lp(lp):
+    if not lp.is_contiguous() or (lp.data_ptr() & 15):
+        lp = lp.contiguous()
+        if lp.data_ptr() & 15:                      # (a storage-offset view whose start is not 16-byte aligned)
+            lp = lp.clone(memory_format=torch.contiguous_format)
+    return lp
+
+
+def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J, fmt):
     """viterbi_decode_batch for a handful of videos (the latency path: NumPy's record-array set-up costs more than it saves here)."""
     nv = len(lps)
     vids = (_lib.ViterbiVideo * nv)()
@@ -889,12 +940,13 @@ def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J
     for v in range(nv):
         lp = lps[v]
         if not lp.is_contiguous() or (lp.data_ptr() & 15):
-            lp = lp.contiguous()
-            if lp.data_ptr() & 15:                      # (a storage-offset view whose start is not 16-byte aligned)
-                lp = lp.clone(memory_format=torch.contiguous_format)
-        tr = np.ascontiguousarray(transcripts[v], dtype=np.int32)
-        tab = np.ascontiguousarray(tables[v], dtype=np.float64)
-        T, N = int(lp.shape[0]), int(tr.shape[0])
+            lp = _aligned_lp(lp)
+        tr, tab = transcripts[v], tables[v]
+        if not (type(tr) is np.ndarray and tr.dtype == np.int32 and tr.flags.c_contiguous):
+            tr = np.ascontiguousarray(tr, dtype=np.int32)
+        if not (type(tab) is np.ndarray and tab.dtype == np.float64 and tab.flags.c_contiguous):
+            tab = np.ascontiguousarray(tab, dtype=np.float64)
+        T, N = lp.shape[0], tr.shape[0]
         if tab.shape != (J, N) or lp.shape[1] != C:
             raise ValueError(f"video {v}: length table {tab.shape} (expected {(J, N)}) / {lp.shape[1]} classes (expected {C})")
         keep.append((lp, tr, tab))
@@ -905,21 +957,29 @@ def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J
         q.force_n, q.force_j = (int(f[0]), int(f[1])) if f is not None else (-1, -1)
         sum_T += max(T, 1)
         sum_N += N
-    score = np.empty(nv, np.float64)
-    n_seg = np.empty(nv, np.int32)
-    status = np.empty(nv, np.int32)
-    labels = np.empty(sum_T, np.int32)
-    seg = np.empty(sum_N, np.int32)
-    _lib.check(lib.mucon_viterbi_decode_host(nv, vids, C, fs, max_len, score.ctypes.data, n_seg.ctypes.data, status.ctypes.data,
-                                             labels.ctypes.data, seg.ctypes.data, _lib.current_stream_ptr()),
+    # one host buffer for the small results: [score f64 nv][n_seg i32 nv][status i32 nv][seg_len i32 sum_N]
+    small = np.empty(nv + (2 * nv + sum_N + 1) // 2, np.float64)
+    base = small.ctypes.data
+    i32 = small.view(np.int32)
+    n_seg, status, seg = i32[2 * nv: 3 * nv], i32[3 * nv: 4 * nv], i32[4 * nv: 4 * nv + sum_N]
+    if fmt == _lib.VIT_LABELS_NONE:
+        labels, lab_ptr = None, None
+    else:
+        labels = np.empty(sum_T, np.int32 if fmt == _lib.VIT_LABELS_I32 else np.uint8)
+        lab_ptr = labels.ctypes.data
+    _lib.check(lib.mucon_viterbi_decode_host(nv, vids, C, fs, max_len, base, base + 8 * nv, base + 12 * nv, lab_ptr, fmt,
+                                             base + 16 * nv, _lib.current_stream_ptr()),
                "mucon_viterbi_decode_host")
     out, lab_off, seg_off = [], 0, 0
     for v in range(nv):
         T, N = vids[v].T, vids[v].N
-        ns = int(n_seg[v])
-        ok = int(status[v]) in (_lib.VIT_OK, _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
-        out.append(ViterbiResult(score=np.float64(score[v]), labels=labels[lab_off: lab_off + T] if ok else np.empty(0, np.int32),
-                                 seg_len=seg[seg_off: seg_off + ns], n_seg=ns, status=int(status[v])))
+        ns, st = int(n_seg[v]), int(status[v])
+        ok = st == _lib.VIT_OK or st == _lib.VIT_TRUNCATED      # the error branches write status / n_seg / score only
+        if labels is None:
+            lab, lazy = (None, (keep[v][1], T, fs)) if ok else (_EMPTY_I32, None)
+        else:
+            lab, lazy = (labels[lab_off: lab_off + T] if ok else _EMPTY_I32), None
+        out.append(ViterbiResult(small[v], lab, seg[seg_off: seg_off + ns], ns, st, lazy))
         lab_off += max(T, 1)
         seg_off += N
     return out
@@ -927,34 +987,38 @@ def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J
 
 def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
                          tables: Sequence[np.ndarray], fs: int, max_len: int,
-                         forces: Optional[Sequence[Optional[tuple]]] = None) -> List[ViterbiResult]:
+                         forces: Optional[Sequence[Optional[tuple]]] = None, labels: str = "lazy") -> List[ViterbiResult]:
     """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
 
     lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
     concatenated or copied); transcripts[v]: int [N_v]; tables[v]: float64 [J, N_v] with J = max_len // fs;
     forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved degenerate outcomes of the
     reference).  The library reads the small inputs from and writes the results to its own pinned host buffers; a single
-    short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation)."""
+    short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation).
+
+    labels: the form the per-frame labels leave the GPU in (include/mucon_hip.h, MUCON_VIT_LABELS_*): "int32" (the reference's
+    ints, 4 T bytes per video over PCIe), "uint8" (T bytes) or "lazy" (default: none -- the kernels write the segmentation only and
+    ViterbiResult.labels expands it on first access; at 256 videos of T = 16,384 the int32 labels were 16.8 MB of a call whose
+    decode proper is 0.3 ms).  ViterbiResult.labels is an int32 array [T] whichever form was asked for."""
     lib = _lib.load()
     nv = len(lps)
     if nv == 0:
         return []
     _check_dev(*lps)
+    fmt = _VIT_LABEL_FORMATS[labels]
     C = int(lps[0].shape[1])
     J = max_len // fs
+    if nv <= _VIT_FEW:
+        return _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J, fmt)
     # the per-video records as one NumPy record array in mucon_viterbi_video's layout, filled column by column (a ctypes structure
     # per video cost ~4 us of Python each: more than the decode itself at 256 videos in flight)
-    if nv <= 4:
-        return _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J)
     rec = np.empty(nv, dtype=_VITERBI_VIDEO_DTYPE)
     keep = []                      # the arrays the pointers below refer to
     p_lp, p_tr, p_tab, Ts, Ns = [], [], [], [], []
     for v in range(nv):
         lp = lps[v]
         if not lp.is_contiguous() or (lp.data_ptr() & 15):
-            lp = lp.contiguous()
-            if lp.data_ptr() & 15:                      # (a storage-offset view whose start is not 16-byte aligned)
-                lp = lp.clone(memory_format=torch.contiguous_format)
+            lp = _aligned_lp(lp)
         tr, tab = transcripts[v], tables[v]
         if not (type(tr) is np.ndarray and tr.dtype == np.int32 and tr.flags.c_contiguous):
             tr = np.ascontiguousarray(tr, dtype=np.int32)
@@ -980,19 +1044,104 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     score = np.empty(nv, np.float64)
     n_seg = np.empty(nv, np.int32)
     status = np.empty(nv, np.int32)
-    # the labels in PINNED host memory (torch's caching host allocator): the kernels then write them in place, no staging copy;
-    # the per-video arrays handed back are views of it
-    labels = torch.empty(int(lab_off[-1]), dtype=torch.int32, pin_memory=True).numpy()
+    lab_arr, lab_ptr = None, None
+    if fmt != _lib.VIT_LABELS_NONE:
+        # From MUCON_VIT_LATENCY_VIDEOS videos on the library writes a PINNED labels array in place (no staging copy): take it from
+        # torch's caching host allocator then; below that the results come through the library's own staging buffer anyway.
+        dt, npdt = (torch.int32, np.int32) if fmt == _lib.VIT_LABELS_I32 else (torch.uint8, np.uint8)
+        if nv >= _lib.VIT_LATENCY_VIDEOS:
+            lab_arr = torch.empty(int(lab_off[-1]), dtype=dt, pin_memory=True).numpy()
+        else:
+            lab_arr = np.empty(int(lab_off[-1]), npdt)
+        lab_ptr = lab_arr.ctypes.data
     seg = np.empty(int(seg_off[-1]), np.int32)
     _lib.check(lib.mucon_viterbi_decode_host(nv, rec.ctypes.data_as(ctypes.POINTER(_lib.ViterbiVideo)), C, fs, max_len, score.ctypes.data,
-                                             n_seg.ctypes.data, status.ctypes.data, labels.ctypes.data, seg.ctypes.data,
+                                             n_seg.ctypes.data, status.ctypes.data, lab_ptr, fmt, seg.ctypes.data,
                                              _lib.current_stream_ptr()),
                "mucon_viterbi_decode_host")
     out = []
     ok = (status == _lib.VIT_OK) | (status == _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
     lab_off, seg_off, ns_l, st_l, ok_l = lab_off.tolist(), seg_off.tolist(), n_seg.tolist(), status.tolist(), ok.tolist()
-    empty = np.empty(0, np.int32)
     for v in range(nv):
-        out.append(ViterbiResult(score[v], labels[lab_off[v]: lab_off[v] + Ts[v]] if ok_l[v] else empty,
-                                 seg[seg_off[v]: seg_off[v] + ns_l[v]], ns_l[v], st_l[v]))
+        if not ok_l[v]:
+            lab, lazy = _EMPTY_I32, None
+        elif lab_arr is None:
+            lab, lazy = None, (keep[v][1], Ts[v], fs)
+        else:
+            lab, lazy = lab_arr[lab_off[v]: lab_off[v] + Ts[v]], None
+        out.append(ViterbiResult(score[v], lab, seg[seg_off[v]: seg_off[v] + ns_l[v]], ns_l[v], st_l[v], lazy))
     return out
+
+
+class ViterbiDeviceResult:
+    """Results of viterbi_decode_batch_device: device tensors, valid once the stream has run the decode.
+    labels: uint8 / int32 [sum max(T, 1)] (None with label_dtype=None), video v's at label_off[v]; seg_len int32 [sum N], video v's
+    at seg_off[v]; n_seg int32 [nv]; score float64 [nv]; status int32 [nv]."""
+    __slots__ = ("labels", "seg_len", "n_seg", "score", "status", "label_off", "seg_off", "T", "N", "_keep")
+
+
+def viterbi_decode_batch_device(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray], tables: Sequence[np.ndarray],
+                                fs: int, max_len: int, forces: Optional[Sequence[Optional[tuple]]] = None,
+                                label_dtype: Optional[torch.dtype] = torch.uint8) -> ViterbiDeviceResult:
+    """The all-device decode, mucon_viterbi_decode_batch: nothing comes back to the host and the call does not synchronise --
+    the job table, transcripts and length tables go up in ONE pinned copy on the current stream, the two launches (frame scores,
+    DP) follow, the results stay in HBM for whatever consumes them there (device metrics, a later gather).  Arguments as
+    viterbi_decode_batch; label_dtype: torch.uint8 (default), torch.int32 or None (segments only)."""
+    lib = _lib.load()
+    nv = len(lps)
+    if nv == 0:
+        raise ValueError("viterbi_decode_batch_device: no videos")
+    _check_dev(*lps)
+    dev = lps[0].device
+    C, J = int(lps[0].shape[1]), max_len // fs
+    fmt = {torch.uint8: _lib.VIT_LABELS_U8, torch.int32: _lib.VIT_LABELS_I32, None: _lib.VIT_LABELS_NONE}[label_dtype]
+    lps = [_aligned_lp(lp) for lp in lps]
+    trs = [np.ascontiguousarray(t, dtype=np.int32) for t in transcripts]
+    tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+    Ts = np.array([lp.shape[0] for lp in lps], dtype=np.int64)
+    Ns = np.array([t.shape[0] for t in trs], dtype=np.int64)
+    for v in range(nv):
+        if tabs[v].shape != (J, Ns[v]) or lps[v].shape[1] != C:
+            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(J, int(Ns[v]))}) / {lps[v].shape[1]} classes (expected {C})")
+    tr_off = np.concatenate(([0], np.cumsum(Ns)))
+    lab_off = np.concatenate(([0], np.cumsum(np.maximum(Ts, 1))))
+    ws_each = np.array([(lib.mucon_viterbi_job_workspace_bytes(int(T), C, int(N), fs) + 255) & ~255 for T, N in zip(Ts, Ns)], dtype=np.int64)
+    ws_off = np.concatenate(([0], np.cumsum(ws_each)))
+    jobs = np.zeros(nv, dtype=_VITERBI_JOB_DTYPE)
+    jobs["lp"] = [lp.data_ptr() for lp in lps]
+    jobs["tr_off"], jobs["p_off"], jobs["label_off"], jobs["seg_off"], jobs["ws_off"] = tr_off[:-1], tr_off[:-1] * J, lab_off[:-1], tr_off[:-1], ws_off[:-1]
+    jobs["T"], jobs["N"] = Ts, Ns
+    if forces is None:
+        jobs["force_n"] = jobs["force_j"] = -1
+    else:
+        jobs["force_n"] = [int(f[0]) if f is not None else -1 for f in forces]
+        jobs["force_j"] = [int(f[1]) if f is not None else -1 for f in forces]
+    # one pinned staging tensor [jobs | length tables f64 | transcripts i32] -> one H2D copy
+    sum_N = int(tr_off[-1])
+    o_tab = (jobs.nbytes + 15) & ~15
+    o_tr = o_tab + 8 * J * sum_N
+    total = (o_tr + 4 * sum_N + 15) & ~15
+    stage = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    sn = stage.numpy()
+    sn[:jobs.nbytes] = jobs.view(np.uint8)
+    tab_v = sn[o_tab:o_tr].view(np.float64)
+    tr_v = sn[o_tr:o_tr + 4 * sum_N].view(np.int32)
+    for v in range(nv):
+        tab_v[tr_off[v] * J: tr_off[v + 1] * J] = tabs[v].reshape(-1)
+        tr_v[tr_off[v]: tr_off[v + 1]] = trs[v]
+    up = stage.to(dev, non_blocking=True)
+    r = ViterbiDeviceResult()
+    r.labels = torch.empty(int(lab_off[-1]), dtype=label_dtype, device=dev) if label_dtype is not None else None
+    r.seg_len = torch.empty(sum_N, dtype=torch.int32, device=dev)
+    r.n_seg = torch.empty(nv, dtype=torch.int32, device=dev)
+    r.score = torch.empty(nv, dtype=torch.float64, device=dev)
+    r.status = torch.empty(nv, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(ws_off[-1]) + 256, dtype=torch.uint8, device=dev)
+    r.label_off, r.seg_off, r.T, r.N = lab_off, tr_off, Ts, Ns
+    r._keep = (lps, up, ws, stage)
+    base = up.data_ptr()
+    _lib.check(lib.mucon_viterbi_decode_batch(nv, base, C, fs, max_len, int(Ns.max()), base + o_tr, base + o_tab,
+                                              _lib.ptr(r.labels), fmt, _lib.ptr(r.seg_len), _lib.ptr(r.n_seg), _lib.ptr(r.score),
+                                              _lib.ptr(r.status), _lib.ptr(ws), _lib.current_stream_ptr()),
+               "mucon_viterbi_decode_batch")
+    return r

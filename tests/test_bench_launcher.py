@@ -1,0 +1,60 @@
+"""CPU: `python bench.py --gpus 2` started bare is its own launcher (no torch.distributed.run): two child ranks rendezvous on
+127.0.0.1, run the timing protocol (here on the gloo stub step: MUCON_BENCH_STUB=1, no GPU in this container) and rank 0 prints
+exactly ONE JSON line with the contract's fields; a failing rank makes the launcher exit non-zero."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+
+
+def _run(argv, extra_env=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["MUCON_BENCH_STUB"] = "1"
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_lines(text):
+    """(gloo's C++ side prints "[Gloo] Rank ..." connection notes on stdout; the result is the one line that is a JSON object)"""
+    return [l for l in text.splitlines() if l.strip().startswith("{")]
+
+
+def test_bare_launch_world_2_prints_one_json_line():
+    p = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1 and p.stdout.strip().splitlines()[-1] == lines[0], p.stdout      # one result line, and it is the last line
+    out = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["rccl"]["world"] == 2 and out["rccl"]["collectives_per_step"] == 1
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 16
+    assert len(out["ms_per_step_repeats"]) == 3 and out["data"] == "stub"
+
+
+def test_single_rank_keeps_the_same_schema():
+    p = _run(["--steps", "3", "--warmup", "1", "--repeats", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and all(k in out for k in CONTRACT)
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # WORLD_SIZE disagreeing with --gpus inside the children is not reachable from outside; a bad flag is: every rank exits 2
+    p = _run(["--gpus", "2", "--no-such-flag"])
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_under_torch_distributed_run_it_is_a_rank_not_a_launcher():
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"}
+    p = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--repeats", "1"], env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1

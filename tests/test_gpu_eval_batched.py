@@ -99,3 +99,69 @@ def test_batched_evaluation_equals_the_per_video_path(eos_bias, viterbi):
         assert len(sa[name]) == len(sb[name]), name
         for x, y in zip(sa[name], sb[name]):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
+
+
+def test_more_runs_than_the_kernel_holds_are_marked_not_fatal():
+    """A labelling with more than METRICS_MAX_RUNS runs (a noisy y-head on a long video): its pair's record is {"over_limit": True}
+    and the other pairs of the launch are scored as usual (this used to raise and end the whole evaluation)."""
+    from mucon_amd import _lib
+    from mucon_amd.core.metrics import MoFAccuracyMetric
+    from mucon_amd.core.metrics.device import segmental_counters
+
+    rng = np.random.default_rng(3)
+    T = 3 * _lib.METRICS_MAX_RUNS
+    noisy = (np.arange(T) % 2).astype(np.int64)                       # T runs of one frame each
+    calm_t, calm_p = _labelling(rng, T, 6, 40), _labelling(rng, T, 6, 40)
+    pairs = [(calm_t, calm_p), (calm_t, noisy), (noisy, calm_p), (calm_p, calm_t)]
+    got = segmental_counters([torch.from_numpy(t).cuda() for t, _ in pairs], [torch.from_numpy(p).cuda() for _, p in pairs], (0,))
+    assert [bool(g.get("over_limit")) for g in got] == [False, True, True, False]
+    for (t, p), g in ((pairs[0], got[0]), (pairs[3], got[3])):
+        mof = MoFAccuracyMetric()
+        mof.add(t, p)
+        assert (g["correct"], g["total"]) == (mof.correct, mof.total)
+
+
+def test_batched_evaluation_with_videos_the_batched_path_cannot_take():
+    """The batched / per-video decision is per VIDEO: a video whose encoded length is beyond the native decoder (here: made to look
+    so through can_defer_eval) runs through forward() / batch_eval_calculation in between the chunks, and a noisy labelling with
+    more runs than the metrics kernel holds is scored on the host -- the record and the lists (in dataset order) still equal the
+    per-video path's."""
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.evaluators import RESULT_FIELDS, MuConEvaluator
+    from mucon_amd.mucon.models import create_model
+
+    dev, C = "cuda:0", 48
+    cfg = update_config(get_cfg_defaults(), [], [])
+    torch.manual_seed(4)
+    model = create_model(cfg, C, 9, 2048).to(dev)
+    with torch.no_grad():
+        model.fs_decoder_transcript[2].bias[C] = -20.0
+    db = _Videos(9, C, dev, seed=6)
+    # video 6: a ground truth of alternating labels, 1,500 runs > METRICS_MAX_RUNS (its three pairs go to the host metrics)
+    long_item = db.items[6]
+    T = 1500
+    long_item.feats = torch.randn(1, T, 2048, device=dev)
+    long_item.gt_label = torch.from_numpy((np.arange(T) % 2).astype(np.int64)).to(dev)
+    refuse = {2, 3, 7}                                            # these videos "cannot be deferred"
+    orig = model.can_defer_eval
+
+    def can_defer(batch, on_device=None):
+        return batch.video_name not in {f"v{i}" for i in refuse} and orig(batch, on_device)
+
+    model.can_defer_eval = can_defer
+    records = []
+    for batched in (False, True):
+        ev = MuConEvaluator(cfg, db, model, dev)
+        ev.batched, ev.chunk_videos = batched, 4
+        ev.viterbi_mode(True)
+        res = ev.evaluate()
+        records.append((res, ev.to_save, ev.skipped, list(ev._evaluated)))
+    (ra, sa, ka, ea), (rb, sb, kb, eb) = records
+    assert ka == kb and ea == eb == sorted(eb) and len(eb) + kb == 9
+    for k in RESULT_FIELDS:
+        a, b = np.asarray(ra[k], dtype=np.float64), np.asarray(rb[k], dtype=np.float64)
+        assert a.shape == b.shape and all((np.isnan(x) and np.isnan(y)) or x.tobytes() == y.tobytes() for x, y in zip(a.ravel(), b.ravel())), (k, ra[k], rb[k])
+    for name in sa:
+        assert len(sa[name]) == len(sb[name]), name
+        for x, y in zip(sa[name], sb[name]):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
