@@ -208,6 +208,15 @@ def viterbi_bench(dev, C=48):
             lps = base64 * (nv // 64)          # 256 videos in flight (the 64 emission tensors four times over)
         ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)  # warm-up
         out[f"ms_per_video_{label}"] = round(timed(lambda: ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len), reps, 3) / nv * 1e3, 4)
+        if nv > 1:
+            # the same call with the per-frame labels leaving the GPU (uint8 / the reference's int32, written by the kernels into pinned
+            # host memory), and with the segments expanded to int32 labels on the host for EVERY video (ViterbiResult.labels)
+            for fmt in ("uint8", "int32"):
+                ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len, labels=fmt)
+                out[f"ms_per_video_{label}_{fmt}_labels"] = round(
+                    timed(lambda: ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len, labels=fmt), reps, 3) / nv * 1e3, 4)
+            out[f"ms_per_video_{label}_expanded_on_host"] = round(
+                timed(lambda: [r.labels for r in ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)], reps, 3) / nv * 1e3, 4)
     lp_h = lp.cpu().numpy()
     best = float("inf")
     for _ in range(3):
@@ -217,7 +226,9 @@ def viterbi_bench(dev, C=48):
     out["cpu_oracle_ms_per_video"] = round(best * 1e3, 3)
     out["cpu_oracle_all_cores_ms_per_video"] = round(_cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, 4 * cores, cores), 4)
     out["config"] = (f"ms_per_video_single/batch64/batch256 and cpu_oracle_*: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
-                     f"(K=546 columns, 64x66 hypotheses); every GPU timing is the whole ops.viterbi_decode_batch call: job table / transcripts / length tables read by the kernels from pinned host memory, results written there (no copy calls); "
+                     f"(K=546 columns, 64x66 hypotheses); every GPU timing is the whole ops.viterbi_decode_batch call: job table / transcripts / length tables read by the kernels from pinned host memory, results written there (no copy calls).  "
+                     f"The decode's result is the segmentation (score, segment lengths): ms_per_video_* without a suffix is that call (label format 'lazy': no per-frame labels leave the GPU, ViterbiResult.labels expands the segments on access); "
+                     f"*_uint8_labels / *_int32_labels: the kernels also write the per-frame labels (T or 4 T bytes per video over PCIe); *_expanded_on_host: the lazy call plus the int32 expansion of every video on the host; "
                      f"cpu_oracle_all_cores_*: {cores} threads, one video each, {cores} physical cores")
     out["algorithmic_bytes_per_video"] = T * C * 4 + T * 4
     out["algorithmic_bytes_per_video_T2000_N6"] = bytes_small

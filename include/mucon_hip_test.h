@@ -59,6 +59,11 @@ int mucon_test_set_knob(const char *name, const char *value);
  * phases] (gemm_fused_split.hpp); returns MUCON_E_ARG in a normal build. */
 int mucon_test_read_stamps(long long *out, int32_t n);
 
+/* Host-side phases of the LAST mucon_viterbi_decode_host call, in microseconds (steady_clock): [0] argument scan + staging set-up
+ * (the job table, and the memcpy of every video's transcript and length table into the pinned input buffer), [1] the launches,
+ * [2] waiting for the device (flag spin or stream synchronisation), [3] copying the results out of the pinned output buffer. */
+int mucon_test_vit_host_phases(double *us4);
+
 #ifdef __cplusplus
 }
 #endif

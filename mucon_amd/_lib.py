@@ -129,6 +129,7 @@ SYMBOLS = {
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
     "mucon_test_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "mucon_test_vit_host_phases": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "mucon_test_read_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
@@ -156,10 +157,29 @@ SYMBOLS = {
 }
 
 _lib = None
+_pyhost = None
+PYHOST_PATH = os.path.join(HERE, "libmucon_pyhost.so")
 
 
 class MuconHipError(RuntimeError):
     pass
+
+
+def pyhost():
+    """libmucon_pyhost.so (csrc/pyhost.c): the per-video part of the binding's list handling as a C loop.  ctypes.PyDLL: the calls
+    keep the GIL and Python exceptions raised inside propagate."""
+    global _pyhost
+    if _pyhost is None:
+        if not os.path.exists(PYHOST_PATH):
+            from . import build as _build
+
+            _build.build_pyhost()
+        lib = ctypes.PyDLL(PYHOST_PATH)
+        po = ctypes.py_object
+        lib.mucon_py_viterbi_decode.restype = po
+        lib.mucon_py_viterbi_decode.argtypes = [po, po, po, po, po] + [ctypes.c_long] * 6 + [ctypes.c_ulonglong] * 3
+        _pyhost = lib
+    return _pyhost
 
 
 def load(build_if_missing: bool = True):

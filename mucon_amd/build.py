@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmucon_hip.so")
+PYHOST_LIB = os.path.join(HERE, "libmucon_pyhost.so")    # host-side helper of the Python binding (csrc/pyhost.c: CPython API, no HIP)
 ARCH = "gfx950"
 SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shead.hip", []), ("metrics.hip", ["-ffp-contract=off"])]
 DEPS = ["common.hpp", "dispatch.hpp", "gemm_nt.hpp", "gemm_split.hpp", "gemm_tn.hpp", "gemm_tn_split.hpp", "gemm_fused_split.hpp", "gemm_coarse_split.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "decoder.hpp", "loss.hpp", "optim.hpp", "../../include/mucon_hip.h", "../../include/mucon_hip_test.h"]
@@ -44,6 +45,21 @@ def _tu_stale(src, extra):
     return any(os.path.getmtime(f) > t for f in deps + [os.path.join(CSRC, src)])
 
 
+def build_pyhost(force: bool = False, verbose: bool = False) -> str:
+    """gcc for csrc/pyhost.c (the C loop over the Python lists ops.viterbi_decode_batch is handed; loaded with ctypes.PyDLL)."""
+    import sysconfig
+
+    src = os.path.join(CSRC, "pyhost.c")
+    hdr = os.path.join(CSRC, "..", "..", "include", "mucon_hip.h")
+    if not force and os.path.exists(PYHOST_LIB) and os.path.getmtime(PYHOST_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return PYHOST_LIB
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", PYHOST_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return PYHOST_LIB
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -55,6 +71,7 @@ def _stale():
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the translation units whose sources (or compile flags) changed since their object was built, then link.
     force: every translation unit."""
+    build_pyhost(force, verbose)
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -28,7 +28,10 @@
 #include <string.h>
 #include <stdio.h>
 
+#include <chrono>
+
 #include "../../include/mucon_hip.h"
+#include "../../include/mucon_hip_test.h"
 
 namespace {
 
@@ -850,7 +853,11 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
                         xch_v[k & 1][wave] = vout;
                         xch_j[k & 1][wave] = jm;
                     }
-                    __syncthreads();
+                    // LDS-only barrier (r4): __syncthreads() also waits for vmcnt(0) -- the read-ahead of the next chunk's frame scores
+                    // once per chunk and, with the back-pointers in HBM scratch, a global byte store's round trip EVERY column: the
+                    // 256-in-flight DP launch of config 5 lasted 730 us for a 280 us decode (r3 profile) because of that, not
+                    // because of its labels
+                    lds_barrier();
                     if (wave >= 1 && lane < G) {
                         vin = xch_v[k & 1][wave - 1];
                         jin = xch_j[k & 1][wave - 1];
@@ -1446,10 +1453,14 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
                        transcripts, length_tables, labels, seg_len, n_seg, score, status, static_cast<char *>(workspace), C, \
                        fs, J, (int)bp_lds, flag1, done_value)
     if (lanes) {
-        // latency calls (a few videos whose sizes the caller knows): back-pointers in LDS -- the traceback is a chain of N dependent
-        // reads; throughput calls leave the LDS to more workgroups per CU.  One video: the kernel publishes the completion flag.
+        // back-pointers in LDS when the caller knows the sizes and they fit -- the traceback is a chain of N dependent reads (~100
+        // cycles each from LDS, ~1,500 from memory: 45 us of a config-5 video).  Latency calls: up to 96 KB; larger calls: up to
+        // 40 KB (beside the kernel's ~35 KB of static LDS that still leaves two workgroups per CU), and only while the call is
+        // at most two workgroups per CU anyway -- beyond that the LDS goes to more resident videos.  One video: the kernel
+        // publishes the completion flag.
         const size_t bp_need = ((size_t)max_K * max_N + 15) & ~(size_t)15;
-        const size_t bp_lds = (max_K > 0 && n_videos <= kVitLatencyVideos && bp_need <= VL_BP_LDS_MAX) ? bp_need : 0;
+        const size_t bp_cap = n_videos <= kVitLatencyVideos ? VL_BP_LDS_MAX : (n_videos <= 512 ? (size_t)40 * 1024 : 0);
+        const size_t bp_lds = (max_K > 0 && bp_need <= bp_cap) ? bp_need : 0;
         volatile int32_t *flag1 = n_videos == 1 ? done_flag : nullptr;
         // lanes per state x waves, by measurement (single T = 4,000 .. 16,384 decodes): more lanes per state shorten the per-lane
         // slot loop, more waves pay a barrier per column, and past four waves two share a SIMD
@@ -1537,12 +1548,23 @@ int vh_grow(char **buf, size_t *cap, size_t need, bool pinned) {
     return MUCON_OK;
 }
 inline size_t up16(size_t n) { return (n + 15) & ~(size_t)15; }
+double g_vh_phase_us[4];
+inline double vh_now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 }  // namespace
+
+extern "C" int mucon_test_vit_host_phases(double *us4) {
+    if (!us4) return MUCON_E_ARG;
+    for (int i = 0; i < 4; ++i) us4[i] = g_vh_phase_us[i];
+    return MUCON_OK;
+}
 
 extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
                                          double *score, int32_t *n_seg, int32_t *status, void *labels, int32_t label_format,
                                          int32_t *seg_len, void *stream) {
     if (n_videos <= 0) return MUCON_OK;
+    const double t_begin = vh_now_us();
     if (label_format < MUCON_VIT_LABELS_I32 || label_format > MUCON_VIT_LABELS_NONE) {
         snprintf(g_err, sizeof(g_err), "viterbi: label_format %d", label_format);
         VIT_FAIL(MUCON_E_ARG);
@@ -1636,6 +1658,7 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     hipStream_t s = static_cast<hipStream_t>(stream);
     volatile int32_t *flag_h = reinterpret_cast<volatile int32_t *>(st.pin_out);
     const int32_t seq = ++st.seq == 0 ? ++st.seq : st.seq;
+    const double t_staged = vh_now_us();
     // latency path: a handful of short videos in ONE launch each; throughput path: two launches whose second packs many per CU
     const bool want_fused = n_videos == 1;
     const int rc = vit_launch(n_videos, reinterpret_cast<const mucon_viterbi_job *>(din), C, fs, max_len, max_N,
@@ -1645,6 +1668,7 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
                               reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
                               reinterpret_cast<volatile int32_t *>(dout), seq, jobs, st.progress);
     if (rc < 0) return rc;
+    const double t_launched = vh_now_us();
     bool done = false;
     if (rc > 0) {   // a one-video call's last kernel publishes the flag: spin on it (a stream synchronisation costs several microseconds more)
         for (long spin = 0; spin < 40000000L; ++spin) {
@@ -1659,10 +1683,15 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
         snprintf(g_err, sizeof(g_err), "viterbi: the decode failed on the device: %s", hipGetErrorString(hipGetLastError()));
         VIT_FAIL(MUCON_E_HIP);
     }
+    const double t_waited = vh_now_us();
     memcpy(score, st.pin_out + o_score, 8 * (size_t)n_videos);
     memcpy(n_seg, st.pin_out + o_nseg, 4 * (size_t)n_videos);
     memcpy(status, st.pin_out + o_stat, 4 * (size_t)n_videos);
     memcpy(seg_len, st.pin_out + o_seg, 4 * sum_N);
     if (!labels_dev && lab_elem) memcpy(labels, st.pin_out + o_lab, lab_elem * sum_T);
+    g_vh_phase_us[0] = t_staged - t_begin;
+    g_vh_phase_us[1] = t_launched - t_staged;
+    g_vh_phase_us[2] = t_waited - t_launched;
+    g_vh_phase_us[3] = vh_now_us() - t_waited;
     return MUCON_OK;
 }

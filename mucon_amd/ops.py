@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns the HBM buffers, the current HIP stream and au
 all arithmetic of the hot path runs in the hand-written gfx950 kernels.  Device tensors only --
 a CPU tensor raises (there is no CPU fallback in the product).
 """
+import collections.abc
 import ctypes
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -871,7 +872,6 @@ _VITERBI_VIDEO_DTYPE = np.dtype([("lp", np.uint64), ("transcript", np.uint64), (
                                  ("force_n", np.int32), ("force_j", np.int32)])   # = _lib.ViterbiVideo = mucon_viterbi_video
 _VITERBI_JOB_DTYPE = np.dtype([("lp", np.uint64), ("tr_off", np.int64), ("p_off", np.int64), ("label_off", np.int64), ("seg_off", np.int64),
                                ("ws_off", np.int64), ("T", np.int32), ("N", np.int32), ("force_n", np.int32), ("force_j", np.int32)])   # = mucon_viterbi_job
-_VIT_FEW = 4                                   # up to this many videos the per-video ctypes set-up is cheaper than NumPy's record arrays
 _VIT_LABEL_FORMATS = {"int32": _lib.VIT_LABELS_I32, "uint8": _lib.VIT_LABELS_U8, "lazy": _lib.VIT_LABELS_NONE}
 _EMPTY_I32 = np.empty(0, np.int32)
 
@@ -931,63 +931,50 @@ def _aligned_lp(lp):
     return lp
 
 
-def _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J, fmt):
-    """viterbi_decode_batch for a handful of videos (the latency path: NumPy's record-array set-up costs more than it saves here)."""
-    nv = len(lps)
-    vids = (_lib.ViterbiVideo * nv)()
-    keep = []                      # the arrays the pointers below refer to
-    sum_T = sum_N = 0
-    for v in range(nv):
-        lp = lps[v]
-        if not lp.is_contiguous() or (lp.data_ptr() & 15):
-            lp = _aligned_lp(lp)
-        tr, tab = transcripts[v], tables[v]
-        if not (type(tr) is np.ndarray and tr.dtype == np.int32 and tr.flags.c_contiguous):
-            tr = np.ascontiguousarray(tr, dtype=np.int32)
-        if not (type(tab) is np.ndarray and tab.dtype == np.float64 and tab.flags.c_contiguous):
-            tab = np.ascontiguousarray(tab, dtype=np.float64)
-        T, N = lp.shape[0], tr.shape[0]
-        if tab.shape != (J, N) or lp.shape[1] != C:
-            raise ValueError(f"video {v}: length table {tab.shape} (expected {(J, N)}) / {lp.shape[1]} classes (expected {C})")
-        keep.append((lp, tr, tab))
-        q = vids[v]
-        q.lp, q.transcript, q.table = lp.data_ptr(), tr.ctypes.data, tab.ctypes.data
-        q.T, q.N = T, N
-        f = forces[v] if forces is not None else None
-        q.force_n, q.force_j = (int(f[0]), int(f[1])) if f is not None else (-1, -1)
-        sum_T += max(T, 1)
-        sum_N += N
-    # one host buffer for the small results: [score f64 nv][n_seg i32 nv][status i32 nv][seg_len i32 sum_N]
-    small = np.empty(nv + (2 * nv + sum_N + 1) // 2, np.float64)
-    base = small.ctypes.data
-    i32 = small.view(np.int32)
-    n_seg, status, seg = i32[2 * nv: 3 * nv], i32[3 * nv: 4 * nv], i32[4 * nv: 4 * nv + sum_N]
-    if fmt == _lib.VIT_LABELS_NONE:
-        labels, lab_ptr = None, None
-    else:
-        labels = np.empty(sum_T, np.int32 if fmt == _lib.VIT_LABELS_I32 else np.uint8)
-        lab_ptr = labels.ctypes.data
-    _lib.check(lib.mucon_viterbi_decode_host(nv, vids, C, fs, max_len, base, base + 8 * nv, base + 12 * nv, lab_ptr, fmt,
-                                             base + 16 * nv, _lib.current_stream_ptr()),
-               "mucon_viterbi_decode_host")
-    out, lab_off, seg_off = [], 0, 0
-    for v in range(nv):
-        T, N = vids[v].T, vids[v].N
-        ns, st = int(n_seg[v]), int(status[v])
-        ok = st == _lib.VIT_OK or st == _lib.VIT_TRUNCATED      # the error branches write status / n_seg / score only
-        if labels is None:
-            lab, lazy = (None, (keep[v][1], T, fs)) if ok else (_EMPTY_I32, None)
-        else:
-            lab, lazy = (labels[lab_off: lab_off + T] if ok else _EMPTY_I32), None
-        out.append(ViterbiResult(small[v], lab, seg[seg_off: seg_off + ns], ns, st, lazy))
-        lab_off += max(T, 1)
-        seg_off += N
-    return out
+class ViterbiBatchResult(collections.abc.Sequence):
+    """What viterbi_decode_batch returns: a sequence of ViterbiResult, one per video, over the call's flat result arrays
+    (score float64 [nv], n_seg / status int32 [nv], seg_len int32 [sum N], labels [sum max(T, 1)] or None).  The per-video
+    objects are views made on first access: a caller that reads the flat arrays (or a few videos) does not pay 256 object
+    constructions for a call whose decode is shorter than they are."""
+    __slots__ = ("score", "n_seg", "status", "seg_len", "labels_flat", "label_off", "seg_off", "_T", "_tr", "_fs", "_items", "_keep", "_lists")
+
+    def __init__(self, score, n_seg, status, seg_len, labels_flat, label_off, seg_off, Ts, transcripts, fs, keep):
+        self.score, self.n_seg, self.status, self.seg_len, self.labels_flat = score, n_seg, status, seg_len, labels_flat
+        self.label_off, self.seg_off, self._T, self._tr, self._fs = label_off, seg_off, Ts, transcripts, fs
+        self._items = [None] * len(Ts)
+        self._keep = keep
+        self._lists = None
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, v):
+        if isinstance(v, slice):
+            return [self[i] for i in range(*v.indices(len(self._items)))]
+        r = self._items[v]
+        if r is None:
+            if self._lists is None:       # the index arrays as Python lists, once (256 x int(numpy scalar) cost more than the rest)
+                self._lists = (self.status.tolist(), self.n_seg.tolist(), self.seg_off.tolist(),
+                               self.label_off.tolist() if self.labels_flat is not None else None)
+            sts, nss, sos, los = self._lists
+            st, ns, so = sts[v], nss[v], sos[v]
+            if st != _lib.VIT_OK and st != _lib.VIT_TRUNCATED:      # the error branches write status / n_seg / score only
+                lab, lazy = _EMPTY_I32, None
+            elif los is None:
+                lab, lazy = None, (self._tr[v], self._T[v], self._fs)
+            else:
+                lab, lazy = self.labels_flat[los[v]: los[v] + self._T[v]], None
+            r = self._items[v] = ViterbiResult(self.score[v], lab, self.seg_len[so: so + ns], ns, st, lazy)
+        return r
+
+    def __iter__(self):
+        for v in range(len(self._items)):
+            yield self[v]
 
 
 def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
                          tables: Sequence[np.ndarray], fs: int, max_len: int,
-                         forces: Optional[Sequence[Optional[tuple]]] = None, labels: str = "lazy") -> List[ViterbiResult]:
+                         forces: Optional[Sequence[Optional[tuple]]] = None, labels: str = "lazy") -> ViterbiBatchResult:
     """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
 
     lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
@@ -998,79 +985,73 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
 
     labels: the form the per-frame labels leave the GPU in (include/mucon_hip.h, MUCON_VIT_LABELS_*): "int32" (the reference's
     ints, 4 T bytes per video over PCIe), "uint8" (T bytes) or "lazy" (default: none -- the kernels write the segmentation only and
-    ViterbiResult.labels expands it on first access; at 256 videos of T = 16,384 the int32 labels were 16.8 MB of a call whose
-    decode proper is 0.3 ms).  ViterbiResult.labels is an int32 array [T] whichever form was asked for."""
+    ViterbiResult.labels expands it on first access).  ViterbiResult.labels is an int32 array [T] whichever form was asked for.
+
+    Returns a sequence of ViterbiResult (ViterbiBatchResult: per-video views over the flat result arrays, made on access).
+    The per-video argument handling is a C loop (csrc/pyhost.c through ctypes.PyDLL): int32 / float64 C-contiguous NumPy arrays
+    are pointed at where they lie, anything else (lists, other dtypes, strided views) is converted first."""
     lib = _lib.load()
     nv = len(lps)
     if nv == 0:
         return []
-    _check_dev(*lps)
     fmt = _VIT_LABEL_FORMATS[labels]
-    C = int(lps[0].shape[1])
-    J = max_len // fs
-    if nv <= _VIT_FEW:
-        return _viterbi_decode_few(lib, lps, transcripts, tables, fs, max_len, forces, C, J, fmt)
-    # the per-video records as one NumPy record array in mucon_viterbi_video's layout, filled column by column (a ctypes structure
-    # per video cost ~4 us of Python each: more than the decode itself at 256 videos in flight)
-    rec = np.empty(nv, dtype=_VITERBI_VIDEO_DTYPE)
-    keep = []                      # the arrays the pointers below refer to
-    p_lp, p_tr, p_tab, Ts, Ns = [], [], [], [], []
-    for v in range(nv):
-        lp = lps[v]
-        if not lp.is_contiguous() or (lp.data_ptr() & 15):
-            lp = _aligned_lp(lp)
-        tr, tab = transcripts[v], tables[v]
-        if not (type(tr) is np.ndarray and tr.dtype == np.int32 and tr.flags.c_contiguous):
-            tr = np.ascontiguousarray(tr, dtype=np.int32)
-        if not (type(tab) is np.ndarray and tab.dtype == np.float64 and tab.flags.c_contiguous):
-            tab = np.ascontiguousarray(tab, dtype=np.float64)
-        T, N = lp.shape[0], tr.shape[0]
-        if tab.shape != (J, N) or lp.shape[1] != C:
-            raise ValueError(f"video {v}: length table {tab.shape} (expected {(J, N)}) / {lp.shape[1]} classes (expected {C})")
-        keep.append((lp, tr, tab))
-        p_lp.append(lp.data_ptr())
-        p_tr.append(tr.__array_interface__["data"][0])
-        p_tab.append(tab.__array_interface__["data"][0])
-        Ts.append(T)
-        Ns.append(N)
-    rec["lp"], rec["transcript"], rec["table"], rec["T"], rec["N"] = p_lp, p_tr, p_tab, Ts, Ns
-    if forces is None:
-        rec["force_n"] = rec["force_j"] = -1
-    else:
-        rec["force_n"] = [int(f[0]) if f is not None else -1 for f in forces]
-        rec["force_j"] = [int(f[1]) if f is not None else -1 for f in forces]
-    lab_off = np.concatenate(([0], np.cumsum(np.maximum(rec["T"], 1))))
-    seg_off = np.concatenate(([0], np.cumsum(rec["N"])))
-    score = np.empty(nv, np.float64)
-    n_seg = np.empty(nv, np.int32)
-    status = np.empty(nv, np.int32)
-    lab_arr, lab_ptr = None, None
-    if fmt != _lib.VIT_LABELS_NONE:
+    C = lps[0].shape[1]
+    lps = list(lps)
+    for v, lp in enumerate(lps):
+        if not lp.is_cuda or lp.dtype != torch.float32:
+            _check_dev(lp)
+        if lp.shape[1] != C:
+            raise ValueError(f"video {v}: {lp.shape[1]} classes (expected {C})")
+        if not lp.is_contiguous():
+            lps[v] = lp.contiguous()
+    ptrs = [lp.data_ptr() for lp in lps]
+    Ts = [lp.shape[0] for lp in lps]
+    trs, tabs = list(transcripts), list(tables)
+    if forces is not None:
+        forces = list(forces)
+    lab_arr, lab_ptr = None, 0
+    if fmt != _lib.VIT_LABELS_NONE and nv >= _lib.VIT_LATENCY_VIDEOS:
         # From MUCON_VIT_LATENCY_VIDEOS videos on the library writes a PINNED labels array in place (no staging copy): take it from
-        # torch's caching host allocator then; below that the results come through the library's own staging buffer anyway.
-        dt, npdt = (torch.int32, np.int32) if fmt == _lib.VIT_LABELS_I32 else (torch.uint8, np.uint8)
-        if nv >= _lib.VIT_LATENCY_VIDEOS:
-            lab_arr = torch.empty(int(lab_off[-1]), dtype=dt, pin_memory=True).numpy()
-        else:
-            lab_arr = np.empty(int(lab_off[-1]), npdt)
-        lab_ptr = lab_arr.ctypes.data
-    seg = np.empty(int(seg_off[-1]), np.int32)
-    _lib.check(lib.mucon_viterbi_decode_host(nv, rec.ctypes.data_as(ctypes.POINTER(_lib.ViterbiVideo)), C, fs, max_len, score.ctypes.data,
-                                             n_seg.ctypes.data, status.ctypes.data, lab_ptr, fmt, seg.ctypes.data,
-                                             _lib.current_stream_ptr()),
-               "mucon_viterbi_decode_host")
-    out = []
-    ok = (status == _lib.VIT_OK) | (status == _lib.VIT_TRUNCATED)      # the error branches write status / n_seg / score only
-    lab_off, seg_off, ns_l, st_l, ok_l = lab_off.tolist(), seg_off.tolist(), n_seg.tolist(), status.tolist(), ok.tolist()
-    for v in range(nv):
-        if not ok_l[v]:
-            lab, lazy = _EMPTY_I32, None
-        elif lab_arr is None:
-            lab, lazy = None, (keep[v][1], Ts[v], fs)
-        else:
-            lab, lazy = lab_arr[lab_off[v]: lab_off[v] + Ts[v]], None
-        out.append(ViterbiResult(score[v], lab, seg[seg_off[v]: seg_off[v] + ns_l[v]], ns_l[v], st_l[v], lazy))
-    return out
+        # torch's caching host allocator; below that the results come through the library's own staging buffer anyway.
+        lab_t = torch.empty(sum(T if T > 0 else 1 for T in Ts), dtype=torch.int32 if fmt == _lib.VIT_LABELS_I32 else torch.uint8, pin_memory=True)
+        lab_arr, lab_ptr = lab_t.numpy(), lab_t.data_ptr()
+    decode, fn_addr, J = _vit_entry(lib), _VIT_FN_ADDR[0], max_len // fs
+    start = 0
+    while True:
+        rc, bad, sum_T, sum_N, out = decode(ptrs, Ts, trs, tabs, forces, C, fs, max_len, fmt, 1 if (C & 3) == 0 else 0, start, lab_ptr,
+                                            fn_addr, torch.cuda.current_stream().cuda_stream)
+        if bad < 0:
+            break
+        # video `bad`: not an int32 / float64 C-contiguous buffer, or an emission tensor whose start is not 16-byte aligned
+        trs[bad] = np.ascontiguousarray(trs[bad], dtype=np.int32)
+        tabs[bad] = np.ascontiguousarray(tabs[bad], dtype=np.float64)
+        if tabs[bad].shape != (J, trs[bad].shape[0]):
+            raise ValueError(f"video {bad}: length table {tabs[bad].shape} (expected {(J, trs[bad].shape[0])})")
+        if (C & 3) == 0 and (ptrs[bad] & 15):
+            lps[bad] = lps[bad].clone(memory_format=torch.contiguous_format)
+            ptrs[bad] = lps[bad].data_ptr()
+        start = bad
+    if rc != _lib.OK:
+        _lib.check(rc, "mucon_viterbi_decode_host")
+    # out: [score f64 nv][n_seg i32 nv][status i32 nv][seg_len i32 sum_N, padded][label offsets i64 nv + 1][segment offsets i64 nv + 1][labels]
+    n_off = (16 * nv + 4 * sum_N + 7) // 8
+    f64 = np.frombuffer(out, np.float64, n_off + 2 * nv + 2)
+    i32 = f64.view(np.int32)
+    i64 = f64.view(np.int64)
+    if fmt != _lib.VIT_LABELS_NONE and lab_arr is None:
+        lab_arr = np.frombuffer(out, np.int32 if fmt == _lib.VIT_LABELS_I32 else np.uint8, sum_T, 8 * (n_off + 2 * nv + 2))
+    return ViterbiBatchResult(f64[:nv], i32[2 * nv: 3 * nv], i32[3 * nv: 4 * nv], i32[4 * nv: 4 * nv + sum_N], lab_arr,
+                              i64[n_off: n_off + nv + 1], i64[n_off + nv + 1: n_off + 2 * nv + 2], Ts, trs, fs, (lps, tabs))
+
+
+_VIT_FN_ADDR = [0]
+
+
+def _vit_entry(lib):
+    """(pyhost's decode function; the address of mucon_viterbi_decode_host is cached in _VIT_FN_ADDR)"""
+    if not _VIT_FN_ADDR[0]:
+        _VIT_FN_ADDR[0] = ctypes.cast(lib.mucon_viterbi_decode_host, ctypes.c_void_p).value
+    return _lib.pyhost().mucon_py_viterbi_decode
 
 
 class ViterbiDeviceResult:

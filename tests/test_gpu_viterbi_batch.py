@@ -162,3 +162,24 @@ def test_error_statuses_leave_labels_alone():
     assert lib.mucon_viterbi_decode_batch(1, None, C, FS, MAXLEN, 1, None, None, None, 7, None, None, None, None, None, None) == _lib.E_ARG
     assert lib.mucon_viterbi_decode_batch(1, None, C, FS, MAXLEN, 1, None, None, None, _lib.VIT_LABELS_U8, None, None, None, None, None,
                                           None) == _lib.E_ARG      # labels NULL with a format that writes them
+
+
+def test_plain_framescore_kernel_with_odd_class_count():
+    """C not a multiple of 4 (rows of an aligned base are then not 16-byte aligned): viterbi_framescore_kernel, the plain
+    version of phase 1, in front of every lane layout's DP -- both entries."""
+    Cc = 10
+    cases = []
+    for i, (T, N) in enumerate(((700, 3), (2500, 12), (5000, 20), (9000, 40), (6100, 70), (3000, 5), (4000, 9), (1200, 2), (2000, 17))):
+        tr = synth.transcript(8000 + i, N, Cc).astype(np.int32)
+        lp = synth.emissions(8100 + i, T, Cc, labels=synth.segment_labels(8200 + i, T, tr))
+        mu = np.ones(Cc)
+        mu[np.unique(tr)] = T / N
+        cases.append((lp, tr, oracle.length_rows(oracle.poisson_table(mu, MAXLEN), tr, FS, MAXLEN)))
+    wants = [_want(*c) for c in cases]
+    _check_device(_device(cases, torch.uint8), cases, wants, torch.uint8)
+    for c, w in zip(cases, wants):                         # one video per call too (the layout of ITS transcript)
+        _check_device(_device([c], torch.int32), [c], [w], torch.int32)
+    lps = [torch.from_numpy(lp).cuda() for lp, _, _ in cases]
+    res = ops.viterbi_decode_batch(lps, [tr for _, tr, _ in cases], [P for _, _, P in cases], FS, MAXLEN, labels="uint8")
+    for r, (lp, _, _), w in zip(res, cases, wants):
+        _check_host(r, w, lp.shape[0])
