@@ -174,6 +174,7 @@ inline bool fs_level(const mucon_encoder_cfg *cfg, const Plan &pl, int l) {
     return g_fs && !g_no_fuse && l >= 0 && l < pl.L && (long)pl.B * pl.Tl[l] >= g_fs_rows && cfg->dilation[l] < pl.Tl[l];
 }
 inline bool cs_on() { return g_cs && !g_no_fuse; }
+int g_pack_f32 = 0;     // MUCON_PACK_ALL=1: every weight re-layout is written whether or not a launch of the pass reads it (A/B of the r4 trimming; tests)
 int g_tail_chain = 1;   // MUCON_TAIL_CHAIN=0: the row-local launches at the coarsest level one by one (cs_kernel) instead of chained (ct_kernel)
 inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t, 4 / 5 centre taps of W1f / W1b in accumulator order
     const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : 2L * FS_IMG_K384 + (long)(mat - 2) * FS_IMG_K128);
@@ -374,6 +375,9 @@ void prof_mark(int slot, bool stop, hipStream_t s) {
 
 // every weight re-layout of a forward pass in one launch: rows [0, ypack) of the grid are pack_weights' blocks (small_kernels.hpp),
 // the rows behind them fs_pack's (gemm_fused_split.hpp: 20,480 fragments per layer slot = 20 blocks of 1,024 threads)
+// (r4: staging the fragment images through LDS -- a block loading 32 output rows of a layer once and emitting every fragment that
+// depends on them -- was built and measured: 13.5 us against 13.5 us for the gather below, bit-identical images; what the launch costs is
+// not fs_pack_body's scattered reads.  Not kept.)
 __global__ __launch_bounds__(PACK_THREADS) void pack_all_kernel(const PackArgs a, const FsPackArgs f, const int ypack) {
     __shared__ float lds[PACK_LDS_FLOATS];
     if ((int)blockIdx.y < ypack) pack_weights_body(a, lds);
@@ -393,6 +397,10 @@ extern int g_vit_lanes;   // viterbi.hip
 static bool apply_knob(const char *name, const char *e) {
     if (!strcmp(name, "MUCON_TAIL_CHAIN")) {
         if (e) g_tail_chain = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_PACK_ALL")) {
+        if (e) g_pack_f32 = atoi(e) ? 1 : 0;
         return true;
     }
     if (!strcmp(name, "MUCON_VIT_LANES")) {
@@ -453,7 +461,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -562,7 +570,12 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         pa.pw_w[l] = prm->pw_w[l];
     }
     pa.last_w = prm->last_w;
-    pa.W1f = ws + pl.W1f;
+    // The f32 operand layouts (W1f / W1b / W2t / Wlt) feed the f32-MFMA kernels only.  When every launch of this forward AND of its
+    // backward takes the split-bf16 images (the default configuration: k-split kernels on, pooled boundaries fused, biases present, no
+    // pooling behind the last layer) they are not written at all: 5 MB of stores and 56 transposing workgroups less per pass (r4).
+    bool need_f32 = !cs_on() || !kPoolFuse || cfg->pool_after[L - 1] || !prm->last_b || (long)B * pl.T > kFuseMaxRows || g_pack_f32;
+    for (int l = 0; l < L; ++l) need_f32 = need_f32 || !prm->dil_b[l] || !prm->pw_b[l];
+    pa.W1f = need_f32 ? ws + pl.W1f : nullptr;
     pa.W1b = ws + pl.W1b;
     pa.W2t = ws + pl.W2t;
     pa.Wlt = ws + pl.Wlt;
@@ -573,7 +586,9 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     pa.first_w = prm->first_w;
     pa.first_planes = split_first ? reinterpret_cast<uint16_t *>(ws + pl.W0s) : nullptr;
     // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
-    const bool split_dgrad0 = kNtSplitDgrad0 && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T;
+    // (mucon_encoder_bwd reaches that launch only when neither two-stage split kernel takes layer 0: same conditions here)
+    const bool split_dgrad0 = kNtSplitDgrad0 && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T &&
+                              ((!fs_level(cfg, pl, 0) && !cs_on()) || g_pack_f32);
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
     {   // ... and, in the SAME launch, the split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp
         // (a layer's images sit at its own slot): two launches were 8 + 7 us at the head of every forward pass

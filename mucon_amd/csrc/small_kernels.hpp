@@ -21,7 +21,7 @@ struct PackArgs {
     const float *dil_w[16];
     const float *pw_w[16];
     const float *last_w;
-    float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]
+    float *W1f, *W1b, *W2t, *Wlt;  // [L][128][384], [L][128][384], [L][128][128], [128][128]; W1f null: none of the four is written
     const float *first_w;          // [128][D]; split into first_planes when that is non-null
     uint16_t *first_planes;        // hi / mid / lo bf16 of first_conv.weight in the fragment order of gemm_split.hpp (3*128*D values)
     uint16_t *dgrad0_planes;       // same for layer 0's data-gradient operand W1b[i][tap*128 + o] (3*128*384 values), or null
@@ -49,7 +49,7 @@ __device__ __forceinline__ void pack_image_tile(const float *tile, uint16_t *img
 __device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds) {
     const int y = blockIdx.y, x = blockIdx.x, tid = threadIdx.x;
     if (y <= a.L) {
-        if (x >= 4) return;
+        if (x >= 4 || !a.W1f) return;       // (W1f null: no launch of this pass reads the f32 layouts)
         const int o0 = 32 * x;
         if (y < a.L) {
             // 32 output channels of dilated_conv.weight: 32 x 384 contiguous floats -> lds[o][385]

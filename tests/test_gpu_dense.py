@@ -548,3 +548,32 @@ def test_unchained_coarsest_level():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("B,T,training", [(1, 2000, False), (8, 4096, True), (2, 777, True)])
+def test_trimmed_weight_relayout_is_bitwise_neutral(B, T, training):
+    """Since r4 the weight re-layout at the head of a forward pass (pack_all_kernel) leaves out the f32 operand layouts and layer 0's
+    data-gradient planes when no launch of the pass and its backward reads them (the default configuration); MUCON_PACK_ALL=1
+    writes everything as before.  The encoder output and every parameter gradient must be bitwise the same either way."""
+    from mucon_amd import _lib, ops
+    from oracle import dense as od
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 57)
+    names = ops.param_names(spec)
+    tape = torch.tensor(synth.tape(58, B, T, 2048), device=DEV)
+    v = torch.tensor(synth.uniform_pm1(59, (B, spec.out_length(T), 128)), device=DEV)
+
+    def run():
+        P = _dev_params(params_np, names)
+        enc = ops.encoder_forward(tape, P, spec, training=training, seed=1234)
+        (v * enc).sum().backward()
+        return [enc.detach().clone()] + [p.grad.detach().clone() for p in P]
+
+    base = run()
+    try:
+        _lib.set_knob("MUCON_PACK_ALL", 1)
+        other = run()
+    finally:
+        _lib.set_knob("MUCON_PACK_ALL", 0)
+    for name, a_, b_ in zip(["enc"] + names, base, other):
+        assert torch.equal(a_, b_), name
