@@ -378,8 +378,13 @@ static_assert(DEC_SB * DEC_D == DEC_THREADS && DEC_SB * DEC_THREADS <= DEC_SCR, 
 // mp[t][k] = sum_j memory[t][j] W1[j][k]; grid (ceil(Tz/4)), 512 threads = 4 quarters of j x 128 columns, every thread all 4 rows.
 // (A thread per (row, column) walking all ME values of j was a chain of dependent L2 round trips: 11 us at Tz = 125.  Here a
 // thread loads ME/4 weights, 16 in flight, each used for four rows, and the quarters meet in LDS in order.)
-__global__ __launch_bounds__(512) void dec_memproj_kernel(const float *memory, const float *w1, float *mp, int Tz, int ME) {
+// (r4: also clears what the step kernel behind it expects cleared: `zero_words` 8-byte words at `zero` -- the exchange granules of
+// decoder_fwd_mw_kernel and its step counter -- so that no stale tag can be met)
+__global__ __launch_bounds__(512) void dec_memproj_kernel(const float *memory, const float *w1, float *mp, int Tz, int ME,
+                                                          unsigned long long *zero, int zero_words, int *zero_int) {
     __shared__ float ms[4][DEC_MAXME];
+    for (int e = blockIdx.x * 512 + threadIdx.x; e < zero_words; e += gridDim.x * 512) zero[e] = 0ull;
+    if (zero_int && blockIdx.x == 0 && threadIdx.x == 0) *zero_int = 0;
     __shared__ float part[4][4][DEC_D];
     const int t0 = blockIdx.x * 4;
     for (int e = threadIdx.x; e < 4 * ME; e += 512) {

@@ -1,0 +1,391 @@
+// The attention decoder's forward step loop on EIGHT workgroups (r4).
+//
+// decoder_fwd_kernel (decoder.hpp) walks the steps on ONE workgroup: a step touches ~1 MB of weights (LSTM cell 512 KB,
+// attn_combine 196 KB, the encoder memory 128 KB, ...) and costs what one CU's L1 path needs to stream them, 13.5 us.
+// Here MW_G = 8 workgroups each keep an eighth of every per-step operand RESIDENT IN LDS for all steps -- nothing is
+// streamed inside the loop -- and exchange three short vectors per step:
+//   workgroup j owns   hidden units 16 j .. 16 j + 15:  their 64 gate rows of W_ih | W_hh            (64 KB, transposed [256][64])
+//                      rows 16 j .. of attention_l2 (its slice of q), the same columns of V and of the memory projection mp
+//                      memory columns 32 j .. 32 j + 31 (its slice of the context)
+//                      columns {16 j .. (embedding), 128 + 32 j .. (context)} of attn_combine, all 128 rows   (24 KB)
+//   per step           q slice -> PARTIAL scores over its 16 columns            -> exchange 1: all 8 partial score vectors [Tz]
+//                      softmax (every workgroup, same bits) -> context slice -> PARTIAL attn_combine over its 48 inputs
+//                                                                               -> exchange 2: all 8 partial `mixed` vectors [128]
+//                      its 64 gate rows -> cell update of its 16 units          -> exchange 3: the 8 slices of h [16]
+// An exchange is an all-gather through global memory of 8-byte {value, tag} granules (tag = step + 1; the buffers are zeroed by the
+// launch in front, dec_memproj_kernel): a producer's relaxed agent-scope 8-byte atomic store is the write-through `sc1` store,
+// consumers poll the granules themselves with relaxed agent-scope atomic loads -- no flags, no fences (MI355X_MICROARCH.md:
+// "8-B agent atomics both sides"); two buffers alternate by step parity (a workgroup can be at most one exchange ahead of the
+// slowest one).  Partial sums are added in workgroup order by every consumer, so all eight hold the same bits and results do not
+// depend on timing.  Correctness needs the eight workgroups to be co-resident (8 << 256 CUs) and nothing about their placement.
+// A poll that does not complete within MW_SPIN_LIMIT re-reads gives up, marks the launch failed (*nsteps_out = -1) and lets the
+// kernel run to its end: a broken hand-over can not hang the GPU.
+// The transcript / length heads do not feed the recurrence (teacher forcing) or only through the arg-max token (greedy decoding):
+// they run after the loop for all steps at once in decoder_heads_kernel; with greedy decoding the loop computes t1 / logits /
+// arg-max itself, every workgroup the same bits.
+#pragma once
+#include "decoder.hpp"
+
+constexpr int MW_G = 8;                       // workgroups
+constexpr int MW_T = 256;                     // threads each
+constexpr int MW_U = DEC_D / MW_G;            // 16: hidden units / q rows / embedding columns per workgroup
+constexpr int MW_MC = DEC_MAXME / MW_G;       // 32: memory (context) columns per workgroup; the kernel takes ME == 256 only
+constexpr int MW_XI = MW_U + MW_MC;           // 48: attn_combine inputs per workgroup
+constexpr int MW_TZ = 192;                    // longest encoder sequence whose slices fit the LDS beside the weights
+constexpr int MW_SPIN_LIMIT = 1 << 21;
+// granules of the exchange buffers: [2 parities][MW_G producers][vector length]
+constexpr size_t MW_X_SCORE = 2 * MW_G * MW_TZ, MW_X_MIXED = 2 * MW_G * DEC_D, MW_X_H = 2 * MW_G * MW_U;
+constexpr size_t MW_X_WORDS = MW_X_SCORE + MW_X_MIXED + MW_X_H;
+constexpr int MW_WTP = 65, MW_CMBP = 129;    // LDS pitches of the transposed gate / attn_combine slices: odd, so that the one-time fill (lanes along the
+                                              // input index) and the per-step reads (lanes along the row) both fall on 32 different banks
+static inline size_t mw_fwd_lds_bytes(int Tz) { return sizeof(float) * ((size_t)256 * MW_WTP + MW_XI * MW_CMBP + MW_U * DEC_D + (size_t)Tz * (MW_U + MW_MC)); }
+
+__device__ __forceinline__ void mw_pub(unsigned long long *p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the MW_G partial values of one element (producer stride `ps` granules), all requested together, re-read until every tag matches;
+// summed in producer order
+__device__ __forceinline__ float mw_gather_sum(const unsigned long long *p, const int ps, const unsigned tag, int *err) {
+    unsigned long long v[MW_G];
+    int spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int g = 0; g < MW_G; ++g) v[g] = __hip_atomic_load(p + (size_t)g * ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int g = 0; g < MW_G; ++g) ok = ok && (unsigned)(v[g] >> 32) == tag;
+        if (ok) break;
+        if (++spins > MW_SPIN_LIMIT) {
+            *err = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    float s = __uint_as_float((unsigned)v[0]);
+#pragma unroll
+    for (int g = 1; g < MW_G; ++g) s += __uint_as_float((unsigned)v[g]);
+    return s;
+}
+__device__ __forceinline__ float mw_get(const unsigned long long *p, const unsigned tag, int *err) {
+    unsigned long long v;
+    int spins = 0;
+    while ((unsigned)((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
+        if (++spins > MW_SPIN_LIMIT) {
+            *err = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __uint_as_float((unsigned)v);
+}
+// out[r] = act(b[r] + W[r][0..127] . x) for r < rows, W from global memory, 4 waves: wave w takes rows w, w + 4, ... in groups of 8,
+// every group's loads (16 per lane) requested before the first is used; all groups of a wave requested up front (rows <= 128: 64 loads)
+template <int ACT>
+__device__ __forceinline__ void mw_matvec_rows128(const int tid, const float *__restrict__ W, const float *__restrict__ b, const int rows,
+                                                  const float *x, float *out) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const float x0 = x[lane], x1 = x[lane + 64];
+    const int ngroups = (rows + 31) / 32;                 // groups of 8 rows per wave (4 waves x 8 rows = 32 rows a round)
+    float w[4][8][2];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+        if (gq < ngroups) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = min(gq * 32 + wave * 8 + i, rows - 1);
+                w[gq][i][0] = W[(long)r * DEC_D + lane];
+                w[gq][i][1] = W[(long)r * DEC_D + 64 + lane];
+            }
+        }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+        if (gq < ngroups) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = w[gq][i][0] * x0 + w[gq][i][1] * x1;
+            const float sum = wave_sum_rows<8>(lane, acc);
+            const int r = gq * 32 + wave * 8 + ((lane >> 3) & 7);
+            if ((lane & 7) == 0 && r < rows) {
+                const float v = sum + b[r];
+                out[r] = ACT ? fmaxf(v, 0.f) : v;
+            }
+        }
+}
+
+// grid MW_G, MW_T threads, dynamic LDS mw_fwd_lds_bytes(Tz).  Requires ME == 256, Tz <= MW_TZ, NC <= 128 (host: mw_fwd_ok).
+__global__ __launch_bounds__(MW_T) void decoder_fwd_mw_kernel(DecDims dm, DecParams p, DecSaved sv, const float *memory, const float *hn,
+                                                             const float *cn, const long *tf_input, const float *dropmask,
+                                                             float *logits_out, unsigned long long *xbuf, int *nsteps_out) {
+    extern __shared__ __attribute__((aligned(16))) float mw_dyn[];
+    float *s_wt = mw_dyn;                               // [256 inputs: mixed | h][64 gate rows: gate * 16 + unit]
+    float *s_cmb = s_wt + 256 * MW_WTP;                 // [48 inputs: 16 embedding | 32 context][128 rows]
+    float *s_l2 = s_cmb + MW_XI * MW_CMBP;              // [16 rows][128]
+    float *s_mp = s_l2 + MW_U * DEC_D;                  // [Tz][16]
+    float *s_mem = s_mp + (size_t)dm.Tz * MW_U;         // [Tz][32]
+    __shared__ float s_h[DEC_D], s_c[MW_U], s_q[MW_U], s_x[MW_XI], s_mixed[DEC_D], s_score[MW_TZ], s_attn[MW_TZ];
+    __shared__ float s_part[256], s_gates[64], s_hc[2 * DEC_MAXME], s_t1[DEC_D], s_logits[DEC_MAXNC];
+    __shared__ int s_tok, s_stop, s_err;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = blockIdx.x;
+    const int Tz = dm.Tz, ME = dm.ME, NC = dm.NC, CW = DEC_D + ME;
+    unsigned long long *x_score = xbuf, *x_mixed = xbuf + MW_X_SCORE, *x_h = x_mixed + MW_X_MIXED;
+
+    // ---- residents
+    for (int e = tid; e < 64 * 256; e += MW_T) {        // gate row r = gate * 16 + unit  <-  global row gate * 128 + 16 j + unit
+        const int r = e >> 8, c = e & 255, grow = (r >> 4) * DEC_D + MW_U * j + (r & 15);
+        s_wt[c * MW_WTP + r] = c < DEC_D ? p.w_ih[(long)grow * DEC_D + c] : p.w_hh[(long)grow * DEC_D + c - DEC_D];
+    }
+    for (int e = tid; e < DEC_D * MW_XI; e += MW_T) {   // attn_combine [128][128 + 256]: columns 16 j .. and 128 + 32 j ..
+        const int row = e / MW_XI, c = e - row * MW_XI;
+        s_cmb[c * MW_CMBP + row] = p.cmb_w[(long)row * CW + (c < MW_U ? MW_U * j + c : DEC_D + MW_MC * j + c - MW_U)];
+    }
+    for (int e = tid; e < MW_U * DEC_D; e += MW_T) s_l2[e] = p.l2_w[(long)(MW_U * j) * DEC_D + e];
+    for (int e = tid; e < Tz * MW_U; e += MW_T) s_mp[e] = sv.mp[(long)(e >> 4) * DEC_D + MW_U * j + (e & 15)];
+    for (int e = tid; e < Tz * MW_MC; e += MW_T) s_mem[e] = memory[(long)(e >> 5) * ME + MW_MC * j + (e & 31)];
+    // initial state (models.py:612-617), every workgroup all 128 units of h, its own 16 of c
+    for (int e = tid; e < ME; e += MW_T) {
+        s_hc[e] = hn[e];
+        s_hc[DEC_MAXME + e] = cn[e];
+    }
+    if (tid == 0) {
+        s_tok = (int)tf_input[0];
+        s_stop = 0;
+        s_err = 0;
+    }
+    __syncthreads();
+    {   // rows of hidden_out (all 128) and cn_out (this workgroup's 16): lanes along the 256 columns, a wave takes rows w, w + 4, ...;
+        // two round trips (rows 0..127, then the 16 rows of cn_out), every load of a round requested before the first is used
+        const float xh[4] = {s_hc[lane], s_hc[64 + lane], s_hc[128 + lane], s_hc[192 + lane]};
+        float w[4][8][4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float *wrow = p.ho_w + (long)(gq * 32 + wave * 8 + i) * ME;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[gq][i][q] = wrow[q * 64 + lane];
+            }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = ((w[gq][i][0] * xh[0] + w[gq][i][1] * xh[1]) + w[gq][i][2] * xh[2]) + w[gq][i][3] * xh[3];
+            const float sum = wave_sum_rows<8>(lane, acc);
+            const int r = gq * 32 + wave * 8 + ((lane >> 3) & 7);
+            if ((lane & 7) == 0) s_h[r] = sum + p.ho_b[r];
+        }
+        if (wave < 2) {
+            const float xc[4] = {s_hc[DEC_MAXME + lane], s_hc[DEC_MAXME + 64 + lane], s_hc[DEC_MAXME + 128 + lane], s_hc[DEC_MAXME + 192 + lane]};
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float *wrow = p.co_w + (long)(MW_U * j + wave * 8 + i) * ME;
+                acc[i] = ((wrow[lane] * xc[0] + wrow[64 + lane] * xc[1]) + wrow[128 + lane] * xc[2]) + wrow[192 + lane] * xc[3];
+            }
+            const float sum = wave_sum_rows<8>(lane, acc);
+            const int r = wave * 8 + ((lane >> 3) & 7);
+            if ((lane & 7) == 0) s_c[r] = sum + p.co_b[MW_U * j + r];
+        }
+    }
+    __syncthreads();
+    if (j == 0 && tid < DEC_D) sv.h[tid] = s_h[tid];
+    if (tid < MW_U) sv.c[MW_U * j + tid] = s_c[tid];
+    const float l2b = p.l2_b[MW_U * j + (tid >> 4)];
+    float vsl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vsl[i] = p.v[MW_U * j + (tid & 1) * 8 + i];
+    const float cmb_b = tid < DEC_D ? p.cmb_b[tid] : 0.f;
+    const int grow_g = tid < 64 ? (tid >> 4) * DEC_D + MW_U * j + (tid & 15) : 0;
+    const float gate_b = tid < 64 ? p.b_ih[grow_g] + p.b_hh[grow_g] : 0.f;
+    const bool heads_in_loop = !(dm.teacher_forcing && !dm.stop_on_eos);
+
+    int s = 0, err = 0;
+    for (; s < dm.S; ++s) {
+        const unsigned tag = (unsigned)s + 1u;
+        const int par = s & 1;
+        int tok = dm.teacher_forcing ? (int)tf_input[s] : s_tok;
+        tok = tok < 0 ? 0 : tok >= dm.n_emb ? dm.n_emb - 1 : tok;
+        // -- q slice = attention_l2(h)[16 j ..]: 16 lanes (a DPP row) share a row, 8 columns each
+        {
+            const int row = tid >> 4, cg = tid & 15;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += s_l2[row * DEC_D + cg * 8 + i] * s_h[cg * 8 + i];
+            a += dpp_f<DPP_XOR1>(a);
+            a += dpp_f<DPP_XOR2>(a);
+            a += dpp_f<DPP_HALF_MIRROR>(a);
+            a += dpp_f<DPP_MIRROR>(a);
+            if (cg == 0) {
+                s_q[row] = a + l2b;
+                sv.q[s * DEC_D + MW_U * j + row] = a + l2b;
+            }
+        }
+        __syncthreads();
+        // -- partial score[t] over this workgroup's 16 columns: a lane pair per encoder state
+        for (int t0 = 0; t0 < Tz; t0 += 128) {
+            const int t = t0 + (tid >> 1), hf = tid & 1;
+            const int tc = min(t, Tz - 1);
+            const f32x4 m0 = *reinterpret_cast<const f32x4 *>(s_mp + tc * MW_U + hf * 8), m1 = *reinterpret_cast<const f32x4 *>(s_mp + tc * MW_U + hf * 8 + 4);
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += vsl[i] * tanh_f((i < 4 ? m0[i] : m1[i - 4]) + s_q[hf * 8 + i]);
+            a += dpp_f<DPP_XOR1>(a);
+            if (hf == 0 && t < Tz) mw_pub(x_score + ((size_t)par * MW_G + j) * MW_TZ + t, a, tag);
+        }
+        // embedded = dropout(relu(embedding(input)))[16 j ..]
+        if (tid < MW_U) {
+            float e = fmaxf(p.emb[(long)tok * DEC_D + MW_U * j + tid], 0.f);
+            if (dropmask) e *= dropmask[s * DEC_D + MW_U * j + tid];
+            s_x[tid] = e;
+            sv.cat[(long)s * CW + MW_U * j + tid] = e;
+        }
+        if (j == 0 && tid == 0) sv.toks[s] = tok;
+        // -- exchange 1: the scores
+        if (tid < Tz) s_score[tid] = mw_gather_sum(x_score + (size_t)par * MW_G * MW_TZ + tid, MW_TZ, tag, &err);
+        __syncthreads();
+        // softmax: every wave reduces all scores itself (same bits in every wave of every workgroup)
+        {
+            float mx = -INFINITY;
+            for (int t = lane; t < Tz; t += 64) mx = fmaxf(mx, s_score[t]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int t = lane; t < Tz; t += 64) sum += expf(s_score[t] - mx);
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+            for (int t = tid; t < Tz; t += MW_T) {
+                const float a = expf(s_score[t] - mx) * inv;
+                s_attn[t] = a;
+                if (j == 0) sv.attn[(long)s * Tz + t] = a;
+            }
+        }
+        __syncthreads();
+        // -- context slice: 8 groups of states x 32 columns, the groups meet in LDS in order
+        {
+            const int col = tid & 31, tq = tid >> 5;
+            float a = 0.f;
+            for (int t = tq; t < Tz; t += 8) a += s_attn[t] * s_mem[t * MW_MC + col];
+            s_part[tq * 32 + col] = a;
+        }
+        __syncthreads();
+        if (tid < MW_MC) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += s_part[g * 32 + tid];
+            s_x[MW_U + tid] = v;
+            sv.cat[(long)s * CW + DEC_D + MW_MC * j + tid] = v;
+        }
+        __syncthreads();
+        // -- partial attn_combine over this workgroup's 48 inputs: two halves of 24 per row
+        {
+            const int row = tid & 127, hf = tid >> 7;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) a += s_cmb[(hf * 24 + c) * MW_CMBP + row] * s_x[hf * 24 + c];
+            s_part[hf * 128 + row] = a;
+        }
+        __syncthreads();
+        if (tid < DEC_D) mw_pub(x_mixed + ((size_t)par * MW_G + j) * DEC_D + tid, s_part[tid] + s_part[128 + tid], tag);
+        // -- exchange 2: mixed = relu(sum of the partials + bias)
+        if (tid < DEC_D) {
+            const float m = fmaxf(mw_gather_sum(x_mixed + (size_t)par * MW_G * DEC_D + tid, DEC_D, tag, &err) + cmb_b, 0.f);
+            s_mixed[tid] = m;
+            if (j == 0) sv.mixed[s * DEC_D + tid] = m;
+        }
+        __syncthreads();
+        // -- this workgroup's 64 gate rows: wave w multiplies inputs 64 w .. 64 w + 63 of [mixed | h], lane = gate row
+        {
+            const float xv = wave < 2 ? s_mixed[64 * wave + lane] : s_h[64 * (wave - 2) + lane];
+            const float *wt = s_wt + (64 * wave) * MW_WTP + lane;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) a += wt[c * MW_WTP] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c));
+            s_part[wave * 64 + lane] = a;
+        }
+        __syncthreads();
+        if (tid < 64) s_gates[tid] = (((s_part[tid] + s_part[64 + tid]) + s_part[128 + tid]) + s_part[192 + tid]) + gate_b;
+        __syncthreads();
+        if (tid < MW_U) {
+            const float gi = sigmoid_f(s_gates[tid]), gf = sigmoid_f(s_gates[16 + tid]);
+            const float gg = tanh_f(s_gates[32 + tid]), go = sigmoid_f(s_gates[48 + tid]);
+            const float c = gf * s_c[tid] + gi * gg;
+            const float h = go * tanh_f(c);
+            s_c[tid] = c;
+            const int u = MW_U * j + tid;
+            float *gs = sv.gates + (long)s * 4 * DEC_D;
+            gs[u] = gi;
+            gs[DEC_D + u] = gf;
+            gs[2 * DEC_D + u] = gg;
+            gs[3 * DEC_D + u] = go;
+            sv.c[(s + 1) * DEC_D + u] = c;
+            sv.h[(s + 1) * DEC_D + u] = h;
+            mw_pub(x_h + ((size_t)par * MW_G + j) * MW_U + tid, h, tag);
+        }
+        // -- exchange 3: h
+        if (tid < DEC_D) s_h[tid] = mw_get(x_h + ((size_t)par * MW_G + (tid >> 4)) * MW_U + (tid & 15), tag, &err);
+        __syncthreads();
+        if (!heads_in_loop) continue;
+        // greedy decoding: the arg-max word feeds the next step -- t1, logits and arg-max in every workgroup (the same bits)
+        mw_matvec_rows128<1>(tid, p.t1_w, p.t1_b, DEC_D, s_h, s_t1);
+        __syncthreads();
+        mw_matvec_rows128<0>(tid, p.t2_w, p.t2_b, NC, s_t1, s_logits);
+        __syncthreads();
+        if (j == 0 && tid < DEC_D) sv.t1[s * DEC_D + tid] = s_t1[tid];
+        if (j == 0 && tid < NC) logits_out[(long)s * NC + tid] = s_logits[tid];
+        if (wave == 0) {   // arg-max, lowest index on ties
+            const float x0 = lane < NC ? s_logits[lane] : -INFINITY, x1 = lane + 64 < NC ? s_logits[lane + 64] : -INFINITY;
+            const float mx = wave_max(fmaxf(x0, x1));
+            int cand = x0 == mx ? lane : x1 == mx ? lane + 64 : 1 << 20;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+            if (lane == 0) {
+                s_tok = cand;
+                if (dm.stop_on_eos && cand == dm.eos) s_stop = 1;
+            }
+        }
+        __syncthreads();
+        if (s_stop) {
+            ++s;
+            break;
+        }
+    }
+    if (err) s_err = 1;
+    __syncthreads();
+    if (tid == 0) {
+        if (s_err) atomicExch(nsteps_out, -1);               // (any workgroup that gave up marks the launch)
+        else if (j == 0) atomicCAS(nsteps_out, 0, s);         // (0 = the value dec_memproj_kernel left: not marked failed)
+    }
+}
+
+// The heads for all steps at once, one workgroup of DEC_THREADS (decoder_fwd_kernel's code behind its loop, as a launch of its own):
+// have_logits: t1 and the raw logits were computed inside the loop (greedy decoding); *nsteps = the steps that ran (<= 0: nothing).
+__global__ __launch_bounds__(DEC_THREADS) void decoder_heads_kernel(DecDims dm, DecParams p, DecSaved sv, float *logp_out, float *len_out,
+                                                                    const int *nsteps, const int have_logits) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = min(*nsteps, dm.S), NC = dm.NC, LW = DEC_D + NC;
+    if (S <= 0) return;
+    if (!have_logits) {
+        matvec_rows_steps<1, 8, 2>(tid, p.t1_w, p.t1_b, DEC_D, DEC_D, sv.h + DEC_D, DEC_D, S, sv.t1, DEC_D);
+        __syncthreads();
+        matvec_rows_steps<0, 4, 2>(tid, p.t2_w, p.t2_b, NC, DEC_D, sv.t1, DEC_D, S, logp_out, NC);   // the logits, for now
+        __syncthreads();
+    }
+    for (int e = tid; e < S * LW; e += DEC_THREADS) {
+        const int st = e / LW, k = e - st * LW;
+        sv.lencat[e] = k < DEC_D ? sv.mixed[st * DEC_D + k] : fmaxf(logp_out[(long)st * NC + k - DEC_D], 0.f);
+    }
+    __syncthreads();
+    matvec_rows_steps<1, 4, 4>(tid, p.n1_w, p.n1_b, DEC_NL, LW, sv.lencat, LW, S, sv.l1, DEC_NL);
+    for (int st = wave; st < S; st += DEC_WAVES) {   // log-softmax in place
+        float *row = logp_out + (long)st * NC;
+        const float x0 = lane < NC ? row[lane] : -INFINITY, x1 = lane + 64 < NC ? row[lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(x0, x1));
+        const float se = wave_sum((lane < NC ? expf(x0 - mx) : 0.f) + (lane + 64 < NC ? expf(x1 - mx) : 0.f));
+        const float lse = mx + logf(se);
+        if (lane < NC) row[lane] = x0 - lse;
+        if (lane + 64 < NC) row[lane + 64] = x1 - lse;
+    }
+    __syncthreads();
+    for (int st = wave; st < S; st += DEC_WAVES) {
+        const float a = wave_sum(p.n2_w[lane] * sv.l1[st * DEC_NL + lane]);
+        if (lane == 0) len_out[st] = a + p.n2_b[0];
+    }
+}

@@ -373,15 +373,24 @@ void prof_mark(int slot, bool stop, hipStream_t s) {
     if (stop) ++g_prof.n[slot];
 }
 
-// every weight re-layout of a forward pass in one launch: rows [0, ypack) of the grid are pack_weights' blocks (small_kernels.hpp),
-// the rows behind them fs_pack's (gemm_fused_split.hpp: 20,480 fragments per layer slot = 20 blocks of 1,024 threads)
+// every weight re-layout of a forward pass in one launch.  The grid is the list of blocks that HAVE work (r4: the (32, L + 3 + slots)
+// grid of r3 launched 832 workgroups of 1,024 threads of which ~560 returned at once): [n_f32 = 4 (L + 1) blocks of the f32 layouts, if
+// any launch reads them][32 blocks of first_conv's planes][6 blocks of layer 0's data-gradient planes][20 blocks per fragment-image slot]
+struct PackGrid {
+    int n_f32, n_first, n_d0, n_fs;   // block counts of the four sections, in this order
+};
 // (r4: staging the fragment images through LDS -- a block loading 32 output rows of a layer once and emitting every fragment that
-// depends on them -- was built and measured: 13.5 us against 13.5 us for the gather below, bit-identical images; what the launch costs is
-// not fs_pack_body's scattered reads.  Not kept.)
-__global__ __launch_bounds__(PACK_THREADS) void pack_all_kernel(const PackArgs a, const FsPackArgs f, const int ypack) {
+// depends on them -- was built and measured: 13.5 us against 13.5 us for fs_pack_body's gather, bit-identical images.  Not kept.)
+__global__ __launch_bounds__(PACK_THREADS) void pack_all_kernel(const PackArgs a, const FsPackArgs f, const PackGrid g) {
     __shared__ float lds[PACK_LDS_FLOATS];
-    if ((int)blockIdx.y < ypack) pack_weights_body(a, lds);
-    else if (blockIdx.x < 20) fs_pack_body(f, blockIdx.y - ypack, blockIdx.x * PACK_THREADS + threadIdx.x);
+    int b = blockIdx.x;
+    if (b < g.n_f32) return pack_weights_body(a, lds, b >> 2, b & 3, 4);
+    b -= g.n_f32;
+    if (b < g.n_first) return pack_weights_body(a, lds, a.L + 1, b, g.n_first);
+    b -= g.n_first;
+    if (b < g.n_d0) return pack_weights_body(a, lds, a.L + 2, b, g.n_d0);
+    b -= g.n_d0;
+    fs_pack_body(f, b / 20, (b % 20) * PACK_THREADS + threadIdx.x);
 }
 
 __global__ void dropout_mask_kernel(uint8_t *mask, long n, DropCfg d) {
@@ -394,6 +403,7 @@ __global__ void dropout_mask_kernel(uint8_t *mask, long n, DropCfg d) {
 // Tuning / regression knobs: read from the environment once when the library is first used; the test hook
 // mucon_test_set_knob applies the same parsing at run time (tests compare code paths inside one process).
 extern int g_vit_lanes;   // viterbi.hip
+extern int g_dec_mw;      // shead.hip
 static bool apply_knob(const char *name, const char *e) {
     if (!strcmp(name, "MUCON_TAIL_CHAIN")) {
         if (e) g_tail_chain = atoi(e);
@@ -405,6 +415,10 @@ static bool apply_knob(const char *name, const char *e) {
     }
     if (!strcmp(name, "MUCON_VIT_LANES")) {
         if (e) g_vit_lanes = atoi(e);
+        return true;
+    }
+    if (!strcmp(name, "MUCON_DEC_MW")) {
+        if (e) g_dec_mw = atoi(e) ? 1 : 0;
         return true;
     }
     if (!strcmp(name, "MUCON_NT_BM")) {
@@ -461,7 +475,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -592,7 +606,6 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
     {   // ... and, in the SAME launch, the split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp
         // (a layer's images sit at its own slot): two launches were 8 + 7 us at the head of every forward pass
-        const int ypack = L + (split_dgrad0 ? 3 : (split_first ? 2 : 1));
         FsPackArgs fa;
         memset(&fa, 0, sizeof(fa));
         int lo = -1, hi = -1;
@@ -612,7 +625,13 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             fa.img = reinterpret_cast<uint16_t *>(ws + pl.Wfs) + (long)lo * FS_LAYER_ELEMS;
             yfs = fa.nl + (fa.last_w ? 1 : 0);
         }
-        hipLaunchKernelGGL(pack_all_kernel, dim3(32, ypack + yfs), dim3(PACK_THREADS), 0, s, pa, fa, ypack);
+        PackGrid pg;
+        pg.n_f32 = need_f32 ? 4 * (L + 1) : 0;
+        pg.n_first = split_first ? 32 : 0;
+        pg.n_d0 = split_dgrad0 ? 6 : 0;
+        pg.n_fs = 20 * yfs;
+        const int nblocks = pg.n_f32 + pg.n_first + pg.n_d0 + pg.n_fs;
+        if (nblocks > 0) hipLaunchKernelGGL(pack_all_kernel, dim3(nblocks), dim3(PACK_THREADS), 0, s, pa, fa, pg);
         HIPCHK(hipGetLastError());
     }
 

@@ -10,6 +10,7 @@
 #include "../../include/mucon_hip.h"
 #include "lstm.hpp"
 #include "decoder.hpp"
+#include "decoder_mw.hpp"
 #include "loss.hpp"
 #include "optim.hpp"
 #include <vector>
@@ -132,8 +133,10 @@ static int dec_check(const mucon_decoder_cfg *c) {
 struct DecLayout {
     DecSaved sv;
     DecDeltas dl;
+    unsigned long long *xbuf;   // exchange granules of decoder_fwd_mw_kernel
     size_t floats;
 };
+int g_dec_mw = 1;   // MUCON_DEC_MW=0: the decoder's forward step loop on one workgroup (decoder_fwd_kernel) also where the eight-workgroup kernel applies (tests, A/B)
 static DecLayout dec_layout(const mucon_decoder_cfg *c, float *base) {
     DecLayout L;
     size_t off = 0;
@@ -167,6 +170,7 @@ static DecLayout dec_layout(const mucon_decoder_cfg *c, float *base) {
     L.dl.len = take(S);
     L.dl.h0 = take(DEC_D);
     L.dl.c0 = take(DEC_D);
+    L.xbuf = reinterpret_cast<unsigned long long *>(take(2 * MW_X_WORDS));   // exchange granules of the eight-workgroup step kernel (8 bytes each)
     L.floats = off;
     return L;
 }
@@ -194,7 +198,9 @@ static int dec_lds_attr() {
     static int rc = hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         DEC_MAX_DYN_LDS) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DEC_MAX_DYN_LDS_BWD) != hipSuccess;
+                                        DEC_MAX_DYN_LDS_BWD) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)mw_fwd_lds_bytes(MW_TZ)) != hipSuccess;
     return rc ? sfail(MUCON_E_HIP, "decoder: hipFuncSetAttribute failed") : MUCON_OK;
 }
 
@@ -226,8 +232,20 @@ extern "C" int mucon_decoder_fwd(const mucon_decoder_cfg *cfg, const mucon_decod
     if ((rc = dec_lds_attr()) != MUCON_OK) return rc;
     const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dec_memproj_kernel, dim3((cfg->Tz + 3) / 4), dim3(512), 0, s, memory, p.w1, L.sv.mp, cfg->Tz, cfg->ME);
     DecDims dm = dec_dims(cfg, cfg->max_steps);
+    if (g_dec_mw && cfg->ME == DEC_MAXME && cfg->Tz <= MW_TZ) {
+        // eight workgroups, every per-step operand resident in their LDS, three exchanges per step (decoder_mw.hpp); the memory
+        // projection launch in front clears the exchange granules and the step counter
+        hipLaunchKernelGGL(dec_memproj_kernel, dim3((cfg->Tz + 3) / 4), dim3(512), 0, s, memory, p.w1, L.sv.mp, cfg->Tz, cfg->ME, L.xbuf,
+                           (int)MW_X_WORDS, n_steps);
+        hipLaunchKernelGGL(decoder_fwd_mw_kernel, dim3(MW_G), dim3(MW_T), mw_fwd_lds_bytes(cfg->Tz), s, dm, p, L.sv, memory, hn, cn,
+                           reinterpret_cast<const long *>(tf_input), dropmask, logp, L.xbuf, n_steps);
+        const int greedy = !(cfg->teacher_forcing && !cfg->stop_on_eos);
+        hipLaunchKernelGGL(decoder_heads_kernel, dim3(1), dim3(DEC_THREADS), 0, s, dm, p, L.sv, logp, lengths, n_steps, greedy);
+        SHIPCHK(hipGetLastError());
+        return MUCON_OK;
+    }
+    hipLaunchKernelGGL(dec_memproj_kernel, dim3((cfg->Tz + 3) / 4), dim3(512), 0, s, memory, p.w1, L.sv.mp, cfg->Tz, cfg->ME, nullptr, 0, nullptr);
     const size_t lds = dec_fwd_lds_bytes(cfg->Tz, &dm.mp_lds);
     hipLaunchKernelGGL(decoder_fwd_kernel, dim3(1), dim3(DEC_THREADS), lds, s, dm, p,
                        L.sv, memory, hn, cn, reinterpret_cast<const long *>(tf_input), dropmask, logp, lengths, n_steps);

@@ -46,8 +46,9 @@ __device__ __forceinline__ void pack_image_tile(const float *tile, uint16_t *img
     }
 }
 
-__device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds) {
-    const int y = blockIdx.y, x = blockIdx.x, tid = threadIdx.x;
+// (y, x): the block's place in the logical grid of the comment above; nx = blocks of a row that loop over k-tiles (32)
+__device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds, const int y, const int x, const int nx) {
+    const int tid = threadIdx.x;
     if (y <= a.L) {
         if (x >= 4 || !a.W1f) return;       // (W1f null: no launch of this pass reads the f32 layouts)
         const int o0 = 32 * x;
@@ -90,7 +91,7 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds)
         }
     } else if (y == a.L + 1) {
         if (!a.first_planes) return;
-        for (int S = x; S < (a.D >> 6); S += gridDim.x) {
+        for (int S = x; S < (a.D >> 6); S += nx) {
             __syncthreads();
             for (int e = tid; e < 128 * 64; e += PACK_THREADS) lds[(e >> 6) * 65 + (e & 63)] = a.first_w[(long)(e >> 6) * a.D + 64 * S + (e & 63)];
             __syncthreads();

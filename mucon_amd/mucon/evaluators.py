@@ -219,6 +219,9 @@ class MuConEvaluator:
         # -- sync 1: how many words every video decoded, and which
         S = model.max_decoding_steps
         n_steps = torch.cat([v["out"]["n_steps"] for v in vids]).cpu().numpy()
+        if (n_steps < 0).any():
+            from .. import _lib, ops
+            raise _lib.MuconHipError(ops.DECODER_HANDOVER_FAILED)
         alive = []
         for v, n in zip(vids, n_steps):
             n = int(n)

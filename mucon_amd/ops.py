@@ -490,6 +490,10 @@ def _decoder_params(tensors):
     return p
 
 
+DECODER_HANDOVER_FAILED = ("mucon_decoder_fwd: a hand-over between the eight workgroups of the step kernel did not complete (they were not "
+                           "co-resident for about a second: the GPU is oversubscribed); n_steps = -1, the outputs of this call are invalid")
+
+
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, memory, hn, cn, tf_input, dropmask, opts, *params):
@@ -522,6 +526,8 @@ class _DecoderFn(torch.autograd.Function):
                                          _lib.ptr(n_steps), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_decoder_fwd")
         n = int(n_steps.item()) if stop_on_eos else max_steps
+        if n < 0:
+            raise _lib.MuconHipError(DECODER_HANDOVER_FAILED)
         logp, lengths = logp[:n], lengths[:n]
         ctx.cfg, ctx.n, ctx.ws, ctx.nbytes, ctx.dropmask = cfg, n, ws, nbytes, dropmask
         ctx.save_for_backward(memory, hn, cn, logp, *params)
@@ -1019,7 +1025,7 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     start = 0
     while True:
         rc, bad, sum_T, sum_N, out = decode(ptrs, Ts, trs, tabs, forces, C, fs, max_len, fmt, 1 if (C & 3) == 0 else 0, start, lab_ptr,
-                                            fn_addr, torch.cuda.current_stream().cuda_stream)
+                                            fn_addr, _lib.current_stream_raw())
         if bad < 0:
             break
         # video `bad`: not an int32 / float64 C-contiguous buffer, or an emission tensor whose start is not 16-byte aligned

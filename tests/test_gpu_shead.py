@@ -153,3 +153,43 @@ def test_decoder_rejects_bad_arguments():
         ops.decoder_forward(mem, h, c, torch.tensor([49, 1], device=DEV), params, 5, True, False, 48)   # too few tokens
     with pytest.raises(_lib.MuconHipError):
         ops.decoder_forward(torch.zeros(5, 512, device=DEV), h, c, torch.tensor([49], device=DEV), params, 1, True, False, 48)
+
+
+@pytest.mark.parametrize("Tz,steps,teacher", [(125, 7, True), (125, 12, False), (3, 4, True), (192, 31, False), (64, 31, True)])
+def test_eight_workgroup_step_kernel_against_the_one_workgroup_kernel(Tz, steps, teacher):
+    """The decoder's forward step loop runs on eight workgroups with LDS-resident operand slices and three exchanges per step
+    (csrc/decoder_mw.hpp) where the shape allows (ME = 256, Tz <= 192); MUCON_DEC_MW=0 keeps the one-workgroup kernel.  Both against
+    each other (sums are taken in a different order: 2e-5), every saved activation the backward reads included -- checked through
+    the gradients the (shared) backward kernel derives from them -- and the eight-workgroup kernel against itself bitwise (its
+    exchanges add partial sums in workgroup order: results do not depend on timing)."""
+    from mucon_amd import _lib
+    c = shead_case(GOLD, "a")
+    torch.manual_seed(Tz)
+    enc = torch.randn(Tz, 128, device=DEV)
+    tf_in = torch.randint(0, 48, (steps,), device=DEV)
+    tf_in[0] = 49
+    R1 = torch.randn(steps, 49, device=DEV)
+    r2 = torch.randn(steps, device=DEV)
+
+    def run(mw):
+        _lib.set_knob("MUCON_DEC_MW", mw)
+        P = {k: v.to(DEV).requires_grad_(True) for k, v in shead_params(GOLD, "a").items()}
+        e = enc.clone().requires_grad_(True)
+        logp, lens = _hip_shead(P, e, tf_in, steps, teacher, not teacher, c["eos"])
+        n = logp.shape[0]
+        ((logp * R1[:n]).sum() + (lens * r2[:n]).sum()).backward()
+        return logp.detach(), lens.detach(), e.grad.detach(), {k: v.grad.detach() for k, v in P.items() if v.grad is not None}
+
+    try:
+        a, b, a2 = run(1), run(0), run(1)
+    finally:
+        _lib.set_knob("MUCON_DEC_MW", 1)
+    assert a[0].shape == b[0].shape
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), atol=2e-5, rtol=0)
+    assert _rel(a[2], b[2]) < 1e-4
+    for k in a[3]:
+        assert _rel(a[3][k], b[3][k]) < 1e-4, k
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], a2[3][k]), k

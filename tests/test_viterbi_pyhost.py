@@ -79,10 +79,7 @@ def fake_decode(monkeypatch):
     monkeypatch.setattr(_lib, "load", lambda *a, **k: Lib)
     monkeypatch.setattr(ops, "_VIT_FN_ADDR", [0])
 
-    class Stream:
-        cuda_stream = 0x1234
-
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: Stream)
+    monkeypatch.setattr(_lib, "current_stream_raw", lambda: 0x1234)
     return seen
 
 
