@@ -389,3 +389,294 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_kernel(DecDims dm, 
         if (lane == 0) len_out[st] = a + p.n2_b[0];
     }
 }
+
+// ============================================================================================================ backward
+// The backward step loop on the same eight workgroups, same slices, three exchanges per step as well:
+//   cell backward of the workgroup's 16 units -> its 64 gate deltas
+//   PARTIAL d mixed = W_ih[its 64 rows]^T dgates and PARTIAL dh_a = W_hh[its 64 rows]^T dgates      -> exchange A (256 values)
+//   d mixed (+ the length head's share, through the ReLU) -> d cat over its 48 attn_combine columns: d embedding, d context slice
+//   PARTIAL d attn[t] = memory[t][its 32 columns] . d context slice                                     -> exchange B (Tz values)
+//   softmax backward (every workgroup, same bits) -> d score -> d q over its 16 rows (through the tanh; dV alongside)
+//   PARTIAL dh_b = attention_l2[its 16 rows]^T d q                                                      -> exchange C (128 values)
+//   dh(s - 1) = dh_a + dh_b (+ the transcript head's share, added by the next step's cell backward)
+// The heads' backward (all steps at once) runs in front as a launch of its own (decoder_heads_bwd_kernel: decoder_bwd_kernel's code in
+// front of its loop); it also clears the exchange granules.  Every per-step delta the weight-gradient kernels read (dl.gates, dl.mixed,
+// dl.ctx, dl.score, dl.q) is written exactly as decoder_bwd_kernel writes it.
+constexpr size_t MWB_X_A = 2 * MW_G * 256, MWB_X_B = 2 * MW_G * MW_TZ, MWB_X_C = 2 * MW_G * DEC_D, MWB_X_D = MW_G * MW_U;
+constexpr size_t MWB_X_WORDS = MWB_X_A + MWB_X_B + MWB_X_C + MWB_X_D;
+static_assert(MWB_X_WORDS <= 2 * MW_X_WORDS, "the backward's granules fit the buffer dec_layout reserves (twice the forward's)");
+static inline size_t mw_bwd_lds_bytes(int Tz) { return sizeof(float) * ((size_t)2 * 64 * DEC_D + MW_XI * MW_CMBP + MW_U * DEC_D + (size_t)Tz * MW_U + (size_t)MW_MC * (Tz | 1)); }
+
+// decoder_bwd_kernel's prologue as a kernel: zeroes d_emb, back-propagates the heads for all steps; parks what reaches the recurrence in
+// dl.q[s] (d dec_out from the transcript MLP) and dl.mixed[s] (d mixed from the length MLP).  One workgroup of DEC_THREADS.
+__global__ __launch_bounds__(DEC_THREADS) void decoder_heads_bwd_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl, const float *logp,
+                                                                        const float *d_logp, const float *d_len, float *d_emb,
+                                                                        unsigned long long *zero, int zero_words) {
+    __shared__ __attribute__((aligned(16))) float s_scr[DEC_SCR];
+    __shared__ float s_sd[DEC_SB * DEC_D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NC = dm.NC, LW = DEC_D + NC;
+    for (int e = tid; e < zero_words; e += DEC_THREADS) zero[e] = 0ull;
+    for (long e = tid; e < (long)dm.n_emb * DEC_D; e += DEC_THREADS) d_emb[e] = 0.f;
+    __syncthreads();
+    for (int s0 = 0; s0 < dm.S; s0 += DEC_SB) {
+        const int ns = min(DEC_SB, dm.S - s0);
+        if (wave < DEC_SB) {            // log-softmax backward
+            const int st = s0 + wave;
+            if (wave < ns) {
+                const float g0 = (d_logp && lane < NC) ? d_logp[(long)st * NC + lane] : 0.f;
+                const float g1 = (d_logp && lane + 64 < NC) ? d_logp[(long)st * NC + lane + 64] : 0.f;
+                const float tot = wave_sum(g0 + g1);
+                if (lane < NC) dl.logits[(long)st * NC + lane] = g0 - expf(logp[(long)st * NC + lane]) * tot;
+                if (lane + 64 < NC) dl.logits[(long)st * NC + lane + 64] = g1 - expf(logp[(long)st * NC + lane + 64]) * tot;
+            }
+        } else {                        // length MLP output layer backward
+            const int st = s0 + wave - DEC_SB;
+            if (wave - DEC_SB < ns) {
+                const float dlen = d_len ? d_len[st] : 0.f;
+                dl.l1[st * DEC_NL + lane] = sv.l1[st * DEC_NL + lane] > 0.f ? dlen * p.n2_w[lane] : 0.f;
+                if (lane == 0) dl.len[st] = dlen;
+            }
+        }
+        matvec_cols_steps(tid, p.n1_w, DEC_NL, LW, dl.l1 + s0 * DEC_NL, DEC_NL, ns, s_sd, s_scr, [&](int st, int j, float sum) {
+            st += s0;
+            const float v = sv.lencat[(long)st * LW + j] > 0.f ? sum : 0.f;
+            if (j < DEC_D) dl.mixed[st * DEC_D + j] = v;
+            else dl.logits[(long)st * NC + j - DEC_D] += v;
+        });
+        matvec_cols_steps(tid, p.t2_w, NC, DEC_D, dl.logits + (long)s0 * NC, NC, ns, s_sd, s_scr, [&](int st, int j, float sum) {
+            st += s0;
+            dl.t1[st * DEC_D + j] = sv.t1[st * DEC_D + j] > 0.f ? sum : 0.f;
+        });
+        matvec_cols_steps(tid, p.t1_w, DEC_D, DEC_D, dl.t1 + s0 * DEC_D, DEC_D, ns, s_sd, s_scr,
+                          [&](int st, int j, float sum) { dl.q[(s0 + st) * DEC_D + j] = sum; });
+    }
+}
+
+// grid MW_G, MW_T threads, dynamic LDS mw_bwd_lds_bytes(Tz); behind decoder_heads_bwd_kernel.
+__global__ __launch_bounds__(MW_T) void decoder_bwd_mw_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl, const float *memory,
+                                                             const float *dropmask, float *d_emb, float *d_v, float *d_hn, float *d_cn,
+                                                             unsigned long long *xbuf) {
+    extern __shared__ __attribute__((aligned(16))) float mwb_dyn[];
+    float *s_wih = mwb_dyn;                             // [64 gate rows: gate * 16 + unit][128]
+    float *s_whh = s_wih + 64 * DEC_D;                  // [64][128]
+    float *s_cmb = s_whh + 64 * DEC_D;                  // [48 columns: 16 embedding | 32 context][128 rows], pitch MW_CMBP
+    float *s_l2 = s_cmb + MW_XI * MW_CMBP;              // [16 rows][128]
+    float *s_mp = s_l2 + MW_U * DEC_D;                  // [Tz][16]
+    float *s_mem = s_mp + (size_t)dm.Tz * MW_U;         // [32 columns][Tz | 1]: transposed, the d attn phase runs a lane per state
+    __shared__ float s_dh[DEC_D], s_dha[DEC_D], s_dc[MW_U], s_dg[64], s_dmixed[DEC_D], s_dctx[MW_MC], s_ds[MW_TZ], s_dq[MW_U], s_part[256];
+    __shared__ float s_attn[MW_TZ];
+    __shared__ int s_errb;
+    __shared__ float s_dcfull[DEC_D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = blockIdx.x;
+    const int Tz = dm.Tz, ME = dm.ME, CW = DEC_D + ME, S = dm.S;
+    unsigned long long *x_a = xbuf, *x_b = xbuf + MWB_X_A, *x_c = x_b + MWB_X_B, *x_d = x_c + MWB_X_C;
+
+    for (int e = tid; e < 64 * DEC_D; e += MW_T) {
+        const int r = e >> 7, c = e & 127, grow = (r >> 4) * DEC_D + MW_U * j + (r & 15);
+        s_wih[e] = p.w_ih[(long)grow * DEC_D + c];
+        s_whh[e] = p.w_hh[(long)grow * DEC_D + c];
+    }
+    for (int e = tid; e < DEC_D * MW_XI; e += MW_T) {
+        const int row = e / MW_XI, c = e - row * MW_XI;
+        s_cmb[c * MW_CMBP + row] = p.cmb_w[(long)row * CW + (c < MW_U ? MW_U * j + c : DEC_D + MW_MC * j + c - MW_U)];
+    }
+    for (int e = tid; e < MW_U * DEC_D; e += MW_T) s_l2[e] = p.l2_w[(long)(MW_U * j) * DEC_D + e];
+    for (int e = tid; e < Tz * MW_U; e += MW_T) s_mp[e] = sv.mp[(long)(e >> 4) * DEC_D + MW_U * j + (e & 15)];
+    const int TzP = Tz | 1;
+    for (int e = tid; e < Tz * MW_MC; e += MW_T) s_mem[(e & 31) * TzP + (e >> 5)] = memory[(long)(e >> 5) * ME + MW_MC * j + (e & 31)];
+    if (tid < DEC_D) s_dh[tid] = 0.f;
+    if (tid < MW_U) s_dc[tid] = 0.f;
+    if (tid == 0) s_errb = 0;
+    const float vq = p.v[MW_U * j + (tid & 15)];       // d q phase: thread (d = tid & 15, state group tid >> 4)
+    float dv_acc = 0.f;
+    int err = 0;
+    __syncthreads();
+
+    // the cell backward's operands travel one step ahead (threads < 16: their unit's gates, cell states, the heads' share of dh)
+    float nx[7];
+    auto fetch_step = [&](int st) {
+        const int u = MW_U * j + tid;
+        const float *gs = sv.gates + (long)st * 4 * DEC_D;
+        nx[0] = gs[u];
+        nx[1] = gs[DEC_D + u];
+        nx[2] = gs[2 * DEC_D + u];
+        nx[3] = gs[3 * DEC_D + u];
+        nx[4] = sv.c[(st + 1) * DEC_D + u];
+        nx[5] = sv.c[st * DEC_D + u];
+        nx[6] = dl.q[st * DEC_D + u];
+    };
+    if (tid < MW_U) fetch_step(S - 1);
+    for (int s = S - 1; s >= 0; --s) {
+        const unsigned tag = (unsigned)(S - s);
+        const int par = (S - 1 - s) & 1;
+        // operands of the later phases, requested now: the length head's share of d mixed and the ReLU mask, the attention weights, q
+        const float park_mixed = tid < DEC_D ? dl.mixed[s * DEC_D + tid] : 0.f, sv_mixed = tid < DEC_D ? sv.mixed[s * DEC_D + tid] : 0.f;
+        const float attn_t = tid < Tz ? sv.attn[(long)s * Tz + tid] : 0.f;
+        if (tid < Tz) s_attn[tid] = attn_t;       // (read behind exchange B: several barriers away)
+        const float q_d = sv.q[s * DEC_D + MW_U * j + (tid & 15)];
+        const int tok = sv.toks[s];
+        // -- LSTM cell backward of this workgroup's units
+        if (tid < MW_U) {
+            const float gi = nx[0], gf = nx[1], gg = nx[2], go = nx[3], ct = nx[4], cp = nx[5];
+            const float dh = s_dh[MW_U * j + tid] + nx[6], th = tanh_f(ct);
+            const float dct = s_dc[tid] + dh * go * (1.f - th * th);
+            const float dpi = dct * gg * gi * (1.f - gi), dpf = dct * cp * gf * (1.f - gf);
+            const float dpg = dct * gi * (1.f - gg * gg), dpo = dh * th * go * (1.f - go);
+            s_dc[tid] = dct * gf;
+            s_dg[tid] = dpi;
+            s_dg[16 + tid] = dpf;
+            s_dg[32 + tid] = dpg;
+            s_dg[48 + tid] = dpo;
+            float *o = dl.gates + (long)s * 4 * DEC_D + MW_U * j + tid;
+            o[0] = dpi;
+            o[DEC_D] = dpf;
+            o[2 * DEC_D] = dpg;
+            o[3 * DEC_D] = dpo;
+        }
+        __syncthreads();
+        if (tid < MW_U && s > 0) fetch_step(s - 1);
+        // -- partial d mixed (threads 0..127) and partial dh_a (threads 128..255) over this workgroup's 64 gate rows
+        {
+            const float dgv = s_dg[lane];
+            const float *w = (tid < DEC_D ? s_wih : s_whh) + (tid & 127);
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) a += w[r * DEC_D] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dgv), r));
+            mw_pub(x_a + ((size_t)par * MW_G + j) * 256 + tid, a, tag);
+        }
+        // -- exchange A
+        {
+            const float v = mw_gather_sum(x_a + (size_t)par * MW_G * 256 + tid, 256, tag, &err);
+            if (tid < DEC_D) {
+                const float dm_ = sv_mixed > 0.f ? v + park_mixed : 0.f;
+                s_dmixed[tid] = dm_;
+                if (j == 0) dl.mixed[s * DEC_D + tid] = dm_;
+            } else {
+                s_dha[tid - DEC_D] = v;
+            }
+        }
+        __syncthreads();
+        // -- d cat over this workgroup's 48 columns of attn_combine: four lanes per column (32 rows each)
+        if (tid < 4 * MW_XI) {
+            const int col = tid >> 2, qd = tid & 3;
+            float a = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int rr = qd * 32 + ((r + 8 * qd) & 31);     // (the four lanes of a column start eight banks apart)
+                a += s_cmb[col * MW_CMBP + rr] * s_dmixed[rr];
+            }
+            a += dpp_f<DPP_XOR1>(a);
+            a += dpp_f<DPP_XOR2>(a);
+            if (qd == 0) {
+                if (col < MW_U) {   // embedding row gradient (this workgroup is the only writer of its 16 columns)
+                    float g = p.emb[(long)tok * DEC_D + MW_U * j + col] > 0.f ? a : 0.f;
+                    if (dropmask) g *= dropmask[s * DEC_D + MW_U * j + col];
+                    d_emb[(long)tok * DEC_D + MW_U * j + col] += g;
+                } else {
+                    s_dctx[col - MW_U] = a;
+                    dl.ctx[(long)s * ME + MW_MC * j + col - MW_U] = a;
+                }
+            }
+        }
+        __syncthreads();
+        // -- partial d attn[t] over this workgroup's 32 memory columns: a lane per state
+        {
+            const float dcv = s_dctx[lane & 31];
+            const int tc = min(tid, Tz - 1);
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < MW_MC; ++c) a += s_mem[c * TzP + tc] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcv), c));
+            if (tid < Tz) mw_pub(x_b + ((size_t)par * MW_G + j) * MW_TZ + tid, a, tag);
+        }
+        // -- exchange B, softmax backward (every wave reduces the dot product itself: same bits everywhere)
+        if (tid < Tz) s_ds[tid] = mw_gather_sum(x_b + (size_t)par * MW_G * MW_TZ + tid, MW_TZ, tag, &err);
+        __syncthreads();
+        {
+            float part = 0.f;
+            for (int t = lane; t < Tz; t += 64) part += s_attn[t] * s_ds[t];
+            const float dot = wave_sum(part);
+            __syncthreads();
+            if (tid < Tz) {
+                const float v = attn_t * (s_ds[tid] - dot);
+                s_ds[tid] = v;
+                if (j == 0) dl.score[(long)s * Tz + tid] = v;
+            }
+        }
+        __syncthreads();
+        // -- d q over this workgroup's 16 rows through the tanh (dV alongside): thread (d, state group of 16)
+        {
+            const int d = tid & 15, tg = tid >> 4;
+            float dq = 0.f;
+            for (int t = tg; t < Tz; t += 16) {
+                const float u = tanh_f(s_mp[t * MW_U + d] + q_d);
+                const float dsv = s_ds[t];
+                dv_acc += dsv * u;
+                dq += dsv * vq * (1.f - u * u);
+            }
+            s_part[tg * 16 + d] = dq;
+        }
+        __syncthreads();
+        if (tid < MW_U) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += s_part[g * 16 + tid];
+            s_dq[tid] = v;
+            dl.q[s * DEC_D + MW_U * j + tid] = v;
+        }
+        __syncthreads();
+        // -- partial dh_b = attention_l2[its 16 rows]^T d q                                              -> exchange C
+        if (tid < DEC_D) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < MW_U; ++r) a += s_l2[r * DEC_D + tid] * s_dq[r];
+            mw_pub(x_c + ((size_t)par * MW_G + j) * DEC_D + tid, a, tag);
+            s_dh[tid] = s_dha[tid] + mw_gather_sum(x_c + (size_t)par * MW_G * DEC_D + tid, DEC_D, tag, &err);
+        }
+        __syncthreads();
+    }
+    // ---- initial state: d h0 / d c0, d h_n / d c_n through hidden_out / cn_out (this workgroup: 32 of the 256 columns), dV
+    if (tid < MW_U) mw_pub(x_d + (size_t)j * MW_U + tid, s_dc[tid], (unsigned)S + 1u);
+    if (tid < DEC_D) s_dcfull[tid] = mw_get(x_d + (size_t)(tid >> 4) * MW_U + (tid & 15), (unsigned)S + 1u, &err);
+    __syncthreads();
+    if (j == 0 && tid < DEC_D) {
+        dl.h0[tid] = s_dh[tid];
+        dl.c0[tid] = s_dcfull[tid];
+    }
+    {
+        const int col = MW_MC * j + (tid & 31), ig = tid >> 5;     // 8 groups of 16 rows
+        float ah = 0.f, ac = 0.f;
+#pragma unroll 8
+        for (int i = ig * 16; i < ig * 16 + 16; ++i) {
+            ah += p.ho_w[(long)i * ME + col] * s_dh[i];
+            ac += p.co_w[(long)i * ME + col] * s_dcfull[i];
+        }
+        s_part[tid] = ah;
+        __syncthreads();
+        if (tid < MW_MC) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += s_part[g * 32 + tid];
+            d_hn[MW_MC * j + tid] = v;
+        }
+        __syncthreads();
+        s_part[tid] = ac;
+        __syncthreads();
+        if (tid < MW_MC) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += s_part[g * 32 + tid];
+            d_cn[MW_MC * j + tid] = v;
+        }
+        __syncthreads();
+    }
+    s_part[tid] = dv_acc;
+    if (err) s_errb = 1;
+    __syncthreads();
+    if (tid < MW_U) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += s_part[g * 16 + tid];
+        d_v[MW_U * j + tid] = s_errb ? NAN : v;      // a hand-over that gave up poisons this workgroup's slice of dV: the step is loudly invalid
+    }
+}

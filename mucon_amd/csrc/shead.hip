@@ -170,7 +170,7 @@ static DecLayout dec_layout(const mucon_decoder_cfg *c, float *base) {
     L.dl.len = take(S);
     L.dl.h0 = take(DEC_D);
     L.dl.c0 = take(DEC_D);
-    L.xbuf = reinterpret_cast<unsigned long long *>(take(2 * MW_X_WORDS));   // exchange granules of the eight-workgroup step kernel (8 bytes each)
+    L.xbuf = reinterpret_cast<unsigned long long *>(take(2 * 2 * MW_X_WORDS));   // exchange granules of the eight-workgroup step kernels (8 bytes each; the backward's set is the larger, + its failure word)
     L.floats = off;
     return L;
 }
@@ -200,7 +200,9 @@ static int dec_lds_attr() {
                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         DEC_MAX_DYN_LDS_BWD) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)mw_fwd_lds_bytes(MW_TZ)) != hipSuccess;
+                                        (int)mw_fwd_lds_bytes(MW_TZ)) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)mw_bwd_lds_bytes(MW_TZ)) != hipSuccess;
     return rc ? sfail(MUCON_E_HIP, "decoder: hipFuncSetAttribute failed") : MUCON_OK;
 }
 
@@ -271,8 +273,16 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     const DecLayout L = dec_layout(cfg, static_cast<float *>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int S = n_steps, Tz = cfg->Tz, ME = cfg->ME, NC = cfg->NC, CW = DEC_D + ME, LW = DEC_D + NC;
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), dec_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
-                       logp, d_logp, d_lengths, dropmask, d_memory, W(g.emb), W(g.v), d_hn, d_cn);
+    if (g_dec_mw && cfg->ME == DEC_MAXME && Tz <= MW_TZ) {
+        // the heads for all steps (one workgroup; clears the exchange granules), then the step loop on eight workgroups (decoder_mw.hpp)
+        hipLaunchKernelGGL(decoder_heads_bwd_kernel, dim3(1), dim3(DEC_THREADS), 0, s, dec_dims(cfg, S), p, L.sv, L.dl, logp, d_logp, d_lengths,
+                           W(g.emb), L.xbuf, (int)MWB_X_WORDS);
+        hipLaunchKernelGGL(decoder_bwd_mw_kernel, dim3(MW_G), dim3(MW_T), mw_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
+                           dropmask, W(g.emb), W(g.v), d_hn, d_cn, L.xbuf);
+    } else {
+        hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), dec_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
+                           logp, d_logp, d_lengths, dropmask, d_memory, W(g.emb), W(g.v), d_hn, d_cn);
+    }
     OuterBatch ob;
     int nj = 0, blocks = 0;
     auto job = [&](const float *A, int lda, int ra, const float *B, int ldb, int cb, int n, const float *out, const float *bias,
