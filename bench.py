@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--tapes", type=int, default=4, help="distinct tape batches rotated through the steps (4 x 256 MiB)")
     ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
     ap.add_argument("--frames", type=int, default=4096, help="frames per video")
+    ap.add_argument("--time-every", type=int, default=8, help="HIP-event timing of the two tape-streaming kernels on every n-th step "
+                    "(an event pair opens two ~6 us bubbles on the stream: timing every step taxes the step it reports)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-viterbi", action="store_true")
     return ap.parse_args()
@@ -515,6 +517,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
+    _lib.check(lib.mucon_profile_stride(max(1, args.time_every)), "profile_stride")
     _lib.check(lib.mucon_profile_begin(args.steps * args.repeats), "profile_begin")
     regions = []
     for r in range(args.repeats):        # each region: exactly --steps steps between two (barrier + synchronize) brackets
@@ -618,6 +621,7 @@ def main():
                          "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
                          "flops_per_launch": flops_wg, "launches_timed": int(cnt[1]),
+                         "timed_every_nth_step": max(1, args.time_every),
                          "issued_bf16_tflops": round((6 if split_tn else 1) * achieved, 1) if split_tn else None,
                          "frac_of_bf16_mfma_peak": round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4) if split_tn else None,
                          "hbm_frac": round(bytes_wg / (dom[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),

@@ -49,6 +49,9 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
  * summed milliseconds and the launch count per slot (arrays of 2). */
 int mucon_profile_begin(int32_t max_records);
 int mucon_profile_end(float *total_ms_host, int32_t *count_host);
+/* Time only every `every`-th launch of a slot (default 1: all).  A recorded event pair costs two ~6 us bubbles on the stream, which
+ * a bench that times EVERY launch adds to every step it reports; sampled launches are timed exactly as before. */
+int mucon_profile_stride(int32_t every);
 
 /* Sets one tuning / regression knob by its environment name (e.g. "MUCON_TN_SPLIT", "0"), with the parsing the
  * environment gets when the library is first used.  Affects later calls; workspaces sized before a change that

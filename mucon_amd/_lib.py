@@ -132,6 +132,7 @@ SYMBOLS = {
     "mucon_test_vit_host_phases": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "mucon_test_read_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
+    "mucon_profile_stride": (ctypes.c_int, [_i32]),
     "mucon_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_first_conv_split": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32,
                                                   ctypes.POINTER(ctypes.c_float), _vp]),

@@ -360,15 +360,20 @@ NtParams nt_base(const float *A, long a_bstride, int lda, int Ta, int Trows, int
 
 // --- optional in-library timing of the two tape-streaming kernels (bench.py's roofline leg) ---
 // slot 0: first_conv forward (NT core on the tape); slot 1: first_conv weight gradient (TN core).
+// An event record is not free: each one opens a ~6 us bubble on the stream (r4 timeline: the four records of a step were the step's
+// whole 24 us of gaps), so a run times every `stride`-th launch of a slot only (mucon_profile_stride; 1 = every launch).
 struct ProfState {
     bool on = false;
-    int cap = 0;
-    int n[2] = {0, 0};
+    int cap = 0, stride = 1;
+    int n[2] = {0, 0}, seen[2] = {0, 0};
+    bool armed[2] = {false, false};
     hipEvent_t *ev[2] = {nullptr, nullptr};  // pairs (start, stop)
 } g_prof;
 
 void prof_mark(int slot, bool stop, hipStream_t s) {
     if (!g_prof.on || g_prof.n[slot] >= g_prof.cap) return;
+    if (!stop) g_prof.armed[slot] = (g_prof.seen[slot]++ % g_prof.stride) == 0;
+    if (!g_prof.armed[slot]) return;
     (void)hipEventRecord(g_prof.ev[slot][2 * g_prof.n[slot] + (stop ? 1 : 0)], s);
     if (stop) ++g_prof.n[slot];
 }
@@ -1448,10 +1453,17 @@ int mucon_profile_begin(int32_t max_records) {
     for (int k = 0; k < 2; ++k) {
         g_prof.ev[k] = new hipEvent_t[2 * (size_t)max_records];
         for (int i = 0; i < 2 * max_records; ++i) HIPCHK(hipEventCreate(&g_prof.ev[k][i]));
-        g_prof.n[k] = 0;
+        g_prof.n[k] = g_prof.seen[k] = 0;
+        g_prof.armed[k] = false;
     }
     g_prof.cap = max_records;
     g_prof.on = true;
+    return MUCON_OK;
+}
+
+int mucon_profile_stride(int32_t every) {
+    if (every < 1) return fail(MUCON_E_ARG, "profile stride %d", every);
+    g_prof.stride = every;
     return MUCON_OK;
 }
 
