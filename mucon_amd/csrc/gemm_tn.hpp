@@ -337,6 +337,15 @@ __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch 
         col = e - row * J.ncols;
         const float *p = J.slabs + (long)row * J.ld + J.coff + col;
         int i = g;
+        if (G >= 16) {   // few deep jobs (the y-head's 256 slabs): sixteen loads per lane in flight -- the pass is its chain of round trips
+            for (; i + 15 * G < J.nslabs; i += 16 * G) {
+                f32x4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * J.slab_stride);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+        }
         for (; i + 3 * G < J.nslabs; i += 4 * G) {
             f32x4 v[4];
 #pragma unroll
