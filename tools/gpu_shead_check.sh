@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r04_c8
+OUT=$R/gpurun_out/shead_check
 rm -rf $OUT && mkdir -p $OUT
 cd $R
 timeout 900 python3 -m pytest tests/test_gpu_shead.py tests/test_gpu_model.py tests/test_gpu_trajectory.py tests/test_gpu_fused_step.py -m gpu -x -q > $OUT/tests.log 2>&1
