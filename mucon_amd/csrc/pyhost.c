@@ -37,7 +37,7 @@ static size_t up8(size_t n) { return (n + 7) & ~(size_t)7; }
  *   tables       list        C-contiguous float64 buffers [J, N]
  *   forces       None, or list of None | (n, j)
  * (the arrays' memory is only pointed at: the caller keeps the lists alive), calls mucon_viterbi_decode_host (its address in
- * `decode_fn`: this library does not link against libmucon_hip.so) with the GIL released, and returns
+ * `decode_fn`: this library does not link against libmucon_hip.so), and returns
  *   (rc, bad, sum_T, sum_N, out)
  * out = a bytearray [score f64 nv][n_seg i32 nv][status i32 nv][seg_len i32 sum_N, padded to 8 bytes][label offsets i64 nv + 1]
  * [segment offsets i64 nv + 1][labels, when label_format != NONE and labels_addr == 0]; labels_addr != 0: the caller's
@@ -148,12 +148,11 @@ PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *tra
     lo[nv] = a;
     so[nv] = c;
     void *labels = lab_elem ? (labels_addr ? (void *)(uintptr_t)labels_addr : (void *)(b + o_lab)) : NULL;
-    int rc;
-    Py_BEGIN_ALLOW_THREADS
-    rc = ((decode_host_fn)(uintptr_t)decode_fn)((int32_t)nv, rec, (int32_t)C, (int32_t)fs, (int32_t)max_len, (double *)b,
-                                                (int32_t *)(b + o_nseg), (int32_t *)(b + o_stat), labels, (int32_t)label_format,
-                                                (int32_t *)(b + o_seg), (void *)(uintptr_t)stream);
-    Py_END_ALLOW_THREADS
+    /* (the GIL stays held: the library keeps per-device staging state and this file a record scratch, both written for ONE host thread
+     * per process -- include/mucon_hip.h; a second Python thread entering here during a 0.05 - 0.9 ms decode would share them) */
+    const int rc = ((decode_host_fn)(uintptr_t)decode_fn)((int32_t)nv, rec, (int32_t)C, (int32_t)fs, (int32_t)max_len, (double *)b,
+                                                          (int32_t *)(b + o_nseg), (int32_t *)(b + o_stat), labels, (int32_t)label_format,
+                                                          (int32_t *)(b + o_seg), (void *)(uintptr_t)stream);
     PyObject *res = Py_BuildValue("inLLO", rc, (Py_ssize_t)-1, sum_T, sum_N, out);
     Py_DECREF(out);
     return res;

@@ -195,15 +195,21 @@ static int dec_params(DecParams &p, const mucon_decoder_params *q, const char *w
 // the step kernels keep attention_l2's weight (and the forward, when it fits, the attention projection) in dynamic LDS: more
 // than the 64 KB a kernel gets by default
 static int dec_lds_attr() {
-    static int rc = hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DEC_MAX_DYN_LDS) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DEC_MAX_DYN_LDS_BWD) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)mw_fwd_lds_bytes(MW_TZ)) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)mw_bwd_lds_bytes(MW_TZ)) != hipSuccess;
-    return rc ? sfail(MUCON_E_HIP, "decoder: hipFuncSetAttribute failed") : MUCON_OK;
+    static int done_dev = -1;      // (the > 64 KB opt-ins are per device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sfail(MUCON_E_HIP, "decoder: hipGetDevice failed");
+    if (done_dev == dev) return MUCON_OK;
+    const bool bad = hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         DEC_MAX_DYN_LDS) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         DEC_MAX_DYN_LDS_BWD) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)mw_fwd_lds_bytes(MW_TZ)) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_bwd_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)mw_bwd_lds_bytes(MW_TZ)) != hipSuccess;
+    if (bad) return sfail(MUCON_E_HIP, "decoder: hipFuncSetAttribute failed");
+    done_dev = dev;
+    return MUCON_OK;
 }
 
 static DecDims dec_dims(const mucon_decoder_cfg *c, int S) {

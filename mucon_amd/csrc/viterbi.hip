@@ -1298,7 +1298,8 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
                       const int32_t *transcripts, const double *length_tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
                       double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int max_K, bool cols_ok,
                       volatile int32_t *done_flag, int32_t done_value, const mucon_viterbi_job *host_jobs,
-                      unsigned long long *progress_words = nullptr) {
+                      unsigned long long *progress_words = nullptr, hipEvent_t tables_ready = nullptr) {
+    // tables_ready: an event the DP launch (not the frame-score launch, which reads neither transcripts nor length tables) has to wait for
     // host_jobs: the job table where the host can read it (the one-launch kernel takes its job as a kernel argument), or nullptr;
     // max_K: the longest video's column count when the caller knows it (LDS sizing of the latency paths), else 0
     if (fs <= 0 || max_len < fs || C <= 0 || C > 64 || max_N <= 0) {
@@ -1447,6 +1448,10 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
         hipLaunchKernelGGL(viterbi_framescore_kernel, dim3(n_videos), dim3(FS_THREADS), fs_smem, s, jobs,
                            static_cast<char *>(workspace), C, fs);
     }
+    if (tables_ready && hipStreamWaitEvent(s, tables_ready, 0) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "viterbi: hipStreamWaitEvent failed");
+        VIT_FAIL(MUCON_E_HIP);
+    }
     // the DP: up to 66 length slots run in the registers of one wave (<= 16 states), four (<= 64) or eight (<= 128) ...
 #define VL_LAUNCH(G, JG, NW)                                                                                          \
     hipLaunchKernelGGL((viterbi_dp_lanes_kernel<G, JG, NW>), dim3(n_videos), dim3(NW == 1 ? VL_THREADS : 64 * NW), bp_lds, s, jobs, \
@@ -1528,6 +1533,10 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
 namespace {
 struct VitHostState {
     char *pin_in = nullptr, *pin_out = nullptr, *ws = nullptr;
+    char *dev_in = nullptr;                   // device copy of the pinned input buffer's tables / transcripts (throughput calls)
+    size_t dev_in_cap = 0;
+    hipStream_t side = nullptr;               // ... made on this stream, under the frame-score launch
+    hipEvent_t tables_ready = nullptr;
     unsigned long long *progress = nullptr;   // the pair kernel's "columns done" words: kVitLatencyVideos x 64 bytes, zeroed once, nothing else
     size_t in_cap = 0, out_cap = 0, ws_cap = 0;
     int32_t seq = 0;
@@ -1655,18 +1664,40 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
         snprintf(g_err, sizeof(g_err), "viterbi: hipHostGetDevicePointer failed");
         VIT_FAIL(MUCON_E_HIP);
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
     volatile int32_t *flag_h = reinterpret_cast<volatile int32_t *>(st.pin_out);
     const int32_t seq = ++st.seq == 0 ? ++st.seq : st.seq;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Throughput calls with large tables: every decoding workgroup reads its transcript and its J x N length scores (33 KB at N = 64) when
+    // it starts -- from PINNED HOST memory, i.e. over PCIe, all workgroups at once: 9 MB at 256 videos of config 5, ~0.2 ms in front of
+    // the first column (r4: why the DP launch took 530 us at 256 in flight and 315 us at 9; profiles/r04_viterbi_inflight_sweep.txt).
+    // They are copied to the device on a side stream instead, UNDER the frame-score launch, which needs neither; the DP launch waits for
+    // the copy's event.  (The job table stays pinned: 64 bytes per workgroup.)
+    const char *tab_base = din;
+    hipEvent_t wait_ev = nullptr;
+    if (n_videos > kVitLatencyVideos && in_bytes - o_tab >= ((size_t)1 << 20)) {
+        if (!st.side && (hipStreamCreateWithFlags(&st.side, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&st.tables_ready, hipEventDisableTiming) != hipSuccess)) {
+            snprintf(g_err, sizeof(g_err), "viterbi: side stream / event creation failed");
+            VIT_FAIL(MUCON_E_HIP);
+        }
+        if (vh_grow(&st.dev_in, &st.dev_in_cap, in_bytes, false) != MUCON_OK ||
+            hipMemcpyAsync(st.dev_in + o_tab, st.pin_in + o_tab, in_bytes - o_tab, hipMemcpyHostToDevice, st.side) != hipSuccess ||
+            hipEventRecord(st.tables_ready, st.side) != hipSuccess) {
+            snprintf(g_err, sizeof(g_err), "viterbi: table upload failed");
+            VIT_FAIL(MUCON_E_HIP);
+        }
+        tab_base = st.dev_in;
+        wait_ev = st.tables_ready;
+    }
     const double t_staged = vh_now_us();
     // latency path: a handful of short videos in ONE launch each; throughput path: two launches whose second packs many per CU
     const bool want_fused = n_videos == 1;
     const int rc = vit_launch(n_videos, reinterpret_cast<const mucon_viterbi_job *>(din), C, fs, max_len, max_N,
-                              reinterpret_cast<const int32_t *>(din + o_tr), reinterpret_cast<const double *>(din + o_tab),
+                              reinterpret_cast<const int32_t *>(tab_base + o_tr), reinterpret_cast<const double *>(tab_base + o_tab),
                               VitLabels{labels_dev ? labels_dev : static_cast<void *>(dout + o_lab), label_format}, reinterpret_cast<int32_t *>(dout + o_seg),
                               reinterpret_cast<int32_t *>(dout + o_nseg), reinterpret_cast<double *>(dout + o_score),
                               reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
-                              reinterpret_cast<volatile int32_t *>(dout), seq, jobs, st.progress);
+                              reinterpret_cast<volatile int32_t *>(dout), seq, jobs, st.progress, wait_ev);
     if (rc < 0) return rc;
     const double t_launched = vh_now_us();
     bool done = false;
