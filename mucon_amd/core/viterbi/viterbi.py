@@ -107,11 +107,19 @@ class Viterbi(object):
         if not isinstance(self.grammar, SingleTranscriptGrammar):
             raise NotImplementedError("the HIP decoder implements SingleTranscriptGrammar only (the one the "
                                       "reference decodes with, evaluators.py:148-150)")
-        if np.isfinite(self.max_hypotheses):
-            raise NotImplementedError("pruning (max_hypotheses) is not implemented; the reference never enables it")
         fs = self.frame_sampling
         tr = np.asarray(self.grammar.transcript, dtype=np.int32)
         N = len(tr)
+        if np.isfinite(self.max_hypotheses):
+            # prune() (viterbi.py:74-79) drops the lowest-scoring hypotheses once there are more than max_hypotheses of them.  A single
+            # transcript never has more than N * J hypotheses alive (J = max_length // frame_sampling length slots per transcript state):
+            # from that bound on the pruning never triggers and the decode is the reference's, bit for bit.  Below it the reference's
+            # result depends on the pruning (it may drop the best path); that is not implemented.
+            max_len = self.length_model.max_length()
+            bound = N * (int(max_len) // fs) if np.isfinite(max_len) else np.inf
+            if self.max_hypotheses < bound:
+                raise NotImplementedError(f"max_hypotheses = {self.max_hypotheses} could prune this transcript ({N} states x {int(max_len) // fs} length slots = "
+                                          f"{bound} hypotheses at most); pruning is not implemented -- the reference never enables it (evaluators.py:80)")
         if N == 0:
             raise NoHypothesisError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
         if T < fs:

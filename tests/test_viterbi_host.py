@@ -107,3 +107,21 @@ def test_wrapper_raises_like_reference():
         v.length_model = PoissonModel(mu)
     with pytest.raises(AttributeError):
         v._prepare(900)
+
+
+def test_max_hypotheses_that_can_never_prune_is_accepted():
+    """prune() (reference viterbi.py:74-79) only acts when more than max_hypotheses hypotheses are alive; a single transcript of N
+    states has at most N * (max_length // frame_sampling) of them, so from that bound on the decode is the unpruned one (checked
+    against the reference itself when the bound was derived: identical results for max_hypotheses = inf and = N * J).  Below the
+    bound the reference's result depends on its pruning, which is not implemented: a loud error, not a different answer."""
+    from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
+    tr = [3, 7, 3, 1]
+    mu = np.full(12, 200.0)
+    for mh, ok in ((np.inf, True), (4 * 66, True), (10 ** 6, True), (4 * 66 - 1, False), (50, False)):
+        v = Viterbi(SingleTranscriptGrammar(tr, 12), PoissonModel(mu), frame_sampling=30, max_hypotheses=mh)
+        if ok:
+            t, P, force = v._prepare(900)
+            assert P.shape == (66, 4) and force is None
+        else:
+            with pytest.raises(NotImplementedError, match="max_hypotheses"):
+                v._prepare(900)
