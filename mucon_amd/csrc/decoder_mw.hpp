@@ -18,8 +18,8 @@
 // "8-B agent atomics both sides"); two buffers alternate by step parity (a workgroup can be at most one exchange ahead of the
 // slowest one).  Partial sums are added in workgroup order by every consumer, so all eight hold the same bits and results do not
 // depend on timing.  Correctness needs the eight workgroups to be co-resident (8 << 256 CUs) and nothing about their placement.
-// A poll that does not complete within MW_SPIN_LIMIT re-reads gives up, marks the launch failed (*nsteps_out = -1) and lets the
-// kernel run to its end: a broken hand-over can not hang the GPU.
+// A poll that does not complete within MW_SPIN_LIMIT re-reads gives up, marks the launch failed (*nsteps_out = -1; the heads kernel then
+// fills the outputs with NaN, the backward poisons dV) and lets the kernel run to its end: a broken hand-over can not hang the GPU.
 // The transcript / length heads do not feed the recurrence (teacher forcing) or only through the arg-max token (greedy decoding):
 // they run after the loop for all steps at once in decoder_heads_kernel; with greedy decoding the loop computes t1 / logits /
 // arg-max itself, every workgroup the same bits.
@@ -361,7 +361,13 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_kernel(DecDims dm, 
                                                                     const int *nsteps, const int have_logits) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = min(*nsteps, dm.S), NC = dm.NC, LW = DEC_D + NC;
-    if (S <= 0) return;
+    if (S < 0) {   // a hand-over of the step kernel gave up (n_steps = -1): every output of the call is poisoned, so that a caller which never
+                   // reads the step count (teacher-forced training) cannot mistake it for a result
+        for (int e = tid; e < dm.S * NC; e += DEC_THREADS) logp_out[e] = NAN;
+        for (int e = tid; e < dm.S; e += DEC_THREADS) len_out[e] = NAN;
+        return;
+    }
+    if (S == 0) return;
     if (!have_logits) {
         matvec_rows_steps<1, 8, 2>(tid, p.t1_w, p.t1_b, DEC_D, DEC_D, sv.h + DEC_D, DEC_D, S, sv.t1, DEC_D);
         __syncthreads();

@@ -193,3 +193,52 @@ def test_eight_workgroup_step_kernel_against_the_one_workgroup_kernel(Tz, steps,
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
     for k in a[3]:
         assert torch.equal(a[3][k], a2[3][k]), k
+
+
+def test_eight_workgroup_kernels_under_concurrent_load():
+    """The exchanges of the eight-workgroup decoder kernels must not depend on timing or placement: eight decodes enqueued round-robin on
+    four streams while a fifth stream keeps every CU busy with large matmuls (uneven load: workgroups of one decode start at different
+    times, on whatever CUs are free) give, bitwise, what each decode gives alone on an idle GPU -- outputs and parameter gradients."""
+    from mucon_amd import ops
+    c = shead_case(GOLD, "a")
+    P = {k: v.to(DEV) for k, v in shead_params(GOLD, "a").items()}
+    dec = [P[n] for n in ops.DECODER_STATE_NAMES]
+    torch.manual_seed(11)
+    jobs = []
+    for i in range(8):
+        Tz, steps = (125, 7) if i % 2 == 0 else (64 + 8 * i, 5 + i)
+        tf = torch.randint(0, 48, (steps,), device=DEV)
+        tf[0] = 49
+        jobs.append(dict(memory=torch.randn(Tz, 256, device=DEV), hn=torch.randn(256, device=DEV), cn=torch.randn(256, device=DEV), tf=tf,
+                         steps=steps, R1=torch.randn(steps, 49, device=DEV), r2=torch.randn(steps, device=DEV)))
+
+    def run(j):
+        (logp, lens), ctx = ops.run_forward(ops._DecoderFn, j["memory"], j["hn"], j["cn"], j["tf"], None, (j["steps"], True, False, c["eos"]), *dec)
+        grads = ops.run_backward(ops._DecoderFn, ctx, j["R1"], j["r2"])
+        return [logp, lens] + [g for g in grads if torch.is_tensor(g)]
+
+    alone = []
+    for j in jobs:
+        alone.append([t.clone() for t in run(j)])
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    load = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    busy = []
+    with torch.cuda.stream(load):
+        for _ in range(12):
+            busy.append(a @ a)
+    for rep in range(3):
+        res = [None] * len(jobs)
+        for i, j in enumerate(jobs):
+            with torch.cuda.stream(streams[i % 4]):
+                res[i] = run(j)
+        with torch.cuda.stream(load):
+            for _ in range(6):
+                busy.append(a @ a)
+        torch.cuda.synchronize()
+        for i, (got, want) in enumerate(zip(res, alone)):
+            assert len(got) == len(want)
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert torch.equal(g, w), (rep, i, k)
