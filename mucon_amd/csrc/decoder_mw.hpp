@@ -355,44 +355,51 @@ __global__ __launch_bounds__(MW_T) void decoder_fwd_mw_kernel(DecDims dm, DecPar
     }
 }
 
-// The heads for all steps at once, one workgroup of DEC_THREADS (decoder_fwd_kernel's code behind its loop, as a launch of its own):
-// have_logits: t1 and the raw logits were computed inside the loop (greedy decoding); *nsteps = the steps that ran (<= 0: nothing).
+// The heads of every step that ran, ONE WORKGROUP PER STEP (grid = max steps, DEC_THREADS threads; decoder_fwd_kernel's per-step head code):
+// transcript MLP -> log-softmax, length MLP.  The steps are independent of each other here, so they run side by side instead of as a walk
+// over the steps inside one workgroup (13.5 -> ~6.5 us at 7 steps).  have_logits: t1 and the raw logits were computed inside the loop
+// (greedy decoding); *nsteps = the steps that ran (-1: a hand-over gave up -- every output is poisoned with NaN).
 __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_kernel(DecDims dm, DecParams p, DecSaved sv, float *logp_out, float *len_out,
                                                                     const int *nsteps, const int have_logits) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_h[DEC_D], s_t1[DEC_D], s_logits[DEC_MAXNC], s_lencat[DEC_D + DEC_MAXNC], s_l1[DEC_NL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, st = blockIdx.x;
     const int S = min(*nsteps, dm.S), NC = dm.NC, LW = DEC_D + NC;
-    if (S < 0) {   // a hand-over of the step kernel gave up (n_steps = -1): every output of the call is poisoned, so that a caller which never
-                   // reads the step count (teacher-forced training) cannot mistake it for a result
-        for (int e = tid; e < dm.S * NC; e += DEC_THREADS) logp_out[e] = NAN;
-        for (int e = tid; e < dm.S; e += DEC_THREADS) len_out[e] = NAN;
+    if (S < 0) {   // (a caller that never reads the step count -- teacher-forced training -- cannot mistake this for a result)
+        for (int e = tid; e < NC; e += DEC_THREADS) logp_out[(long)st * NC + e] = NAN;
+        if (tid == 0) len_out[st] = NAN;
         return;
     }
-    if (S == 0) return;
+    if (st >= S) return;
     if (!have_logits) {
-        matvec_rows_steps<1, 8, 2>(tid, p.t1_w, p.t1_b, DEC_D, DEC_D, sv.h + DEC_D, DEC_D, S, sv.t1, DEC_D);
+        if (tid < DEC_D) s_h[tid] = sv.h[(st + 1) * DEC_D + tid];
         __syncthreads();
-        matvec_rows_steps<0, 4, 2>(tid, p.t2_w, p.t2_b, NC, DEC_D, sv.t1, DEC_D, S, logp_out, NC);   // the logits, for now
+        matvec_rows<1, 8, DEC_D, false>(tid, p.t1_w, p.t1_b, DEC_D, DEC_D, s_h, s_t1);
         __syncthreads();
-    }
-    for (int e = tid; e < S * LW; e += DEC_THREADS) {
-        const int st = e / LW, k = e - st * LW;
-        sv.lencat[e] = k < DEC_D ? sv.mixed[st * DEC_D + k] : fmaxf(logp_out[(long)st * NC + k - DEC_D], 0.f);
+        if (tid < DEC_D) sv.t1[st * DEC_D + tid] = s_t1[tid];
+        matvec_rows<0, 4, DEC_D, false>(tid, p.t2_w, p.t2_b, NC, DEC_D, s_t1, s_logits);
+    } else if (tid < NC) {
+        s_logits[tid] = logp_out[(long)st * NC + tid];
     }
     __syncthreads();
-    matvec_rows_steps<1, 4, 4>(tid, p.n1_w, p.n1_b, DEC_NL, LW, sv.lencat, LW, S, sv.l1, DEC_NL);
-    for (int st = wave; st < S; st += DEC_WAVES) {   // log-softmax in place
-        float *row = logp_out + (long)st * NC;
-        const float x0 = lane < NC ? row[lane] : -INFINITY, x1 = lane + 64 < NC ? row[lane + 64] : -INFINITY;
+    if (tid < LW) {
+        const float v = tid < DEC_D ? sv.mixed[st * DEC_D + tid] : fmaxf(s_logits[tid - DEC_D], 0.f);
+        s_lencat[tid] = v;
+        sv.lencat[(long)st * LW + tid] = v;
+    }
+    __syncthreads();
+    matvec_rows<1, 4, 0, false>(tid, p.n1_w, p.n1_b, DEC_NL, LW, s_lencat, s_l1);
+    __syncthreads();
+    if (wave == 0) {
+        sv.l1[st * DEC_NL + lane] = s_l1[lane];
+        const float a = wave_sum(p.n2_w[lane] * s_l1[lane]);
+        if (lane == 0) len_out[st] = a + p.n2_b[0];
+    } else if (wave == 1) {
+        const float x0 = lane < NC ? s_logits[lane] : -INFINITY, x1 = lane + 64 < NC ? s_logits[lane + 64] : -INFINITY;
         const float mx = wave_max(fmaxf(x0, x1));
         const float se = wave_sum((lane < NC ? expf(x0 - mx) : 0.f) + (lane + 64 < NC ? expf(x1 - mx) : 0.f));
         const float lse = mx + logf(se);
-        if (lane < NC) row[lane] = x0 - lse;
-        if (lane + 64 < NC) row[lane + 64] = x1 - lse;
-    }
-    __syncthreads();
-    for (int st = wave; st < S; st += DEC_WAVES) {
-        const float a = wave_sum(p.n2_w[lane] * sv.l1[st * DEC_NL + lane]);
-        if (lane == 0) len_out[st] = a + p.n2_b[0];
+        if (lane < NC) logp_out[(long)st * NC + lane] = x0 - lse;
+        if (lane + 64 < NC) logp_out[(long)st * NC + lane + 64] = x1 - lse;
     }
 }
 
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_kernel(DecDims dm, 
 //   softmax backward (every workgroup, same bits) -> d score -> d q over its 16 rows (through the tanh; dV alongside)
 //   PARTIAL dh_b = attention_l2[its 16 rows]^T d q                                                      -> exchange C (128 values)
 //   dh(s - 1) = dh_a + dh_b (+ the transcript head's share, added by the next step's cell backward)
-// The heads' backward (all steps at once) runs in front as a launch of its own (decoder_heads_bwd_kernel: decoder_bwd_kernel's code in
+// The heads' backward runs in front as a launch of its own, a workgroup per step (decoder_heads_bwd_kernel: what decoder_bwd_kernel does in
 // front of its loop); it also clears the exchange granules.  Every per-step delta the weight-gradient kernels read (dl.gates, dl.mixed,
 // dl.ctx, dl.score, dl.q) is written exactly as decoder_bwd_kernel writes it.
 constexpr size_t MWB_X_A = 2 * MW_G * 256, MWB_X_B = 2 * MW_G * MW_TZ, MWB_X_C = 2 * MW_G * DEC_D, MWB_X_D = MW_G * MW_U;
@@ -413,50 +420,52 @@ constexpr size_t MWB_X_WORDS = MWB_X_A + MWB_X_B + MWB_X_C + MWB_X_D;
 static_assert(MWB_X_WORDS <= 2 * MW_X_WORDS, "the backward's granules fit the buffer dec_layout reserves (twice the forward's)");
 static inline size_t mw_bwd_lds_bytes(int Tz) { return sizeof(float) * ((size_t)2 * 64 * DEC_D + MW_XI * MW_CMBP + MW_U * DEC_D + (size_t)Tz * MW_U + (size_t)MW_MC * (Tz | 1)); }
 
-// decoder_bwd_kernel's prologue as a kernel: zeroes d_emb, back-propagates the heads for all steps; parks what reaches the recurrence in
-// dl.q[s] (d dec_out from the transcript MLP) and dl.mixed[s] (d mixed from the length MLP).  One workgroup of DEC_THREADS.
+// decoder_bwd_kernel's prologue as a kernel, ONE WORKGROUP PER STEP (grid = steps, DEC_THREADS threads): back-propagates the heads of its step
+// and parks what reaches the recurrence in dl.q[s] (d dec_out from the transcript MLP) and dl.mixed[s] (d mixed from the length MLP); the
+// workgroups together zero d_emb and the exchange granules of the step kernel behind them.
 __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_bwd_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl, const float *logp,
                                                                         const float *d_logp, const float *d_len, float *d_emb,
                                                                         unsigned long long *zero, int zero_words) {
-    __shared__ __attribute__((aligned(16))) float s_scr[DEC_SCR];
-    __shared__ float s_sd[DEC_SB * DEC_D];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float s_scr[DEC_THREADS];
+    __shared__ float s_dlog[DEC_MAXNC], s_dl1[DEC_NL], s_out[DEC_D + DEC_MAXNC], s_dt1[DEC_D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, st = blockIdx.x;
     const int NC = dm.NC, LW = DEC_D + NC;
-    for (int e = tid; e < zero_words; e += DEC_THREADS) zero[e] = 0ull;
-    for (long e = tid; e < (long)dm.n_emb * DEC_D; e += DEC_THREADS) d_emb[e] = 0.f;
-    __syncthreads();
-    for (int s0 = 0; s0 < dm.S; s0 += DEC_SB) {
-        const int ns = min(DEC_SB, dm.S - s0);
-        if (wave < DEC_SB) {            // log-softmax backward
-            const int st = s0 + wave;
-            if (wave < ns) {
-                const float g0 = (d_logp && lane < NC) ? d_logp[(long)st * NC + lane] : 0.f;
-                const float g1 = (d_logp && lane + 64 < NC) ? d_logp[(long)st * NC + lane + 64] : 0.f;
-                const float tot = wave_sum(g0 + g1);
-                if (lane < NC) dl.logits[(long)st * NC + lane] = g0 - expf(logp[(long)st * NC + lane]) * tot;
-                if (lane + 64 < NC) dl.logits[(long)st * NC + lane + 64] = g1 - expf(logp[(long)st * NC + lane + 64]) * tot;
-            }
-        } else {                        // length MLP output layer backward
-            const int st = s0 + wave - DEC_SB;
-            if (wave - DEC_SB < ns) {
-                const float dlen = d_len ? d_len[st] : 0.f;
-                dl.l1[st * DEC_NL + lane] = sv.l1[st * DEC_NL + lane] > 0.f ? dlen * p.n2_w[lane] : 0.f;
-                if (lane == 0) dl.len[st] = dlen;
-            }
-        }
-        matvec_cols_steps(tid, p.n1_w, DEC_NL, LW, dl.l1 + s0 * DEC_NL, DEC_NL, ns, s_sd, s_scr, [&](int st, int j, float sum) {
-            st += s0;
-            const float v = sv.lencat[(long)st * LW + j] > 0.f ? sum : 0.f;
-            if (j < DEC_D) dl.mixed[st * DEC_D + j] = v;
-            else dl.logits[(long)st * NC + j - DEC_D] += v;
-        });
-        matvec_cols_steps(tid, p.t2_w, NC, DEC_D, dl.logits + (long)s0 * NC, NC, ns, s_sd, s_scr, [&](int st, int j, float sum) {
-            st += s0;
-            dl.t1[st * DEC_D + j] = sv.t1[st * DEC_D + j] > 0.f ? sum : 0.f;
-        });
-        matvec_cols_steps(tid, p.t1_w, DEC_D, DEC_D, dl.t1 + s0 * DEC_D, DEC_D, ns, s_sd, s_scr,
-                          [&](int st, int j, float sum) { dl.q[(s0 + st) * DEC_D + j] = sum; });
+    for (int e = st * DEC_THREADS + tid; e < zero_words; e += gridDim.x * DEC_THREADS) zero[e] = 0ull;
+    for (long e = (long)st * DEC_THREADS + tid; e < (long)dm.n_emb * DEC_D; e += (long)gridDim.x * DEC_THREADS) d_emb[e] = 0.f;
+    if (wave == 0) {            // log-softmax backward
+        const float g0 = (d_logp && lane < NC) ? d_logp[(long)st * NC + lane] : 0.f;
+        const float g1 = (d_logp && lane + 64 < NC) ? d_logp[(long)st * NC + lane + 64] : 0.f;
+        const float tot = wave_sum(g0 + g1);
+        if (lane < NC) s_dlog[lane] = g0 - expf(logp[(long)st * NC + lane]) * tot;
+        if (lane + 64 < NC) s_dlog[lane + 64] = g1 - expf(logp[(long)st * NC + lane + 64]) * tot;
+    } else if (wave == 1) {     // length MLP output layer backward
+        const float dlen = d_len ? d_len[st] : 0.f;
+        const float v = sv.l1[st * DEC_NL + lane] > 0.f ? dlen * p.n2_w[lane] : 0.f;
+        s_dl1[lane] = v;
+        dl.l1[st * DEC_NL + lane] = v;
+        if (lane == 0) dl.len[st] = dlen;
     }
+    __syncthreads();
+    matvec_cols<false>(tid, p.n1_w, DEC_NL, LW, s_dl1, s_out, s_scr);
+    __syncthreads();
+    if (tid < LW) {
+        const float v = sv.lencat[(long)st * LW + tid] > 0.f ? s_out[tid] : 0.f;
+        if (tid < DEC_D) dl.mixed[st * DEC_D + tid] = v;
+        else s_dlog[tid - DEC_D] += v;
+    }
+    __syncthreads();
+    if (tid < NC) dl.logits[(long)st * NC + tid] = s_dlog[tid];
+    matvec_cols<false>(tid, p.t2_w, NC, DEC_D, s_dlog, s_out, s_scr);       // transcript MLP backward -> d dec_out
+    __syncthreads();
+    if (tid < DEC_D) {
+        const float v = sv.t1[st * DEC_D + tid] > 0.f ? s_out[tid] : 0.f;
+        s_dt1[tid] = v;
+        dl.t1[st * DEC_D + tid] = v;
+    }
+    __syncthreads();
+    matvec_cols<false>(tid, p.t1_w, DEC_D, DEC_D, s_dt1, s_out, s_scr);
+    __syncthreads();
+    if (tid < DEC_D) dl.q[st * DEC_D + tid] = s_out[tid];
 }
 
 // grid MW_G, MW_T threads, dynamic LDS mw_bwd_lds_bytes(Tz); behind decoder_heads_bwd_kernel.

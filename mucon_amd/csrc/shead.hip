@@ -249,7 +249,7 @@ extern "C" int mucon_decoder_fwd(const mucon_decoder_cfg *cfg, const mucon_decod
         hipLaunchKernelGGL(decoder_fwd_mw_kernel, dim3(MW_G), dim3(MW_T), mw_fwd_lds_bytes(cfg->Tz), s, dm, p, L.sv, memory, hn, cn,
                            reinterpret_cast<const long *>(tf_input), dropmask, logp, L.xbuf, n_steps);
         const int greedy = !(cfg->teacher_forcing && !cfg->stop_on_eos);
-        hipLaunchKernelGGL(decoder_heads_kernel, dim3(1), dim3(DEC_THREADS), 0, s, dm, p, L.sv, logp, lengths, n_steps, greedy);
+        hipLaunchKernelGGL(decoder_heads_kernel, dim3(cfg->max_steps), dim3(DEC_THREADS), 0, s, dm, p, L.sv, logp, lengths, n_steps, greedy);
         SHIPCHK(hipGetLastError());
         return MUCON_OK;
     }
@@ -281,7 +281,7 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     const int S = n_steps, Tz = cfg->Tz, ME = cfg->ME, NC = cfg->NC, CW = DEC_D + ME, LW = DEC_D + NC;
     if (g_dec_mw && cfg->ME == DEC_MAXME && Tz <= MW_TZ) {
         // the heads for all steps (one workgroup; clears the exchange granules), then the step loop on eight workgroups (decoder_mw.hpp)
-        hipLaunchKernelGGL(decoder_heads_bwd_kernel, dim3(1), dim3(DEC_THREADS), 0, s, dec_dims(cfg, S), p, L.sv, L.dl, logp, d_logp, d_lengths,
+        hipLaunchKernelGGL(decoder_heads_bwd_kernel, dim3(S), dim3(DEC_THREADS), 0, s, dec_dims(cfg, S), p, L.sv, L.dl, logp, d_logp, d_lengths,
                            W(g.emb), L.xbuf, (int)MWB_X_WORDS);
         hipLaunchKernelGGL(decoder_bwd_mw_kernel, dim3(MW_G), dim3(MW_T), mw_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
                            dropmask, W(g.emb), W(g.v), d_hn, d_cn, L.xbuf);
