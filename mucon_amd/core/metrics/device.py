@@ -23,8 +23,9 @@ def overlap_counters(targets: Sequence[torch.Tensor], predictions: Sequence[torc
     assert all(t.is_cuda and p.is_cuda and t.shape == p.shape and t.dim() == 1 for t, p in zip(targets, predictions))
     lens = [int(t.shape[0]) for t in targets]
     off = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int64).to(dev)
-    tg = torch.cat([t.to(torch.int32) for t in targets]).contiguous()
-    pr = torch.cat([p.to(torch.int32) for p in predictions]).contiguous()
+    # (one conversion per side, not one per pair; pairs of one video usually share the target tensor and a cat of views is one launch)
+    tg = (torch.cat(list(targets)) if len({t.dtype for t in targets}) == 1 else torch.cat([t.to(torch.int64) for t in targets])).to(torch.int32).contiguous()
+    pr = (torch.cat(list(predictions)) if len({p.dtype for p in predictions}) == 1 else torch.cat([p.to(torch.int64) for p in predictions])).to(torch.int32).contiguous()
     ign = sorted(int(i) for i in (ignore_ids or ()))
     ign_d = torch.tensor(ign, dtype=torch.int32).to(dev) if ign else None
     R = _lib.METRICS_MAX_RUNS
@@ -90,8 +91,9 @@ def segmental_counters(targets: Sequence[torch.Tensor], predictions: Sequence[to
     assert len(overlaps) <= 4
     lens = [int(t.shape[0]) for t in targets]
     off = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int64)).to(dev, non_blocking=True)
-    tg = torch.cat([t.to(torch.int32) for t in targets]).contiguous()
-    pr = torch.cat([p.to(torch.int32) for p in predictions]).contiguous()
+    # (one conversion per side, not one per pair; pairs of one video usually share the target tensor and a cat of views is one launch)
+    tg = (torch.cat(list(targets)) if len({t.dtype for t in targets}) == 1 else torch.cat([t.to(torch.int64) for t in targets])).to(torch.int32).contiguous()
+    pr = (torch.cat(list(predictions)) if len({p.dtype for p in predictions}) == 1 else torch.cat([p.to(torch.int64) for p in predictions])).to(torch.int32).contiguous()
     ign = sorted(int(i) for i in (ignore_ids or ()))
     ign_d = torch.tensor(ign, dtype=torch.int32).to(dev) if ign else None
     thr_d = torch.tensor(list(overlaps), dtype=torch.float64).to(dev)
@@ -115,24 +117,31 @@ def segmental_counters(targets: Sequence[torch.Tensor], predictions: Sequence[to
     nmax = max(int(np.minimum(runs_h[:, 0], R).max()), 1)
     per_run = torch.cat([iod[:, :nmax], iou[:, :nmax], run_label[:, :nmax].to(torch.float64)], dim=1).cpu().numpy()   # labels are exact in f64
     iod_h, iou_h, lab_h = per_run[:, :nmax], per_run[:, nmax: 2 * nmax], per_run[:, 2 * nmax:].astype(np.int64)
+    # the clamp and the ignore mask once for the chunk; the means stay per pair, over the compressed values, as the host classes take them
+    # (np.mean's pairwise grouping depends on the array it is handed: a masked full-width sum would round differently)
+    iod_m, iou_m = np.maximum(iod_h, 0.0), np.maximum(iou_h, 0.0)
+    not_ign = ~np.isin(lab_h, ign) if ign else None
     out = []
-    for v in range(n):
-        if over[v]:
-            out.append({"over_limit": True})
-            continue
-        nt, npred, kept_pred = int(runs_h[v, 0]), int(runs_h[v, 1]), int(runs_h[v, 2])
-        res = {"correct": int(mof_h[v, 0]), "total": int(mof_h[v, 1]), "correct_nbg": int(mof_h[v, 2]), "total_nbg": int(mof_h[v, 3])}
-        keep_nbg = ~np.isin(lab_h[v, :nt], ign) if ign else np.ones(nt, dtype=bool)
-        for suffix, keep, kp in (("", np.ones(nt, dtype=bool), npred), ("_nbg", keep_nbg, kept_pred)):
-            for name, vals in (("iod", iod_h), ("iou", iou_h)):
-                if lens[v] == 0 or not keep.any():
-                    res[name + suffix] = float("nan")
-                elif kp == 0:
-                    res[name + suffix] = 0.0
-                else:
-                    res[name + suffix] = float(np.maximum(vals[v, :nt][keep], 0.0).mean())
-        with np.errstate(all="ignore"):
+    nan = float("nan")
+    with np.errstate(all="ignore"):
+        for v in range(n):
+            if over[v]:
+                out.append({"over_limit": True})
+                continue
+            nt, npred, kept_pred = int(runs_h[v, 0]), int(runs_h[v, 1]), int(runs_h[v, 2])
+            res = {"correct": int(mof_h[v, 0]), "total": int(mof_h[v, 1]), "correct_nbg": int(mof_h[v, 2]), "total_nbg": int(mof_h[v, 3])}
+            keep = not_ign[v, :nt] if not_ign is not None else None
+            any_kept = nt > 0 and (keep is None or bool(keep.any()))
+            for suffix, mask, kp, some in (("", None, npred, nt > 0), ("_nbg", keep, kept_pred, any_kept)):
+                for name, vals in (("iod", iod_m), ("iou", iou_m)):
+                    if lens[v] == 0 or not some:
+                        res[name + suffix] = nan
+                    elif kp == 0:
+                        res[name + suffix] = 0.0
+                    else:
+                        row = vals[v, :nt] if mask is None else vals[v, :nt][mask]
+                        res[name + suffix] = float(np.add.reduce(row) / row.size)       # ndarray.mean() of a float64 row, minus its Python wrapper
             res["edit"] = float((1 - np.float64(float(seg_h[v, 0])) / max(npred, nt)) * 100)
-        res["f1"] = [(float(seg_h[v, 1 + 3 * s]), float(seg_h[v, 2 + 3 * s]), float(seg_h[v, 3 + 3 * s])) for s in range(len(overlaps))]
-        out.append(res)
+            res["f1"] = [(float(seg_h[v, 1 + 3 * s]), float(seg_h[v, 2 + 3 * s]), float(seg_h[v, 3 + 3 * s])) for s in range(len(overlaps))]
+            out.append(res)
     return out

@@ -142,12 +142,14 @@ class Viterbi(object):
 
     # ------------------------------------------------------------------------------ decode
     def decode_batch(self, log_frame_probs: Sequence, transcripts: Sequence[Sequence[int]],
-                     length_models: Sequence, return_exceptions: bool = False) -> List[tuple]:
+                     length_models: Sequence, return_exceptions: bool = False, labels_as_arrays: bool = False) -> List[tuple]:
         """Decode several videos in one kernel launch (one workgroup per video).  Each result is
         what decode() returns.  Not in the reference (it decodes one video at a time).
 
         return_exceptions: a video the reference's decode raises for (ShortSequenceError, NoHypothesisError) yields that
-        exception object in its place instead of ending the whole batch (the batched evaluation skips such videos one by one)."""
+        exception object in its place instead of ending the whole batch (the batched evaluation skips such videos one by one).
+        labels_as_arrays: the labels of each triple as an int32 numpy array instead of the reference's Python list (a caller that goes
+        on with numpy saves building a T-element list per video and parsing it again)."""
         import torch
         from ... import _lib, ops
 
@@ -199,7 +201,7 @@ class Viterbi(object):
                 out[i] = err
                 continue
             segs = [Viterbi.Segment(int(t[s]), int(r.seg_len[s])) for s in range(r.n_seg)]
-            out[i] = (r.score, r.labels.tolist(), segs)
+            out[i] = (r.score, r.labels if labels_as_arrays else r.labels.tolist(), segs)
         return out
 
     def _decode_host(self, lp, transcript, length_model):

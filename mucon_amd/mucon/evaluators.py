@@ -265,7 +265,7 @@ class MuConEvaluator:
                 with np.errstate(all="ignore"):
                     lms.append(PoissonModel(lengths))
             res = self.vi_decoder.decode_batch([v["out"]["logp"] for v in alive], [v["transcript"][:-1] for v in alive], lms,
-                                               return_exceptions=True)
+                                               return_exceptions=True, labels_as_arrays=True)
             kept = []
             for v, r in zip(alive, res):
                 if isinstance(r, Exception):
@@ -285,7 +285,7 @@ class MuConEvaluator:
             v["y_same"] = v["y_pred"] if len(v["y_pred"]) == len(target) else make_same_size_interpolate(v["y_pred"], len(target))
             heads = [v["y_same"], v["s_same"]]
             if self.enable_viterbi:
-                vl = np.asarray(v["vit"][1])
+                vl = v["vit"][1].astype(np.int64)          # (what np.array of the reference's label list is)
                 v["vit_same"] = vl if len(vl) == len(target) else make_same_size_interpolate(vl, len(target))
                 heads.append(v["vit_same"])
             for h in heads:

@@ -151,6 +151,7 @@ class MuCon(nn.Module):
         self.native_lstm = True     # s-head biLSTM through the HIP kernels (False: torch's nn.LSTM / MIOpen)
         self.native_decoder = True  # s-head decoding loop as one persistent HIP kernel (False: the torch loop)
         self.native_loss = True     # the four losses + gradients in the fused HIP kernels (False: the torch formulation)
+        self.fast_eval_forward = True   # forward_deferred through mucon/eval_forward.py (False: the generic ops, call by call)
 
     def get_params(self, original_lr):  # fandak.Model.get_params
         return [{"params": self.parameters(), "lr": original_lr}]
@@ -303,18 +304,22 @@ class MuCon(nn.Module):
         """The evaluation forward without host round trips exists for the all-HIP configuration (device tensors, the native LSTM and
         decoder at the reference's sizes, one video per batch); everything else takes forward() / predict().  Depends on the VIDEO
         (its encoded length): callers ask per video.  on_device: the answer for this batch once it has been moved to the GPU."""
-        enc_len = batch.feats.shape[1]
         is_cuda = batch.feats.is_cuda if on_device is None else on_device
-        for i in range(len(self.cfg.model.ft.stages)):
-            if self.cfg.model.ft.pooling and i in self.cfg.model.ft.pooling_layers:
-                enc_len //= 2
-        lstm, d = self.fs_encoder_lstm, self.fs_decoder_lstm
-        return (not self.training and not self.teacher_forcing and is_cuda and batch.feats.shape[0] == 1
-                and isinstance(self.ft, WaveNetBlock) and self.native_lstm and self.native_decoder
-                and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
-                and d.input_size == 128 and d.hidden_size == 128 and d.num_layers == 1 and self.num_classes + 1 <= 128
-                and self.fs_decoder_embedding.embedding_dim == 128 and (2 if lstm.bidirectional else 1) * lstm.hidden_size <= 256
-                and 1 <= enc_len <= 4096)
+        key = (self.training, self.teacher_forcing, self.native_lstm, self.native_decoder)
+        st = self.__dict__.get("_defer_static")
+        if st is None or st[0] != key:
+            # what does not depend on the video: the module sizes the kernels are built for, and how often the encoder halves the tape
+            # (module sizes are fixed at construction; the four flags above are the things a caller flips)
+            ft = self.cfg.model.ft
+            halvings = sum(1 for i in range(len(ft.stages)) if ft.pooling and i in ft.pooling_layers)
+            lstm, d = self.fs_encoder_lstm, self.fs_decoder_lstm
+            ok = (not self.training and not self.teacher_forcing and isinstance(self.ft, WaveNetBlock) and self.native_lstm
+                  and self.native_decoder and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
+                  and d.input_size == 128 and d.hidden_size == 128 and d.num_layers == 1 and self.num_classes + 1 <= 128
+                  and self.fs_decoder_embedding.embedding_dim == 128 and (2 if lstm.bidirectional else 1) * lstm.hidden_size <= 256)
+            st = self.__dict__["_defer_static"] = (key, bool(ok), halvings)
+        shape = batch.feats.shape
+        return st[1] and is_cuda and shape[0] == 1 and 1 <= (shape[1] >> st[2]) <= 4096
 
     @torch.no_grad()
     def forward_deferred(self, batch: Batch) -> dict:
@@ -322,6 +327,12 @@ class MuCon(nn.Module):
         evaluators.py:316-318 drives it) as the same launches, but nothing is read back: the number of decoded words stays on
         the device.  -> {"logp" [T x M] log-softmaxed y-head output, "segmentation" [T x M] logits, "transcript" [S x (M+1)]
         log-probs of all S = max_decoding_steps rows (rows >= n_steps unwritten), "lengths" [S], "n_steps" int32 [1]}."""
+        if self.fast_eval_forward and self.ft.out_dims == 128:
+            # the same four library calls with the per-call Python trimmed (parameter structs and per-length plans cached, one
+            # allocation per video): mucon/eval_forward.py
+            from .eval_forward import for_model
+            self._step += 1           # as temporal_modeling_forward counts it
+            return for_model(self)(batch.feats, batch.transcript_tf_input)
         Tf = batch.feats.shape[1]
         temporal_encoded = self.temporal_modeling_forward(input=batch.feats)
         enc_out, h_n, c_n = self._sequence_encoder(temporal_encoded)

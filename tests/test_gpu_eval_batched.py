@@ -165,3 +165,52 @@ def test_batched_evaluation_with_videos_the_batched_path_cannot_take():
         assert len(sa[name]) == len(sb[name]), name
         for x, y in zip(sa[name], sb[name]):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
+
+
+def test_trimmed_eval_forward_equals_the_generic_one_bit_for_bit():
+    """mucon/eval_forward.py (cached parameter structs and per-length plans, one allocation per video) against the same four
+    library calls made through the generic ops: every output equal bit for bit, for several tape lengths, on a side stream, and
+    after the parameters moved to other storage (the cached pointers must be noticed stale)."""
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.models import create_model
+
+    dev, C = "cuda:0", 48
+    cfg = update_config(get_cfg_defaults(), [], [])
+    torch.manual_seed(11)
+    model = create_model(cfg, C, 9, 2048).to(dev).eval()
+    model.set_teacher_forcing(False)
+    with torch.no_grad():
+        model.fs_decoder_transcript[2].bias[C] = -3.0
+    db = _Videos(5, C, dev, seed=8)
+
+    def both(batch):
+        outs = []
+        for fast in (False, True):
+            model.fast_eval_forward = fast
+            assert model.can_defer_eval(batch)
+            outs.append(model.forward_deferred(batch))
+        torch.cuda.synchronize()
+        a, b = outs
+        n = int(a["n_steps"].item())
+        assert n == int(b["n_steps"].item()) and n >= 1
+        for k in ("logp", "segmentation"):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+        assert torch.equal(a["transcript"][:n], b["transcript"][:n]) and torch.equal(a["lengths"][:n], b["lengths"][:n])
+        return b
+
+    for i in range(len(db)):
+        both(db[i])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        first = both(db[0])
+    side.synchronize()
+    before = first["logp"].clone()
+    with torch.no_grad():                       # new storage for every parameter, new values for some
+        for p in model.parameters():
+            p.data = p.data.clone()
+        model.conv_classifier.bias.add_(0.25)
+        model.ft.last_conv.weight.mul_(1.5)
+    after = both(db[0])
+    assert not torch.equal(before, after["logp"])
+    model.fast_eval_forward = True
