@@ -20,6 +20,7 @@ reference's degenerate outcomes, which depend on the iteration order of its hypo
     score -inf and a truncated transcript.  `last_in_dict_order` reproduces that order in
     closed form (verified against the literal oracle in tests/test_viterbi_host.py).
 """
+import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -78,6 +79,8 @@ class Viterbi(object):
         def __repr__(self):
             return f"Segment(label={self.label}, length={self.length})"
 
+    _warned_no_pruning = False
+
     def __init__(self, grammar, length_model, frame_sampling=1, max_hypotheses=np.inf):
         self.grammar = grammar
         self.length_model = length_model
@@ -113,13 +116,16 @@ class Viterbi(object):
         if np.isfinite(self.max_hypotheses):
             # prune() (viterbi.py:74-79) drops the lowest-scoring hypotheses once there are more than max_hypotheses of them.  A single
             # transcript never has more than N * J hypotheses alive (J = max_length // frame_sampling length slots per transcript state):
-            # from that bound on the pruning never triggers and the decode is the reference's, bit for bit.  Below it the reference's
-            # result depends on the pruning (it may drop the best path); that is not implemented.
+            # from that bound on the pruning never triggers and the decode is the reference's, bit for bit.  Below it the reference
+            # searches a beam; the kernels search everything: the result is the optimum the beam approximates -- score >= the
+            # reference's, equal whenever its beam kept the best path.  Said once per process, not silently.
             max_len = self.length_model.max_length()
             bound = N * (int(max_len) // fs) if np.isfinite(max_len) else np.inf
-            if self.max_hypotheses < bound:
-                raise NotImplementedError(f"max_hypotheses = {self.max_hypotheses} could prune this transcript ({N} states x {int(max_len) // fs} length slots = "
-                                          f"{bound} hypotheses at most); pruning is not implemented -- the reference never enables it (evaluators.py:80)")
+            if self.max_hypotheses < bound and not Viterbi._warned_no_pruning:
+                Viterbi._warned_no_pruning = True
+                warnings.warn(f"max_hypotheses = {self.max_hypotheses} could prune this transcript ({N} states x {int(max_len) // fs} length slots = "
+                              f"{bound} hypotheses at most): the HIP decoder does not prune, it returns the exact optimum (score >= the reference's "
+                              f"beam result; the reference itself never enables pruning, evaluators.py:80)", RuntimeWarning, stacklevel=3)
         if N == 0:
             raise NoHypothesisError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
         if T < fs:

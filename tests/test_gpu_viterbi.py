@@ -207,3 +207,32 @@ def test_lds_kernel_on_the_golden_cases():
         _check(v.decode(torch.from_numpy(lp).cuda()), *oracle.viterbi_decode(lp, tr, mu, FS, MAXLEN))
     finally:
         _lib.set_knob("MUCON_VIT_LANES", 1)
+
+
+def test_finite_max_hypotheses_decodes_exactly_against_the_references_beam():
+    """The reference prunes to a beam for finite max_hypotheses (viterbi.py:74-79); the kernels do not prune.  Against the
+    reference's own beam results (tests/golden/viterbi_pruned.json): the decode equals the UNPRUNED golden result bit for bit for
+    every max_hypotheses, its score is never below the beam's, and it is the beam's result wherever the beam kept the best path."""
+    import json
+    import os
+    import warnings
+
+    from mucon_amd.core.viterbi import SingleTranscriptGrammar, Viterbi
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "viterbi_pruned.json")))
+    by_name = {c["name"]: c for c in META["cases"]}
+    same = 0
+    for r in fx["cases"]:
+        nm = r["case"]
+        lp = torch.from_numpy(viterbi_case_inputs(Z, by_name[nm])).cuda()
+        v = Viterbi(None, None, frame_sampling=FS, max_hypotheses=r["max_hypotheses"])
+        v.grammar = SingleTranscriptGrammar([int(x) for x in Z[f"{nm}__transcript"]], lp.shape[1])
+        v.length_model = TableModel(Z[f"{nm}__P"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            got = v.decode(lp)
+        _check(got, Z[f"{nm}__score"][0], Z[f"{nm}__labels"], Z[f"{nm}__seg_label"], Z[f"{nm}__seg_len"])
+        beam = float(r["score"])
+        assert got[0] >= beam
+        if r["same_labels"] and beam == r["unpruned_score"]:
+            same += 1
+    assert same >= 25          # most beams of the fixture keep the best path: there the result IS the reference's

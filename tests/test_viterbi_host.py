@@ -109,19 +109,43 @@ def test_wrapper_raises_like_reference():
         v._prepare(900)
 
 
-def test_max_hypotheses_that_can_never_prune_is_accepted():
+def test_max_hypotheses_never_prunes():
     """prune() (reference viterbi.py:74-79) only acts when more than max_hypotheses hypotheses are alive; a single transcript of N
     states has at most N * (max_length // frame_sampling) of them, so from that bound on the decode is the unpruned one (checked
-    against the reference itself when the bound was derived: identical results for max_hypotheses = inf and = N * J).  Below the
-    bound the reference's result depends on its pruning, which is not implemented: a loud error, not a different answer."""
+    against the reference itself: tests/golden/viterbi_pruned.json, last record of every case).  Below the bound the reference
+    searches a beam; the HIP decoder searches everything and says so, once per process, in a RuntimeWarning."""
+    import warnings
+
     from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
     tr = [3, 7, 3, 1]
     mu = np.full(12, 200.0)
-    for mh, ok in ((np.inf, True), (4 * 66, True), (10 ** 6, True), (4 * 66 - 1, False), (50, False)):
+    Viterbi._warned_no_pruning = False
+    for mh, warns in ((np.inf, False), (4 * 66, False), (10 ** 6, False), (4 * 66 - 1, True), (50, False)):     # (50: already said)
         v = Viterbi(SingleTranscriptGrammar(tr, 12), PoissonModel(mu), frame_sampling=30, max_hypotheses=mh)
-        if ok:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
             t, P, force = v._prepare(900)
-            assert P.shape == (66, 4) and force is None
-        else:
-            with pytest.raises(NotImplementedError, match="max_hypotheses"):
-                v._prepare(900)
+        assert P.shape == (66, 4) and force is None
+        said = [x for x in w if issubclass(x.category, RuntimeWarning) and "max_hypotheses" in str(x.message)]
+        assert bool(said) == warns, (mh, [str(x.message) for x in w])
+    Viterbi._warned_no_pruning = False
+
+
+def test_the_beam_fixture_says_what_the_docs_say():
+    """tests/golden/viterbi_pruned.json (the reference's own beam search, tools/make_golden_pruned.py): a beam never scores above the
+    exact decode, equals it from N * J hypotheses on, and a beam of one loses every path (score -inf)."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "viterbi_pruned.json")))
+    J = fx["max_length"] // fx["fs"]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "viterbi_cases.npz"))
+    assert len(fx["cases"]) >= 40
+    for r in fx["cases"]:
+        assert "exception" not in r
+        score = float(r["score"])
+        assert score <= r["unpruned_score"]
+        N = len(gold[f"{r['case']}__transcript"])
+        if r["max_hypotheses"] >= N * J:
+            assert score == r["unpruned_score"] and r["same_labels"]
+        if r["max_hypotheses"] == 1:
+            assert score == -np.inf
