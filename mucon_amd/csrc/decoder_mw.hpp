@@ -483,7 +483,7 @@ __global__ __launch_bounds__(MW_T) void decoder_bwd_mw_kernel(DecDims dm, DecPar
     __shared__ float s_attn[MW_TZ];
     __shared__ int s_errb;
     __shared__ float s_dcfull[DEC_D];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;
     const int Tz = dm.Tz, ME = dm.ME, CW = DEC_D + ME, S = dm.S;
     unsigned long long *x_a = xbuf, *x_b = xbuf + MWB_X_A, *x_c = x_b + MWB_X_B, *x_d = x_c + MWB_X_C;
 
