@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
         const int t = d == 0 ? s : T - 1 - s;
         const int cur = s & 1;
         const float g0 = gnext;
-        if (s + 1 < T) gnext = gx[(long)(d == 0 ? s + 1 : T - 2 - s) * LSTM_G];  // next step's input projection: in flight
+        gnext = gx[(long)(d == 0 ? min(s + 1, T - 1) : max(T - 2 - s, 0)) * LSTM_G];  // next step's input projection: in flight (unconditional: see the backward's load_step)
         // packed FMAs (v_pk_fma_f32: two per lane and instruction), one accumulator pair per gate
         f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         // all eight reads of h first (the compiler pairs them with their FMAs otherwise, two in flight: four LDS latencies per step; 80.6 -> 76 us at Tz = 125)
@@ -242,27 +242,32 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
         v.gg = gs[2 * LSTM_H + unit];
         v.go = gs[3 * LSTM_H + unit];
         v.ct = cells[((long)d * T + t) * LSTM_H + unit];
-        v.cp = s > 0 ? cells[((long)d * T + tp) * LSTM_H + unit] : 0.f;
-        v.dout = d_out ? d_out[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit] : 0.f;
+        // every load unconditional (clamped row, the value dropped by a select): a load behind a branch makes the number of loads in flight depend on
+        // the path, and the compiler then waits for (nearly) all of them in front of the step that needs only the older set -- the read-ahead would
+        // be waited for one step early
+        const float cpv = cells[((long)d * T + (s > 0 ? tp : t)) * LSTM_H + unit];
+        const float dov = (d_out ? d_out : out)[(long)t * (ndir * LSTM_H) + d * LSTM_H + unit];
+        v.cp = s > 0 ? cpv : 0.f;
+        v.dout = d_out ? dov : 0.f;
         return v;
     };
-    StepIn nx = load_step(T - 1);
-    for (int s = T - 1; s >= 0; --s) {           // reverse of the processing order
+    // The gate role without divergent paths: which gate a lane derives is fixed for the whole launch (q = rho & 3), so the four formulas
+    //   q = 0: dct gg gi (1 - gi)    q = 1: dct cp gf (1 - gf)    q = 2: dct gi (1 - gg^2)    q = 3: dh th go (1 - go)
+    // are ONE, dp = X Y (Z' - Z^2) with lane-constant selections X in {dct, dh}, Y in {gg, cp, gi, th}, Z in {gi, gf, gg, go}, Z' = q == 2 ? 1 : Z
+    // (four if-else paths cost the wave the sum of all four plus the exec bookkeeping: the step is bound by vector-instruction issue).
+    const bool q0 = q == 0, q1 = q == 1, q2 = q == 2, q3 = q == 3;
+    auto step = [&](const int s, const StepIn &in) {
         const int t = d == 0 ? s : T - 1 - s;
         const int cur = s & 1;                   // double-buffered: a fast wave may post step s-1 while a slow one still reads s
-        const StepIn in = nx;
-        if (s > 0) nx = load_step(s - 1);
         {
-            const float gi = in.gi, gf = in.gf, gg = in.gg, go = in.go, ct = in.ct, cp = in.cp;
             const float dh = in.dout + dh_rec;
-            const float th = tanh_f(ct);
-            const float dct = dc + dh * go * (1.f - th * th);
-            dc = dct * gf;
-            float dp;
-            if (q == 0) dp = dct * gg * gi * (1.f - gi);
-            else if (q == 1) dp = dct * cp * gf * (1.f - gf);
-            else if (q == 2) dp = dct * gi * (1.f - gg * gg);
-            else dp = dh * th * go * (1.f - go);
+            const float th = tanh_f(in.ct);
+            const float dct = dc + dh * in.go * (1.f - th * th);
+            dc = dct * in.gf;
+            const float X = q3 ? dh : dct;
+            const float Y = q0 ? in.gg : q1 ? in.cp : q2 ? in.gi : th;
+            const float Z = q0 ? in.gi : q1 ? in.gf : q2 ? in.gg : in.go;
+            const float dp = X * Y * fmaf(-Z, Z, q2 ? 1.f : Z);
             dgs[cur][gslot] = dp;
             dG[((long)d * T + t) * LSTM_G + grow] = dp;
         }
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};     // packed FMAs: columns (0, 1) and (2, 3)
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
-            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[cur][rho * LSTM_SEG + r4 * 4]);   // (all eight reads in front, as in the forward: 106 us against 103)
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&dgs[cur][rho * LSTM_SEG + r4 * 4]);   // (all eight reads in front, as in the forward: slower, 106 us against 103)
             const f32x2 g01 = {gv[0], gv[1]}, g23 = {gv[2], gv[3]};
             pk_fma_lo(a0, wt[r4 * 4 + 0][0], g01);
             pk_fma_lo(a1, wt[r4 * 4 + 0][1], g01);
@@ -290,6 +295,15 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
             col[k] += lstm_dpp<0x140>(col[k]);      // row_mirror
         }
         dh_rec = rho < 4 ? col[0] : rho < 8 ? col[1] : rho < 12 ? col[2] : col[3];
+    };
+    // two steps per trip with two register sets for the saved activations: the single-set loop copied a set per step (15 v_mov)
+    StepIn sa = load_step(T - 1), sb = sa;
+    for (int s = T - 1; s >= 0; s -= 2) {        // reverse of the processing order
+        sb = load_step(max(s - 1, 0));          // (s = 0: re-loads step 0, nobody uses it)
+        step(s, sa);
+        if (s == 0) break;
+        sa = load_step(max(s - 2, 0));
+        step(s - 1, sb);
     }
 }
 
