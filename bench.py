@@ -649,9 +649,11 @@ def main():
         }
         if rccl is not None:
             out["rccl"] = rccl
-        if not args.no_cpu_baseline:
+        # the single-GPU legs (CPU baseline, Viterbi, end-to-end, evaluation) belong to the N = 1 line: at N > 1 the other ranks would sit in the
+        # closing barrier for their two minutes
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
-        if not args.no_viterbi:
+        if not args.no_viterbi and world == 1:
             out["viterbi"] = viterbi_bench(dev, C)
             out["roofline_viterbi"] = viterbi_roofline(out["viterbi"])
             out["end_to_end"] = end_to_end_bench(dev)
