@@ -17,7 +17,9 @@
  *
  * Parity pin: tests/golden/viterbi_*.npz were produced by tools/make_golden.py importing the
  * reference itself in the build container; tests/test_oracle_viterbi.py checks this file
- * against every one of them (score bits, labels, segments).
+ * against every one of them (score bits, labels, segments).  The beam (max_hypotheses, prune():
+ * viterbi.py:74-79) is restated too and pinned by tests/golden/viterbi_pruned.* (75 decodes of the
+ * reference under finite beams, tools/make_golden_pruned.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -65,14 +67,72 @@ static int dict_update(hypdict_t *d, int J, int n, int j, double score) {
     return 0;
 }
 
+/* ---- prune (viterbi.py:74-79): `sorted([(hyps[key].score, key) for key in hyps])`, the first len - max_hypotheses entries deleted.
+ * Python sorts the (score, key) tuples: by score, ties by the KEY TUPLE key = (-1, a_0, .., a_n, length) compared element by element, a tuple
+ * that is a prefix of the other being the smaller one.  Restated literally (no closed form), so that it can check the device kernel's. */
+typedef struct {
+    const int32_t *tr; /* transcript */
+    int fs;
+} keyctx_t;
+static keyctx_t g_keyctx;   /* (qsort has no context argument; the oracle is single-threaded test infrastructure) */
+static int key_elem(const hyp_t *h, int i, int *len_out) {   /* element i of the key tuple of h, its length in *len_out */
+    *len_out = h->n + 3;                  /* -1, a_0 .. a_n, length */
+    if (i == 0) return -1;
+    if (i <= h->n + 1) return g_keyctx.tr[i - 1];
+    return (h->j + 1) * g_keyctx.fs;
+}
+static int cmp_score_key(const void *pa, const void *pb) {
+    const hyp_t *a = (const hyp_t *)pa, *b = (const hyp_t *)pb;
+    if (a->score < b->score) return -1;
+    if (a->score > b->score) return 1;
+    int la, lb;
+    key_elem(a, 0, &la);
+    key_elem(b, 0, &lb);
+    const int l = la < lb ? la : lb;
+    for (int i = 0; i < l; ++i) {
+        const int ea = key_elem(a, i, &la), eb = key_elem(b, i, &lb);
+        if (ea != eb) return ea < eb ? -1 : 1;
+    }
+    return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+/* Returns 0, or 1 when a score is NaN (Python's sort of tuples with NaN is not an order: outside what the oracle restates). */
+static int dict_prune(hypdict_t *d, int J, long max_hyp) {
+    if (max_hyp < 0 || d->count <= max_hyp) return 0;       /* `if len(hyps) > self.max_hypotheses` */
+    const int ndel = max_hyp == 0 ? 0 : d->count - (int)max_hyp;   /* tmp[0:-max_hypotheses]: -0 is 0, the slice is empty */
+    if (ndel == 0) return 0;
+    for (int i = 0; i < d->count; ++i)
+        if (d->items[i].score != d->items[i].score) return 1;
+    hyp_t *tmp = (hyp_t *)malloc(sizeof(hyp_t) * (size_t)d->count);
+    memcpy(tmp, d->items, sizeof(hyp_t) * (size_t)d->count);
+    qsort(tmp, (size_t)d->count, sizeof(hyp_t), cmp_score_key);
+    for (int i = 0; i < ndel; ++i) d->pos[tmp[i].n * J + tmp[i].j] = -2;   /* marked */
+    free(tmp);
+    int w = 0;                                                /* `del hyps[key]`: the others keep their order */
+    for (int i = 0; i < d->count; ++i) {
+        const hyp_t h = d->items[i];
+        if (d->pos[h.n * J + h.j] == -2) {
+            d->pos[h.n * J + h.j] = -1;
+            continue;
+        }
+        d->items[w] = h;
+        d->pos[h.n * J + h.j] = w;
+        ++w;
+    }
+    d->count = w;
+    return 0;
+}
+
 /* lp: [T x C] row-major float32.  P: [J x N] float64, P[j*N+n] = length_model.score((j+1)*fs, a_n)
  * with J = max_len / fs (rows for lengths fs, 2fs, .. J*fs).
  * Outputs: labels[T]; seg_label/seg_len[<=N], *n_seg; *score.  Returns a status code. */
-int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *transcript, int N,
-                                const double *P, int fs, int max_len, int32_t *labels,
-                                int32_t *seg_label, int32_t *seg_len, int32_t *n_seg,
-                                double *score_out) {
+static int decode_impl(const float *lp, int T, int C, const int32_t *transcript, int N,
+                       const double *P, int fs, int max_len, long max_hyp, int32_t *labels,
+                       int32_t *seg_label, int32_t *seg_len, int32_t *n_seg,
+                       double *score_out) {
     if (T < 0 || C <= 0 || N <= 0 || fs <= 0 || max_len < fs) return ST_BAD_ARG;
+    g_keyctx.tr = transcript;
+    g_keyctx.fs = fs;
+    int nan_in_prune = 0;
     if (T < fs) return ST_INDEX_ERROR; /* frame_scores[fs-1] out of range (viterbi.py:87) */
     const int J = max_len / fs;
     const int K = T / fs;
@@ -121,7 +181,7 @@ int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *tr
         dict_update(old, J, 0, 0, (double)s0);
     }
 
-    /* decode_frame for t = 2fs-1, 3fs-1, ...  (viterbi.py:57-61, 92-123); prune is a no-op */
+    /* decode_frame for t = 2fs-1, 3fs-1, ...  (viterbi.py:57-61, 92-123), each followed by prune (:61) */
     for (int k = 1; k < K; ++k) {
         dict_clear(cur, N, J);
         for (int i = 0; i < old->count; ++i) {
@@ -145,6 +205,7 @@ int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *tr
                 if (dict_update(cur, J, h.n + 1, 0, s2)) bp[(size_t)k * N + h.n + 1] = (int16_t)h.j;
             }
         }
+        nan_in_prune |= dict_prune(cur, J, max_hyp);
         hypdict_t *tmp = old;
         old = cur;
         cur = tmp;
@@ -164,7 +225,9 @@ int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *tr
         }
     }
     int status = ST_OK;
-    if (best_n < 0) {
+    if (nan_in_prune) {
+        status = ST_BAD_ARG;
+    } else if (best_n < 0) {
         status = ST_NO_HYPOTHESIS;
     } else {
         /* traceback (viterbi.py:140-158): every node covers fs frames; leftover frames are
@@ -199,6 +262,22 @@ int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *tr
     free(b.pos);
     free(bp);
     return status;
+}
+
+int mucon_oracle_viterbi_decode(const float *lp, int T, int C, const int32_t *transcript, int N,
+                                const double *P, int fs, int max_len, int32_t *labels,
+                                int32_t *seg_label, int32_t *seg_len, int32_t *n_seg,
+                                double *score_out) {
+    return decode_impl(lp, T, C, transcript, N, P, fs, max_len, -1, labels, seg_label, seg_len, n_seg, score_out);
+}
+
+/* The same with Viterbi(max_hypotheses = max_hyp) (viterbi.py:34): max_hyp >= 0; 0 never deletes anything (Python's tmp[0:-0]). */
+int mucon_oracle_viterbi_decode_pruned(const float *lp, int T, int C, const int32_t *transcript, int N,
+                                       const double *P, int fs, int max_len, long max_hyp, int32_t *labels,
+                                       int32_t *seg_label, int32_t *seg_len, int32_t *n_seg,
+                                       double *score_out) {
+    if (max_hyp < 0) return ST_BAD_ARG;
+    return decode_impl(lp, T, C, transcript, N, P, fs, max_len, max_hyp, labels, seg_label, seg_len, n_seg, score_out);
 }
 
 /* Frame scores only (for unit-testing the GPU kernel's first phase): F[K x C] float32. */

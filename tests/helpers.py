@@ -137,3 +137,34 @@ def loss_inputs(T, N, seed):
     if N >= 2:
         tr[0] = 0
     return seg, tl, ln, tr
+
+
+def load_pruned_golden():
+    """tests/golden/viterbi_pruned.{npz,json}: the reference's beam search (tools/make_golden_pruned.py)."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "viterbi_pruned.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "viterbi_pruned.json")))
+    return z, meta
+
+
+def pruned_case_inputs(rec):
+    """(lp [T x C] float32, transcript int32 [N], P [J x N] float64) of one record of viterbi_pruned.json -- the generator's inputs,
+    restated (tools/make_golden_pruned.py:build_inputs)."""
+    import oracle
+    from mucon_amd import synth
+    T, seed, tr = rec["T"], rec["seed"], np.asarray(rec["transcript"], dtype=np.int64)
+    if rec["emissions"] == "const":
+        lp = np.full((T, C), np.float32(-1.0), np.float32)
+    elif rec["emissions"] == "noise":
+        lp = synth.emissions(seed, T, C, labels=None)
+    else:
+        lp = synth.emissions(seed, T, C, labels=synth.segment_labels(seed + 11, T, tr))
+    fs, max_len = rec["fs"], rec["max_len"]
+    J = max_len // fs
+    if rec["length_model"] == "flat":
+        P = np.zeros((J, len(tr)), dtype=np.float64)
+        P[(np.arange(1, J + 1) * fs) >= max_len, :] = -np.inf
+    else:
+        with np.errstate(all="ignore"):
+            P = oracle.length_rows(oracle.poisson_table(np.asarray(rec["mu"]), max_len), tr, fs, max_len)
+    return lp, tr.astype(np.int32), P

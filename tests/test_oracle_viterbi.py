@@ -65,3 +65,40 @@ def test_oracle_frame_scores_sequential_f32():
     for k in range(1, 700 // 30):
         want[k] = cs[(k + 1) * 30 - 1] - cs[(k + 1) * 30 - 1 - 30]
     np.testing.assert_array_equal(F.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- the beam (max_hypotheses)
+from helpers import load_pruned_golden, pruned_case_inputs  # noqa: E402
+
+PZ, PMETA = load_pruned_golden()
+
+
+@pytest.mark.parametrize("rec", PMETA["cases"], ids=[r["name"] for r in PMETA["cases"]])
+def test_oracle_beam_matches_the_references(rec):
+    """oracle/viterbi_oracle.c:dict_prune (a literal restatement of prune(), viterbi.py:74-79, with Python's tuple comparison of the
+    (score, key) pairs) against the reference's own results for finite max_hypotheses: bit-exact, including the decodes whose beam lost
+    every path to the last transcript state (score -inf, the labelling of the last hypothesis in dict order) and those that end with no
+    hypothesis at all (AttributeError in the reference)."""
+    lp, tr, P = pruned_case_inputs(rec)
+    nm = rec["name"]
+    if rec["exception"] is not None:
+        assert rec["exception"] == "AttributeError"
+        with pytest.raises(oracle.OracleDecodeError) as e:
+            oracle.viterbi_decode_table(lp, tr, P, rec["fs"], rec["max_len"], max_hypotheses=rec["max_hypotheses"])
+        assert e.value.status == oracle.ST_NO_HYPOTHESIS
+        return
+    score, labels, seg_label, seg_len = oracle.viterbi_decode_table(lp, tr, P, rec["fs"], rec["max_len"], max_hypotheses=rec["max_hypotheses"])
+    assert f64_bits(score) == f64_bits(PZ[f"{nm}__score"][0]), (score, PZ[f"{nm}__score"][0])
+    np.testing.assert_array_equal(labels, PZ[f"{nm}__labels"])
+    np.testing.assert_array_equal(seg_label, PZ[f"{nm}__seg_label"])
+    np.testing.assert_array_equal(seg_len, PZ[f"{nm}__seg_len"])
+
+
+def test_oracle_beam_that_cannot_prune_equals_no_beam():
+    cs = META["cases"][5]
+    nm = cs["name"]
+    lp, tr = viterbi_case_inputs(Z, cs), Z[f"{nm}__transcript"]
+    a = oracle.viterbi_decode_table(lp, tr, Z[f"{nm}__P"], FS, MAXLEN)
+    for mh in (len(tr) * (MAXLEN // FS), 10 ** 6, 0):          # (0: Python's tmp[0:-0] deletes nothing)
+        b = oracle.viterbi_decode_table(lp, tr, Z[f"{nm}__P"], FS, MAXLEN, max_hypotheses=mh)
+        assert f64_bits(a[0]) == f64_bits(b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))

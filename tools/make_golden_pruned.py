@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""HERE (reference mounted): what the REFERENCE's beam search returns for finite max_hypotheses (src/core/viterbi/viterbi.py:34, :74-79),
-for cases of tests/golden/viterbi_cases.npz -> tests/golden/viterbi_pruned.json: per (case, max_hypotheses) the pruned score, whether the
-labelling equals the unpruned one, and the unpruned score.  The HIP decoder does not prune (it returns the exact optimum and says so in a
-warning); tests/test_gpu_viterbi.py checks the relation the fixture pins: score >= the beam's, the same result wherever the beam kept the
-best path.  Data only -- no reference source."""
+"""HERE (reference mounted): the REFERENCE's beam search -- Viterbi(max_hypotheses = M), src/core/viterbi/viterbi.py:34, :74-79 -- run on
+seeded inputs -> tests/golden/viterbi_pruned.npz / .json: per (case, M) the full result (score, labels, segments) or the exception.
+
+Two groups:
+  * seven cases of tests/golden/viterbi_cases.npz (same synthetic inputs) under six beams each, from 1 to N * J (which never prunes);
+  * cases built to exercise the TIE order of prune()'s `sorted([(score, key) ...])`: constant emissions with a flat length model (every score
+    ties, the key tuples decide) and small frame_sampling / max_length, where segment lengths and class labels collide inside the key tuples.
+Pins oracle/viterbi_oracle.c:dict_prune (tests/test_oracle_viterbi.py) and, through it and directly, the device kernel
+(tests/test_gpu_viterbi.py).  Data only -- no reference source."""
 import json
 import os
 import sys
@@ -18,42 +22,92 @@ import ref_harness  # noqa: E402
 ref_harness.install()
 from mucon_amd import synth  # noqa: E402
 
-FS, MAXLEN, C = 30, 2000, 48
+C = 48
+
+
+def build_inputs(rec):
+    """(lp [T x C] float32, table P [J x N] float64 is derived by the tests from `mu` / flat) for one record -- shared with the tests
+    (tests/helpers.py:pruned_case_inputs restates it)."""
+    T, seed, tr = rec["T"], rec["seed"], np.asarray(rec["transcript"], dtype=np.int64)
+    if rec["emissions"] == "const":
+        return np.full((T, C), np.float32(-1.0), np.float32)
+    if rec["emissions"] == "noise":
+        return synth.emissions(seed, T, C, labels=None)
+    return synth.emissions(seed, T, C, labels=synth.segment_labels(seed + 11, T, tr))
 
 
 def main():
     from core.viterbi.grammar import SingleTranscriptGrammar
-    from core.viterbi.length_model import PoissonModel
+    from core.viterbi.length_model import LengthModel, PoissonModel
     from core.viterbi.viterbi import Viterbi
+
+    class Flat(LengthModel):      # a float64 length model with no preference
+        def __init__(self, max_len):
+            self.max_len = max_len
+
+        def score(self, length, label):
+            return -np.inf if length >= self.max_len else np.float64(0.0)
+
+        def max_length(self):
+            return self.max_len
 
     gold = np.load(os.path.join(ROOT, "tests", "golden", "viterbi_cases.npz"))
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "viterbi_cases.json")))
     by_name = {c["name"]: c for c in meta["cases"]}
-    out = []
+    recs = []
     for name in ("rand03", "rand05", "rand07", "rand16", "repeat_adjacent", "uninformative", "stress_small"):
         cs = by_name[name]
-        T, seed, kind = cs["T"], cs["seed"], cs["kind"]
-        tr = gold[f"{name}__transcript"].astype(np.int64)
-        gt = synth.segment_labels(seed + 11, T, tr)
-        lp = synth.emissions(seed, T, C, labels=None if kind == "poisson_noise" else gt)
+        tr = [int(x) for x in gold[f"{name}__transcript"]]
+        for mh in (1, 3, 10, 40, 200, len(tr) * (2000 // 30)):
+            recs.append(dict(name=f"{name}_m{mh}", T=cs["T"], seed=cs["seed"], transcript=tr, fs=30, max_len=2000, max_hypotheses=mh,
+                             emissions="noise" if cs["kind"] == "poisson_noise" else "labels", length_model="poisson",
+                             mu=[float(x) for x in gold[f"{name}__mu"]]))
+    ties = [
+        ("ties30", 1500, [5, 30, 40, 30, 7], 30, 2000, (2, 7, 19, 50, 120)),          # labels below / equal to / above the shortest length (30)
+        ("ties30b", 900, [47, 0, 31, 29], 30, 2000, (3, 11, 40)),
+        ("ties_fs1", 130, [3, 17, 40, 9, 25], 1, 40, (2, 5, 13, 37, 90)),              # lengths 1..40 against labels 3..40 inside the key tuples
+        ("ties_fs1b", 97, [20, 20, 1, 39, 2, 38], 1, 40, (4, 17, 60)),
+        ("ties_fs7", 700, [6, 14, 7, 35, 21, 8], 7, 300, (3, 9, 25, 77)),
+    ]
+    for name, T, tr, fs, max_len, beams in ties:
+        for mh in beams:
+            recs.append(dict(name=f"{name}_m{mh}", T=T, seed=0, transcript=tr, fs=fs, max_len=max_len, max_hypotheses=mh, emissions="const",
+                             length_model="flat"))
+    small = [
+        ("fs1_poisson", 150, [3, 17, 40, 9, 25], 1, 40, 501, (2, 6, 20, 70)),
+        ("fs7_poisson", 800, [6, 14, 7, 35, 21, 8], 7, 300, 502, (3, 10, 30, 100)),
+        ("fs30_short", 400, [2, 45, 11], 30, 2000, 503, (1, 2, 4, 9)),
+    ]
+    for name, T, tr, fs, max_len, seed, beams in small:
+        rng = np.random.default_rng(seed)
+        mu = np.full(C, float(T) / len(tr))
+        mu[np.asarray(tr)] = rng.uniform(0.6, 1.6, len(tr)) * T / len(tr)
+        for mh in beams:
+            recs.append(dict(name=f"{name}_m{mh}", T=T, seed=seed, transcript=tr, fs=fs, max_len=max_len, max_hypotheses=mh, emissions="labels",
+                             length_model="poisson", mu=[float(x) for x in mu]))
+    out = {}
+    for rec in recs:
+        lp = build_inputs(rec)
         with np.errstate(all="ignore"):
-            lm = PoissonModel(gold[f"{name}__mu"])
-        full_score = float(gold[f"{name}__score"][0])
-        full_labels = gold[f"{name}__labels"]
-        for mh in (1, 3, 10, 40, 200, len(tr) * (MAXLEN // FS)):
-            v = Viterbi(None, None, frame_sampling=FS, max_hypotheses=mh)
-            v.grammar = SingleTranscriptGrammar([int(x) for x in tr], C)
-            v.length_model = lm
-            try:
-                score, labels, _ = v.decode(lp)
-                rec = dict(case=name, max_hypotheses=mh, score=float(score) if np.isfinite(score) else str(score),
-                           same_labels=bool(np.array_equal(np.asarray(labels), full_labels)), unpruned_score=full_score)
-            except Exception as e:  # noqa: BLE001  (the beam can lose every hypothesis that reaches the last state)
-                rec = dict(case=name, max_hypotheses=mh, exception=type(e).__name__, unpruned_score=full_score)
-            out.append(rec)
-            print(rec)
+            lm = Flat(rec["max_len"]) if rec["length_model"] == "flat" else PoissonModel(np.asarray(rec["mu"]), max_length=rec["max_len"])
+        v = Viterbi(None, None, frame_sampling=rec["fs"], max_hypotheses=rec["max_hypotheses"])
+        v.grammar = SingleTranscriptGrammar([int(x) for x in rec["transcript"]], C)
+        v.length_model = lm
+        try:
+            score, labels, segments = v.decode(lp)
+            nm = rec["name"]
+            out[f"{nm}__score"] = np.asarray([score], dtype=np.float64)
+            out[f"{nm}__labels"] = np.asarray(labels, dtype=np.int32)
+            out[f"{nm}__seg_label"] = np.asarray([s.label for s in segments], dtype=np.int32)
+            out[f"{nm}__seg_len"] = np.asarray([s.length for s in segments], dtype=np.int32)
+            rec["exception"] = None
+            print(f"  {nm:22s} T={rec['T']:5d} N={len(rec['transcript'])} fs={rec['fs']:2d} M={rec['max_hypotheses']:5d} score={score!r} segs={len(segments)}")
+        except Exception as e:  # noqa: BLE001
+            rec["exception"] = type(e).__name__
+            print(f"  {rec['name']:22s} -> {type(e).__name__}")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "viterbi_pruned.npz"), **out)
     with open(os.path.join(ROOT, "tests", "golden", "viterbi_pruned.json"), "w") as f:
-        json.dump(dict(fs=FS, max_length=MAXLEN, C=C, numpy=np.__version__, cases=out), f, indent=1)
+        json.dump(dict(C=C, numpy=np.__version__, cases=recs), f, indent=1)
 
 
 if __name__ == "__main__":
