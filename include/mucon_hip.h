@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 5   /* 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 6   /* 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -268,6 +268,21 @@ typedef struct {
 int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs,
                               int32_t max_len, double *score, int32_t *n_seg, int32_t *status,
                               void *labels, int32_t label_format, int32_t *seg_len, void *stream);
+
+/* Viterbi.decode of a decoder built with a finite max_hypotheses (reference src/core/viterbi/viterbi.py:34; prune(), :74-79, after
+ * every column :57-61): the beam search, bit for bit -- which hypothesis wins a tie depends on the iteration order of the reference's
+ * hypothesis dict and on Python's tuple order of prune()'s (score, key) pairs; both are reproduced (csrc/viterbi_beam.hip).
+ * The reference's callers never pass max_hypotheses (evaluators.py:80): this entry exists for those who do.  Same inputs as
+ * mucon_viterbi_decode_host (force_n / force_j are ignored: the degenerate outcomes they encode fall out of the list the kernel keeps);
+ * 1 <= max_hypotheses, max_hypotheses + N <= MUCON_VIT_BEAM_MAX_ITEMS, N <= 128, max_len / fs <= 128, C <= 64.  A max_hypotheses of at least
+ * N * (max_len / fs) never prunes: mucon_viterbi_decode_host is the entry for that (and for inf).  Outputs are HOST arrays: score, n_seg,
+ * status [n_videos], seg_len (video v's entries at the sum of N before it); the per-frame labels are the expansion of the segments
+ * (viterbi.py:140-158: the frames beyond T // fs * fs carry the last label and come first).  status: MUCON_VIT_OK, MUCON_VIT_INDEX_ERROR,
+ * MUCON_VIT_NO_HYPOTHESIS (every hypothesis outlived max_length or was pruned), MUCON_VIT_TRUNCATED (the beam lost every path into the last
+ * transcript state: score -inf and n_seg < N segments, what the reference returns then).  Synchronous. */
+#define MUCON_VIT_BEAM_MAX_ITEMS 4096
+int mucon_viterbi_decode_beam(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
+                              int64_t max_hypotheses, double *score, int32_t *n_seg, int32_t *status, int32_t *seg_len, void *stream);
 
 /* ---- s-head sequence encoder: bidirectional LSTM --------------------------------
  * Replaces torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True) as the reference's s-head calls

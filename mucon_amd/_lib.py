@@ -9,11 +9,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 METRICS_MAX_RUNS = 1024   # MUCON_METRICS_MAX_RUNS
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
 VIT_OK, VIT_INDEX_ERROR, VIT_NO_HYPOTHESIS, VIT_TRUNCATED = 0, 1, 2, 3
+VIT_BEAM_MAX_ITEMS = 4096           # MUCON_VIT_BEAM_MAX_ITEMS: max_hypotheses + N of mucon_viterbi_decode_beam
 VIT_LABELS_I32, VIT_LABELS_U8, VIT_LABELS_NONE = 0, 1, 2   # MUCON_VIT_LABELS_*
 VIT_LATENCY_VIDEOS = 8                                    # MUCON_VIT_LATENCY_VIDEOS
 
@@ -123,6 +124,7 @@ SYMBOLS = {
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_viterbi_decode_host": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "mucon_viterbi_decode_beam": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mucon_encoder_saved_view": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), _i32, _i32, ctypes.POINTER(ctypes.c_size_t),
                                                 ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

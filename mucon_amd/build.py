@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmucon_hip.so")
 PYHOST_LIB = os.path.join(HERE, "libmucon_pyhost.so")    # host-side helper of the Python binding (csrc/pyhost.c: CPython API, no HIP)
 ARCH = "gfx950"
-SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("shead.hip", []), ("metrics.hip", ["-ffp-contract=off"])]
+SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", []),
+           ("metrics.hip", ["-ffp-contract=off"])]
 DEPS = ["common.hpp", "dispatch.hpp", "gemm_nt.hpp", "gemm_split.hpp", "gemm_tn.hpp", "gemm_tn_split.hpp", "gemm_fused_split.hpp", "gemm_coarse_split.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "decoder.hpp", "loss.hpp", "optim.hpp", "../../include/mucon_hip.h", "../../include/mucon_hip_test.h"]
 
 

@@ -20,7 +20,6 @@ reference's degenerate outcomes, which depend on the iteration order of its hypo
     score -inf and a truncated transcript.  `last_in_dict_order` reproduces that order in
     closed form (verified against the literal oracle in tests/test_viterbi_host.py).
 """
-import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -79,8 +78,6 @@ class Viterbi(object):
         def __repr__(self):
             return f"Segment(label={self.label}, length={self.length})"
 
-    _warned_no_pruning = False
-
     def __init__(self, grammar, length_model, frame_sampling=1, max_hypotheses=np.inf):
         self.grammar = grammar
         self.length_model = length_model
@@ -113,19 +110,8 @@ class Viterbi(object):
         fs = self.frame_sampling
         tr = np.asarray(self.grammar.transcript, dtype=np.int32)
         N = len(tr)
-        if np.isfinite(self.max_hypotheses):
-            # prune() (viterbi.py:74-79) drops the lowest-scoring hypotheses once there are more than max_hypotheses of them.  A single
-            # transcript never has more than N * J hypotheses alive (J = max_length // frame_sampling length slots per transcript state):
-            # from that bound on the pruning never triggers and the decode is the reference's, bit for bit.  Below it the reference
-            # searches a beam; the kernels search everything: the result is the optimum the beam approximates -- score >= the
-            # reference's, equal whenever its beam kept the best path.  Said once per process, not silently.
-            max_len = self.length_model.max_length()
-            bound = N * (int(max_len) // fs) if np.isfinite(max_len) else np.inf
-            if self.max_hypotheses < bound and not Viterbi._warned_no_pruning:
-                Viterbi._warned_no_pruning = True
-                warnings.warn(f"max_hypotheses = {self.max_hypotheses} could prune this transcript ({N} states x {int(max_len) // fs} length slots = "
-                              f"{bound} hypotheses at most): the HIP decoder does not prune, it returns the exact optimum (score >= the reference's "
-                              f"beam result; the reference itself never enables pruning, evaluators.py:80)", RuntimeWarning, stacklevel=3)
+        if self._beam(N) is not None:
+            raise AssertionError("_prepare is the no-beam path: decode_batch routes beams to _prepare_beam")
         if N == 0:
             raise NoHypothesisError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
         if T < fs:
@@ -145,6 +131,42 @@ class Viterbi(object):
         elif K > J * N:
             raise NoHypothesisError("'NoneType' object has no attribute 'label'")
         return tr, P, force
+
+    def _beam(self, N: int) -> Optional[int]:
+        """max_hypotheses as the beam the decode runs under, or None when prune() (viterbi.py:74-79) can never act: inf, 0 (Python's
+        `tmp[0:-0]` is empty: nothing is ever deleted) and anything from N * J on, the most hypotheses a transcript of N states has alive."""
+        mh = self.max_hypotheses
+        if not np.isfinite(mh):
+            return None
+        if not isinstance(mh, (int, np.integer)):      # the reference slices a list with it: TypeError for a float, also an integral one
+            raise TypeError("slice indices must be integers or None or have an __index__ method")
+        if mh < 0:
+            raise ValueError("max_hypotheses < 0 (the reference would delete its |max_hypotheses| best... lowest hypotheses every column: not supported)")
+        max_len = self.length_model.max_length()
+        if mh == 0 or (np.isfinite(max_len) and mh >= N * (int(max_len) // self.frame_sampling)):
+            return None
+        return int(mh)
+
+    def _prepare_beam(self, T: int):
+        """-> (transcript, table P[J x N]) for a decode under a beam (csrc/viterbi_beam.hip keeps the hypothesis list itself: the degenerate
+        outcomes _prepare resolves on the host -- fewer columns than states, every hypothesis dead -- fall out of that list)."""
+        from ... import _lib
+        if not isinstance(self.grammar, SingleTranscriptGrammar):
+            raise NotImplementedError("the HIP decoder implements SingleTranscriptGrammar only (the one the "
+                                      "reference decodes with, evaluators.py:148-150)")
+        tr = np.asarray(self.grammar.transcript, dtype=np.int32)
+        N = len(tr)
+        if N == 0:
+            raise NoHypothesisError("'NoneType' object has no attribute 'label'")
+        if T < self.frame_sampling:
+            raise ShortSequenceError(f"index {self.frame_sampling - 1} is out of bounds for axis 0 with size {T}")
+        P = self._table(tr)
+        if np.isnan(P).any():
+            raise NotImplementedError("a beam (max_hypotheses) over a length model with NaN scores: Python's sort of NaN scores is not an order")
+        if self.max_hypotheses + N > _lib.VIT_BEAM_MAX_ITEMS or N > 128 or P.shape[0] > 128:
+            raise NotImplementedError(f"max_hypotheses + N = {self.max_hypotheses + N}: the beam kernel holds {_lib.VIT_BEAM_MAX_ITEMS} hypotheses "
+                                      f"(N <= 128 states, <= 128 length slots)")
+        return tr, P
 
     # ------------------------------------------------------------------------------ decode
     def decode_batch(self, log_frame_probs: Sequence, transcripts: Sequence[Sequence[int]],
@@ -171,7 +193,7 @@ class Viterbi(object):
                         raise
                     out.append(e)
             return out
-        lps, trs, tabs, forces, slots = [], [], [], [], []
+        lps, trs, tabs, forces, slots, beams = [], [], [], [], [], []
         out: List = [None] * len(log_frame_probs)
         max_len = None
         for i, (lp, tr, lm) in enumerate(zip(log_frame_probs, transcripts, length_models)):
@@ -179,6 +201,10 @@ class Viterbi(object):
                 lp = torch.from_numpy(np.ascontiguousarray(lp, dtype=np.float32)).cuda()
             v = Viterbi(SingleTranscriptGrammar(tr, lp.shape[1]), lm, fs, self.max_hypotheses)
             try:
+                if v._beam(len(tr)) is not None:
+                    t, P = v._prepare_beam(int(lp.shape[0]))
+                    beams.append((i, lp, t, P, int(lm.max_length())))
+                    continue
                 t, P, force = v._prepare(int(lp.shape[0]))
             except (ShortSequenceError, NoHypothesisError) as e:
                 if not return_exceptions:
@@ -194,7 +220,14 @@ class Viterbi(object):
             tabs.append(P)
             forces.append(force)
             slots.append(i)
-        res = ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces) if lps else []
+        res = list(ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces)) if lps else []
+        if beams:      # the reference's beam search (max_hypotheses below N * J): csrc/viterbi_beam.hip, one call per max_length
+            for ml in sorted({b[4] for b in beams}):
+                grp = [b for b in beams if b[4] == ml]
+                rb = ops.viterbi_decode_beam([b[1] for b in grp], [b[2] for b in grp], [b[3] for b in grp], fs, ml, int(self.max_hypotheses))
+                slots += [b[0] for b in grp]
+                trs += [b[2] for b in grp]
+                res += rb
         for i, r, t in zip(slots, res, trs):
             err = None
             if r.status == _lib.VIT_INDEX_ERROR:
@@ -215,6 +248,8 @@ class Viterbi(object):
         from ... import cpu_plumbing
 
         v = Viterbi(SingleTranscriptGrammar(transcript, lp.shape[1]), length_model, self.frame_sampling, self.max_hypotheses)
+        if v._beam(len(transcript)) is not None:
+            raise NotImplementedError("the CPU plumbing path has no beam (max_hypotheses): it exists on the device, csrc/viterbi_beam.hip")
         t, P, force = v._prepare(int(lp.shape[0]))
         score, labels, seg_len, alive = cpu_plumbing.viterbi_decode(lp.detach().numpy(), t, P, self.frame_sampling, force)
         if not alive:

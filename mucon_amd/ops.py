@@ -929,6 +929,47 @@ class ViterbiResult:
         return f"ViterbiResult(score={self.score!r}, n_seg={self.n_seg}, status={self.status})"
 
 
+def viterbi_decode_beam(lps: Sequence[torch.Tensor], transcripts: Sequence, tables: Sequence[np.ndarray], fs: int, max_len: int,
+                        max_hypotheses: int) -> List["ViterbiResult"]:
+    """Viterbi.decode under the reference's beam (Viterbi(max_hypotheses=M), reference viterbi.py:34, :74-79) for M below the
+    N * (max_len // fs) hypotheses a transcript can have alive: mucon_viterbi_decode_beam (csrc/viterbi_beam.hip), bit for bit.
+    lps: device tensors [T x C] float32; transcripts: int sequences; tables: float64 [J x N].  -> a ViterbiResult per video (labels
+    expanded from the segments on access).  A beam that lost every path into the last transcript state yields, as in the reference,
+    score -inf and fewer segments than the transcript has entries (status VIT_TRUNCATED)."""
+    lib = _lib.load()
+    nv = len(lps)
+    if nv == 0:
+        return []
+    J = int(max_len) // int(fs)
+    vids = (_lib.ViterbiVideo * nv)()
+    keep, trs = [], []
+    C = int(lps[0].shape[1])
+    for v, (lp, tr, P) in enumerate(zip(lps, transcripts, tables)):
+        if not isinstance(lp, torch.Tensor) or not lp.is_cuda or lp.dtype != torch.float32:
+            raise _lib.MuconHipError("mucon_amd ops need float32 device tensors: there is no CPU fallback")
+        lp = _aligned_lp(lp)
+        tr = np.ascontiguousarray(tr, dtype=np.int32)
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        if int(lp.shape[1]) != C or P.shape != (J, len(tr)):
+            raise ValueError(f"viterbi_decode_beam: video {v}: emissions [T x {C}] and a length table [{J} x {len(tr)}] expected")
+        keep += [lp, tr, P]
+        trs.append(tr)
+        q = vids[v]
+        q.lp, q.transcript, q.table, q.T, q.N, q.force_n, q.force_j = lp.data_ptr(), tr.ctypes.data, P.ctypes.data, int(lp.shape[0]), len(tr), -1, -1
+    sum_n = sum(len(t) for t in trs)
+    score, n_seg, status = np.empty(nv, np.float64), np.empty(nv, np.int32), np.empty(nv, np.int32)
+    seg_len = np.zeros(max(sum_n, 1), np.int32)
+    _lib.check(lib.mucon_viterbi_decode_beam(nv, vids, C, int(fs), int(max_len), int(max_hypotheses), score.ctypes.data, n_seg.ctypes.data,
+                                             status.ctypes.data, seg_len.ctypes.data, _lib.current_stream_ptr()), "mucon_viterbi_decode_beam")
+    out, off = [], 0
+    for v in range(nv):
+        n = len(trs[v])
+        ns = int(n_seg[v])
+        out.append(ViterbiResult(np.float64(score[v]), None, seg_len[off: off + ns].copy(), ns, int(status[v]), lazy=(trs[v], int(lps[v].shape[0]), int(fs))))
+        off += n
+    return out
+
+
 def _aligned_lp(lp):
     if not lp.is_contiguous() or (lp.data_ptr() & 15):
         lp = lp.contiguous()

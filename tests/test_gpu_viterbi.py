@@ -209,36 +209,106 @@ def test_lds_kernel_on_the_golden_cases():
         _lib.set_knob("MUCON_VIT_LANES", 1)
 
 
-def test_finite_max_hypotheses_decodes_exactly_against_the_references_beam():
-    """The reference prunes to a beam for finite max_hypotheses (viterbi.py:74-79); the kernels do not prune.  Against the
-    reference's own beam results (tests/golden/viterbi_pruned.*, also at frame_sampling 1 and 7 and with all-ties inputs): the decode
-    equals the UNPRUNED result (the golden one where there is one, the oracle's otherwise) bit for bit for every max_hypotheses, its
-    score is never below the beam's, and with informative emissions it is the beam's labelling wherever the beam kept the best path."""
-    import warnings
+# ---------------------------------------------------------------------------------------------- the beam (max_hypotheses)
+from helpers import load_pruned_golden, pruned_case_inputs  # noqa: E402
 
-    from helpers import load_pruned_golden, pruned_case_inputs
+PZ, PMETA = load_pruned_golden()
+
+
+def _beam_decode(lp, tr, P, fs, max_len, mh):
     from mucon_amd.core.viterbi import SingleTranscriptGrammar, Viterbi
-    pz, pmeta = load_pruned_golden()
-    same = 0
-    for r in pmeta["cases"]:
-        nm, base = r["name"], r["name"].rsplit("_m", 1)[0]
-        lp, tr, P = pruned_case_inputs(r)
-        v = Viterbi(None, None, frame_sampling=r["fs"], max_hypotheses=r["max_hypotheses"])
-        v.grammar = SingleTranscriptGrammar([int(x) for x in tr], lp.shape[1])
-        v.length_model = TableModel(P, r["max_len"])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", RuntimeWarning)
-            got = v.decode(torch.from_numpy(lp).cuda())
-        if f"{base}__score" in Z.files:
-            want = (Z[f"{base}__score"][0], Z[f"{base}__labels"], Z[f"{base}__seg_label"], Z[f"{base}__seg_len"])
-        else:
-            want = oracle.viterbi_decode_table(lp, tr, P, r["fs"], r["max_len"])
-        _check(got, *want)
-        if r["exception"] is not None:
-            continue                                         # the reference's beam lost every hypothesis; the exact decode has a result
-        beam = float(pz[f"{nm}__score"][0])
-        assert got[0] >= beam
-        if f"{base}__score" in Z.files and beam == float(got[0]):
-            np.testing.assert_array_equal(np.asarray(got[1], dtype=np.int32), pz[f"{nm}__labels"])
-            same += 1
-    assert same >= 25
+    v = Viterbi(None, None, frame_sampling=fs, max_hypotheses=mh)
+    v.grammar = SingleTranscriptGrammar([int(x) for x in tr], lp.shape[1])
+    v.length_model = TableModel(P, max_len)
+    return v.decode(torch.from_numpy(lp).cuda() if isinstance(lp, np.ndarray) else lp)
+
+
+@pytest.mark.parametrize("rec", PMETA["cases"], ids=[r["name"] for r in PMETA["cases"]])
+def test_beam_decode_matches_the_references_beam(rec):
+    """Viterbi(max_hypotheses = M).decode through csrc/viterbi_beam.hip against the reference's own beam search (75 decodes,
+    tools/make_golden_pruned.py): score bits, labels, segments -- also where every score ties and the key tuples decide, at
+    frame_sampling 1 and 7, where the beam loses every path into the last state (score -inf, truncated labelling of the last hypothesis
+    in dict order) and where it loses every hypothesis (AttributeError)."""
+    from mucon_amd.core.viterbi.viterbi import NoHypothesisError
+    lp, tr, P = pruned_case_inputs(rec)
+    nm = rec["name"]
+    if rec["exception"] is not None:
+        with pytest.raises(NoHypothesisError):
+            _beam_decode(lp, tr, P, rec["fs"], rec["max_len"], rec["max_hypotheses"])
+        return
+    got = _beam_decode(lp, tr, P, rec["fs"], rec["max_len"], rec["max_hypotheses"])
+    _check(got, PZ[f"{nm}__score"][0], PZ[f"{nm}__labels"], PZ[f"{nm}__seg_label"], PZ[f"{nm}__seg_len"])
+
+
+def test_beam_decode_against_the_oracle_random_and_tied():
+    """Further seeded cases against the literal oracle (oracle/viterbi_oracle.c:dict_prune): small and large beams, integer-valued
+    emissions and length scores (ties everywhere), -inf length scores, frame_sampling 1 / 2 / 7 / 30, several videos per call."""
+    from mucon_amd.core.viterbi import SingleTranscriptGrammar, Viterbi
+    from mucon_amd.core.viterbi.viterbi import NoHypothesisError
+    rng = np.random.default_rng(7)
+    for fs in (1, 2, 7, 30):
+        J = int(rng.integers(3, 20))
+        max_len = J * fs + int(rng.integers(0, fs))
+        for mh in (1, 2, 5, 17, 60):
+            lps, trs, lms, wants = [], [], [], []
+            for i in range(6):
+                N = int(rng.integers(1, 9))
+                if mh >= N * J:
+                    N = mh // J + 1
+                K = int(rng.integers(1, J * N + 1))
+                T = K * fs + int(rng.integers(0, fs))
+                tr = rng.integers(0, C, N).astype(np.int32)
+                mode = i % 3
+                lp = (rng.integers(-3, 1, (T, C)).astype(np.float32) if mode == 0 else
+                      rng.standard_normal((T, C)).astype(np.float32) if mode == 1 else np.full((T, C), -1.0, np.float32))
+                P = rng.integers(-2, 1, (J, N)).astype(np.float64) if mode != 1 else rng.standard_normal((J, N))
+                P[rng.random((J, N)) < 0.1] = -np.inf
+                try:
+                    wants.append(oracle.viterbi_decode_table(lp, tr, P, fs, max_len, max_hypotheses=mh))
+                except oracle.OracleDecodeError as e:
+                    assert e.status == oracle.ST_NO_HYPOTHESIS
+                    wants.append(None)
+                lps.append(torch.from_numpy(lp).cuda())
+                trs.append([int(x) for x in tr])
+                lms.append(TableModel(P, max_len))
+            got = Viterbi(None, None, frame_sampling=fs, max_hypotheses=mh).decode_batch(lps, trs, lms, return_exceptions=True)
+            for g, w in zip(got, wants):
+                if w is None:
+                    assert isinstance(g, NoHypothesisError), g
+                else:
+                    _check(g, *w)
+
+
+def test_beam_decode_long_video_wide_beam():
+    """T = 9,741 / N = 30 (the longest Breakfast video) under beams of 100 and 1,000, and a config-5-sized video (T = 16,384, N = 64)
+    under 500, against the oracle."""
+    for T, N, mh, seed in ((9741, 30, 100, 1), (9741, 30, 1000, 2), (16384, 64, 500, 3)):
+        tr = synth.transcript(seed, N, C)
+        lp = synth.emissions(seed + 1, T, C, labels=synth.segment_labels(seed + 2, T, tr))
+        mu = np.full(C, float(T) / N)
+        P = oracle.length_rows(oracle.poisson_table(mu, MAXLEN), tr, FS, MAXLEN)
+        want = oracle.viterbi_decode_table(lp, tr, P, FS, MAXLEN, max_hypotheses=mh)
+        _check(_beam_decode(lp, tr, P, FS, MAXLEN, mh), *want)
+
+
+def test_beam_entry_argument_checks():
+    import ctypes
+
+    from mucon_amd import _lib
+    lib = _lib.load()
+    vids = (_lib.ViterbiVideo * 1)()
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 10, None, None, None, None, None) == _lib.E_ARG
+    sc, ns, st, sg = np.zeros(1), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(8, np.int32)
+    lp = torch.zeros(90, C, device="cuda")
+    tr, P = np.zeros(3, np.int32), np.zeros((66, 3))
+    q = vids[0]
+    q.lp, q.transcript, q.table, q.T, q.N, q.force_n, q.force_j = lp.data_ptr(), tr.ctypes.data, P.ctypes.data, 90, 3, -1, -1
+    args = (sc.ctypes.data, ns.ctypes.data, st.ctypes.data, sg.ctypes.data, None)
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 0, *args) == _lib.E_ARG           # 0 never prunes: the other entry
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 4094, *args) == _lib.E_ARG        # 4094 + 3 > 4096
+    assert lib.mucon_viterbi_decode_beam(1, vids, 65, FS, MAXLEN, 10, *args) == _lib.E_ARG
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, 1, 200, 10, *args) == _lib.E_ARG              # 200 length slots
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 10, *args) == _lib.OK and st[0] == _lib.VIT_OK and ns[0] == 3
+    q.T = 20
+    assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 10, *args) == _lib.OK and st[0] == _lib.VIT_INDEX_ERROR
+    del ctypes

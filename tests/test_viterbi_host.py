@@ -109,26 +109,39 @@ def test_wrapper_raises_like_reference():
         v._prepare(900)
 
 
-def test_max_hypotheses_never_prunes():
+def test_max_hypotheses_routing():
     """prune() (reference viterbi.py:74-79) only acts when more than max_hypotheses hypotheses are alive; a single transcript of N
-    states has at most N * (max_length // frame_sampling) of them, so from that bound on the decode is the unpruned one (checked
-    against the reference itself: tests/golden/viterbi_pruned.json, last record of every case).  Below the bound the reference
-    searches a beam; the HIP decoder searches everything and says so, once per process, in a RuntimeWarning."""
-    import warnings
-
+    states has at most N * (max_length // frame_sampling) of them: from that bound on (and for inf, and for 0 -- Python's tmp[0:-0] is
+    empty) the decode is the unpruned one and takes the ordinary kernels; below it the decode runs under the reference's beam
+    (csrc/viterbi_beam.hip).  A float max_hypotheses makes the reference's slice raise TypeError."""
     from mucon_amd.core.viterbi import PoissonModel, SingleTranscriptGrammar, Viterbi
     tr = [3, 7, 3, 1]
     mu = np.full(12, 200.0)
-    Viterbi._warned_no_pruning = False
-    for mh, warns in ((np.inf, False), (4 * 66, False), (10 ** 6, False), (4 * 66 - 1, True), (50, False)):     # (50: already said)
+    for mh, beam in ((np.inf, None), (4 * 66, None), (10 ** 6, None), (0, None), (4 * 66 - 1, 263), (50, 50), (np.int64(7), 7)):
         v = Viterbi(SingleTranscriptGrammar(tr, 12), PoissonModel(mu), frame_sampling=30, max_hypotheses=mh)
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
+        assert v._beam(len(tr)) == beam
+        if beam is None:
             t, P, force = v._prepare(900)
-        assert P.shape == (66, 4) and force is None
-        said = [x for x in w if issubclass(x.category, RuntimeWarning) and "max_hypotheses" in str(x.message)]
-        assert bool(said) == warns, (mh, [str(x.message) for x in w])
-    Viterbi._warned_no_pruning = False
+            assert P.shape == (66, 4) and force is None
+        else:
+            t, P = v._prepare_beam(900)
+            assert P.shape == (66, 4) and t.dtype == np.int32
+            with pytest.raises(IndexError):
+                v._prepare_beam(29)
+    for mh, exc in ((50.0, TypeError), (50.5, TypeError), (-3, ValueError)):
+        with pytest.raises(exc):
+            Viterbi(SingleTranscriptGrammar(tr, 12), PoissonModel(mu), frame_sampling=30, max_hypotheses=mh)._beam(len(tr))
+    long_tr = list(range(40)) + list(range(24))                  # N = 64: 64 x 66 = 4,224 hypotheses at most
+    v = Viterbi(SingleTranscriptGrammar(long_tr, 48), PoissonModel(np.full(48, 200.0)), frame_sampling=30, max_hypotheses=4100)
+    assert v._beam(64) == 4100
+    with pytest.raises(NotImplementedError, match="holds 4096"):
+        v._prepare_beam(9000)
+    mu_nan = mu.copy()
+    mu_nan[7] = 0.3                                              # mean length < 0.5: NaN length scores (length_model.py:56-58)
+    with np.errstate(all="ignore"):
+        v = Viterbi(SingleTranscriptGrammar(tr, 12), PoissonModel(mu_nan), frame_sampling=30, max_hypotheses=20)
+    with pytest.raises(NotImplementedError, match="NaN"):
+        v._prepare_beam(900)
 
 
 def test_the_beam_fixture_says_what_the_docs_say():
