@@ -18,7 +18,7 @@
  * Parity pin: tests/golden/viterbi_*.npz were produced by tools/make_golden.py importing the
  * reference itself in the build container; tests/test_oracle_viterbi.py checks this file
  * against every one of them (score bits, labels, segments).  The beam (max_hypotheses, prune():
- * viterbi.py:74-79) is restated too and pinned by tests/golden/viterbi_pruned.* (75 decodes of the
+ * viterbi.py:74-79) is restated too and pinned by tests/golden/viterbi_pruned.* (74 decodes of the
  * reference under finite beams, tools/make_golden_pruned.py).
  */
 #include <math.h>

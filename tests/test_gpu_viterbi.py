@@ -225,7 +225,7 @@ def _beam_decode(lp, tr, P, fs, max_len, mh):
 
 @pytest.mark.parametrize("rec", PMETA["cases"], ids=[r["name"] for r in PMETA["cases"]])
 def test_beam_decode_matches_the_references_beam(rec):
-    """Viterbi(max_hypotheses = M).decode through csrc/viterbi_beam.hip against the reference's own beam search (75 decodes,
+    """Viterbi(max_hypotheses = M).decode through csrc/viterbi_beam.hip against the reference's own beam search (74 decodes,
     tools/make_golden_pruned.py): score bits, labels, segments -- also where every score ties and the key tuples decide, at
     frame_sampling 1 and 7, where the beam loses every path into the last state (score -inf, truncated labelling of the last hypothesis
     in dict order) and where it loses every hypothesis (AttributeError)."""
