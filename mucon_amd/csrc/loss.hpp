@@ -1,4 +1,4 @@
-// The four MuCon losses and their gradients in five launches.
+// The four MuCon losses and their gradients in four launches.
 //   reference src/mucon/masks.py:8-74          project_lengths_softmax, create_masks (affine_grid + grid_sample)
 //   reference src/mucon/models.py:376-396      loss(): main = sum of multiplier * component
 //   reference src/mucon/models.py:398-412      smoothing loss (mse of consecutive rows, right side detached, clamp)
@@ -19,8 +19,9 @@
 //   scale = T / L, shift = (start' + L/2 - T/2) / (-L/2)
 // (create_masks rescales the lengths IN PLACE, so the "flint" division uses L, not A).
 //
-//   loss_prep_kernel   1 workgroup : segment geometry; transcript + length losses and their gradients
-//   loss_acc_kernel    T/32 wgs    : masks of 32 frames, partial windows / arithmetic sums / smoothing sums -> slabs
+//   loss_acc_kernel    T/32 wgs    : every workgroup derives the segment geometry itself (64 lanes of arithmetic; workgroup 0 also writes it out,
+//                                    with the transcript + length losses and their gradients: until r4 a launch of its own, loss_prep_kernel),
+//                                    then: masks of its 32 frames, partial windows / arithmetic sums / smoothing sums -> slabs
 //   loss_mid_kernel    1 workgroup : ordered slab reduction, per-segment log-softmax, the five loss values, d windows
 //   loss_grad_kernel   T/32 wgs    : d segmentation, d smoothing input, d mask -> partial d scale / d shift slabs
 //   loss_fin_kernel    1 workgroup : ordered slab reduction, chain through the geometry and the softmax -> d lengths
@@ -107,7 +108,9 @@ __device__ __forceinline__ void mask_sample(const float *tmpl, float scale, floa
     dval = t1 - t0;
 }
 
-__global__ __launch_bounds__(64) void loss_prep_kernel(LossDims d, LossBufs b) {
+// Wave 0 of every loss_acc_kernel workgroup (64 lanes; lane = segment).  s_geo [6][LOSS_MAXN]: L, scale, shift, start', p (softmax), w[target].
+// write_out: workgroup 0 -- the same values to b.geo, the transcript / length losses and the weight sum to b.small, and d_tlogp.
+__device__ __forceinline__ void loss_geometry(const LossDims &d, const LossBufs &b, float (*s_geo)[LOSS_MAXN], bool write_out) {
     const int lane = threadIdx.x;
     const int N = d.N;
     // absolute lengths = T softmax(lengths)
@@ -134,13 +137,14 @@ __global__ __launch_bounds__(64) void loss_prep_kernel(LossDims d, LossBufs b) {
     if (lane < N) {
         const int tg = (int)b.mtarget[lane];
         wt = b.mweight ? b.mweight[tg] : 1.f;
-        b.geo[0 * LOSS_MAXN + lane] = L;
-        b.geo[1 * LOSS_MAXN + lane] = scale;
-        b.geo[2 * LOSS_MAXN + lane] = shift;
-        b.geo[3 * LOSS_MAXN + lane] = startp;
-        b.geo[4 * LOSS_MAXN + lane] = p;
-        b.geo[5 * LOSS_MAXN + lane] = wt;
+        const float v[6] = {L, scale, shift, startp, p, wt};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            s_geo[k][lane] = v[k];
+            if (write_out) b.geo[k * LOSS_MAXN + lane] = v[k];
+        }
     }
+    if (!write_out) return;
     const float wsum = loss_wave_sum(lane < N ? wt : 0.f);
     // length loss: relu(s - w).sum() + relu(-w - s).sum()
     float ll = 0.f;
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(64) void loss_prep_kernel(LossDims d, LossBufs b) {
 
 // grid (chunks), 256 threads.  LDS: seg chunk [FB][M], masks [N][FB]
 __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
+    __shared__ float s_geo[6][LOSS_MAXN];
     __shared__ float s_seg[LOSS_FB][LOSS_MAXM + 1];
     __shared__ float s_mask[LOSS_MAXN][LOSS_FB + 1];
     __shared__ float s_lse[LOSS_FB];
@@ -183,6 +188,8 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     const int tid = threadIdx.x, t0 = blockIdx.x * LOSS_FB;
     const int T = d.T, M = d.M, N = d.N;
     const int nf = min(LOSS_FB, T - t0);
+    if (tid < 64) loss_geometry(d, b, s_geo, blockIdx.x == 0);
+    __syncthreads();
     for (int e = tid; e < LOSS_FB * M; e += 256) {
         const int f = e / M, m = e - f * M;
         s_seg[f][m] = f < nf ? b.seg[(long)(t0 + f) * M + m] : 0.f;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     for (int e = tid; e < N * LOSS_FB; e += 256) {
         const int n = e / LOSS_FB, f = e - n * LOSS_FB;
         float v = 0.f, dv, xb;
-        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, d.align_corners, v, dv, xb);
+        if (f < nf) mask_sample(b.tmpl, s_geo[1][n], s_geo[2][n], t0 + f, T, d.align_corners, v, dv, xb);
         s_mask[n][f] = v;
     }
     // smoothing partial: sum over the chunk's frames t (t + 1 < T) of (x[t+1] - x[t])^2
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
             const int n = e / LOSS_FB, f = e - n * LOSS_FB;
             if (f < nf) {
                 const int tg = (int)b.mtarget[n];
-                acc += s_mask[n][f] * (-b.geo[5 * LOSS_MAXN + n] * (s_seg[f][tg] - s_lse[f]));
+                acc += s_mask[n][f] * (-s_geo[5][n] * (s_seg[f][tg] - s_lse[f]));
             }
         }
         acc = loss_wave_sum(acc);

@@ -411,7 +411,6 @@ extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmen
     b.d_lengths = d_lengths;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int chunks = (cfg->T + LOSS_FB - 1) / LOSS_FB;
-    hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(64), 0, s, d, b);
     hipLaunchKernelGGL(loss_acc_kernel, dim3(chunks), dim3(256), 0, s, d, b);
     hipLaunchKernelGGL(loss_mid_kernel, dim3(1), dim3(256), 0, s, d, b, chunks);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks), dim3(256), 0, s, d, b);
