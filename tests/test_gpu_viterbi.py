@@ -281,8 +281,8 @@ def test_beam_decode_against_the_oracle_random_and_tied():
 
 def test_beam_decode_long_video_wide_beam():
     """T = 9,741 / N = 30 (the longest Breakfast video) under beams of 100 and 1,000, and a config-5-sized video (T = 16,384, N = 64)
-    under 500, against the oracle."""
-    for T, N, mh, seed in ((9741, 30, 100, 1), (9741, 30, 1000, 2), (16384, 64, 500, 3)):
+    under 500 and 4,000 (the list nearly full), a one-state transcript, a one-column video, against the oracle."""
+    for T, N, mh, seed in ((9741, 30, 100, 1), (9741, 30, 1000, 2), (16384, 64, 500, 3), (16384, 64, 4000, 4), (2000, 1, 20, 5), (45, 3, 2, 6)):
         tr = synth.transcript(seed, N, C)
         lp = synth.emissions(seed + 1, T, C, labels=synth.segment_labels(seed + 2, T, tr))
         mu = np.full(C, float(T) / N)
