@@ -50,7 +50,7 @@ static int vit_fail(int code, const char *fmt, ...) {
 
 namespace {
 
-constexpr int VB_T = 256;
+constexpr int VB_T = 256;          // (the radix select clears its 256 histogram bins with one store per thread)
 constexpr int VB_MAX_ITEMS = MUCON_VIT_BEAM_MAX_ITEMS;
 constexpr int VB_MAX_N = 128, VB_MAX_J = 128, VB_MAX_C = 64;
 
@@ -355,6 +355,7 @@ struct VbState {
     std::mutex mu;
     char *dev = nullptr, *pin = nullptr;
     size_t dev_cap = 0, pin_cap = 0;
+    int device = -1;          // the device `dev` lives on and the kernel attribute was set for
     bool attr_set = false;
 };
 VbState g_vb;
@@ -400,6 +401,20 @@ extern "C" int mucon_viterbi_decode_beam(int32_t n_videos, const mucon_viterbi_v
     const size_t o_score = vb_al(o_tab + 8 * (size_t)J * sum_N), o_nseg = vb_al(o_score + 8 * (size_t)n_videos), o_stat = vb_al(o_nseg + 4 * (size_t)n_videos);
     const size_t o_seg = vb_al(o_stat + 4 * (size_t)n_videos), o_ws = vb_al(o_seg + 4 * sum_N), total = o_ws + ws_bytes;
     std::lock_guard<std::mutex> lock(g_vb.mu);
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess) return vit_fail(MUCON_E_HIP, "viterbi beam: hipGetDevice failed");
+    if (cur_dev != g_vb.device) {          // another device than last time: its own scratch, its own kernel attribute
+        if (g_vb.dev) {
+            const int old_dev = g_vb.device;
+            (void)hipSetDevice(old_dev);
+            (void)hipFree(g_vb.dev);
+            (void)hipSetDevice(cur_dev);
+        }
+        g_vb.dev = nullptr;
+        g_vb.dev_cap = 0;
+        g_vb.attr_set = false;
+        g_vb.device = cur_dev;
+    }
     int rc = vb_grow(&g_vb.dev, &g_vb.dev_cap, total, false);
     if (rc != MUCON_OK) return rc;
     rc = vb_grow(&g_vb.pin, &g_vb.pin_cap, o_ws, true);
