@@ -1,0 +1,132 @@
+"""GPU fuzz tests against the oracles: seeded random cases beyond the fixed lists of the other test files.  The default sizes keep the three
+tests at a few seconds each; MUCON_FUZZ=k multiplies the iteration counts and MUCON_FUZZ_SEED moves the seeds (round 4 ran k = 5 .. 10 on
+several seeds: 14,837 decodes without a beam, 9,028 under beams, 164 dense forward / backward cases -- 0 mismatches).
+
+  * the Viterbi decode without a beam (csrc/viterbi.hip through Viterbi.decode_batch: 1 .. 12 videos per call, so the latency kernels and the
+    throughput kernels; frame_sampling 1 .. 30, 2 .. 66 length slots, fewer columns than states, integer-valued / constant / zero / Gaussian
+    emissions and length scores -- ties everywhere -- and -inf entries) against the literal C oracle: score bits, labels, segments, errors;
+  * the decode under the reference's beam (csrc/viterbi_beam.hip) against the oracle's literal prune();
+  * encoder + y-head forward and backward against the float64 oracle at random (B, T, config) on both sides of every kernel-selection
+    threshold (tests/test_gpu_dense.py's two oracle tests, called with random arguments)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import C, f64_bits
+
+pytestmark = pytest.mark.gpu
+SCALE = max(1, int(os.environ.get("MUCON_FUZZ", "1")))
+SEED = int(os.environ.get("MUCON_FUZZ_SEED", "0"))
+
+
+class _Table:
+    def __init__(self, P, max_len):
+        self.P, self.max_len = P, max_len
+
+    def max_length(self):
+        return self.max_len
+
+    def rows_for(self, transcript, fs):
+        return self.P
+
+
+def _emissions_and_table(rng, T, J, N, inf_rate):
+    mode = int(rng.integers(0, 4))
+    lp = (rng.integers(-3, 1, (T, C)).astype(np.float32) if mode == 0 else rng.standard_normal((T, C)).astype(np.float32) if mode == 1
+          else np.full((T, C), -1.0, np.float32) if mode == 2 else np.zeros((T, C), np.float32))
+    P = rng.integers(-2, 1, (J, N)).astype(np.float64) if mode != 1 else rng.standard_normal((J, N))
+    if mode == 3:
+        P = np.zeros((J, N))
+    P[rng.random((J, N)) < inf_rate] = -np.inf
+    return lp, P
+
+
+def test_viterbi_decode_fuzz():
+    from mucon_amd.core.viterbi import Viterbi
+    from mucon_amd.core.viterbi.viterbi import NoHypothesisError, ShortSequenceError
+    rng = np.random.default_rng(100 + SEED)
+    n = 0
+    for it in range(150 * SCALE):
+        fs = int(rng.choice([1, 2, 3, 7, 30]))
+        J = int(rng.integers(2, 67))
+        max_len = J * fs + int(rng.integers(0, fs))
+        lps, trs, lms, wants = [], [], [], []
+        for v in range(int(rng.choice([1, 1, 2, 3, 8, 9, 12]))):
+            N = int(rng.integers(1, 21))
+            K = int(rng.integers(1, min(J * N, 400) + 1))
+            T = K * fs + int(rng.integers(0, fs))
+            tr = rng.integers(0, C, N).astype(np.int32)
+            lp, P = _emissions_and_table(rng, T, J, N, 0.05)
+            try:
+                w = oracle.viterbi_decode_table(lp, tr, P, fs, max_len)
+            except oracle.OracleDecodeError as e:
+                w = e.status
+            lps.append(torch.from_numpy(lp).cuda())
+            trs.append([int(x) for x in tr])
+            lms.append(_Table(P, max_len))
+            wants.append(w)
+        got = Viterbi(None, None, frame_sampling=fs).decode_batch(lps, trs, lms, return_exceptions=True)
+        for g, w, lp in zip(got, wants, lps):
+            n += 1
+            where = (it, fs, J, tuple(lp.shape))
+            if isinstance(w, int):
+                assert isinstance(g, NoHypothesisError if w == oracle.ST_NO_HYPOTHESIS else ShortSequenceError), where
+            else:
+                assert not isinstance(g, Exception), (where, g)
+                assert f64_bits(g[0]) == f64_bits(w[0]), (where, g[0], w[0])
+                np.testing.assert_array_equal(np.asarray(g[1]), w[1], err_msg=str(where))
+                assert [s.length for s in g[2]] == w[3].tolist() and [s.label for s in g[2]] == w[2].tolist(), where
+    assert n >= 150 * SCALE
+
+
+def test_beam_decode_fuzz():
+    from mucon_amd import _lib, ops
+    rng = np.random.default_rng(200 + SEED)
+    n = 0
+    for it in range(250 * SCALE):
+        fs = int(rng.choice([1, 2, 3, 7, 30]))
+        J = int(rng.integers(2, 40))
+        max_len = J * fs + int(rng.integers(0, fs))
+        mh = int(rng.choice([1, 2, 3, 5, 9, 20, 50, 150]))
+        lps, trs, Ps, wants = [], [], [], []
+        for v in range(int(rng.integers(1, 6))):
+            N = int(rng.integers(1, 12))
+            K = int(rng.integers(1, J * N + 2))
+            T = K * fs + int(rng.integers(0, fs))
+            tr = rng.integers(0, C, N).astype(np.int32)
+            lp, P = _emissions_and_table(rng, T, J, N, 0.1)
+            try:
+                w = oracle.viterbi_decode_table(lp, tr, P, fs, max_len, max_hypotheses=mh)
+            except oracle.OracleDecodeError as e:
+                w = e.status
+            lps.append(torch.from_numpy(lp).cuda())
+            trs.append(tr)
+            Ps.append(P)
+            wants.append(w)
+        for r, w, lp in zip(ops.viterbi_decode_beam(lps, trs, Ps, fs, max_len, mh), wants, lps):
+            n += 1
+            where = (it, fs, J, mh, tuple(lp.shape))
+            if isinstance(w, int):
+                assert w == oracle.ST_NO_HYPOTHESIS and r.status == _lib.VIT_NO_HYPOTHESIS, (where, w, r)
+            else:
+                assert r.status in (_lib.VIT_OK, _lib.VIT_TRUNCATED) and f64_bits(r.score) == f64_bits(w[0]), (where, r, w[0])
+                np.testing.assert_array_equal(r.seg_len, w[3], err_msg=str(where))
+                np.testing.assert_array_equal(r.labels, w[1], err_msg=str(where))
+    assert n >= 250 * SCALE
+
+
+def test_dense_forward_backward_fuzz():
+    import test_gpu_dense as td
+    rng = np.random.default_rng(300 + SEED)
+    overs = [{}, {}, {}, {"pooling_type": "sum"}, {"leaky_relu": True}, {"last_gn": False}, {"last_relu": False}, {"last_gn_num_groups": 16}]
+    for i in range(6 * SCALE):
+        B = int(rng.choice([1, 1, 2, 3, 4, 8]))
+        rows = int(rng.choice([rng.integers(16, 400), rng.integers(400, 4200), rng.integers(4000, 8300), rng.integers(8000, 17000),
+                               rng.integers(16000, 34000)]))
+        T = max(16, rows // B + int(rng.integers(0, 3)))
+        over = overs[int(rng.integers(0, len(overs)))]
+        td.test_forward_matches_oracle_f64(B, T, over)
+        td.test_backward_matches_oracle_f64(B, T, over)
