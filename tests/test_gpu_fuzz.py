@@ -1,13 +1,14 @@
 """GPU fuzz tests against the oracles: seeded random cases beyond the fixed lists of the other test files.  The default sizes keep the three
 tests at a few seconds each; MUCON_FUZZ=k multiplies the iteration counts and MUCON_FUZZ_SEED moves the seeds (round 4 ran k = 5 .. 10 on
-several seeds: 14,837 decodes without a beam, 9,028 under beams, 164 dense forward / backward cases -- 0 mismatches).
+several seeds: 14,837 decodes without a beam, 9,028 under beams, 164 dense and 64 s-head forward / backward cases -- 0 mismatches).
 
   * the Viterbi decode without a beam (csrc/viterbi.hip through Viterbi.decode_batch: 1 .. 12 videos per call, so the latency kernels and the
     throughput kernels; frame_sampling 1 .. 30, 2 .. 66 length slots, fewer columns than states, integer-valued / constant / zero / Gaussian
     emissions and length scores -- ties everywhere -- and -inf entries) against the literal C oracle: score bits, labels, segments, errors;
   * the decode under the reference's beam (csrc/viterbi_beam.hip) against the oracle's literal prune();
   * encoder + y-head forward and backward against the float64 oracle at random (B, T, config) on both sides of every kernel-selection
-    threshold (tests/test_gpu_dense.py's two oracle tests, called with random arguments)."""
+    threshold (tests/test_gpu_dense.py's two oracle tests, called with random arguments);
+  * the s-head forward and backward against the float64 formulas of oracle/shead.py at random sizes."""
 import os
 
 import numpy as np
@@ -130,3 +131,17 @@ def test_dense_forward_backward_fuzz():
         over = overs[int(rng.integers(0, len(overs)))]
         td.test_forward_matches_oracle_f64(B, T, over)
         td.test_backward_matches_oracle_f64(B, T, over)
+
+
+def test_shead_forward_backward_fuzz():
+    """The s-head (persistent biLSTM + attention decoder, forward and backward) against the float64 formulas of oracle/shead.py at random
+    memory lengths (1 .. 250: the eight-workgroup kernels up to 192 states, the one-workgroup kernels above and for one direction), transcript
+    lengths, class counts, with / without teacher forcing and an embedding-dropout mask (tests/test_gpu_shead.py's oracle test, random arguments)."""
+    import test_gpu_shead as ts
+    rng = np.random.default_rng(400 + SEED)
+    for i in range(8 * SCALE):
+        Tz = int(rng.choice([rng.integers(1, 8), rng.integers(8, 130), rng.integers(120, 193), rng.integers(193, 251)]))
+        N = int(rng.integers(1, 31))
+        bidir = bool(rng.random() < 0.8)
+        classes = int(rng.choice([7, 16, 48, 100]))
+        ts.test_against_float64_oracle(Tz, N, bidir, classes, bool(rng.random() < 0.6), bool(rng.random() < 0.5))
