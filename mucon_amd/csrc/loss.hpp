@@ -59,6 +59,7 @@ struct LossBufs {
     float *d_seg, *d_sx, *d_tlogp, *d_lengths;
     // workspace
     float *geo;              // [6][LOSS_MAXN]: L, scale, shift, start', p (softmax), w[target]
+    double *geod;            // [2][LOSS_MAXN]: scale, shift in double (what the masks are sampled with)
     float *small;            // [8]: transcript loss, length loss, sum of mucon weights
     float *slab;             // [chunks][N*M + 2]  (windows partials | arithmetic partial | smoothing partial)
     float *gwin;             // [N][M] d loss / d (mask-sum), already divided by L and scaled
@@ -68,6 +69,11 @@ struct LossBufs {
 };
 
 __device__ __forceinline__ float loss_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double loss_wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
     return v;
@@ -93,13 +99,20 @@ __device__ __forceinline__ float loss_ordered_sum(const float *p, long stride, i
 // (align_corners: base grid linspace(-1, 1, T) and ix = (x + 1) / 2 * (W - 1), the corner pixels' CENTRES at -1 and 1; otherwise
 // the half-pixel forms.  d ix / d x is mask_dix(ac).)
 __device__ __forceinline__ float mask_dix(int ac) { return ac ? (float)(LOSS_TW - 1) * 0.5f : (float)LOSS_TW * 0.5f; }
-__device__ __forceinline__ void mask_sample(const float *tmpl, float scale, float shift, int t, int T, int ac, float &val, float &dval,
+// The sampling coordinate in DOUBLE (r4).  A segment of L frames maps a frame step to 100 / L template samples, and the gradient of a bilinearly
+// sampled template w.r.t. the coordinate is piecewise constant: a frame whose ix sits within float32 rounding of a sample point (the start of
+// a segment is a float32 cumsum of lengths up to T ~ 1e4, ulp 1e-3 frames = 4e-3 samples at L = 24) takes the slope of the wrong interval, and
+// with two dozen frames per segment one such frame moved d lengths by 1 % (found by tests/test_gpu_fuzz.py: gaussian template, 49 segments,
+// T = 10,965; torch's float32 path has the same sensitivity, at other frames).  In double the kernels sample what the float64 oracle samples.
+__device__ __forceinline__ void mask_sample(const float *tmpl, double scale, double shift, int t, int T, int ac, float &val, float &dval,
                                             float &xb) {
-    xb = ac ? (T > 1 ? 2.f * (float)t / (float)(T - 1) - 1.f : 0.f) : (2.f * (float)t + 1.f) / (float)T - 1.f;
-    const float x = scale * xb + shift;
-    const float ix = ac ? (x + 1.f) * 0.5f * (float)(LOSS_TW - 1) : ((x + 1.f) * (float)LOSS_TW - 1.f) * 0.5f;
-    const float f0 = floorf(ix);
-    const float fx = ix - f0;
+    const double xbd = ac ? (T > 1 ? 2.0 * (double)t / (double)(T - 1) - 1.0 : 0.0) : (2.0 * (double)t + 1.0) / (double)T - 1.0;
+    xb = (float)xbd;
+    const double x = scale * xbd + shift;
+    const double ixd = ac ? (x + 1.0) * 0.5 * (double)(LOSS_TW - 1) : ((x + 1.0) * (double)LOSS_TW - 1.0) * 0.5;
+    const double f0d = floor(ixd);
+    const float f0 = (float)fmin(fmax(f0d, -4.0), (double)LOSS_TW + 4.0);
+    const float fx = (float)(ixd - f0d);
     // clamp before the int conversion: far-away segments give huge |ix|
     const int i0 = (int)fminf(fmaxf(f0, -2.f), (float)LOSS_TW + 1.f);
     const float t0 = (i0 >= 0 && i0 < LOSS_TW) ? tmpl[i0] : 0.f;
@@ -110,29 +123,37 @@ __device__ __forceinline__ void mask_sample(const float *tmpl, float scale, floa
 
 // Wave 0 of every loss_acc_kernel workgroup (64 lanes; lane = segment).  s_geo [6][LOSS_MAXN]: L, scale, shift, start', p (softmax), w[target].
 // write_out: workgroup 0 -- the same values to b.geo, the transcript / length losses and the weight sum to b.small, and d_tlogp.
-__device__ __forceinline__ void loss_geometry(const LossDims &d, const LossBufs &b, float (*s_geo)[LOSS_MAXN], bool write_out) {
+__device__ __forceinline__ void loss_geometry(const LossDims &d, const LossBufs &b, float (*s_geo)[LOSS_MAXN], double (*s_geod)[LOSS_MAXN], bool write_out) {
     const int lane = threadIdx.x;
     const int N = d.N;
-    // absolute lengths = T softmax(lengths)
+    // absolute lengths = T softmax(lengths); start = cumsum(A) - A; scale / shift of the sampling grid -- in double (see mask_sample)
     const float l = lane < N ? b.lengths[lane] : -INFINITY;
-    float mx = l;
+    double mxd = (double)l;
 #pragma unroll
-    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float e = lane < N ? expf(l - mx) : 0.f;
-    const float p = e / loss_wave_sum(e);
-    const float A = (float)d.T * p;
-    // start = cumsum(A) - A   (inclusive scan in lane order, as torch.cumsum)
-    float cs = A;
+    for (int o = 32; o; o >>= 1) mxd = fmax(mxd, __shfl_xor(mxd, o));
+    const double ed = lane < N ? exp((double)l - mxd) : 0.0;
+    const double pd = ed / loss_wave_sum_d(ed);
+    const double Ad = (double)d.T * pd;
+    double csd = Ad;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const float up = __shfl_up(cs, o);
-        if (lane >= o) cs += up;
+        const double up = __shfl_up(csd, o);
+        if (lane >= o) csd += up;
     }
-    const float start = cs - A;
-    const float L = A * (1.f + 2.f * d.overlap);
-    const float startp = start - L * (d.overlap * 0.5f);
-    const float scale = (float)d.T / L;
-    const float shift = (startp + L * 0.5f - (float)d.T * 0.5f) / (-(L * 0.5f));
+    const double startd = csd - Ad;
+    const double Ld = Ad * (1.0 + 2.0 * (double)d.overlap);
+    const double startpd = startd - Ld * ((double)d.overlap * 0.5);
+    const double scaled = (double)d.T / Ld;
+    const double shiftd = (startpd + Ld * 0.5 - (double)d.T * 0.5) / (-(Ld * 0.5));
+    const float p = (float)pd, L = (float)Ld, startp = (float)startpd, scale = (float)scaled, shift = (float)shiftd;
+    if (lane < N) {
+        s_geod[0][lane] = scaled;
+        s_geod[1][lane] = shiftd;
+        if (write_out) {
+            b.geod[lane] = scaled;
+            b.geod[LOSS_MAXN + lane] = shiftd;
+        }
+    }
     float wt = 1.f;
     if (lane < N) {
         const int tg = (int)b.mtarget[lane];
@@ -181,6 +202,7 @@ __device__ __forceinline__ void loss_geometry(const LossDims &d, const LossBufs 
 // grid (chunks), 256 threads.  LDS: seg chunk [FB][M], masks [N][FB]
 __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     __shared__ float s_geo[6][LOSS_MAXN];
+    __shared__ double s_geod[2][LOSS_MAXN];
     __shared__ float s_seg[LOSS_FB][LOSS_MAXM + 1];
     __shared__ float s_mask[LOSS_MAXN][LOSS_FB + 1];
     __shared__ float s_lse[LOSS_FB];
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     const int tid = threadIdx.x, t0 = blockIdx.x * LOSS_FB;
     const int T = d.T, M = d.M, N = d.N;
     const int nf = min(LOSS_FB, T - t0);
-    if (tid < 64) loss_geometry(d, b, s_geo, blockIdx.x == 0);
+    if (tid < 64) loss_geometry(d, b, s_geo, s_geod, blockIdx.x == 0);
     __syncthreads();
     for (int e = tid; e < LOSS_FB * M; e += 256) {
         const int f = e / M, m = e - f * M;
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     for (int e = tid; e < N * LOSS_FB; e += 256) {
         const int n = e / LOSS_FB, f = e - n * LOSS_FB;
         float v = 0.f, dv, xb;
-        if (f < nf) mask_sample(b.tmpl, s_geo[1][n], s_geo[2][n], t0 + f, T, d.align_corners, v, dv, xb);
+        if (f < nf) mask_sample(b.tmpl, s_geod[0][n], s_geod[1][n], t0 + f, T, d.align_corners, v, dv, xb);
         s_mask[n][f] = v;
     }
     // smoothing partial: sum over the chunk's frames t (t + 1 < T) of (x[t+1] - x[t])^2
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
     for (int e = tid; e < N * LOSS_FB; e += 256) {
         const int n = e / LOSS_FB, f = e - n * LOSS_FB;
         float v = 0.f, dv = 0.f, xb = 0.f;
-        if (f < nf) mask_sample(b.tmpl, b.geo[1 * LOSS_MAXN + n], b.geo[2 * LOSS_MAXN + n], t0 + f, T, d.align_corners, v, dv, xb);
+        if (f < nf) mask_sample(b.tmpl, b.geod[n], b.geod[LOSS_MAXN + n], t0 + f, T, d.align_corners, v, dv, xb);
         s_mask[n][f] = v;
         s_dmask[n][f] = dv;
         if (n == 0) s_xb[f] = xb;

@@ -345,9 +345,10 @@ static size_t loss_layout(const mucon_loss_cfg *c, float *base, LossBufs *b) {
     };
     const size_t chunks = (c->T + LOSS_FB - 1) / LOSS_FB, NM = (size_t)c->N * c->M;
     float *geo = take(6 * LOSS_MAXN), *small = take(8), *slab = take(chunks * (NM + 2)), *gwin = take(NM);
-    float *glwin = take(LOSS_MAXN), *gsm = take(1), *gslab = take(chunks * c->N * 2);
+    float *glwin = take(LOSS_MAXN), *gsm = take(1), *gslab = take(chunks * c->N * 2), *geod = take(4 * LOSS_MAXN);
     if (b) {
         b->geo = geo;
+        b->geod = reinterpret_cast<double *>(geod);
         b->small = small;
         b->slab = slab;
         b->gwin = gwin;

@@ -145,3 +145,41 @@ def test_shead_forward_backward_fuzz():
         bidir = bool(rng.random() < 0.8)
         classes = int(rng.choice([7, 16, 48, 100]))
         ts.test_against_float64_oracle(Tz, N, bidir, classes, bool(rng.random() < 0.6), bool(rng.random() < 0.5))
+
+
+def test_losses_fuzz():
+    """The four losses and their gradients (csrc/loss.hpp) against the float64 formulation of oracle/losses.py at random (frames, segments,
+    classes, config): both mucon types, the three templates, overlap, smoothing on logits / log-probs, both align_corners conventions.
+    Tolerances as in tests/test_gpu_losses.py, except for the gradient of the length logits with many segments: there float32 itself is
+    the limit (the softmax backward subtracts nearly equal numbers) -- the oracle's own formulas evaluated in float32, i.e. what the
+    reference computes, are 2.5e-4 .. 9e-4 from float64 at 48 .. 64 segments -- so the kernels must stay within 5e-4 or twice that distance."""
+    import test_gpu_losses as tl
+    from oracle import losses
+    rng = np.random.default_rng(500 + SEED)
+    for i in range(12 * SCALE):
+        T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 3000), rng.integers(3000, 12000)]))
+        N = int(rng.integers(1, 65))
+        M = int(rng.choice([3, 16, 48, 64]))
+        over = ["model.loss.mucon.type", str(rng.choice(["flint", "arithmetic"])), "model.loss.mucon.template", str(rng.choice(["box", "gaussian", "trapezoid"])),
+                "model.loss.mucon.overlap", float(rng.choice([0.0, 0.1, 0.3])), "model.loss.smoothing.log_softmax_before", bool(rng.random() < 0.5),
+                "model.loss.smoothing.clamp", bool(rng.random() < 0.5), "model.loss.mucon.align_corners", bool(rng.random() < 0.5)]
+        ocfg = losses.LossConfig.from_overrides(over)
+        g = torch.Generator().manual_seed(T + N)
+        seg = ((torch.rand((T, M), generator=g) * 2 - 1) * 3).float()
+        tlp = torch.log_softmax(((torch.rand((N + 1, M + 1), generator=g) * 2 - 1) * 2).double(), dim=1).float()
+        ln = ((torch.rand((N,), generator=g) * 2 - 1) * 2).float()
+        mt = torch.randint(0, M, (N,), generator=g)
+        tt = torch.cat([mt, torch.tensor([M])])
+        a = [seg.double().requires_grad_(True), tlp.double().requires_grad_(True), ln.double().requires_grad_(True)]
+        want = losses.loss(ocfg, a[0], a[1], a[2], mt, tt)
+        want[0].backward()
+        a32 = [seg.clone().requires_grad_(True), tlp.clone().requires_grad_(True), ln.clone().requires_grad_(True)]
+        losses.loss(ocfg, a32[0], a32[1], a32[2], mt, tt)[0].backward()
+        b = [seg.cuda().requires_grad_(True), tlp.cuda().requires_grad_(True), ln.cuda().requires_grad_(True)]
+        main, parts = tl._hip_loss(ocfg, b[0], b[1], b[2], mt.cuda(), tt.cuda())
+        where = (T, N, M, over)
+        np.testing.assert_allclose(np.asarray([main.item()] + parts.tolist()), [float(v.detach()) for v in want], rtol=3e-5, atol=2e-6, err_msg=str(where))
+        main.backward()
+        assert tl._rel(b[0].grad, a[0].grad) < 5e-4, where
+        assert tl._rel(b[1].grad, a[1].grad) < 1e-5, where
+        assert tl._rel(b[2].grad, a[2].grad) < max(5e-4, 2.0 * tl._rel(a32[2].grad, a[2].grad)), where
