@@ -183,3 +183,49 @@ def test_losses_fuzz():
         assert tl._rel(b[0].grad, a[0].grad) < 5e-4, where
         assert tl._rel(b[1].grad, a[1].grad) < 1e-5, where
         assert tl._rel(b[2].grad, a[2].grad) < max(5e-4, 2.0 * tl._rel(a32[2].grad, a[2].grad)), where
+
+
+def test_metrics_fuzz():
+    """The device metric counters (MoF / IoD / IoU / edit / F1 in one launch, csrc/metrics.hip) against the host metric classes (the reference's
+    formulas, mucon_amd/core/metrics) on random labelling pairs: 1 .. 6,000 frames, 1 .. 48 classes, runs of 1 .. 500 frames, predictions that are
+    noisy copies of the target, several ignore sets -- bit for bit."""
+    from mucon_amd.core.metrics import Edit, F1Score, IoDMetric, IoUMetric, MoFAccuracyMetric
+    from mucon_amd.core.metrics.device import segmental_counters
+    rng = np.random.default_rng(600 + SEED)
+
+    def labelling(T, ncls, run):
+        out = []
+        while len(out) < T:
+            out += [int(rng.integers(0, ncls))] * int(max(1, rng.poisson(run)))
+        return np.asarray(out[:T], dtype=np.int64)
+
+    for it in range(6 * SCALE):
+        ignore = [(), (0,), (0, 3), (1, 2, 5)][int(rng.integers(0, 4))]
+        pairs = []
+        for _ in range(int(rng.integers(1, 24))):
+            T = int(rng.choice([rng.integers(1, 20), rng.integers(20, 1500), rng.integers(1500, 6000)]))
+            ncls = int(rng.integers(1, 49))
+            t = labelling(T, ncls, float(rng.choice([1, 3, 20, 120, 500])))
+            if rng.random() < 0.5:                                   # a noisy copy: shifted boundaries, some frames re-labelled
+                p = np.roll(t, int(rng.integers(-30, 31)))
+                flip = rng.random(T) < 0.05
+                p = np.where(flip, rng.integers(0, ncls, T), p)
+            else:
+                p = labelling(T, ncls, float(rng.choice([1, 3, 20, 120, 500])))
+            pairs.append((t, p.astype(np.int64)))
+        got = segmental_counters([torch.from_numpy(t).cuda() for t, _ in pairs], [torch.from_numpy(p).cuda() for _, p in pairs], ignore)
+        for (t, p), g in zip(pairs, got):
+            if g.get("over_limit"):
+                continue                                             # more than 1,024 runs: the caller scores such a pair on the host
+            mof, mof_i = MoFAccuracyMetric(), MoFAccuracyMetric(ignore_ids=ignore)
+            mof.add(t, p), mof_i.add(t, p)
+            assert (g["correct"], g["total"], g["correct_nbg"], g["total_nbg"]) == (mof.correct, mof.total, mof_i.correct, mof_i.total)
+            with np.errstate(all="ignore"):
+                for key, metric in (("iod", IoDMetric()), ("iou", IoUMetric()), ("iod_nbg", IoDMetric(ignore_ids=ignore)), ("iou_nbg", IoUMetric(ignore_ids=ignore))):
+                    want = metric.add(targets=t, predictions=p)
+                    assert (np.isnan(want) and np.isnan(g[key])) or np.float64(want).tobytes() == np.float64(g[key]).tobytes(), (key, want, g[key], len(t), ignore)
+                want = Edit().add(targets=t, predictions=p)
+                assert np.float64(want).tobytes() == np.float64(g["edit"]).tobytes(), (want, g["edit"], len(t))
+            f1 = F1Score()
+            f1.add(targets=t, predictions=p)
+            assert [x[0] for x in g["f1"]] == f1.tp and [x[1] for x in g["f1"]] == f1.fp and [x[2] for x in g["f1"]] == f1.fn, (len(t), ignore)
