@@ -229,3 +229,49 @@ def test_metrics_fuzz():
             f1 = F1Score()
             f1.add(targets=t, predictions=p)
             assert [x[0] for x in g["f1"]] == f1.tp and [x[1] for x in g["f1"]] == f1.fp and [x[2] for x in g["f1"]] == f1.fn, (len(t), ignore)
+
+
+def test_evaluation_fuzz():
+    """MuConEvaluator: the batched path (pooled round trips, trimmed evaluation forward, one Viterbi launch and one metrics launch per chunk) against
+    the one-video-at-a-time path on random test sets -- videos of 40 .. 5,000 frames, random model seeds and EOS biases (how soon the untrained
+    s-head stops decoding: videos that end at the first word are skipped by both), chunk sizes 1 .. 7: every result field and saved list equal."""
+    import test_gpu_eval_batched as te
+    from mucon_amd import synth
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.core.datasets import Batch
+    from mucon_amd.mucon.evaluators import RESULT_FIELDS, MuConEvaluator
+    from mucon_amd.mucon.models import create_model
+    rng = np.random.default_rng(700 + SEED)
+    dev = "cuda:0"
+    cfg = update_config(get_cfg_defaults(), [], [])
+    for it in range(2 * SCALE):
+        torch.manual_seed(int(rng.integers(0, 1 << 30)))
+        model = create_model(cfg, C, int(rng.integers(4, 12)), 2048).to(dev)
+        with torch.no_grad():
+            model.fs_decoder_transcript[2].bias[C] = float(rng.choice([-20.0, -3.0, -0.5, 0.3]))
+        db = te._Videos(0, C, dev, 0)
+        for v in range(int(rng.integers(3, 10))):
+            T = int(rng.choice([rng.integers(40, 150), rng.integers(150, 1500), rng.integers(1500, 5000)]))
+            N = int(rng.integers(1, 8))
+            tr = synth.transcript(int(rng.integers(0, 10 ** 6)), N, C, allow_repeats=False)
+            db.items.append(Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(int(rng.integers(0, 10 ** 6)), T, tr)),
+                                  transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
+                                  transcript_tf_target=torch.tensor(tr.tolist() + [C]), video_name=f"v{v}").to(dev))
+        records = []
+        for batched in (False, True):
+            ev = MuConEvaluator(cfg, db, model, dev)
+            ev.batched, ev.chunk_videos = batched, int(rng.integers(1, 8))
+            ev.viterbi_mode(bool(it % 2 == 0 or rng.random() < 0.7))
+            if batched:
+                ev.viterbi_mode(records[0][4])
+            res = ev.evaluate()
+            records.append((res, ev.to_save, ev.skipped, list(ev._evaluated), ev.enable_viterbi))
+        (ra, sa, ka, ea, _), (rb, sb, kb, eb, _) = records
+        assert ka == kb and ea == eb
+        for k in RESULT_FIELDS:
+            a, b = np.asarray(ra[k], dtype=np.float64), np.asarray(rb[k], dtype=np.float64)
+            assert a.shape == b.shape and all((np.isnan(x) and np.isnan(y)) or x.tobytes() == y.tobytes() for x, y in zip(a.ravel(), b.ravel())), (k, ra[k], rb[k])
+        for name in sa:
+            assert len(sa[name]) == len(sb[name]), name
+            for x, y in zip(sa[name], sb[name]):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
