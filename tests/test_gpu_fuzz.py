@@ -8,7 +8,9 @@ several seeds: 14,837 decodes without a beam, 9,028 under beams, 164 dense and 6
   * the decode under the reference's beam (csrc/viterbi_beam.hip) against the oracle's literal prune();
   * encoder + y-head forward and backward against the float64 oracle at random (B, T, config) on both sides of every kernel-selection
     threshold (tests/test_gpu_dense.py's two oracle tests, called with random arguments);
-  * the s-head forward and backward against the float64 formulas of oracle/shead.py at random sizes."""
+  * the s-head forward and backward against the float64 formulas of oracle/shead.py at random sizes;
+  * the four losses and their gradients against oracle/losses.py in float64 (and against the oracle's own float32 evaluation where float32 itself is the limit);
+  * the device metric counters against the host metric classes; the batched evaluation against the one-video-at-a-time path on random test sets."""
 import os
 
 import numpy as np
