@@ -277,3 +277,19 @@ def test_evaluation_fuzz():
             assert len(sa[name]) == len(sb[name]), name
             for x, y in zip(sa[name], sb[name]):
                 np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
+
+
+def test_head_fuzz():
+    """The y-head alone (nearest upsample Tz -> Tf with torch's float32 index rule, 1x1 conv, log-softmax; forward and backward) at random
+    (B, Tz, Tf, H, C): both head kernels (H % 16 == 0 and not), frame counts that are no multiple of the encoded length, Tf = Tz, one encoded
+    row (tests/test_gpu_dense.py's head test, random arguments).  The index rule itself is torch's: checked against F.interpolate on the host."""
+    import torch.nn.functional as F
+    import test_gpu_dense as td
+    rng = np.random.default_rng(800 + SEED)
+    for i in range(12 * SCALE):
+        Tz = int(rng.choice([1, rng.integers(2, 40), rng.integers(40, 700)]))
+        Tf = int(rng.integers(Tz, 16 * Tz + 16))
+        x = torch.arange(Tz, dtype=torch.float32).view(1, 1, Tz)
+        idx = torch.clamp(torch.floor(torch.arange(Tf, dtype=torch.float32) * (torch.tensor(Tz, dtype=torch.float32) / torch.tensor(Tf, dtype=torch.float32))), max=Tz - 1)
+        assert torch.equal(F.interpolate(x, size=Tf, mode="nearest").view(-1), idx)
+        td.test_head_kernels_against_torch(int(rng.integers(1, 5)), Tz, Tf, int(rng.choice([128, 128, 48, 40, 20, 64])), int(rng.choice([3, 7, 48, 64])))
