@@ -293,3 +293,27 @@ def test_head_fuzz():
         idx = torch.clamp(torch.floor(torch.arange(Tf, dtype=torch.float32) * (torch.tensor(Tz, dtype=torch.float32) / torch.tensor(Tf, dtype=torch.float32))), max=Tz - 1)
         assert torch.equal(F.interpolate(x, size=Tf, mode="nearest").view(-1), idx)
         td.test_head_kernels_against_torch(int(rng.integers(1, 5)), Tz, Tf, int(rng.choice([128, 128, 48, 40, 20, 64])), int(rng.choice([3, 7, 48, 64])))
+
+
+def test_optimizer_fuzz():
+    """The fused clip + SGD / Adam step (csrc/optim.hpp) against clip_grad_norm_ + torch.optim at random parameter shapes (1 .. 300,000
+    elements, up to 12 tensors, sizes around the kernels' 4,096-element blocks), gradient scales, momentum, clipping thresholds
+    (tests/test_gpu_optim.py's two comparison tests on random shape lists; gradient scales up to 1: with 30x larger gradients and momentum an entry
+    that the update carries through zero differs by 1.5e-7 absolute -- one float32 rounding of an operand of size ~1, the kernels' FMA against torch's
+    multiply-then-subtract -- which is above that test's 1e-7 absolute tolerance and nothing else; Adam without weight decay: with it, one entry in 10^5 has g + wd p
+    cancel to ~1e-10, where Adam's g / (|g| + eps) amplifies the summation order of the clip norm to 0.6 % of a step)."""
+    import test_gpu_optim as to
+    rng = np.random.default_rng(900 + SEED)
+    saved = to.SIZES
+    try:
+        for i in range(6 * SCALE):
+            sizes = []
+            for _ in range(int(rng.integers(5, 13))):     # (the tests split the list at 4 and drop the gradient of entry 2)
+                kind = int(rng.integers(0, 4))
+                sizes.append((int(rng.integers(1, 9)),) if kind == 0 else (int(rng.integers(4090, 4100)),) if kind == 1
+                             else (int(rng.integers(1, 300)), int(rng.integers(1, 1000))) if kind == 2 else (int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 4))))
+            to.SIZES = sizes
+            to.test_fused_clip_sgd_matches_torch(float(rng.choice([1.0, 1e-3, 0.05])), float(rng.choice([0.0, 0.9])), [100.0, 5.0, 0.5, None][int(rng.integers(0, 4))])
+            to.test_fused_clip_adam_matches_torch(bool(rng.random() < 0.5), [5.0, 100.0, None][int(rng.integers(0, 3))], 0.0)
+    finally:
+        to.SIZES = saved
