@@ -92,3 +92,60 @@ class PoissonModel(LengthModel):
         ok = lengths < self.max_len
         P[ok, :] = self._table(lengths[ok].astype(np.int64), tr)
         return np.ascontiguousarray(P)
+
+
+class PoissonRows(LengthModel):
+    """A PoissonModel reduced to what the decoder reads of it: the rows P[j, n] = score((j+1) * fs, a_n) of ONE transcript (poisson_rows_for_many
+    builds them for a whole evaluation chunk in a handful of array operations instead of a model object per video)."""
+
+    def __init__(self, rows: np.ndarray, max_length: int, frame_sampling: int):
+        self.rows, self.max_len, self.frame_sampling = rows, int(max_length), int(frame_sampling)
+
+    def max_length(self):
+        return self.max_len
+
+    def rows_for(self, transcript, frame_sampling):
+        if int(frame_sampling) != self.frame_sampling or self.rows.shape[1] != len(transcript):
+            raise ValueError("PoissonRows was built for another transcript / frame_sampling")
+        return self.rows
+
+    def score(self, length, label):
+        raise NotImplementedError("PoissonRows holds the decoder's rows only; build a PoissonModel for single scores")
+
+
+def poisson_rows_for_many(mean_lengths, transcripts, frame_sampling: int, max_length: int = 2000):
+    """[PoissonModel(mu).rows_for(tr, fs) for mu, tr in zip(mean_lengths, transcripts)], bit for bit, computed together: the same
+    element-wise expressions (reference length_model.py:43-80: norms from round(mu), the table `l * log(mu_c) - mu_c - logFak(l) - norm_c`
+    left to right) on the concatenation of all videos' transcript classes.  -> list of float64 [J x N_v] arrays, J = max_length // fs."""
+    nv = len(transcripts)
+    if nv == 0:
+        return []
+    mu = np.asarray(mean_lengths, dtype=np.float64).reshape(nv, -1)
+    max_len, fs = int(max_length), int(frame_sampling)
+    J = max_len // fs
+    trs = [np.asarray(t, dtype=np.int64) for t in transcripts]
+    counts = [len(t) for t in trs]
+    vid = np.repeat(np.arange(nv), counts)
+    cls = np.concatenate(trs) if sum(counts) else np.zeros(0, np.int64)
+    with np.errstate(all="ignore"):
+        lf = _log_factorials(max(max_len, 2))
+        r = np.round(mu)
+        norms = r * np.log(r) - r
+        finite = np.where(np.isfinite(mu), mu, 0)
+        kmax = int(np.nanmax(finite)) if mu.size else 0
+        lf2 = np.concatenate(([0.0, 0.0], np.cumsum(np.log(np.arange(2, max(kmax + 1, 3))))))     # sum_{k=2..m} log k: a prefix of it is a video's own
+        m = finite.astype(np.int64)
+        norms = norms - np.where(m >= 2, lf2[np.clip(m, 0, len(lf2) - 1)], 0)
+        logmu = np.log(mu)
+        lengths = (np.arange(J, dtype=np.int64) + 1) * fs
+        ok = lengths < max_len
+        P = np.full((J, len(cls)), -np.inf, dtype=np.float64)
+        lo = lengths[ok]
+        t = lo[:, None] * logmu[vid, cls][None, :] - mu[vid, cls][None, :] - lf[lo, None] - norms[vid, cls][None, :]
+        t[lo == 0, :] = -np.inf
+        P[ok, :] = t
+    out, at = [], 0
+    for n in counts:
+        out.append(np.ascontiguousarray(P[:, at: at + n]))
+        at += n
+    return out

@@ -12,7 +12,8 @@ import torch
 from .models import EmptyTranscriptError
 from ..core.metrics import (AbsLenDiffMetric, Edit, F1Score, IoDMetric, IoUMetric, MatchingScoreMetric,  # noqa: F401
                             MoFAccuracyMetric)
-from ..core.viterbi import NoHypothesisError, PoissonModel, ShortSequenceError, SingleTranscriptGrammar, Viterbi
+from ..core.viterbi import (NoHypothesisError, PoissonModel, PoissonRows, ShortSequenceError, SingleTranscriptGrammar, Viterbi,
+                            poisson_rows_for_many)
 
 
 def one_hot(a: np.ndarray, num_classes: int) -> np.ndarray:
@@ -258,12 +259,11 @@ class MuConEvaluator:
             to += k
         # -- Viterbi: one launch for the chunk (the emissions stay where the y-head wrote them)
         if self.enable_viterbi:
-            lms = []
-            for v in alive:
-                s_tr = v["transcript"][:-1]
-                lengths = mean_lengths_from_s_head(v["rel"], s_tr, int(v["out"]["logp"].shape[0]), C)
-                with np.errstate(all="ignore"):
-                    lms.append(PoissonModel(lengths))
+            # the chunk's length tables in one go (PoissonModel(lengths).rows_for(transcript, fs) per video, bit for bit: poisson_rows_for_many)
+            fs = self.vi_decoder.frame_sampling
+            mus = [mean_lengths_from_s_head(v["rel"], v["transcript"][:-1], int(v["out"]["logp"].shape[0]), C) for v in alive]
+            rows = poisson_rows_for_many(mus, [v["transcript"][:-1] for v in alive], fs, 2000)      # (2000: PoissonModel's default max_length, evaluators.py:167)
+            lms = [PoissonRows(r, 2000, fs) for r in rows]
             res = self.vi_decoder.decode_batch([v["out"]["logp"] for v in alive], [v["transcript"][:-1] for v in alive], lms,
                                                return_exceptions=True, labels_as_arrays=True)
             kept = []

@@ -167,3 +167,28 @@ def test_the_beam_fixture_says_what_the_docs_say():
         if r["max_hypotheses"] == 1:
             assert score == -np.inf
     assert seen == 42
+
+
+def test_poisson_rows_for_many_equals_a_model_per_video():
+    """poisson_rows_for_many (the evaluation's chunk-wide table builder) against PoissonModel(mu).rows_for(transcript, fs) per video, bit for bit:
+    mean lengths from 0.2 (NaN norms, length_model.py:56-58) to 5,000, repeated classes, one-state transcripts, frame_sampling 1 / 7 / 30."""
+    from mucon_amd.core.viterbi import PoissonModel, PoissonRows, poisson_rows_for_many
+    rng = np.random.default_rng(3)
+    for fs, max_len in ((30, 2000), (7, 300), (1, 40)):
+        mus, trs = [], []
+        for v in range(25):
+            mu = rng.uniform(0.6, 900.0, 48)
+            mu[rng.integers(0, 48, 3)] = rng.choice([0.2, 0.49, 1.0, 1.5, 2.0, 2.5, 4999.7])
+            mus.append(mu)
+            trs.append(rng.integers(0, 48, int(rng.integers(1, 20))).tolist())
+        got = poisson_rows_for_many(mus, trs, fs, max_len)
+        for mu, tr, g in zip(mus, trs, got):
+            with np.errstate(all="ignore"):
+                want = PoissonModel(mu, max_length=max_len).rows_for(tr, fs)
+            assert g.shape == want.shape and g.flags.c_contiguous
+            assert g.tobytes() == want.tobytes()
+            lm = PoissonRows(g, max_len, fs)
+            assert lm.max_length() == max_len and lm.rows_for(tr, fs) is g
+            with pytest.raises(ValueError):
+                lm.rows_for(tr + [1], fs)
+    assert poisson_rows_for_many([], [], 30, 2000) == []
