@@ -167,6 +167,17 @@ class SimpleTrainer:
             groups, mx = [list(self.model.parameters())], self.clip_grad_norm
         return (ops.FusedClipAdam if adam else ops.FusedClipSGD)(groups, mx, self.optimizer)
 
+    def _zero_grad(self):
+        """optimizer.zero_grad() (set_to_none, torch's default) for the parameters of the model: `p.grad = None` in a plain loop.  torch's version
+        takes ~35 us of host time for this model's 90 parameters (profiler hooks, foreach grouping) -- 5 % of a one-video training step, which is
+        bound by host code as much as by the GPU."""
+        cached = self.__dict__.get("_zero_params")
+        n = sum(len(g["params"]) for g in self.optimizer.param_groups)
+        if cached is None or len(cached) != n:
+            cached = self._zero_params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        for p in cached:
+            p.grad = None
+
     def on_start_epoch(self, epoch_num: int):
         self.model.set_teacher_forcing(self.cfg.model.teacher_forcing)
 
@@ -174,7 +185,7 @@ class SimpleTrainer:
         """One video per rank (reference trainers.py:108-155)."""
         acc = self.cfg.trainer.accumulate_grad_every or 1
         if iter_num % acc == 0:
-            self.optimizer.zero_grad()
+            self._zero_grad()
         batch.to(self.device)
         if acc == 1 and self.fuse_step and hasattr(self.model, "can_fuse_step") and self.model.can_fuse_step(batch):
             # forward + loss + backward as one straight line of launches, no autograd graph (MuCon.fused_train_step)

@@ -705,32 +705,49 @@ class FusedClipSGD:
         lib = _lib.load()
         pg = self.optimizer.param_groups[0]
         lr, wd, mom = float(pg["lr"]), float(pg["weight_decay"]), float(pg["momentum"])
-        entries = []
-        for gi, params in enumerate(self.groups):
-            for p in params:
-                if p.grad is None:
-                    continue
-                _check_dev(p, p.grad)
-                if not p.is_contiguous() or not p.grad.is_contiguous():
+        # The table of (parameter, gradient, momentum buffer) records is kept between steps: which parameters have a gradient, their sizes and
+        # groups rarely change; per step only the addresses are refreshed (a training step of one video is bound by this host code as much as by
+        # the GPU: tools/e2e_host_vs_gpu.py).  A parameter's dtype / device / layout is checked when the table is built; its gradient has the
+        # parameter's dtype and device by torch's own rules, its contiguity is checked every step.
+        flat = self.__dict__.get("_flat")
+        if flat is None:
+            flat = self._flat = [(p, gi) for gi, params in enumerate(self.groups) for p in params]
+        grads = [p.grad for p, _ in flat]
+        have = tuple(g is not None for g in grads)
+        plan = self.__dict__.get("_plan")
+        if plan is None or plan[0] != have or plan[1] != (mom != 0.0):
+            idx = [i for i, h in enumerate(have) if h]
+            if not idx:
+                return
+            tab = (_lib.SgdTensor * len(idx))()
+            total, bufs = 0, []
+            for k, i in enumerate(idx):
+                p, gi = flat[i]
+                _check_dev(p, grads[i])
+                if not p.is_contiguous():
                     raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
                 buf = None
                 if mom != 0.0:
                     buf = self._mom.get(id(p))
                     if buf is None:
                         buf = self._mom[id(p)] = torch.zeros_like(p)   # buf = 0 -> first step gives buf = grad, as torch
-                entries.append((p, p.grad, buf, gi))
-        if not entries:
+                bufs.append(buf)
+                tab[k].n, tab[k].group = p.numel(), gi
+                tab[k].momentum_buf = buf.data_ptr() if buf is not None else None
+                total += p.numel()
+            plan = self._plan = (have, mom != 0.0, idx, tab, total, bufs)
+        _, _, idx, tab, total, bufs = plan
+        if not idx:
             return
-        n = len(entries)
-        tab = (_lib.SgdTensor * n)()
-        total = 0
-        for i, (p, g, buf, gi) in enumerate(entries):
-            tab[i].param, tab[i].grad = p.data_ptr(), g.data_ptr()
-            tab[i].momentum_buf = buf.data_ptr() if buf is not None else None
-            tab[i].n, tab[i].group = p.numel(), gi
-            total += p.numel()
+        for k, i in enumerate(idx):
+            g = grads[i]
+            if not g.is_contiguous():
+                raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
+            t = tab[k]
+            t.param, t.grad = flat[i][0].data_ptr(), g.data_ptr()
+        n = len(idx)
         nbytes = lib.mucon_sgd_workspace_bytes(n, total)
-        dev = entries[0][0].device
+        dev = flat[idx[0]][0].device
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self.last_norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
