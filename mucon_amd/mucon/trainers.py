@@ -229,8 +229,13 @@ class SimpleTrainer:
         for s in range(steps):
             batch = self.train_db[order[s * self.world_size + self.rank]]
             loss, _ = self._train_1_batch(self.iter_num, batch)
-            losses.append(loss.main.detach())      # stays on the device: no host sync per step (the step is ~2 ms of
+            losses.append(loss.main.detach())      # stays on the device: no host sync per step (the step is ~0.7 ms of
             self.iter_num += 1                     # asynchronous launches; a .item() here would serialise host and GPU)
+            if (s & 31) == 31 and torch.cuda.is_available() and str(self.device).startswith("cuda"):
+                # ... but the host must not run FAR ahead either: with ~700 launches queued (it enqueues a step in 0.6 ms, the GPU needs 0.72) the
+                # HIP runtime stalls for 15 - 140 ms at a time (tools/e2e_queue_probe.py: 0.875 ms per step un-synchronised, 0.750 with a
+                # synchronisation every 40 steps).  Draining every 32 steps costs one ~20 us pipeline restart per 32 steps.
+                torch.cuda.current_stream().synchronize()
         if self.scheduler is not None and not isinstance(self.scheduler, ReduceLROnPlateau):
             self.scheduler.step()
         return torch.stack(losses).tolist() if losses else []

@@ -6,6 +6,7 @@ a CPU tensor raises (there is no CPU fallback in the product).
 """
 import collections.abc
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -93,6 +94,27 @@ def _check_dev(*ts):
             raise _lib.MuconHipError(f"float32 expected, got {t.dtype}")
 
 
+_STRUCT_CACHE = {}
+
+
+def _param_struct(kind, tensors, build):
+    """The ctypes struct of device pointers `build(tensors)` for a list of PARAMETER tensors, kept while they live where they did: a struct is a
+    function of the addresses alone, so the key is (kind, addresses).  On a miss the tensors are checked (device, float32, contiguous); on a hit
+    nothing but 46 data_ptr() calls happens -- these lists were re-checked and re-packed three times per training step (0.1 ms of the host's
+    0.7 ms per one-video step, which is bound by host code as much as by the GPU: tools/e2e_host_profile.py)."""
+    key = (kind,) + tuple(t.data_ptr() for t in tensors)
+    hit = None if os.environ.get("MUCON_NO_STRUCT_CACHE") else _STRUCT_CACHE.get(key)
+    if hit is None:
+        _check_dev(*tensors)
+        for t in tensors:
+            if not t.is_contiguous():
+                raise _lib.MuconHipError("tensor handed to the C ABI must be contiguous")
+        if len(_STRUCT_CACHE) >= 64:
+            _STRUCT_CACHE.clear()
+        hit = _STRUCT_CACHE[key] = build(tensors)
+    return hit
+
+
 class _NoGradCtx:
     """Stands in for autograd's context when gradients are off (evaluation): `Fn.forward(_NoGradCtx(), ...)` runs the same code
     without torch.autograd.Function.apply's bookkeeping (~10 us per call of a forward that is ~35 launches of ~3.5 us each)."""
@@ -119,9 +141,9 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tape, spec, training, seed, *params):
         lib = _lib.load()
-        _check_dev(tape, *params)
+        _check_dev(tape)
         tape = tape.contiguous()
-        params = [p.contiguous() for p in params]
+        params = [p if p.is_contiguous() else p.contiguous() for p in params]
         B, T, D = tape.shape
         if D != spec.in_dim:
             raise ValueError(f"tape feature dim {D} != {spec.in_dim}")
@@ -132,7 +154,7 @@ class _EncoderFn(torch.autograd.Function):
         Tz = lib.mucon_encoder_out_length(ctypes.byref(cfg))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=tape.device)
         enc = torch.empty((B, Tz, spec.hidden), dtype=torch.float32, device=tape.device)
-        cp = _pack_params(spec, params)
+        cp = _param_struct(("enc", len(spec.stages)), params, lambda ts: _pack_params(spec, ts))
         _lib.check(lib.mucon_encoder_fwd(ctypes.byref(cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(enc),
                                          _lib.ptr(ws), nbytes, _lib.current_stream_ptr()), "mucon_encoder_fwd")
         ctx.spec, ctx.cfg, ctx.ws, ctx.nbytes = spec, cfg, ws, nbytes
@@ -156,7 +178,7 @@ class _EncoderFn(torch.autograd.Function):
         for p, n in zip(params, sizes):
             grads.append(flat[off: off + p.numel()].view(p.shape))
             off += n
-        cp, cg = _pack_params(ctx.spec, params), _pack_params(ctx.spec, grads)
+        cp, cg = _param_struct(("enc", len(ctx.spec.stages)), params, lambda ts: _pack_params(ctx.spec, ts)), _pack_params(ctx.spec, grads)
         _lib.check(lib.mucon_encoder_bwd(ctypes.byref(ctx.cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(d_enc),
                                          _lib.ptr(ctx.ws), ctx.nbytes, ctypes.byref(cg), _lib.current_stream_ptr()),
                    "mucon_encoder_bwd")
@@ -411,9 +433,9 @@ class _LstmFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ndir, *weights):
         lib = _lib.load()
-        _check_dev(x, *weights)
+        _check_dev(x)
         x = x.contiguous()
-        weights = [w.contiguous() for w in weights]
+        weights = [w if w.is_contiguous() else w.contiguous() for w in weights]
         T, I = x.shape
         H = weights[1].shape[1]
         nbytes = lib.mucon_lstm_workspace_bytes(T, ndir)
@@ -421,7 +443,7 @@ class _LstmFn(torch.autograd.Function):
         out = torch.empty((T, ndir * H), dtype=torch.float32, device=x.device)
         hn = torch.empty((ndir, H), dtype=torch.float32, device=x.device)
         cn = torch.empty((ndir, H), dtype=torch.float32, device=x.device)
-        _lib.check(lib.mucon_lstm_fwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_lstm_params(weights, ndir)), _lib.ptr(out),
+        _lib.check(lib.mucon_lstm_fwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_param_struct(("lstm", ndir), weights, lambda ts: _lstm_params(ts, ndir))), _lib.ptr(out),
                                       _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_lstm_fwd")
         ctx.dims, ctx.ws, ctx.nbytes = (T, I, H, ndir), ws, nbytes
@@ -442,7 +464,7 @@ class _LstmFn(torch.autograd.Function):
         acc = getattr(ctx, "dx_accumulate", None)
         d_x = acc if acc is not None else torch.empty_like(x)
         grads = [torch.empty_like(w) for w in weights]
-        _lib.check(lib.mucon_lstm_bwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_lstm_params(weights, ndir)), _lib.ptr(out),
+        _lib.check(lib.mucon_lstm_bwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_param_struct(("lstm", ndir), weights, lambda ts: _lstm_params(ts, ndir))), _lib.ptr(out),
                                       _lib.ptr(d_out), _lib.ptr(d_hn), _lib.ptr(d_cn), _lib.ptr(d_x), _lib.ptr(acc),
                                       ctypes.byref(_lstm_params(grads, ndir)), _lib.ptr(ctx.ws), ctx.nbytes,
                                       _lib.current_stream_ptr()), "mucon_lstm_bwd")
@@ -498,11 +520,11 @@ class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, memory, hn, cn, tf_input, dropmask, opts, *params):
         lib = _lib.load()
-        _check_dev(memory, hn, cn, dropmask, *params)
+        _check_dev(memory, hn, cn, dropmask)
         if not tf_input.is_cuda:
             raise _lib.MuconHipError("mucon_amd ops need device tensors: there is no CPU fallback")
         memory, hn, cn = memory.contiguous(), hn.contiguous(), cn.contiguous()
-        params = [w.contiguous() for w in params]
+        params = [w if w.is_contiguous() else w.contiguous() for w in params]
         tf_input = tf_input.contiguous().to(torch.int64)
         if dropmask is not None:
             dropmask = dropmask.contiguous()
@@ -521,7 +543,7 @@ class _DecoderFn(torch.autograd.Function):
         logp = torch.empty((max_steps, cfg.NC), dtype=torch.float32, device=dev)
         lengths = torch.empty(max_steps, dtype=torch.float32, device=dev)
         n_steps = torch.empty(1, dtype=torch.int32, device=dev)
-        _lib.check(lib.mucon_decoder_fwd(ctypes.byref(cfg), ctypes.byref(_decoder_params(params)), _lib.ptr(memory), _lib.ptr(hn),
+        _lib.check(lib.mucon_decoder_fwd(ctypes.byref(cfg), ctypes.byref(_param_struct(("dec",), params, _decoder_params)), _lib.ptr(memory), _lib.ptr(hn),
                                          _lib.ptr(cn), _lib.ptr(tf_input), _lib.ptr(dropmask), _lib.ptr(logp), _lib.ptr(lengths),
                                          _lib.ptr(n_steps), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_decoder_fwd")
@@ -542,7 +564,7 @@ class _DecoderFn(torch.autograd.Function):
         d_len = d_len.contiguous() if d_len is not None else None
         d_memory, d_hn, d_cn = torch.empty_like(memory), torch.empty_like(hn), torch.empty_like(cn)
         grads = [torch.empty_like(w) for w in params]
-        _lib.check(lib.mucon_decoder_bwd(ctypes.byref(ctx.cfg), ctx.n, ctypes.byref(_decoder_params(params)), _lib.ptr(memory),
+        _lib.check(lib.mucon_decoder_bwd(ctypes.byref(ctx.cfg), ctx.n, ctypes.byref(_param_struct(("dec",), params, _decoder_params)), _lib.ptr(memory),
                                          _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(logp), _lib.ptr(d_logp), _lib.ptr(d_len),
                                          _lib.ptr(ctx.dropmask), _lib.ptr(d_memory), _lib.ptr(d_hn), _lib.ptr(d_cn),
                                          ctypes.byref(_decoder_params(grads)), _lib.ptr(ctx.ws), ctx.nbytes,
