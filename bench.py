@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=4096, help="frames per video")
     ap.add_argument("--time-every", type=int, default=8, help="HIP-event timing of the two tape-streaming kernels on every n-th step "
                     "(an event pair opens two ~6 us bubbles on the stream: timing every step taxes the step it reports)")
+    ap.add_argument("--prewarm-steps", type=int, default=800, help="untimed steps in front of the --warmup steps: the GPU needs ~0.3 s of sustained "
+                    "load to reach its steady clocks (regions of 200 steps read 0.76, 0.76, 0.71, 0.70, 0.70, ... ms per step from a cold start)")
+    ap.add_argument("--drain-every", type=int, default=0, help="synchronise the stream every n steps INSIDE the timed regions (0: never): bounds how far "
+                    "the host runs ahead of the GPU -- with several hundred launches queued the HIP runtime stalls for milliseconds at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-viterbi", action="store_true")
     return ap.parse_args()
@@ -514,6 +518,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    for i in range(args.prewarm_steps):      # bring the GPU to its steady state (same step, same work, same number on every rank)
+        step(i)
+    sync()
     for i in range(args.warmup):
         step(i)
     sync()
@@ -525,6 +532,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + r * args.steps + i)
+            if args.drain_every and (i + 1) % args.drain_every == 0:
+                torch.cuda.current_stream().synchronize()
         sync()
         regions.append(time.perf_counter() - t0)
     tot_ms = (ctypes.c_float * 2)()
@@ -613,6 +622,10 @@ def main():
                                    f"(dropout on), fwd+bwd+SGD, tapes resident in HBM",
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
+            "prewarm_steps": args.prewarm_steps,
+            "prewarm_note": "untimed steps in front of the --warmup steps: from a cold start this GPU runs the same step 9 % slower for its first ~0.35 s of "
+                            "sustained load (regions of 200 steps: 0.76, 0.76, 0.71, 0.70, 0.70 ms per step; --steps 20 --warmup 5 cold: 0.767, behind 800 steps: 0.703); "
+                            "--prewarm-steps 0 measures the cold start",
             "tape_batches_rotated": len(tapes), "tape_bytes_resident": len(tapes) * B * T * spec.in_dim * 4,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(peak_own, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_own, 4), "traffic": traffic,
