@@ -276,14 +276,14 @@ def end_to_end_bench(dev, steps=40):
     batch = Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(4, T, tr)),
                   transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
                   transcript_tf_target=torch.tensor(tr.tolist() + [C]), video_name="synthetic").to(dev)
-    for i in range(5):
+    for i in range(20):
         trainer._train_1_batch(i, batch)
     rounds = []                      # median of five rounds: one host hiccup does not decide the figure
     for r in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            trainer._train_1_batch(5 + r * steps + i, batch)
+            trainer._train_1_batch(20 + r * steps + i, batch)
         torch.cuda.synchronize()
         rounds.append((time.perf_counter() - t0) / steps)
     dt = sorted(rounds)[2]
