@@ -60,8 +60,13 @@ def parse():
     ap.add_argument("--frames", type=int, default=4096, help="frames per video")
     ap.add_argument("--time-every", type=int, default=8, help="HIP-event timing of the two tape-streaming kernels on every n-th step "
                     "(an event pair opens two ~6 us bubbles on the stream: timing every step taxes the step it reports)")
-    ap.add_argument("--prewarm-steps", type=int, default=800, help="untimed steps in front of the --warmup steps: the GPU needs ~0.3 s of sustained "
-                    "load to reach its steady clocks (regions of 200 steps read 0.76, 0.76, 0.71, 0.70, 0.70, ... ms per step from a cold start)")
+    ap.add_argument("--prewarm-steps", type=int, default=100, help="untimed steps in front of the --warmup steps (the first ~50 steps after a cold start run "
+                    "slower); the random-init weights are restored behind them")
+    ap.add_argument("--keep-drift", action="store_true", help="EXPERIMENT: do NOT restore the random-init weights behind the pre-warm steps and in front of "
+                    "every timed region.  The step's speed depends on the VALUES flowing through it (the MFMA kernels run against the power cap): after ~500 SGD "
+                    "steps on synthetic noise the same launches are up to 9 %% faster (0.77 -> 0.70 ms per step on a power-limited box); with MUCON_BENCH_LR=0 "
+                    "they are not, and GEMMs of other data (--prewarm-seconds) change nothing")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.0, help="EXPERIMENT: seconds of other work (bf16 GEMMs + a tape-sized copy) in front of the warm-up steps")
     ap.add_argument("--drain-every", type=int, default=0, help="synchronise the stream every n steps INSIDE the timed regions (0: never): bounds how far "
                     "the host runs ahead of the GPU -- with several hundred launches queued the HIP runtime stalls for milliseconds at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -467,6 +472,9 @@ def main():
     tapes = [torch.randn(B, T, spec.in_dim, device=dev, generator=g) for _ in range(max(1, args.tapes))]
     dlogp = torch.randn(B, T, C, device=dev, generator=g) / (B * T)     # dL/dlogp handed to the backward
     lr, wd = 0.01, 0.005                                                # reference default.py:21-24
+    if os.environ.get("MUCON_BENCH_LR") is not None:                   # (A/B hook: is the step's speed a function of the weights?)
+        lr = float(os.environ["MUCON_BENCH_LR"])
+        wd = 0.0 if lr == 0.0 else wd
     import types
     sgd = ops.FusedClipSGD([flat_params], None,                         # SGD(lr, weight_decay) in one launch (csrc/optim.hpp)
                            types.SimpleNamespace(param_groups=[{"lr": lr, "weight_decay": wd, "momentum": 0.0}]))
@@ -518,9 +526,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.prewarm_steps):      # bring the GPU to its steady state (same step, same work, same number on every rank)
+    if args.prewarm_seconds > 0:             # bring the GPU to its steady state with work that is NOT the path's (a kernel trace of this command then
+        a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)   # holds the path's kernels in their steady state only): bf16 GEMMs + a tape-sized copy
+        b = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+        scratch = torch.empty_like(tapes[0])
+        t_end = time.perf_counter() + args.prewarm_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                torch.matmul(a, b)
+            scratch.copy_(tapes[0])
+            torch.cuda.synchronize()
+        del a, b, scratch
+    init_state = [p_.detach().clone() for p_ in params]      # every timed region measures the RANDOM-INIT network (the workload BASELINE.json names):
+
+    def restore_init():                                         # SGD on synthetic noise drifts the weights, and the step's speed with them (--keep-drift)
+        with torch.no_grad():
+            for p_, q_ in zip(params, init_state):
+                p_.copy_(q_)
+
+    for i in range(args.prewarm_steps):
         step(i)
     sync()
+    if not args.keep_drift:
+        restore_init()
     for i in range(args.warmup):
         step(i)
     sync()
@@ -528,6 +556,8 @@ def main():
     _lib.check(lib.mucon_profile_begin(args.steps * args.repeats), "profile_begin")
     regions = []
     for r in range(args.repeats):        # each region: exactly --steps steps between two (barrier + synchronize) brackets
+        if r and not args.keep_drift:
+            restore_init()                   # (untimed; region 0 continues from the warm-up steps as the contract describes)
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -623,9 +653,10 @@ def main():
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
             "prewarm_steps": args.prewarm_steps,
-            "prewarm_note": "untimed steps in front of the --warmup steps: from a cold start this GPU runs the same step 9 % slower for its first ~0.35 s of "
-                            "sustained load (regions of 200 steps: 0.76, 0.76, 0.71, 0.70, 0.70 ms per step; --steps 20 --warmup 5 cold: 0.767, behind 800 steps: 0.703); "
-                            "--prewarm-steps 0 measures the cold start",
+            "weights": ("random init, restored (untimed) behind the pre-warm steps and in front of every timed region after the first" if not args.keep_drift
+                        else "left to drift under SGD on synthetic noise (--keep-drift: experiment)"),
+            "data_dependence_note": "the step's speed depends on the values: after ~500 SGD steps on synthetic noise the same launches run 9 % faster (0.77 -> 0.70 ms; "
+                                    "MFMA kernels against the power cap); not with lr = 0, not after GEMMs of other data -- so every region starts from the random-init weights",
             "tape_batches_rotated": len(tapes), "tape_bytes_resident": len(tapes) * B * T * spec.in_dim * 4,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(peak_own, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_own, 4), "traffic": traffic,
