@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--prewarm-steps", type=int, default=100, help="untimed steps in front of the --warmup steps (the first ~50 steps after a cold start run "
                     "slower); the random-init weights are restored behind them")
     ap.add_argument("--keep-drift", action="store_true", help="EXPERIMENT: do NOT restore the random-init weights behind the pre-warm steps and in front of "
-                    "every timed region.  The step's speed depends on the VALUES flowing through it (the MFMA kernels run against the power cap): after ~500 SGD "
+                    "every timed region.  The step's speed depends on the VALUES flowing through it (the MFMA kernels run against the power cap; the synthetic objective has no minimum and drives the weights to NaN): after ~500 SGD "
                     "steps on synthetic noise the same launches are up to 9 %% faster (0.77 -> 0.70 ms per step on a power-limited box); with MUCON_BENCH_LR=0 "
                     "they are not, and GEMMs of other data (--prewarm-seconds) change nothing")
     ap.add_argument("--prewarm-seconds", type=float, default=0.0, help="EXPERIMENT: seconds of other work (bf16 GEMMs + a tape-sized copy) in front of the warm-up steps")
