@@ -569,6 +569,7 @@ def main():
     tot_ms = (ctypes.c_float * 2)()
     cnt = (ctypes.c_int32 * 2)()
     _lib.check(lib.mucon_profile_end(tot_ms, cnt), "profile_end")
+    weights_finite = bool(all(torch.isfinite(p_).all().item() for p_ in params))      # (a region that ran on NaN operands would have been faster: see --keep-drift)
     if dist is not None:
         t = torch.tensor(regions, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -652,7 +653,7 @@ def main():
                                    f"(dropout on), fwd+bwd+SGD, tapes resident in HBM",
                        "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
             "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
-            "prewarm_steps": args.prewarm_steps,
+            "prewarm_steps": args.prewarm_steps, "weights_finite_after_last_region": weights_finite,
             "weights": ("random init, restored (untimed) behind the pre-warm steps and in front of every timed region after the first" if not args.keep_drift
                         else "left to drift under SGD on synthetic noise (--keep-drift: experiment)"),
             "data_dependence_note": "the step's speed depends on the values: after ~500 SGD steps on synthetic noise the same launches run 9 % faster (0.77 -> 0.70 ms; "
