@@ -2,7 +2,7 @@
 
     python -m mucon_amd.build [--force]
 
-Four translation units: mucon_hip.hip (encoder / head, FMA contraction allowed), viterbi.hip
+Translation units (SOURCES): mucon_hip.hip (encoder / head, FMA contraction allowed), viterbi.hip
 (-ffp-contract=off: every add is a single IEEE operation, as the bit-exact decode requires),
 shead.hip (the s-head's bidirectional LSTM) and metrics.hip (evaluation counters).
 The .so lands next to this file (git-ignored; gpurun ships it to the GPU box)."""
@@ -17,7 +17,9 @@ PYHOST_LIB = os.path.join(HERE, "libmucon_pyhost.so")    # host-side helper of t
 ARCH = "gfx950"
 SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", []),
            ("metrics.hip", ["-ffp-contract=off"])]
-DEPS = ["common.hpp", "dispatch.hpp", "gemm_nt.hpp", "gemm_split.hpp", "gemm_tn.hpp", "gemm_tn_split.hpp", "gemm_fused_split.hpp", "gemm_coarse_split.hpp", "small_kernels.hpp", "gemm_fused.hpp", "lstm.hpp", "decoder.hpp", "loss.hpp", "optim.hpp", "../../include/mucon_hip.h", "../../include/mucon_hip_test.h"]
+
+
+last_compiled = []   # the translation units the last build() call compiled (tests/test_build_staleness.py)
 
 
 def _obj(src):
@@ -61,12 +63,18 @@ def build_pyhost(force: bool = False, verbose: bool = False) -> str:
     return PYHOST_LIB
 
 
+def stale_units():
+    """The translation units that must be recompiled: those whose object, dependency file (hipcc -MMD: every header the unit
+    actually included, so no hand-kept list can fall behind an #include) or flags record is missing, or one of whose
+    dependencies is newer than the object."""
+    return [src for src, extra in SOURCES if _tu_stale(src, extra)]
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or stale_units():
         return True
     t = os.path.getmtime(LIB)
-    files = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, d) for d in DEPS]
-    return any(os.path.getmtime(f) > t for f in files)
+    return any(os.path.getmtime(_obj(src)) > t for src, _ in SOURCES)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -79,11 +87,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = []
     procs = []
+    global last_compiled
+    last_compiled = []
     for src, extra in SOURCES:
         obj = _obj(src)
         objs.append(obj)
         if not force and not _tu_stale(src, extra):
             continue
+        last_compiled.append(src)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-MMD", "-MF", obj + ".d",
                "-c", os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("MUCON_HIPCC_FLAGS", "").split()
         if verbose:
