@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--prewarm-seconds", type=float, default=0.0, help="EXPERIMENT: seconds of other work (bf16 GEMMs + a tape-sized copy) in front of the warm-up steps")
     ap.add_argument("--drain-every", type=int, default=0, help="synchronise the stream every n steps INSIDE the timed regions (0: never): bounds how far "
                     "the host runs ahead of the GPU -- with several hundred launches queued the HIP runtime stalls for milliseconds at a time")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration probes behind the timed regions (~1 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-viterbi", action="store_true")
     return ap.parse_args()
@@ -93,6 +94,49 @@ def make_params(spec, C, dev):
         sd[k + ".weight"], sd[k + ".bias"] = m.weight.detach(), m.bias.detach()
     names = ops.param_names(spec) + ["conv_classifier.weight", "conv_classifier.bias"]
     return names, [sd[k].to(dev).contiguous().requires_grad_(True) for k in names]
+
+
+REF_BOX_MFMA_TFLOPS = 1000.0   # the calibration loop's rate on the reference box of DESIGN.md section 5 (normalisation constant, not a peak)
+MFMA_BOUND_SHARE = 0.62        # share of the hot-path step spent in the launches that follow the box's MFMA rate
+
+
+def box_calibration(lib, dev):
+    """What THIS box sustains, measured outside the timed regions (about 0.3 s per figure): a bare all-CU bf16 MFMA loop on
+    pseudo-random operands (csrc/probe.hpp; both MFMA shapes) with its in-kernel shader clock, and a 1 GiB device-to-device copy.
+    The pool's boards differ by up to ~10 % on MFMA-dense kernels (power management); these figures let two bench lines from two
+    boxes be compared."""
+    from mucon_amd import _lib
+
+    scratch = torch.empty(32768, dtype=torch.uint8, device=dev)
+    tf, ghz, ms = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+    s = _lib.current_stream_ptr()
+    out = {}
+    for name, shape16 in (("32x32x16", 0), ("16x16x32", 1)):
+        _lib.check(lib.mucon_test_mfma_probe(shape16, 10, 2000, _lib.ptr(scratch), scratch.numel(), ctypes.byref(tf), ctypes.byref(ghz),
+                                             ctypes.byref(ms), s), "mfma_probe")            # ramp
+        _lib.check(lib.mucon_test_mfma_probe(shape16, 60, 2000, _lib.ptr(scratch), scratch.numel(), ctypes.byref(tf), ctypes.byref(ghz),
+                                             ctypes.byref(ms), s), "mfma_probe")
+        out[f"mfma_tflops_{name}"] = round(tf.value, 1)
+        out[f"clock_ghz_{name}"] = round(ghz.value, 3)
+        out[f"probe_seconds_{name}"] = round(ms.value * 1e-3, 3)
+    out["mfma_tflops"], out["clock_ghz"] = out["mfma_tflops_32x32x16"], out["clock_ghz_32x32x16"]
+    n = 1 << 28                                      # 1 GiB of float32
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    out["copy_gbs"] = round(20 * 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)     # bytes read + bytes written
+    out["note"] = ("mfma_tflops / clock_ghz: 60 launches of 1,024 workgroups x 4 waves x 2,000 x 16 v_mfma_f32_32x32x16_bf16 on pseudo-random operands in registers "
+                   "(the *_16x16x32 pair: the same FLOPs on the narrower shape), HIP events; clock = delta s_memtime / delta s_memrealtime inside the last launch, "
+                   "median over workgroups; copy_gbs: 20 x 1 GiB device-to-device torch copy, read + written bytes")
+    del src, dst
+    return out
 
 
 def physical_cores():
@@ -297,7 +341,7 @@ def end_to_end_bench(dev, steps=40):
             "reference_readme_it_per_s": [14.67, 16.23]}
 
 
-def eval_bench(dev, n_videos=32):
+def eval_bench(dev, n_videos=32, rank=0, world=1, sync=None, allmax=None, T=2000, max_words=8):
     """Evaluation scope: MuConEvaluator.evaluate() per test video = eval-mode forward (greedy s-head decode, at most 8
     words here), predict, Viterbi decode on the device-resident log-probs, and the reference's full metric set
     (reference src/mucon/evaluators.py:121-257) -- batched: one chunk of 32 videos = every forward enqueued, ONE copy of the
@@ -310,19 +354,24 @@ def eval_bench(dev, n_videos=32):
     from mucon_amd.mucon.evaluators import MuConEvaluator
     from mucon_amd.mucon.models import create_model
 
-    T, N, C = 2000, 6, 48
+    N, C = 6, 48
     cfg = update_config(get_cfg_defaults(), [], [])
-    torch.manual_seed(0)
-    model = create_model(cfg, C, 8, 2048).to(dev)
+    if str(dev) == "cpu":
+        cfg.defrost()
+        cfg.system.device = "cpu"        # (the launcher's self-test: the reference's own device switch, mucon_amd/cpu_plumbing.py)
+        cfg.freeze()
+    torch.manual_seed(0)                 # every rank builds the same model
+    model = create_model(cfg, C, max_words, 2048).to(dev)
     with torch.no_grad():
         model.fs_decoder_transcript[2].bias[C] = -20.0
+    total = n_videos * world             # N > 1: the evaluator shards the test videos (video i on rank i mod world); n_videos per rank
 
     class Videos:
         background_class_ids = [0]
 
         def __init__(self):
             self.items = []
-            for v in range(n_videos):
+            for v in range(total):
                 tr = synth.transcript(100 + v, N, C, allow_repeats=False)
                 self.items.append(Batch(feats=torch.randn(1, T, 2048), gt_label=torch.from_numpy(synth.segment_labels(200 + v, T, tr)),
                                         transcript=torch.from_numpy(tr), transcript_tf_input=torch.tensor([C + 1] + tr.tolist()),
@@ -340,16 +389,50 @@ def eval_bench(dev, n_videos=32):
     db = Videos()
     ev = MuConEvaluator(cfg, db, model, dev)
     ev.viterbi_mode(True)
-    ev.evaluate()
-    torch.cuda.synchronize()
+    if sync is None:
+        sync = torch.cuda.synchronize
+    ev.evaluate(rank, world)
+    sync()
     t0 = time.perf_counter()
-    ev.evaluate()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / len(db)
-    return {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3),
-            "config": f"MuConEvaluator.evaluate(): {n_videos} videos, T={T}: eval forward + greedy decode (8 words) + predict + "
+    res = ev.evaluate(rank, world)
+    sync()
+    dt = time.perf_counter() - t0
+    if allmax is not None:
+        dt = allmax(dt)                  # the slowest rank's time for the whole sharded pass
+    dt /= len(db)
+    out = {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3)}
+    if world > 1 or allmax is not None:
+        out.update({"n_gpus": world, "videos": len(db), "videos_per_rank": n_videos, "skipped_videos": int(res.get("skipped_videos", 0)),
+                    "sharding": "video i on rank i mod world (MuConEvaluator.evaluate(rank, world)); metric accumulators all-reduced as one vector, per-video records "
+                                "gathered; ms_per_video = slowest rank's time for the pass / all videos"})
+    out["config"] = (f"MuConEvaluator.evaluate(): {len(db)} videos, T={T}: eval forward + greedy decode ({max_words} words) + predict + "
                       f"Viterbi (fs=30) + MoF/IoD/IoU/edit/F1 for y-, s- and Viterbi segmentations; tapes resident in HBM; batched "
-                      f"(chunks of {ev.chunk_videos} videos: pooled round trips, one Viterbi launch, device metrics)"}
+                      f"(chunks of {ev.chunk_videos} videos: pooled round trips, one Viterbi launch, device metrics)")
+    return out
+
+
+def viterbi_bench_sharded(rank, world, sync, allmax, decode_batch, make_videos, videos=256, rounds=3):
+    """BASELINE.json's "Viterbi ms/video at 1/2/4/8 GPU": decoding shards over videos with nothing exchanged, so at N ranks every rank
+    decodes its OWN `videos` videos per call (seeded by rank), every call bracketed by (synchronize + barrier) on both sides, and
+    ms_per_video = the slowest rank's call time / (world x videos) -- the aggregate rate of the job, as `value` is for the dense path.
+    `decode_batch(lps, trs, Ps)`: the binding's batched call (ops.viterbi_decode_batch); `make_videos(kind, rank, videos)` ->
+    (lps, trs, Ps) for kind "config5" (T = 16,384, N = 64) / "T2000_N6"."""
+    out = {"n_gpus": world, "videos_per_rank_and_call": videos}
+    for kind, key in (("config5", "ms_per_video_batch256"), ("T2000_N6", "ms_per_video_T2000_N6_batch256")):
+        lps, trs, Ps = make_videos(kind, rank, videos)
+        decode_batch(lps, trs, Ps)            # warm-up (allocations, the library's staging buffers)
+        per = []
+        for _ in range(rounds):
+            sync()
+            t0 = time.perf_counter()
+            decode_batch(lps, trs, Ps)
+            sync()
+            per.append(allmax(time.perf_counter() - t0))
+        out[key.replace("256", str(videos)) if videos != 256 else key] = round(sorted(per)[len(per) // 2] / (world * videos) * 1e3, 5)
+        del lps
+    out["config"] = (f"every rank decodes {videos} videos of its own per call (config 5: T=16384 / N=64; Breakfast-typical: T=2000 / N=6), whole "
+                     f"ops.viterbi_decode_batch calls, median of {rounds} barrier-bracketed calls, slowest rank's time / ({world} x {videos}) videos; no collective on the data path")
+    return out
 
 
 def launch_ranks(n: int) -> int:
@@ -419,6 +502,30 @@ def stub_main(args, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     regions = t.tolist()
     elapsed = sorted(regions)[len(regions) // 2]
+
+    # the sharded Viterbi / evaluation legs of the N > 1 line through the same functions, on stand-ins that need no GPU: the NumPy decode of
+    # mucon_amd/cpu_plumbing.py on small videos, the evaluator on cfg.system.device = "cpu"
+    def allmax(x):
+        t_ = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
+    def make_videos(kind, rank_, videos):
+        from mucon_amd.core.viterbi import PoissonModel
+        Tv, Nv = (600, 8) if kind == "config5" else (300, 4)
+        gc = torch.Generator().manual_seed(7000 + rank_)
+        tr = torch.randint(0, 48, (Nv,), generator=gc).numpy().astype(np.int32)
+        mu = np.ones(48)
+        mu[np.unique(tr)] = Tv / Nv
+        P = PoissonModel(mu).rows_for(tr, 30)
+        return [torch.log_softmax(3 * torch.randn(Tv, 48, generator=gc), dim=1).numpy() for _ in range(videos)], [tr] * videos, [P] * videos
+
+    def decode_batch(lps, trs, Ps):
+        from mucon_amd import cpu_plumbing
+        return [cpu_plumbing.viterbi_decode(a, b_, c, 30, None) for a, b_, c in zip(lps, trs, Ps)]
+
+    vit = viterbi_bench_sharded(rank, world, dist.barrier, allmax, decode_batch, make_videos, videos=4, rounds=2)
+    evl = eval_bench("cpu", 2, rank, world, dist.barrier, allmax, T=160, max_words=4)
     if rank == 0:
         B, T = args.batch, args.frames
         out = {"metric": "STUB: launcher / timing-protocol self-test, no GPU work (MUCON_BENCH_STUB=1)", "value": round(world * B * T * args.steps / elapsed, 1),
@@ -426,7 +533,8 @@ def stub_main(args, rank, world):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
                "config": {"workload": "stub", "global_batch": world * B, "frames_per_video": T, "parallelism": f"dp{world}"},
                "repeats": args.repeats, "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
-               "rccl": {"world": world, "backend": dist.get_backend(), "bytes_per_step": int(buf.numel() * 4), "collectives_per_step": 1}}
+               "rccl": {"world": world, "backend": dist.get_backend(), "bytes_per_step": int(buf.numel() * 4), "collectives_per_step": 1},
+               "viterbi": vit, "evaluation": evl}
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -570,6 +678,7 @@ def main():
     cnt = (ctypes.c_int32 * 2)()
     _lib.check(lib.mucon_profile_end(tot_ms, cnt), "profile_end")
     weights_finite = bool(all(torch.isfinite(p_).all().item() for p_ in params))      # (a region that ran on NaN operands would have been faster: see --keep-drift)
+    calib = box_calibration(lib, dev) if (rank == 0 and not args.no_calibration) else None   # behind the timed regions: the box in the state the regions saw
     if dist is not None:
         t = torch.tensor(regions, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -599,6 +708,32 @@ def main():
                 "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
                 "note": "median of 20 all-reduces of the step's flat gradient buffer (encoder + y-head), HIP events on the step's stream, "
                         "max over ranks; measured after the timed regions"}
+
+    sharded = None
+    if dist is not None and not args.no_viterbi:
+        # BASELINE.json's metric names "Viterbi ms/video at 1/2/4/8 GPU": at N > 1 (and with MUCON_BENCH_FORCE_DIST=1) every rank runs the
+        # decode and evaluation legs on its own shard of videos; no collective on the data path, max-over-ranks timing as for the step
+        from mucon_amd.core.viterbi import PoissonModel
+
+        def allmax(x):
+            t_ = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+
+        def make_videos(kind, rank_, videos):
+            Tv, Nv = (16384, 64) if kind == "config5" else (2000, 6)
+            gc = torch.Generator(device="cpu").manual_seed(7000 + rank_)
+            gd = torch.Generator(device=dev).manual_seed(8000 + rank_)
+            tr = torch.randint(0, C, (Nv,), generator=gc).numpy().astype(np.int32)
+            mu = np.ones(C)
+            mu[np.unique(tr)] = Tv / Nv
+            P = PoissonModel(mu).rows_for(tr, 30)
+            distinct = min(videos, 64 if kind == "config5" else videos)      # config 5: 64 emission tensors (3.1 MB each), each used videos / 64 times
+            base = [torch.log_softmax(3 * torch.randn(Tv, C, device=dev, generator=gd), dim=1) for _ in range(distinct)]
+            return (base * (videos // distinct + 1))[:videos], [tr] * videos, [P] * videos
+
+        sharded = {"viterbi": viterbi_bench_sharded(rank, world, sync, allmax, lambda a, b_, c: ops.viterbi_decode_batch(a, b_, c, 30, 2000), make_videos),
+                   "evaluation": eval_bench(dev, 32, rank, world, sync, allmax)}
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -692,13 +827,29 @@ def main():
                                                 "the split-bf16 kernels at about 35%"},
             "fp32_fraction_whole_path": round(value / world * 2.517e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         }
+        if calib is not None:
+            # Normalisation: the launches that follow the box's MFMA rate (weight gradients, first_conv, the chip-filling layer launches: MFMA_BOUND_SHARE of
+            # the step) are scaled to the reference box's rate, the rest (latency-bound coarse chain, small launches) is left as measured.
+            k = calib["mfma_tflops"] / REF_BOX_MFMA_TFLOPS
+            out["box_calibration"] = calib
+            out["ms_per_step_at_reference_box"] = round(out["ms_per_step"] * (MFMA_BOUND_SHARE * k + (1.0 - MFMA_BOUND_SHARE)), 4)
+            out["normalisation"] = (f"ms_per_step x ({MFMA_BOUND_SHARE} x mfma_tflops / {REF_BOX_MFMA_TFLOPS:.0f} + {1 - MFMA_BOUND_SHARE:.2f}): the MFMA-rate-bound share of the step "
+                                    f"scaled to a box whose calibration loop sustains {REF_BOX_MFMA_TFLOPS:.0f} TFLOP/s (DESIGN.md section 5); value / ms_per_step stay raw")
         if rccl is not None:
             out["rccl"] = rccl
         # the single-GPU legs (CPU baseline, Viterbi, end-to-end, evaluation) belong to the N = 1 line: at N > 1 the other ranks would sit in the
         # closing barrier for their two minutes
+        if sharded is not None:
+            out["viterbi"], out["evaluation"] = sharded["viterbi"], sharded["evaluation"]
+            b5 = 16384 * C * 4 + 16384 * 4
+            gbs = b5 / (out["viterbi"]["ms_per_video_batch256"] * world * 1e-3) / 1e9        # per GPU: a rank's own rate
+            out["roofline_viterbi"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "per_gpu": True,
+                                       "config5_T16384_N64": {"algorithmic_bytes_per_video": b5,
+                                                              "batch256": {"ms_per_video_per_gpu": round(out["viterbi"]["ms_per_video_batch256"] * world, 5),
+                                                                           "achieved": round(gbs, 3), "frac": round(gbs / PEAK_HBM_GBS, 6)}}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
-        if not args.no_viterbi and world == 1:
+        if not args.no_viterbi and world == 1 and sharded is None:
             out["viterbi"] = viterbi_bench(dev, C)
             out["roofline_viterbi"] = viterbi_roofline(out["viterbi"])
             out["end_to_end"] = end_to_end_bench(dev)

@@ -57,10 +57,25 @@ int mucon_profile_stride(int32_t every);
  * environment gets when the library is first used.  Affects later calls; workspaces sized before a change that
  * needs more slab space make those calls fail with MUCON_E_WORKSPACE, never overrun. */
 int mucon_test_set_knob(const char *name, const char *value);
+/* The current value of MUCON_MFMA16, MUCON_TN_SPLIT or MUCON_FIRST_CONV_SPLIT (what a test restores after forcing another); -1: not readable. */
+int mucon_test_get_knob(const char *name);
 
 /* Timing builds only (MUCON_HIPCC_FLAGS=-DFS_STAMP=1): the s_memtime sums fs_kernel's block 0 left behind, [64 variants][8 waves][8
  * phases] (gemm_fused_split.hpp); returns MUCON_E_ARG in a normal build. */
 int mucon_test_read_stamps(long long *out, int32_t n);
+
+/* Box calibration (bench.py `box_calibration`; csrc/probe.hpp): 1 + `launches` launches of a bare bf16 MFMA loop (1,024 workgroups of four waves,
+ * `iters` x 16 v_mfma_f32_32x32x16_bf16 -- or, with shape16, the same FLOPs as 16x16x32 -- per wave, pseudo-random operands in registers) on
+ * `stream`: *tflops_host = sustained dense bf16 TFLOP/s over the timed launches (HIP events), *clock_ghz_host = the in-kernel shader clock of the
+ * last launch (delta s_memtime / delta s_memrealtime, median over workgroups), *ms_host = the timed launches' milliseconds.  `scratch`: >= 16,448
+ * bytes of device memory.  Synchronises the stream. */
+int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void *scratch, size_t scratch_bytes, float *tflops_host,
+                          float *clock_ghz_host, float *ms_host, void *stream);
+
+/* Diagnostic builds only (MUCON_HIPCC_FLAGS=-DCLK_STAMP=1): per workgroup of the last launches of slot 0 (first_conv's split-bf16 kernel) or
+ * slot 1 (the split-bf16 weight-gradient launch) the pair (shader cycles, 100 MHz ticks) spent in the kernel's main loop, [4096][2]; returns
+ * the number of workgroup records (0 in a normal build, -1 on a bad argument).  In-kernel clock = cycles / ticks x 100 MHz. */
+int mucon_test_read_clock(int32_t slot, long long *out, int32_t n);
 
 /* Host-side phases of the LAST mucon_viterbi_decode_host call, in microseconds (steady_clock): [0] argument scan + staging set-up
  * (the job table, and the memcpy of every video's transcript and length table into the pinned input buffer), [1] the launches,

@@ -131,6 +131,10 @@ SYMBOLS = {
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
     "mucon_test_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "mucon_test_get_knob": (ctypes.c_int, [ctypes.c_char_p]),
+    "mucon_test_mfma_probe": (ctypes.c_int, [_i32, _i32, _i32, _vp, _sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                             ctypes.POINTER(ctypes.c_float), _vp]),
+    "mucon_test_read_clock": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_test_vit_host_phases": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "mucon_test_read_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_profile_begin": (ctypes.c_int, [_i32]),
@@ -210,6 +214,17 @@ def load(build_if_missing: bool = True):
         raise MuconHipError(f"ABI version mismatch: library {lib.mucon_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+_MFMA16_DEFAULT = None
+
+
+def mfma16_default() -> int:
+    """The MUCON_MFMA16 value this process started with (environment, else the library's default): what tests restore."""
+    global _MFMA16_DEFAULT
+    if _MFMA16_DEFAULT is None:
+        _MFMA16_DEFAULT = int(load().mucon_test_get_knob(b"MUCON_MFMA16"))   # (the library read the environment when it was first used)
+    return _MFMA16_DEFAULT
 
 
 def set_knob(name: str, value) -> None:

@@ -51,6 +51,51 @@ __device__ __forceinline__ void sp_split_weights(const float *W, uint16_t *img, 
     sp_split_weights_fn([=](int n, int k) { return W[(long)n * D + k]; }, img, D, first, stride);
 }
 
+// The image nt_split16_kernel stages (v_mfma_f32_16x16x32_bf16): per 64-deep k-tile [k-step 2][plane 3][h 4][channel 128][slot 8] bf16,
+// with k32 = k mod 32 at h = (k32 >> 2) & 3, slot (k32 & 3) + 4 (k32 >> 4)
+template <class SRC>
+__device__ __forceinline__ void sp_split_weights16_fn(SRC src, uint16_t *img, int D, long first, long stride) {
+    uint32_t *P = reinterpret_cast<uint32_t *>(img);
+    const long n_pairs = 64L * D;
+    for (long e = first; e < n_pairs; e += stride) {
+        const int n = (int)(e / (D / 2)), k = (int)(e - (long)n * (D / 2)) * 2;
+        uint32_t h, m, l;
+        sp_split2(src(n, k), src(n, k + 1), h, m, l);
+        const int S = k >> 6, ks = (k >> 5) & 1, k32 = k & 31;
+        const int hh = (k32 >> 2) & 3, slot = (k32 & 3) + 4 * (k32 >> 4);
+        const long base = (long)S * (24576 / 2) + ((long)((ks * 3) * 4 + hh) * 128 + n) * 4 + (slot >> 1);   // plane stride 4*128*8/2 pairs
+        P[base] = h;
+        P[base + 2048] = m;
+        P[base + 4096] = l;
+    }
+}
+__device__ __forceinline__ void sp_split_weights16(const float *W, uint16_t *img, int D, long first, long stride) {
+    sp_split_weights16_fn([=](int n, int k) { return W[(long)n * D + k]; }, img, D, first, stride);
+}
+
+// Diagnostic build only (MUCON_HIPCC_FLAGS=-DCLK_STAMP=1): the MFMA kernels of gemm_split.hpp (slot 0) and gemm_tn_split.hpp (slot 1)
+// stamp s_memtime (shader cycles) and s_memrealtime (100 MHz) around their main loop; lane 0 of every workgroup's wave 0 leaves the two
+// differences in a buffer of their own, which mucon_test_read_clock copies out: the in-kernel clock = delta cycles / delta real x 100 MHz.
+// No output value depends on a stamp; in the normal build no stamp executes.
+#ifndef CLK_STAMP
+#define CLK_STAMP 0
+#endif
+#if CLK_STAMP
+__device__ long long g_clk[2][4096][2];
+#define CLK_BEGIN() const long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define CLK_END(slot, wg)                                                                          \
+    do {                                                                                           \
+        const long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && (wg) < 4096) {                                                     \
+            g_clk[slot][wg][0] = c1_ - clk_c0_;                                                    \
+            g_clk[slot][wg][1] = r1_ - clk_r0_;                                                    \
+        }                                                                                          \
+    } while (0)
+#else
+#define CLK_BEGIN() do { } while (0)
+#define CLK_END(slot, wg) do { } while (0)
+#endif
+
 #define MUCON_H 128  // hidden width the MFMA kernels are specialised for (cfg.model.ft.hidden_size)
 
 // activation of the reference's apply_non_lin (temporal.py:40-41): relu or leaky_relu(0.01);

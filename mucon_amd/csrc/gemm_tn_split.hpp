@@ -28,6 +28,8 @@
 #include "dispatch.hpp"
 #include "gemm_tn.hpp"
 
+extern int g_mfma16;   // mucon_hip.hip (MUCON_MFMA16): bit 1 = this header's launch on v_mfma_f32_16x16x32_bf16
+
 #ifndef TS_ABL
 #define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
 #endif
@@ -348,10 +350,12 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         __syncthreads();
         TS_T(4);
     };
+    CLK_BEGIN();
     for (int mt = 0; mt < ntiles; mt += 2) {
         tile(mt, I0{}, I1{});
         if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
     }
+    CLK_END(1, blockIdx.x);
 
 #if TS_STAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -386,8 +390,355 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same workgroup on v_mfma_f32_16x16x32_bf16 (round 5: MUCON_MFMA16 bit 1; why a second shape: gemm_split.hpp, and
+// profiles/r05_mfma_shape.txt for the A/B).  Lane (r = lane & 15, h = lane >> 4) holds 8 consecutive TIME steps 8h .. 8h + 7 of a
+// 32-step tile, for channel r of a 16-channel block (G) or column r of a 16-column half (X): a tile is ONE 32-deep step of
+// 8 channel blocks x 2 column halves x 6 products = 96 MFMAs (32x32x16: 2 steps x 4 x 6 = 48 of twice the cycles).
+//   * G image per 32 steps: [plane 3][time group 4][channel 128][8 steps] -- the same 24 KB, staged by the same thread roles
+//     (unit (s, h) of the wide shape is time group 2s + h), conflict-free ds_read_b128 / ds_write_b64.
+//   * a tile runs as two phases of four channel blocks each, both column halves in every phase: every G fragment is read from
+//     LDS once (12 per phase, as before).  The operand planes of BOTH column halves of a tile are complete when it starts; the
+//     split of the next tile's column half 0 / 1 is woven into phase 0 / 1, so the wave's X tile in LDS holds tile mt + 1
+//     while tile mt multiplies (one tile further ahead than the wide shape; the register sets hold tiles mt + 2, mt + 3).
+//   * the X tile is [32 steps][36] floats with columns 16-31 and 0-15 exchanged in steps 16-31: the four time groups of a
+//     column read land in four different bank quarters (row-major [32][32] would collide 4-way on this shape).
+//   * accumulators: [column half][channel block] float4 = channels 16 cb + 4 h + e of column 16 c + r.
+// Summation order differs from the wide shape's (K = 32 per MFMA instead of 16): the gradients of the two shapes agree to
+// fp32 rounding, not bitwise; each shape is bitwise repeatable and batch independent by itself.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TS16_XT_FLOATS = 32 * 36;
+constexpr int TS16_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS16_XT_FLOATS * 4;   // 135,168 B
+
+template <bool TWO_G, bool DROP>
+__device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
+                                          uint16_t *smem) {
+    constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave >> 2, cg = wave & 3;
+    const int r = lane & 15, h = lane >> 4;
+    const int b = mc / p.chunks_per_video;
+    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
+    const int tend = min(tbeg + p.MC, p.Trows);
+    const int ntiles = (tend - tbeg + 31) >> 5;
+    const int last = ntiles - 1;
+    const int nch = p.nk0 + (dual ? 1 : 0);
+    const int kc_raw = 2 * kc2 + hf;
+    const bool active = kc_raw < nch;
+    const int kc = active ? kc_raw : 2 * kc2;
+    const bool second = dual && kc >= p.nk0;
+    const int xoff = (!second && p.taps == 3) ? (kc - 1) * p.tap_step : 0;
+    const int xcol = (second || p.taps == 3) ? 0 : kc * 128;
+    const int ldx = second ? 128 : p.ldx;
+    const int Tx = second ? p.Trows : p.Tx;
+    const float *Xu = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;   // wave-uniform
+    const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
+    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;
+    float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS16_XT_FLOATS;
+
+    const int sn = tid & 127;
+    const int s_hi = wave >> 2, s_lo = (wave >> 1) & 1;
+    const int s_img = TWO_G ? s_hi : 0;
+    const int s_s = TWO_G ? s_lo : s_hi;
+    const float *Yu = ((TWO_G && s_img) ? p.Y1 : p.Y0) + (long)b * p.Trows * 128;   // wave-uniform
+    const uint32_t y_lane = (uint32_t)sn * 4u;
+    auto unit_h = [&](int u) { return TWO_G ? u : s_lo; };
+    DropCfg dcfg = p.drop;
+    dcfg.thresh = s_img ? dcfg.thresh : 0u;
+    dcfg.scale = s_img ? dcfg.scale : 1.f;
+    auto ld_su = [](const float *ubase, uint32_t lane_bytes) {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + lane_bytes);
+    };
+
+    f32x4 rx[2][4];
+    float rawT[8];
+    float rgA[NU][4], rgB[NU][4];
+    float bsum[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
+
+    auto g_int = [&](int tile) { return tbeg + tile * 32 + 32 <= tend; };
+    auto x_int = [&](int tile) {
+        const int t0 = tbeg + tile * 32;
+        return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
+    };
+    auto gloadX = [&](int tile, auto SET) {
+        constexpr int Q = decltype(SET)::value;
+        if (x_int(tile)) {
+            const float *ub = Xu + (long)(tbeg + tile * 32 + xoff) * ldx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ub + (long)(8 * i) * ldx) + x_lane);
+        } else {
+            const int row0 = tbeg + tile * 32 + xrow + xoff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ts = min(max(row0 + 8 * i, 0), Tx - 1);
+                rx[Q][i] = *reinterpret_cast<const f32x4 *>(Xu + (long)ts * ldx + cg * 32 + xc4);
+            }
+        }
+    };
+    // wave-private X tile: rows as loaded (steps 16-31 with the two 16-column halves exchanged), read back by column
+    auto stageX = [&](auto SET) {
+        constexpr int Q = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 36 + (xc4 ^ (16 * (i >> 1)))) = rx[Q][i];
+    };
+    auto readX = [&](int c) {   // column 16 c + r, steps 8h .. 8h + 7
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rawT[j] = xT[(8 * h + j) * 36 + ((16 * c + r) ^ (16 * (h >> 1)))];
+    };
+    auto fixX = [&](float (&raw)[8], int tile) {   // non-linearity of the last_conv job, zero padding, chunk end
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = tbeg + tile * 32 + 8 * h + j;
+            const int ts = t + xoff;
+            float x = raw[j];
+            if (x0_act) x = act_f(x, p.slope);
+            raw[j] = (t < tend && ts >= 0 && ts < Tx) ? x : 0.f;
+        }
+    };
+    auto gloadG = [&](int tile, auto HALF) {
+        constexpr int HB = decltype(HALF)::value;
+        const bool inner = g_int(tile);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;   // wave-uniform
+                if (!inner) t = min(t, p.Trows - 1);
+                const float v = ld_su(Yu + (long)t * 128, y_lane);
+                if constexpr (HB) rgB[u][jj] = v;
+                else rgA[u][jj] = v;
+            }
+    };
+    auto fixG = [&](int tile, auto HALF) {
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                if constexpr (HB) rgB[u][jj] = t < tend ? rgB[u][jj] : 0.f;
+                else rgA[u][jj] = t < tend ? rgA[u][jj] : 0.f;
+            }
+    };
+    auto splitstoreG = [&](int tile, int buf, auto HALF, float bw) {
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                v[jj] = HB ? rgB[u][jj] : rgA[u][jj];
+                if (DROP) {
+                    const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                    v[jj] *= drop_mul(dcfg, (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)sn);
+                }
+                bsum[u] = fmaf(v[jj], bw, bsum[u]);
+            }
+            uint32_t a0, m0, l0, a1, m1, l1;
+            sp_split2(v[0], v[1], a0, m0, l0);
+            sp_split2(v[2], v[3], a1, m1, l1);
+            // image [plane 3][time group 4][channel 128][8]: this unit is time group 2 s + h
+            uint16_t *dst = smem + (buf * 2 + s_img) * TS_IMG + ((2 * s_s + unit_h(u)) * 128 + sn) * 8 + 4 * HB;
+            *reinterpret_cast<u32x2 *>(dst) = u32x2{a0, a1};
+            *reinterpret_cast<u32x2 *>(dst + 4 * 128 * 8) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2 *>(dst + 8 * 128 * 8) = u32x2{l0, l1};
+        }
+    };
+    struct Planes { bf16x8 pl[3]; };
+    auto convertX = [&](const float (&x)[8]) {
+        u32x4 hh, mm, ll;
+        uint32_t a, bb, c;
+        sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
+        sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
+        sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
+        sp_split2(x[6], x[7], a, bb, c); hh[3] = a; mm[3] = bb; ll[3] = c;
+        Planes P;
+        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
+        return P;
+    };
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // G fragment (plane pl, channel block cb): image[pl][h][cb*16 + r][8]
+    const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
+    auto mfma_phase = [&](int buf, auto HALF, const Planes &X0, const Planes &X1) {
+        constexpr int CB0 = 4 * decltype(HALF)::value;
+        const uint16_t *base = smem + buf * 2 * TS_IMG + g_off + CB0 * 16 * 8;
+        bf16x8 w[4][3];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[cb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (4 * 128 * 8) + cb * 16 * 8);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {   // small terms first; all six land in the same fp32 accumulator
+                const Planes &X = c ? X1 : X0;
+                f32x4 a = acc[c][CB0 + cb];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], X.pl[1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][2], X.pl[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[2], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], X.pl[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[0], a, 0, 0, 0);
+                acc[c][CB0 + cb] = a;
+            }
+    };
+    // 48 MFMAs: the first channel block's fragments in front, the other nine under the first 36 MFMAs; 2 * VPM vector
+    // instructions behind every pair of MFMAs (an MFMA holds the SIMD's issue for 8 of its 16 cycles), the LDS stores in the second half
+    constexpr int VPM = DROP ? 7 : (TWO_G ? 4 : 3);
+    auto weave = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 36 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i & 1) __builtin_amdgcn_sched_group_barrier(0x002, VPM - VPM / 2, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, VPM / 2, 0);
+            if (i >= 24 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+
+    auto pin = [](auto &arr) {
+#pragma unroll
+        for (auto &v : arr) asm volatile("" : "+v"(v));
+    };
+    auto use = [](const Planes &P) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
+    };
+    Planes cur0, cur1;
+    {   // prologue: image of tile 0; X tiles 0 .. 3 requested, tile 0 split into both operands, tile 1 staged; first half of image 1 requested
+        gloadG(0, I0{});
+        gloadG(0, I1{});
+        gloadX(0, I0{});
+        gloadX(min(1, last), I1{});
+        if (!g_int(0)) {
+            fixG(0, I0{});
+            fixG(0, I1{});
+        }
+        splitstoreG(0, 0, I0{}, 1.f);
+        splitstoreG(0, 0, I1{}, 1.f);
+        gloadG(min(1, last), I0{});
+        stageX(I0{});
+        gloadX(min(2, last), I0{});
+        readX(0);
+        if (!x_int(0)) fixX(rawT, 0);
+        cur0 = convertX(rawT);
+        readX(1);
+        if (!x_int(0)) fixX(rawT, 0);
+        cur1 = convertX(rawT);
+        stageX(I1{});
+        gloadX(min(3, last), I1{});
+        __syncthreads();
+    }
+
+    // tile mt (image in buffer Q; operands cur0 / cur1; the wave's X tile holds tile mt+1; set Q holds tile mt+2, set O tile mt+3 on its way):
+    //   { second half of image mt+1 requested; X (mt+1, columns 0-15) read back }
+    //   { MFMAs of channel blocks 0-3 | split of X (mt+1, columns 0-15), first half of image mt+1 -> buffer O }
+    //   { X (mt+1, columns 16-31) read back; X tile <- tile mt+2 (set Q), set Q <- tile mt+4 requested; first half of image mt+2 requested }
+    //   { MFMAs of channel blocks 4-7 | split of X (mt+1, columns 16-31), second half of image mt+1 }
+#if TS_STAMP
+    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
+    auto tile = [&](int mt, auto SET, auto OTHER) {
+        constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
+        TS_T(5);
+        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n4 = min(mt + 4, last);
+        const float bw = mt < last ? 1.f : 0.f;
+        gloadG(n1, I1{});
+        readX(0);
+        if (!x_int(n1)) fixX(rawT, n1);
+        if (!g_int(n1)) fixG(n1, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        TS_T(0);
+        pin(rawT);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pin(rgA[u]);
+        mfma_phase(Q, I0{}, cur0, cur1);
+        Planes nxt0 = convertX(rawT);
+        splitstoreG(n1, O, I0{}, bw);
+        weave();
+        use(nxt0);
+        __builtin_amdgcn_sched_barrier(0);
+        TS_T(1);
+        readX(1);
+        stageX(SET);
+        gloadG(n2, I0{});
+        gloadX(n4, SET);
+        if (!x_int(n1)) fixX(rawT, n1);
+        if (!g_int(n1)) fixG(n1, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        TS_T(2);
+        pin(rawT);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pin(rgB[u]);
+        mfma_phase(Q, I1{}, cur0, cur1);
+        Planes nxt1 = convertX(rawT);
+        splitstoreG(n1, O, I1{}, bw);
+        weave();
+        use(nxt1);
+        __builtin_amdgcn_sched_barrier(0);
+        TS_T(3);
+        cur0 = nxt0;
+        cur1 = nxt1;
+        __syncthreads();
+        TS_T(4);
+    };
+    CLK_BEGIN();
+    for (int mt = 0; mt < ntiles; mt += 2) {
+        tile(mt, I0{}, I1{});
+        if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
+    }
+    CLK_END(1, blockIdx.x);
+
+#if TS_STAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
+#endif
+    if (active) {
+        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slab[(long)(cb * 16 + 4 * h + e) * p.Ktot + 16 * c] = acc[c][cb][e];
+    }
+    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
+    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
+    if (bias0 || bias1) {   // workgroup-uniform
+        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
+        float own = bsum[0];
+        if (TWO_G) own += bsum[NU - 1];
+        red[(s_hi * 2 + s_lo) * 128 + sn] = own;
+        __syncthreads();
+        if (TWO_G) {
+            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
+            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
+        } else if (tid < 128 && bias0) {
+            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        }
+    }
+}
+
 // All weight gradients of a backward pass in one launch (the job table of gemm_tn.hpp): a job with n 128-column chunks has
 // ceil(n / 2) workgroups per time chunk.
+template <bool M16>   // M16: v_mfma_f32_16x16x32_bf16 (ts_body16), else 32x32x16 (ts_body)
 __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
     int ji = 0;
@@ -411,19 +762,28 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
         }
     }
     const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
-    if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
-    else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
-    else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
+    if constexpr (M16) {
+        if (!two_g) ts_body16<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
+        else if (job.p.drop.thresh) ts_body16<true, true>(job.p, kc2, mc, true, false, ts_smem);
+        else ts_body16<true, false>(job.p, kc2, mc, true, false, ts_smem);
+    } else {
+        if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
+        else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
+        else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
+    }
 }
 
 static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, TS_SMEM_BYTES);
+    const bool m16 = (g_mfma16 & 2) != 0;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[m16]) {
+        hipError_t e = m16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TS16_SMEM_BYTES)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TS_SMEM_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[m16] = true;
     }
     // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
     TnBatch lb;
@@ -439,7 +799,8 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     }
     lb.nblocks = blocks;
     lb.xcd_order = kTsXcdOrder;
-    hipLaunchKernelGGL(ts_batched_kernel, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
+    if (m16) hipLaunchKernelGGL(ts_batched_kernel<true>, dim3(blocks), dim3(512), TS16_SMEM_BYTES, s, lb);
+    else hipLaunchKernelGGL(ts_batched_kernel<false>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();
 }

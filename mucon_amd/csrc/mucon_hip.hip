@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include "../../include/mucon_hip.h"
 #include "../../include/mucon_hip_test.h"
@@ -22,7 +24,10 @@
 #include "gemm_fused_split.hpp"
 #include "gemm_coarse_split.hpp"
 #include "small_kernels.hpp"
+#include "probe.hpp"
 
+int g_mfma16 = 0;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
+                              // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
 int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
 int g_nt_force_bm = 0;
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
@@ -176,6 +181,38 @@ inline bool fs_level(const mucon_encoder_cfg *cfg, const Plan &pl, int l) {
 inline bool cs_on() { return g_cs && !g_no_fuse; }
 int g_pack_f32 = 0;     // MUCON_PACK_ALL=1: every weight re-layout is written whether or not a launch of the pass reads it (A/B of the r4 trimming; tests)
 int g_tail_chain = 1;   // MUCON_TAIL_CHAIN=0: the row-local launches at the coarsest level one by one (cs_kernel) instead of chained (ct_kernel)
+
+// Which weight re-layouts a forward pass writes.  The backward pass reads them, decides from the same predicates, and refuses to run when
+// its answer differs from what the forward recorded for the workspace (a knob set between the two calls would otherwise make it multiply
+// by workspace nobody wrote).
+struct PackDecision {
+    bool need_f32;       // the f32 operand layouts W1f / W1b / W2t / Wlt
+    bool split_first;    // first_conv.weight's pre-split image (W0s)
+    bool split_dgrad0;   // layer 0's data-gradient image (Wd0s)
+    int img16;           // ... both in the order of the 16x16x32 kernel
+    bool operator==(const PackDecision &o) const {
+        return need_f32 == o.need_f32 && split_first == o.split_first && split_dgrad0 == o.split_dgrad0 && img16 == o.img16;
+    }
+};
+PackDecision pack_decision(const mucon_encoder_cfg *cfg, const mucon_encoder_params *prm, const Plan &pl) {
+    PackDecision d;
+    const int L = pl.L;
+    // The f32 operand layouts feed the f32-MFMA kernels only.  When every launch of a forward AND of its backward takes the split-bf16
+    // images (the default configuration: k-split kernels on, pooled boundaries fused, biases present, no pooling behind the last layer)
+    // they are not written at all: 5 MB of stores and 56 transposing workgroups less per pass (r4).
+    d.need_f32 = !cs_on() || !kPoolFuse || cfg->pool_after[L - 1] || !prm->last_b || (long)pl.B * pl.T > kFuseMaxRows || g_pack_f32;
+    for (int l = 0; l < L; ++l) d.need_f32 = d.need_f32 || !prm->dil_b[l] || !prm->pw_b[l];
+    // first_conv on the bf16 MFMA with exactly split operands: worth it once the launch fills the chip
+    d.split_first = g_first_conv_split && (long)pl.B * pl.T >= g_first_conv_split_rows;
+    // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
+    // (mucon_encoder_bwd reaches that launch only when neither two-stage split kernel takes layer 0)
+    d.split_dgrad0 = kNtSplitDgrad0 && (long)pl.B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T &&
+                     ((!fs_level(cfg, pl, 0) && !cs_on()) || g_pack_f32);
+    d.img16 = g_mfma16 & 1;
+    return d;
+}
+std::mutex g_fwd_mu;
+std::unordered_map<const void *, PackDecision> g_fwd_record;   // workspace -> what its last forward wrote
 inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t, 4 / 5 centre taps of W1f / W1b in accumulator order
     const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : 2L * FS_IMG_K384 + (long)(mat - 2) * FS_IMG_K128);
     return reinterpret_cast<const uint16_t *>(ws + pl.Wfs) + (long)l * FS_LAYER_ELEMS + off;
@@ -446,6 +483,10 @@ static bool apply_knob(const char *name, const char *e) {
         g_fs_rows = atol(e);
         return true;
     }
+    if (!strcmp(name, "MUCON_MFMA16")) {
+        if (e) g_mfma16 = atoi(e) & 3;
+        return true;
+    }
     if (!strcmp(name, "MUCON_TN_SPLIT")) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
@@ -480,7 +521,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_MFMA16", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -501,6 +542,66 @@ int mucon_test_set_knob(const char *name, const char *value) {
     mucon_abi_version();   // the environment first: a later first use must not overwrite this
     if (!name || !value || !apply_knob(name, value)) return fail(MUCON_E_ARG, "unknown tuning knob %s", name ? name : "(null)");
     return MUCON_OK;
+}
+int mucon_test_get_knob(const char *name) {
+    mucon_abi_version();
+    if (name && !strcmp(name, "MUCON_MFMA16")) return g_mfma16;
+    if (name && !strcmp(name, "MUCON_TN_SPLIT")) return g_tn_split;
+    if (name && !strcmp(name, "MUCON_FIRST_CONV_SPLIT")) return g_first_conv_split;
+    return -1;
+}
+int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void *scratch, size_t scratch_bytes, float *tflops_host,
+                          float *clock_ghz_host, float *ms_host, void *stream) {
+    const int grid = 1024;
+    if (launches < 1 || iters < 1 || !scratch || scratch_bytes < grid * sizeof(ProbeOut) + 64)
+        return fail(MUCON_E_ARG, "mfma_probe: launches=%d iters=%d scratch=%zu B (need %zu)", launches, iters, scratch_bytes, grid * sizeof(ProbeOut) + 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProbeOut *po = static_cast<ProbeOut *>(scratch);
+    float *sink = reinterpret_cast<float *>(po + grid);
+    auto go = [&]() {
+        if (shape16) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3(grid), dim3(256), 0, s, iters, po, sink);
+        else hipLaunchKernelGGL(mfma_probe_kernel<false>, dim3(grid), dim3(256), 0, s, iters, po, sink);
+        return hipGetLastError();
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(go());   // ramp
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < launches; ++i) HIPCHK(go());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    static ProbeOut host[1024];
+    HIPCHK(hipMemcpy(host, po, sizeof(host), hipMemcpyDeviceToHost));
+    double ghz[1024];
+    int n = 0;
+    for (int i = 0; i < grid; ++i)
+        if (host[i].ticks > 0) ghz[n++] = (double)host[i].cycles / (double)host[i].ticks * 0.1;
+    std::sort(ghz, ghz + n);
+    if (tflops_host) *tflops_host = (float)((double)launches * grid * 4 * iters * kProbeFlopsPerIter / (ms * 1e-3) / 1e12);
+    if (clock_ghz_host) *clock_ghz_host = n ? (float)ghz[n / 2] : 0.f;
+    if (ms_host) *ms_host = ms;
+    return MUCON_OK;
+}
+int mucon_test_read_clock(int32_t slot, long long *out, int32_t n) {
+#if CLK_STAMP
+    if (!out || slot < 0 || slot > 1 || n < 2 * 4096) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 2 * 4096, sizeof(long long) * 2 * 4096 * slot) != hipSuccess) return -1;
+    int used = 0;
+    for (int i = 0; i < 4096; ++i)
+        if (out[2 * i + 1] > 0) used = i + 1;
+    return used;
+#else
+    (void)slot;
+    (void)out;
+    (void)n;
+    return 0;
+#endif
 }
 const char *mucon_last_error(void) { return g_err; }
 int mucon_test_read_stamps(long long *out, int32_t n) {
@@ -589,26 +690,22 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         pa.pw_w[l] = prm->pw_w[l];
     }
     pa.last_w = prm->last_w;
-    // The f32 operand layouts (W1f / W1b / W2t / Wlt) feed the f32-MFMA kernels only.  When every launch of this forward AND of its
-    // backward takes the split-bf16 images (the default configuration: k-split kernels on, pooled boundaries fused, biases present, no
-    // pooling behind the last layer) they are not written at all: 5 MB of stores and 56 transposing workgroups less per pass (r4).
-    bool need_f32 = !cs_on() || !kPoolFuse || cfg->pool_after[L - 1] || !prm->last_b || (long)B * pl.T > kFuseMaxRows || g_pack_f32;
-    for (int l = 0; l < L; ++l) need_f32 = need_f32 || !prm->dil_b[l] || !prm->pw_b[l];
+    const PackDecision dec = pack_decision(cfg, prm, pl);
+    {
+        std::lock_guard<std::mutex> lk(g_fwd_mu);
+        g_fwd_record[workspace] = dec;
+    }
+    const bool need_f32 = dec.need_f32, split_first = dec.split_first, split_dgrad0 = dec.split_dgrad0;
     pa.W1f = need_f32 ? ws + pl.W1f : nullptr;
     pa.W1b = ws + pl.W1b;
     pa.W2t = ws + pl.W2t;
     pa.Wlt = ws + pl.Wlt;
     pa.L = L;
     pa.D = pl.D;
-    // first_conv on the bf16 MFMA with exactly split operands: worth it once the launch fills the chip
-    const bool split_first = g_first_conv_split && (long)B * pl.T >= g_first_conv_split_rows;
     pa.first_w = prm->first_w;
     pa.first_planes = split_first ? reinterpret_cast<uint16_t *>(ws + pl.W0s) : nullptr;
-    // layer 0's dilated-conv data gradient (the last launch of the backward chain) takes the same kernel
-    // (mucon_encoder_bwd reaches that launch only when neither two-stage split kernel takes layer 0: same conditions here)
-    const bool split_dgrad0 = kNtSplitDgrad0 && (long)B * pl.T >= g_first_conv_split_rows && cfg->dilation[0] < pl.T &&
-                              ((!fs_level(cfg, pl, 0) && !cs_on()) || g_pack_f32);
     pa.dgrad0_planes = split_dgrad0 ? reinterpret_cast<uint16_t *>(ws + pl.Wd0s) : nullptr;
+    pa.img16 = dec.img16;
     {   // ... and, in the SAME launch, the split images of the layers whose launches take gemm_fused_split.hpp / gemm_coarse_split.hpp
         // (a layer's images sit at its own slot): two launches were 8 + 7 us at the head of every forward pass
         FsPackArgs fa;
@@ -818,6 +915,17 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     const float slope = cfg->leaky ? 0.01f : 0.f;
     const int B = pl.B, L = pl.L, Tz = pl.Tz;
     DropCfg nodrop = make_drop(0, 0, 0.f, false);
+    {   // the weight layouts this pass will read are the ones the forward of this workspace wrote
+        const PackDecision now = pack_decision(cfg, prm, pl);
+        std::lock_guard<std::mutex> lk(g_fwd_mu);
+        auto it = g_fwd_record.find(workspace);
+        if (it == g_fwd_record.end()) return fail(MUCON_E_ARG, "encoder_bwd: no forward pass was run on this workspace");
+        if (!(it->second == now))
+            return fail(MUCON_E_ARG, "encoder_bwd: the forward pass wrote other weight layouts than this pass would read (f32 layouts %d/%d, "
+                        "first_conv image %d/%d, layer-0 data-gradient image %d/%d, 16x16x32 order %d/%d): a tuning knob or the parameter "
+                        "set changed between the two calls", (int)it->second.need_f32, (int)now.need_f32, (int)it->second.split_first,
+                        (int)now.split_first, (int)it->second.split_dgrad0, (int)now.split_dgrad0, it->second.img16, now.img16);
+    }
 
     Reducer red(s);
     size_t arena = 0, barena = 0;
@@ -1199,7 +1307,7 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
 }
 
 // ------------------------------------------------------------------------------------------ noft
-__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D);
+__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D, int img16);
 namespace {
 struct LinearPlan {
     size_t planes, slabs, bslabs, total;   // floats
@@ -1248,7 +1356,7 @@ int mucon_linear_fwd(int32_t B, int32_t T, int32_t D, const float *tape, const f
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 1.f);   // slope 1: the activation slot is the identity
     if (g_first_conv_split && (long)B * T >= g_first_conv_split_rows) {
         uint16_t *P = reinterpret_cast<uint16_t *>(ws + lp.planes);
-        hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
+        hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D, g_mfma16 & 1);
         HIPCHK(hipGetLastError());
         HIPCHK((launch_nt_split<false>(p, P, B, s)));
     } else {
@@ -1487,8 +1595,9 @@ int mucon_profile_end(float *total_ms_host, int32_t *count_host) {
     return MUCON_OK;
 }
 
-__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D) {
-    sp_split_weights(W, planes, D, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ void split_weights_kernel(const float *W, uint16_t *planes, int D, int img16) {
+    if (img16) sp_split_weights16(W, planes, D, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+    else sp_split_weights(W, planes, D, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 int mucon_test_first_conv_split(const float *tape, const float *w, const float *b, float *out, int32_t B, int32_t T,
                                 int32_t D, int32_t relu, void *planes, size_t planes_bytes, int32_t iters, float *ms_host,
@@ -1497,7 +1606,7 @@ int mucon_test_first_conv_split(const float *tape, const float *w, const float *
     if (!planes || planes_bytes < (size_t)3 * 128 * D * 2) return fail(MUCON_E_WORKSPACE, "test_first_conv_split: planes buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint16_t *P = static_cast<uint16_t *>(planes);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(128), dim3(256), 0, s, w, P, D, g_mfma16 & 1);
     HIPCHK(hipGetLastError());
     NtParams p = nt_base(tape, (long)T * D, D, T, T, 1, 0, D, w, b, out, 0.f);
     auto go = [&]() { return relu ? launch_nt_split<true>(p, P, B, s) : launch_nt_split<false>(p, P, B, s); };

@@ -26,6 +26,7 @@ struct PackArgs {
     uint16_t *first_planes;        // hi / mid / lo bf16 of first_conv.weight in the fragment order of gemm_split.hpp (3*128*D values)
     uint16_t *dgrad0_planes;       // same for layer 0's data-gradient operand W1b[i][tap*128 + o] (3*128*384 values), or null
     int L, D;
+    int img16;                     // the two images in the order nt_split16_kernel reads (v_mfma_f32_16x16x32_bf16: MUCON_MFMA16 bit 0)
 };
 constexpr int PACK_LDS_FLOATS = 32 * 385;   // 32 rows of dilated_conv.weight, padded; also 128 x 65 for an image k-tile
 
@@ -43,6 +44,21 @@ __device__ __forceinline__ void pack_image_tile(const float *tile, uint16_t *img
         P[base] = h;
         P[base + 1024] = m;
         P[base + 2048] = l;
+    }
+}
+
+// the same k-tile in the order of nt_split16_kernel: [k-step 2][plane 3][h 4][channel 128][slot 8] (common.hpp: sp_split_weights16_fn)
+__device__ __forceinline__ void pack_image_tile16(const float *tile, uint16_t *img_tile) {
+    uint32_t *P = reinterpret_cast<uint32_t *>(img_tile);
+    for (int q = threadIdx.x; q < 2 * 4 * 512; q += PACK_THREADS) {
+        const int sp = q & 3, n = (q >> 2) & 127, hh = (q >> 9) & 3, ks = q >> 11;
+        const int k = 32 * ks + (sp < 2 ? 4 * hh + 2 * sp : 16 + 4 * hh + 2 * (sp - 2));
+        uint32_t h, m, l;
+        sp_split2(tile[n * 65 + k], tile[n * 65 + k + 1], h, m, l);
+        const int base = ((ks * 3) * 4 + hh) * 512 + n * 4 + sp;
+        P[base] = h;
+        P[base + 2048] = m;
+        P[base + 4096] = l;
     }
 }
 
@@ -95,7 +111,8 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds,
             __syncthreads();
             for (int e = tid; e < 128 * 64; e += PACK_THREADS) lds[(e >> 6) * 65 + (e & 63)] = a.first_w[(long)(e >> 6) * a.D + 64 * S + (e & 63)];
             __syncthreads();
-            pack_image_tile(lds, a.first_planes + (long)S * 24576);
+            if (a.img16) pack_image_tile16(lds, a.first_planes + (long)S * 24576);
+            else pack_image_tile(lds, a.first_planes + (long)S * 24576);
         }
     } else {
         if (!a.dgrad0_planes || x >= 6) return;
@@ -107,7 +124,8 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs &a, float *lds,
             lds[i * 65 + kk] = w0[((long)(ob + kk) * 128 + i) * 3 + tap];
         }
         __syncthreads();
-        pack_image_tile(lds, a.dgrad0_planes + (long)x * 24576);
+        if (a.img16) pack_image_tile16(lds, a.dgrad0_planes + (long)x * 24576);
+        else pack_image_tile(lds, a.dgrad0_planes + (long)x * 24576);
     }
 }
 

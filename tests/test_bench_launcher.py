@@ -35,6 +35,12 @@ def test_bare_launch_world_2_prints_one_json_line():
     assert out["rccl"]["world"] == 2 and out["rccl"]["collectives_per_step"] == 1
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 16
     assert len(out["ms_per_step_repeats"]) == 3 and out["data"] == "stub"
+    # BASELINE.json's metric is "frames/sec ... + Viterbi ms/video at 1/2/4/8 GPU": the N > 1 line carries the sharded decode and evaluation
+    # legs (bench.py: viterbi_bench_sharded, eval_bench(rank, world) -- here on their CPU stand-ins, through the same functions)
+    vit, evl = out["viterbi"], out["evaluation"]
+    assert vit["n_gpus"] == 2 and vit["videos_per_rank_and_call"] == 4
+    assert vit["ms_per_video_batch4"] > 0 and vit["ms_per_video_T2000_N6_batch4"] > 0
+    assert evl["n_gpus"] == 2 and evl["videos"] == 4 and evl["videos_per_rank"] == 2 and evl["ms_per_video"] > 0 and evl["skipped_videos"] == 0
 
 
 def test_single_rank_keeps_the_same_schema():

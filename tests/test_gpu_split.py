@@ -16,6 +16,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
+def mfma_shape(request):
+    """Every test of this file runs on both instantiations of the kernel: v_mfma_f32_32x32x16_bf16 (nt_split_kernel) and
+    v_mfma_f32_16x16x32_bf16 (nt_split16_kernel; MUCON_MFMA16 bit 0).  The shipped default is restored afterwards."""
+    from mucon_amd import _lib
+    default = _lib.mfma16_default()
+    _lib.set_knob("MUCON_MFMA16", (default & ~1) | request.param)
+    try:
+        yield request.param
+    finally:
+        _lib.set_knob("MUCON_MFMA16", default)
+
+
 def _run_split(tape, W, bias, relu):
     from mucon_amd import _lib
     lib = _lib.load()
@@ -55,7 +68,7 @@ def test_split_first_conv_matches_float64(B, T, D, kind):
     torch.testing.assert_close(out_relu, torch.relu(out), rtol=0, atol=0)
 
 
-def test_split_is_exact():
+def test_split_is_exact(mfma_shape):
     """hi + mid + lo == x bit for bit (the planes pack_weights writes), for values across the exponent range."""
     D = 256
     g = torch.Generator().manual_seed(5)
@@ -65,10 +78,16 @@ def test_split_is_exact():
     W = w.to(DEV)
     tape = torch.zeros(1, 128, D, device=DEV)
     _, planes = _run_split(tape, W, torch.zeros(128, device=DEV), 0)
-    # fragment order: [k-tile D/64][k-step 4][plane 3][lane half 2][channel 128][slot 8], k16 = 4*half + slot (slot < 4) or 8 + 4*half + slot - 4
-    img = planes.view(torch.bfloat16).reshape(D // 64, 4, 3, 2, 128, 2, 4).double()   # slot = 4*hi + lo4
-    # k = 64*S + 16*s + 8*hi + 4*half + lo4  ->  order the axes as (plane, n, S, s, hi, half, lo4)
-    p = img.permute(2, 4, 0, 1, 5, 3, 6).reshape(3, 128, D)
+    if mfma_shape == 0:
+        # fragment order: [k-tile D/64][k-step 4][plane 3][lane half 2][channel 128][slot 8], k16 = 4*half + slot (slot < 4) or 8 + 4*half + slot - 4
+        img = planes.view(torch.bfloat16).reshape(D // 64, 4, 3, 2, 128, 2, 4).double()   # slot = 4*hi + lo4
+        # k = 64*S + 16*s + 8*hi + 4*half + lo4  ->  order the axes as (plane, n, S, s, hi, half, lo4)
+        p = img.permute(2, 4, 0, 1, 5, 3, 6).reshape(3, 128, D)
+    else:
+        # 16x16x32 order: [k-tile D/64][k-step 2][plane 3][h 4][channel 128][slot 8], k32 = 4*h + slot (slot < 4) or 16 + 4*h + slot - 4
+        img = planes.view(torch.bfloat16).reshape(D // 64, 2, 3, 4, 128, 2, 4).double()   # slot = 4*hi + lo4
+        # k = 64*S + 32*ks + 16*hi + 4*h + lo4  ->  (plane, n, S, ks, hi, h, lo4)
+        p = img.permute(2, 4, 0, 1, 5, 3, 6).reshape(3, 128, D)
     np.testing.assert_array_equal((p[0] + p[1] + p[2]).cpu().numpy(), W.double().cpu().numpy())
 
 
