@@ -756,7 +756,9 @@ def main():
         # ALGORITHMIC fp32 FLOP rate against the f32-MFMA peak (what an exact-f32 instruction stream is capped at; it can pass 1)
         # and the bf16 FLOPs actually issued against the dense bf16 peak -- the number that says how far the kernel is from ITS roof
         split_tn = os.environ.get("MUCON_TN_SPLIT", "1") != "0"
-        dom = (("ts_batched_kernel: all weight gradients of the step in one launch (bf16 MFMA on exactly split fp32 operands)"
+        mfma16 = int(lib.mucon_test_get_knob(b"MUCON_MFMA16"))     # which MFMA shape the two tape-streaming launches ran on
+        dom = ((f"ts_batched_kernel<{'true' if mfma16 & 2 else 'false'}>: all weight gradients of the step in one launch (bf16 MFMA "
+                f"{'16x16x32' if mfma16 & 2 else '32x32x16'} on exactly split fp32 operands)"
                 if split_tn else "tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)"), k_wg_ms)
         achieved = flops_wg / (dom[1] * 1e-3) / 1e12
         # the kernel's OWN ceiling: it issues 6 bf16 MFMA FLOP per algorithmic fp32 FLOP, so 2.5 PFLOP/s dense bf16 / 6 = 416.7 TFLOP/s
@@ -812,7 +814,8 @@ def main():
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
-            "roofline_first_conv_fwd": {"bound": "hbm", "kernel": "nt_split_kernel<true, false, false, false>",
+            "roofline_first_conv_fwd": {"bound": "hbm", "kernel": ("nt_split16_kernel<true, false, false, false> (v_mfma_f32_16x16x32_bf16)" if mfma16 & 1
+                                                                   else "nt_split_kernel<true, false, false, false> (v_mfma_f32_32x32x16_bf16)"),
                                         "achieved": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                         "unit": "GB/s", "frac": round(bytes_fwd / (k_fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                         "traffic": traffic_fwd, "algorithmic_bytes_per_launch": bytes_fwd,

@@ -77,6 +77,11 @@ int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void
  * the number of workgroup records (0 in a normal build, -1 on a bad argument).  In-kernel clock = cycles / ticks x 100 MHz. */
 int mucon_test_read_clock(int32_t slot, long long *out, int32_t n);
 
+/* Timing builds only (MUCON_HIPCC_FLAGS=-DCS_STAMP=1): the phase stamps of the cs_kernel launches since the last call (at most 64; csrc/gemm_coarse_split.hpp):
+ * stamps [64 launches][2 workgroups: first, middle of the grid][4 waves][12] = nine s_memtime values, then s_memrealtime at entry and at the end; info
+ * [64][8] = BWD, POOL, TAPS, ONE, row blocks, grid x, grid y, rows per video.  Returns the number of launches recorded (0 in a normal build). */
+int mucon_test_read_cs_stamps(long long *stamps, int32_t *info, int32_t n_slots);
+
 /* Host-side phases of the LAST mucon_viterbi_decode_host call, in microseconds (steady_clock): [0] argument scan + staging set-up
  * (the job table, and the memcpy of every video's transcript and length table into the pinned input buffer), [1] the launches,
  * [2] waiting for the device (flag spin or stream synchronisation), [3] copying the results out of the pinned output buffer. */

@@ -134,6 +134,7 @@ SYMBOLS = {
     "mucon_test_get_knob": (ctypes.c_int, [ctypes.c_char_p]),
     "mucon_test_mfma_probe": (ctypes.c_int, [_i32, _i32, _i32, _vp, _sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                              ctypes.POINTER(ctypes.c_float), _vp]),
+    "mucon_test_read_cs_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int32), _i32]),
     "mucon_test_read_clock": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_longlong), _i32]),
     "mucon_test_vit_host_phases": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "mucon_test_read_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), _i32]),

@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmucon_hip.so")
 PYHOST_LIB = os.path.join(HERE, "libmucon_pyhost.so")    # host-side helper of the Python binding (csrc/pyhost.c: CPython API, no HIP)
 ARCH = "gfx950"
-SOURCES = [("mucon_hip.hip", []), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", []),
+# mucon_hip.hip: -fno-slp-vectorize -- the SLP pass packs the split's adjacent fp32 subtractions into v_pk_add_f32, which costs issue cycles
+# beside MFMAs (MI355X_MICROARCH.md: "an anti-lever beside MFMAs"); same box, alternated: 0.7571 -> 0.7545 ms per step, the 16x16x32 weight-gradient
+# kernel 236 -> 222 us (profiles/r05_mfma_shape.txt)
+SOURCES = [("mucon_hip.hip", ["-fno-slp-vectorize"]), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", []),
            ("metrics.hip", ["-ffp-contract=off"])]
 
 

@@ -22,12 +22,45 @@
 #include "gemm_fused.hpp"
 #include "gemm_fused_split.hpp"
 
+// Timing builds (MUCON_HIPCC_FLAGS=-DCS_STAMP=1; tools/cs_stamps.py, profiles/r05_cs_kernel_phase_stamps.txt): every cs_kernel launch gets the next
+// of 64 slots; wave w of its first workgroup and of a workgroup in the middle of the grid leave nine s_memtime values (kernel entry, loads
+// issued, operands split = first activation rows arrived, stage-1 MFMAs issued, first exchange done, stage-1 epilogue done, stage-2 MFMAs
+// issued, second exchange done, end) and the s_memrealtime pair of entry / end in a buffer of their own.  No output depends on a stamp.
+#ifndef CS_STAMP
+#define CS_STAMP 0
+#endif
+#if CS_STAMP
+__device__ long long g_cs_stamps[64][2][4][12];
+struct CsStampInfo { int bwd, pool, taps, one, rb, gx, gy, rows; };
+static CsStampInfo g_cs_info[64];
+static int g_cs_slot = 0;
+#define CS_T(k) do { __builtin_amdgcn_sched_barrier(0); st_[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CS_SLOT_PARAM , const int cs_slot
+#else
+#define CS_T(k) do { } while (0)
+#define CS_SLOT_PARAM
+#endif
+
 // TAPS = 1: a 1x1 product (a dilated conv whose dilation reaches past the sequence -- W1img then points at the centre tap's four
 // steps -- or last_conv); ONE: stage 1 only; PRO_ACT: the non-linearity on the loaded rows (last_conv's input, temporal.py:144).
 template <bool BWD, int POOL, int TAPS, bool ONE, bool PRO_ACT, int RB>
-__global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img) {
+__global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img CS_SLOT_PARAM) {
     constexpr bool UNPOOL = BWD && POOL >= 3;
     constexpr int R2 = UNPOOL ? 2 : 1;
+#if CS_STAMP
+    long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long real0_ = __builtin_amdgcn_s_memrealtime();
+    auto cs_publish = [&](int upto) {
+        const int which = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2) ? 1 : -1);
+        if (which >= 0 && (threadIdx.x & 63) == 0) {
+            long long *o = g_cs_stamps[cs_slot & 63][which][threadIdx.x >> 6];
+            for (int k = 0; k < 9; ++k) o[k] = k <= upto ? st_[k] : st_[upto];
+            o[9] = real0_;
+            o[10] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+#endif
+    CS_T(0);
     // one exchange buffer for both reductions ([wave][row set][channel block][lane]): RB * R2 * 32 KB
     __shared__ f32x4 red[4 * RB * R2 * 8 * 64];
     const int tid = threadIdx.x;
@@ -122,6 +155,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
         }
     }
 
+    CS_T(1);
     // ---- stage 1
     Planes xa[RB][TAPS];
 #pragma unroll
@@ -141,6 +175,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
             }
             xa[rb][i] = split8(x);
         }
+    CS_T(2);
     f32x4 acc[RB][8];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -165,12 +200,14 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 #endif
     }
 
+    CS_T(3);
     // ---- first reduction (fixed order), stage-1 epilogue on blocks 2 w, 2 w + 1
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) red[((w * RB + rb) * 8 + nb) * 64 + lane] = acc[rb][nb];
     __syncthreads();
+    CS_T(4);
     f32x4 h[RB][R2][2];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -234,6 +271,10 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
                 }
             }
         }
+    CS_T(5);
+#if CS_STAMP
+    if constexpr (ONE) cs_publish(5);
+#endif
     if constexpr (ONE) return;
 
     // ---- stage 2: this wave's 32 channels are step w of the reduction, in accumulator order
@@ -258,6 +299,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 #pragma unroll
             for (int r = 0; r < R2; ++r) acc2[rb][r][nb] = mfma6(f32x4{0.f, 0.f, 0.f, 0.f}, wf[nb % D], x2[rb][r]);
     }
+    CS_T(6);
     __syncthreads();   // every wave has read its blocks of the first exchange: the buffer is free
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -266,6 +308,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) red[(((w * RB + rb) * R2 + r) * 8 + nb) * 64 + lane] = acc2[rb][r][nb];
     __syncthreads();
+    CS_T(7);
 
     // ---- second reduction, stage-2 epilogue on output blocks 2 w, 2 w + 1
 #pragma unroll
@@ -304,6 +347,10 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
                 }
             }
         }
+    CS_T(8);
+#if CS_STAMP
+    cs_publish(8);
+#endif
 }
 
 // Rows per workgroup: 16, or 32 (two row blocks sharing every weight fragment in registers: half the L2 -> register weight traffic per
@@ -315,6 +362,13 @@ extern int g_cs_rb;   // 0 = by level size (above), 1 = 16 rows, 2 = 32 rows (MU
 template <bool BWD, int POOL, int TAPS, bool ONE = false, bool PRO_ACT = false>
 static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
     const int rb = g_cs_rb ? g_cs_rb : ((long)B * ((p.Trows + 15) / 16) > kCsRb2Workgroups ? 2 : 1);
+#if CS_STAMP
+    const int slot = g_cs_slot++ & 63;
+    g_cs_info[slot] = CsStampInfo{BWD, POOL, TAPS, ONE, rb, (p.Trows + 16 * rb - 1) / (16 * rb), B, p.Trows};
+    if (rb == 2) hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), dim3((p.Trows + 31) / 32, B), dim3(256), 0, s, p, W1img, W2img, slot);
+    else hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), dim3((p.Trows + 15) / 16, B), dim3(256), 0, s, p, W1img, W2img, slot);
+    return hipGetLastError();
+#else
     if (rb == 2) {
         dim3 grid((p.Trows + 31) / 32, B);
         hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img);
@@ -323,6 +377,7 @@ static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const u
         hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p, W1img, W2img);
     }
     return hipGetLastError();
+#endif
 }
 
 // ---- chained row-local launches ---------------------------------------------------------------------------------------------

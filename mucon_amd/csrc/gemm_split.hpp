@@ -382,14 +382,16 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
             }
         }
     };
-    // 48 MFMAs: the first channel block's fragments in front, the other nine under the first 36 MFMAs, one vector instruction
-    // behind every MFMA (the MFMA holds the SIMD's issue for 8 of its 16 cycles: one 4-cycle instruction per gap is what hides)
+    // 48 MFMAs: the first two channel blocks' fragments in front, the other six under the first 12 MFMAs (issued only four 16-cycle
+    // MFMAs ahead of its use a fragment read still exposed its latency: 86.2 -> 86.5 ... against 90-92 us for the wide shape; a tile as
+    // ONE woven region of 96 MFMAs with the fragments streaming two blocks ahead measured slower, 88.7: r05_mfma_shape.txt), one vector
+    // instruction behind every MFMA (the MFMA holds the SIMD's issue for 8 of its 16 cycles: one 4-cycle instruction per gap is what hides)
     auto weave = [&](bool stores) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
         for (int i = 0; i < 48; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 36 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < 12 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             if (stores && i >= 24 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }

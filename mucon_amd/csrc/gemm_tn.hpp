@@ -224,6 +224,7 @@ struct TnBatch {
     TnJob j[TN_MAX_BATCH];
     int njobs, nblocks;
     int xcd_order;        // gemm_tn_split.hpp
+    int st_min_steps;     // gemm_tn_split.hpp: jobs with time chunks of at least this many steps run the staggered schedule
 };
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void tn_batched_kernel(const TnBatch tb) {

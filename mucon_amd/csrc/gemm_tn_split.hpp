@@ -28,7 +28,8 @@
 #include "dispatch.hpp"
 #include "gemm_tn.hpp"
 
-extern int g_mfma16;   // mucon_hip.hip (MUCON_MFMA16): bit 1 = this header's launch on v_mfma_f32_16x16x32_bf16
+extern int g_mfma16;       // mucon_hip.hip (MUCON_MFMA16): bit 1 = this header's launch on v_mfma_f32_16x16x32_bf16
+extern int g_ts_stagger;   // mucon_hip.hip (MUCON_TS_STAGGER): single-image jobs with time chunks of at least this many steps take the staggered schedule ts_body_st (0: none)
 
 #ifndef TS_ABL
 #define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
@@ -391,6 +392,373 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The staggered schedule (round 5; MUCON_TS_STAGGER, ts_batched_kernel<2>): ts_body's workgroup, operands, images, staging roles and
+// arithmetic with the tile re-ordered into blocks so that the two waves of a SIMD never want the same unit -- see the comment at the
+// tile loop below.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TWO_G, bool DROP>
+__device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
+                                        uint16_t *smem) {
+    constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave >> 2, cg = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = mc / p.chunks_per_video;
+    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
+    const int tend = min(tbeg + p.MC, p.Trows);
+    const int ntiles = (tend - tbeg + 31) >> 5;
+    const int last = ntiles - 1;
+    const int nch = p.nk0 + (dual ? 1 : 0);
+    const int kc_raw = 2 * kc2 + hf;
+    const bool active = kc_raw < nch;           // an odd chunk count leaves the last workgroup's second half without columns:
+    const int kc = active ? kc_raw : 2 * kc2;   // it repeats the first half's work and writes nothing
+    const bool second = dual && kc >= p.nk0;
+    const int xoff = (!second && p.taps == 3) ? (kc - 1) * p.tap_step : 0;
+    const int xcol = (second || p.taps == 3) ? 0 : kc * 128;
+    const int ldx = second ? 128 : p.ldx;
+    const int Tx = second ? p.Trows : p.Tx;
+    const float *Xu = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;   // wave-uniform
+    // X is fetched in 16-byte pieces: lane -> (row lane >> 3 of 8, columns 4 (lane & 7) .. + 3), four instructions per 32-step tile
+    // (a 4-byte load per element costs the memory pipeline as much per instruction: 16 of them per tile were its bottleneck)
+    const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
+    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;                              // per-lane byte offset
+    float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS_XT_FLOATS;               // this wave's transposition tile
+
+    // staging role: SAME image -> unit (s, h) = (wave >> 2, (wave >> 1) & 1); TWO_G -> image wave >> 2, s = (wave >> 1) & 1, units h = 0, 1
+    const int sn = tid & 127;
+    const int s_hi = wave >> 2, s_lo = (wave >> 1) & 1;
+    const int s_img = TWO_G ? s_hi : 0;
+    const int s_s = TWO_G ? s_lo : s_hi;
+    const float *Yu = ((TWO_G && s_img) ? p.Y1 : p.Y0) + (long)b * p.Trows * 128;   // wave-uniform
+    const uint32_t y_lane = (uint32_t)sn * 4u;
+    auto unit_h = [&](int u) { return TWO_G ? u : s_lo; };
+    // dropout replay for image 1 only, branch-free (a branch would cut the woven schedule): image 0 keeps every element at scale 1
+    DropCfg dcfg = p.drop;
+    dcfg.thresh = s_img ? dcfg.thresh : 0u;
+    dcfg.scale = s_img ? dcfg.scale : 1.f;
+    // uniform base + 32-bit per-lane byte offset: the scalar-base form of global_load (no 64-bit vector address arithmetic per load)
+    auto ld_su = [](const float *ubase, uint32_t lane_bytes) {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + lane_bytes);
+    };
+
+    constexpr int NXS = TWO_G ? 1 : 2;   // X register sets: two tiles in flight; one for the workgroups that stage two gradient images (register budget)
+    f32x4 rx[NXS][4];        // X: [set][8-row group]
+    float rawT[8], rawU[8];  // the eight time steps of this lane's column for the two MFMA steps of a tile (read back from the X tile)
+    float rgA[NU][4], rgB[NU][4];   // G: time slots 0-3 / 4-7 of the next image
+    float bsum[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
+
+    // A tile is interior when none of its 32 rows needs a mask: inside the chunk (G) and, for this wave's tap, inside the video (X).
+    // Interior tiles are loaded with wave-uniform row addresses and enter the MFMA body as they are; the others are loaded
+    // from clamped rows and masked in their registers by the (rare) fix-up branches in front of the woven phases.
+    auto g_int = [&](int tile) { return tbeg + tile * 32 + 32 <= tend; };
+    auto x_int = [&](int tile) {
+        const int t0 = tbeg + tile * 32;
+        return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
+    };
+    // X rows are ALWAYS fetched from per-lane clamped rows with 32-bit offsets from the wave-uniform video base, and G rows from clamped
+    // wave-uniform rows: no branch between a load and its use anywhere in the tile loop.  (With the interior / edge choice as a branch
+    // inside the loop the compiler's wait-count pass merged the two paths conservatively and made every X tile wait for the loads issued
+    // one block ago instead of two -- one tile of tape in flight per wave, 2.2 TB/s, the staging blocks waiting ~1,500 cycles per tile.)
+    const int ldx4 = ldx * 4, xcb = (cg * 32 + xc4) * 4;
+    auto gloadX = [&](int tile, auto SET) {
+        constexpr int Q = decltype(SET)::value;
+        const int row0 = tbeg + tile * 32 + xoff;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ts = min(max(row0 + 8 * i + xrow, 0), Tx - 1);
+            rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(Xu) + (uint32_t)(ts * ldx4 + xcb));
+        }
+    };
+    // a tile's 32 x 32 values go through the wave's own LDS tile: written as they were loaded (rows), read back by column into
+    // the MFMA operand order (lane (r, h): column r, time steps 8h .. 8h + 7 of step s).  Wave-private: program order is all it needs.
+    auto stageX = [&](auto SET) {
+        constexpr int Q = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 32 + xc4) = rx[Q][i];
+    };
+    auto readX = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rawT[j] = xT[(8 * h + j) * 32 + r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rawU[j] = xT[(16 + 8 * h + j) * 32 + r];
+    };
+    auto fixX = [&](float (&raw)[8], int tile, int s) {   // non-linearity of the last_conv job, zero padding, chunk end
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = tbeg + tile * 32 + 16 * s + 8 * h + j;
+            const int ts = t + xoff;
+            float x = raw[j];
+            if (x0_act) x = act_f(x, p.slope);
+            raw[j] = (t < tend && ts >= 0 && ts < Tx) ? x : 0.f;
+        }
+    };
+    auto gloadG = [&](int tile, auto HALF) {
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int t = min(tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj, p.Trows - 1);   // wave-uniform
+                const float v = ld_su(Yu + (long)t * 128, y_lane);
+                if constexpr (HB) rgB[u][jj] = v;
+                else rgA[u][jj] = v;
+            }
+    };
+    auto fixG = [&](int tile, auto HALF) {   // rows past the chunk end are zero
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                if constexpr (HB) rgB[u][jj] = t < tend ? rgB[u][jj] : 0.f;
+                else rgA[u][jj] = t < tend ? rgA[u][jj] : 0.f;
+            }
+    };
+    // four time slots of every unit: dropout replay, bias sums, exact split, three 8-byte LDS stores
+    // (bw = 0 for the image past the chunk's last tile, which the tail of the pipeline builds from a re-load and nobody reads)
+    auto splitstoreG = [&](int tile, int buf, auto HALF, float bw) {
+        constexpr int HB = decltype(HALF)::value;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                v[jj] = HB ? rgB[u][jj] : rgA[u][jj];
+                if (DROP) {
+                    const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
+                    v[jj] *= drop_mul(dcfg, (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)sn);
+                }
+                bsum[u] = fmaf(v[jj], bw, bsum[u]);
+            }
+            uint32_t a0, m0, l0, a1, m1, l1;
+            sp_split2(v[0], v[1], a0, m0, l0);
+            sp_split2(v[2], v[3], a1, m1, l1);
+            uint16_t *dst = smem + (buf * 2 + s_img) * TS_IMG + (((s_s * 3) * 2 + unit_h(u)) * 128 + sn) * 8 + 4 * HB;
+            *reinterpret_cast<u32x2 *>(dst) = u32x2{a0, a1};
+            *reinterpret_cast<u32x2 *>(dst + 2 * 128 * 8) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2 *>(dst + 4 * 128 * 8) = u32x2{l0, l1};
+        }
+    };
+    struct Planes { bf16x8 pl[3]; };
+    auto convertX = [&](const float (&x)[8]) {
+        u32x4 hh, mm, ll;
+        uint32_t a, bb, c;
+        if (TS_ABL & 2) {
+            Planes P;
+            hh = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+            mm = u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+            P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+            P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+            P.pl[2] = __builtin_bit_cast(bf16x8, hh);
+            return P;
+        }
+        sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
+        sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
+        sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
+        sp_split2(x[6], x[7], a, bb, c); hh[3] = a; mm[3] = bb; ll[3] = c;
+        Planes P;
+        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
+        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
+        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
+        return P;
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // G fragment (step s, plane pl, channel block nb): image[s][pl][h][nb*32 + r][8]
+    const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
+    auto mfma_step = [&](int buf, int s, const Planes &X) {
+        const uint16_t *base = smem + buf * 2 * TS_IMG + s * (3 * 2 * 128 * 8) + g_off;
+        bf16x8 w[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
+        if (TS_ABL & 1) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, w[nb][pl])));
+            return;
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[1], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][2], X.pl[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[2], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[1], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[0], acc[nb], 0, 0, 0);
+        }
+    };
+    auto pin = [](auto &arr) {
+#pragma unroll
+        for (auto &v : arr) asm volatile("" : "+v"(v));
+    };
+    auto use = [](const Planes &P) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
+    };
+    Planes P0, P1;   // the operands of the two MFMA steps of the tile this wave multiplies next
+    // One 32-step tile is two BLOCKS per wave: an MFMA block (both steps: 48 MFMAs, 24 fragment reads, nothing else) and a staging block
+    // (everything else: this wave's units of the next G image -- fix-up, dropout replay, bias sums, split, LDS stores --, its X tile
+    // through LDS into operand position and split, all global loads).  Waves 0-3 run MFMA block then staging block, waves 4-7 (each
+    // shares a SIMD with one of them) staging block then MFMA block, one barrier per tile at the end of both: on every SIMD one wave's
+    // MFMAs run beside the other wave's vector / LDS / memory work for the WHOLE tile.  (Round 4's schedule wove the split between
+    // the MFMAs of each wave and ran all eight waves in lock step: behind the barrier both waves of a SIMD wanted the matrix pipe
+    // together, later both were in their LDS read-backs together -- 5,140 cycles per tile for 3,072 of MFMA, 1,200 of them waves 0-3
+    // waiting at the barrier: profiles/r05_weight_gradient_schedule.txt.)  Same double-buffered image, same staging roles, same
+    // arithmetic and summation order as ts_body: bit-identical results.
+    //   stage(g, u): image g (its raw values are in rgA / rgB) -> buffer g & 1, then image g + 1 requested;
+    //                X tile u (register set u & 1) -> LDS tile -> read back by column -> split into the operands of both steps, then
+    //                X tile u + 2 requested into the freed set.
+    //   waves 0-3, tile mt:  MFMAs(mt) | stage(mt + 1, mt + 1)        waves 4-7, tile mt:  stage(mt + 1, mt) | MFMAs(mt)
+#if TS_STAMP
+    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef TS_ST_PRIO
+#define TS_ST_PRIO 0   // 1: s_setprio around the blocks (experiment)
+#endif
+    auto mfma_block = [&](int buf) {
+        __builtin_amdgcn_sched_barrier(0);
+        // (TS_ST_PRIO: the multiplying wave at priority 0, the staging wave at 2 -- measured without effect, 230.4 against 230.0 us; off)
+        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(0);
+        mfma_step(buf, 0, P0);
+        mfma_step(buf, 1, P1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 36 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // a fragment arrives 12 MFMAs ahead of its first use; 6 - 9 are live
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stageG = [&](int g, int buf, float bw, int gnext, auto EDGE) {   // (buf given, not g & 1: past the chunk's end the last image is staged again, into the idle buffer)
+        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(2);
+        if (decltype(EDGE)::value && !g_int(g)) {
+            fixG(g, I0{});
+            fixG(g, I1{});
+        }
+        if (!(TS_ABL & 4)) {
+            splitstoreG(g, buf, I0{}, bw);
+            splitstoreG(g, buf, I1{}, bw);
+        }
+        if (!(TS_ABL & 8)) {
+            gloadG(gnext, I0{});
+            gloadG(gnext, I1{});
+        }
+    };
+    auto stageXops = [&](int u, int unext, auto XSET, auto EDGE) {
+        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(2);
+        stageX(XSET);
+        if (!(TS_ABL & 8)) gloadX(unext, XSET);
+        readX();
+        if (decltype(EDGE)::value && !x_int(u)) {
+            fixX(rawT, u, 0);
+            fixX(rawU, u, 1);
+        }
+        P0 = convertX(rawT);
+        P1 = convertX(rawU);
+    };
+    const bool lead = hf == 0;   // (wave-uniform)
+    gloadG(0, I0{});
+    gloadG(0, I1{});
+    gloadX(0, I0{});
+    if constexpr (NXS == 2) gloadX(min(1, last), I1{});
+    stageG(0, 0, 1.f, min(1, last), std::true_type{});
+    if (lead) stageXops(0, min(NXS, last), I0{}, std::true_type{});
+    __syncthreads();
+    // (the two roles are two separate loops, not a branch inside one: a tile body holding both orders keeps the registers of both alive;
+    //  the tiles that need a fix-up -- a video edge under a tap, the chunk's partial last tile, the non-linearity of the last_conv job --
+    //  take a second copy of the tile body with the masks applied unconditionally: the interior copy is one straight line)
+    auto tile = [&](int mt, auto SET, auto OTHER, auto LEAD, auto EDGE) {
+        TS_T(5);
+        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n3 = min(mt + 3, last);
+        const float bw = mt < last ? 1.f : 0.f;
+        // (G before X inside a staging block: the gradient rows requested at the end of stageG have the rest of the block, the barrier and the
+        // MFMA block to arrive -- requested at the block's end they were waited for, ~700 cycles per tile -- and the in-order memory counter
+        // then never makes the X tile requested two blocks ago wait for anything younger than itself)
+        if constexpr (decltype(LEAD)::value) {
+            mfma_block(mt & 1);
+            TS_T(0);
+            stageG(n1, (mt + 1) & 1, bw, n2, EDGE);
+            TS_T(2);
+            if constexpr (NXS == 2) stageXops(n1, n3, OTHER, EDGE);
+            else stageXops(n1, n2, I0{}, EDGE);
+            TS_T(1);
+        } else {
+            stageG(n1, (mt + 1) & 1, bw, n2, EDGE);
+            TS_T(2);
+            if constexpr (NXS == 2) stageXops(mt, n2, SET, EDGE);
+            else stageXops(mt, n1, I0{}, EDGE);
+            TS_T(1);
+            mfma_block(mt & 1);
+            TS_T(0);
+        }
+        __syncthreads();
+        TS_T(4);
+    };
+    auto tile2 = [&](int mt, auto SET, auto OTHER, auto LEAD) { tile(mt, SET, OTHER, LEAD, std::true_type{}); };
+    CLK_BEGIN();
+    if (lead) {
+        for (int mt = 0; mt < ntiles; mt += 2) {
+            tile2(mt, I0{}, I1{}, std::true_type{});
+            if (mt + 1 < ntiles) tile2(mt + 1, I1{}, I0{}, std::true_type{});
+        }
+    } else {
+        for (int mt = 0; mt < ntiles; mt += 2) {
+            tile2(mt, I0{}, I1{}, std::false_type{});
+            if (mt + 1 < ntiles) tile2(mt + 1, I1{}, I0{}, std::false_type{});
+        }
+    }
+    CLK_END(1, blockIdx.x);
+
+#if TS_STAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
+#endif
+    if (active) {
+        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                slab[(long)row * p.Ktot] = acc[nb][reg];
+            }
+    }
+    // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
+    // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
+    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
+    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
+    if (bias0 || bias1) {   // workgroup-uniform
+        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
+        float own = bsum[0];
+        if (TWO_G) own += bsum[NU - 1];
+        red[(s_hi * 2 + s_lo) * 128 + sn] = own;
+        __syncthreads();
+        if (TWO_G) {
+            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
+            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
+        } else if (tid < 128 && bias0) {
+            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same workgroup on v_mfma_f32_16x16x32_bf16 (round 5: MUCON_MFMA16 bit 1; why a second shape: gemm_split.hpp, and
 // profiles/r05_mfma_shape.txt for the A/B).  Lane (r = lane & 15, h = lane >> 4) holds 8 consecutive TIME steps 8h .. 8h + 7 of a
 // 32-step tile, for channel r of a 16-channel block (G) or column r of a 16-column half (X): a tile is ONE 32-deep step of
@@ -401,14 +769,15 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
 //     LDS once (12 per phase, as before).  The operand planes of BOTH column halves of a tile are complete when it starts; the
 //     split of the next tile's column half 0 / 1 is woven into phase 0 / 1, so the wave's X tile in LDS holds tile mt + 1
 //     while tile mt multiplies (one tile further ahead than the wide shape; the register sets hold tiles mt + 2, mt + 3).
-//   * the X tile is [32 steps][36] floats with columns 16-31 and 0-15 exchanged in steps 16-31: the four time groups of a
-//     column read land in four different bank quarters (row-major [32][32] would collide 4-way on this shape).
+//   * the X tile is [32 steps][32] floats with columns 0-15 and 16-31 exchanged in the odd groups of 8 steps: ds_read_b32 serves
+//     lanes 0-31 and 32-63 as two groups over 32 banks, a group's two time groups (h = 0, 1 / 2, 3) then sit in different bank halves
+//     (plain row-major would collide 2-way).
 //   * accumulators: [column half][channel block] float4 = channels 16 cb + 4 h + e of column 16 c + r.
 // Summation order differs from the wide shape's (K = 32 per MFMA instead of 16): the gradients of the two shapes agree to
 // fp32 rounding, not bitwise; each shape is bitwise repeatable and batch independent by itself.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TS16_XT_FLOATS = 32 * 36;
-constexpr int TS16_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS16_XT_FLOATS * 4;   // 135,168 B
+constexpr int TS16_XT_FLOATS = 32 * 32;
+constexpr int TS16_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS16_XT_FLOATS * 4;   // 131,072 B
 
 template <bool TWO_G, bool DROP>
 __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
@@ -482,15 +851,15 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
             }
         }
     };
-    // wave-private X tile: rows as loaded (steps 16-31 with the two 16-column halves exchanged), read back by column
+    // wave-private X tile: rows as loaded (the odd groups of 8 steps with the two 16-column halves exchanged), read back by column
     auto stageX = [&](auto SET) {
         constexpr int Q = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 36 + (xc4 ^ (16 * (i >> 1)))) = rx[Q][i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 32 + (xc4 ^ (16 * (i & 1)))) = rx[Q][i];
     };
     auto readX = [&](int c) {   // column 16 c + r, steps 8h .. 8h + 7
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rawT[j] = xT[(8 * h + j) * 36 + ((16 * c + r) ^ (16 * (h >> 1)))];
+        for (int j = 0; j < 8; ++j) rawT[j] = xT[(8 * h + j) * 32 + ((16 * c + r) ^ (16 * (h & 1)))];
     };
     auto fixX = [&](float (&raw)[8], int tile) {   // non-linearity of the last_conv job, zero padding, chunk end
 #pragma unroll
@@ -597,15 +966,16 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
                 acc[c][CB0 + cb] = a;
             }
     };
-    // 48 MFMAs: the first channel block's fragments in front, the other nine under the first 36 MFMAs; 2 * VPM vector
-    // instructions behind every pair of MFMAs (an MFMA holds the SIMD's issue for 8 of its 16 cycles), the LDS stores in the second half
+    // 48 MFMAs: the first two channel blocks' fragments in front, the other six under the first 12 MFMAs (a fragment read issued four
+    // 16-cycle MFMAs ahead of its use still exposed its latency); 2 * VPM vector instructions behind every pair of MFMAs (an MFMA
+    // holds the SIMD's issue for 8 of its 16 cycles), the LDS stores in the second half
     constexpr int VPM = DROP ? 7 : (TWO_G ? 4 : 3);
     auto weave = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
         for (int i = 0; i < 48; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 36 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < 12 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i & 1) __builtin_amdgcn_sched_group_barrier(0x002, VPM - VPM / 2, 0);
             else __builtin_amdgcn_sched_group_barrier(0x002, VPM / 2, 0);
             if (i >= 24 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -662,8 +1032,14 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
         const float bw = mt < last ? 1.f : 0.f;
         gloadG(n1, I1{});
         readX(0);
-        if (!x_int(n1)) fixX(rawT, n1);
-        if (!g_int(n1)) fixG(n1, I0{});
+        if (!x_int(n1)) {
+            asm volatile("");   // (keeps the fix-up a branch: if-converted it is ~80 selects on every tile)
+            fixX(rawT, n1);
+        }
+        if (!g_int(n1)) {
+            asm volatile("");
+            fixG(n1, I0{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         TS_T(0);
         pin(rawT);
@@ -680,8 +1056,14 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
         stageX(SET);
         gloadG(n2, I0{});
         gloadX(n4, SET);
-        if (!x_int(n1)) fixX(rawT, n1);
-        if (!g_int(n1)) fixG(n1, I1{});
+        if (!x_int(n1)) {
+            asm volatile("");
+            fixX(rawT, n1);
+        }
+        if (!g_int(n1)) {
+            asm volatile("");
+            fixG(n1, I1{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         TS_T(2);
         pin(rawT);
@@ -738,7 +1120,7 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
 
 // All weight gradients of a backward pass in one launch (the job table of gemm_tn.hpp): a job with n 128-column chunks has
 // ceil(n / 2) workgroups per time chunk.
-template <bool M16>   // M16: v_mfma_f32_16x16x32_bf16 (ts_body16), else 32x32x16 (ts_body)
+template <int MODE>   // 0: ts_body (32x32x16, round 4's lock-step schedule), 1: ts_body16 (16x16x32), 2: ts_body_st (32x32x16, staggered blocks)
 __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
     int ji = 0;
@@ -762,7 +1144,19 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
         }
     }
     const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
-    if constexpr (M16) {
+    if constexpr (MODE == 2) {
+        // The staggered schedule is taken by the jobs with ONE gradient image and time chunks of at least tb.st_min_steps steps (first_conv's:
+        // 128 workgroups of 64 tiles at the bench shape, 155-160 -> 136-141 us each).  The residual layers' jobs keep round 4's body: their
+        // workgroups that stage two images and replay the dropout mask have twice the staging work per tile and the registers for one X
+        // tile in flight only -- staggered they ran 218 us instead of 200 (profiles/r05_weight_gradient_schedule.txt).
+        if (job.dual || tb.st_min_steps <= 0 || job.p.MC < tb.st_min_steps) {
+            if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
+            else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
+            else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
+        } else if (!two_g) ts_body_st<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
+        else if (job.p.drop.thresh) ts_body_st<true, true>(job.p, kc2, mc, true, false, ts_smem);
+        else ts_body_st<true, false>(job.p, kc2, mc, true, false, ts_smem);
+    } else if constexpr (MODE == 1) {
         if (!two_g) ts_body16<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
         else if (job.p.drop.thresh) ts_body16<true, true>(job.p, kc2, mc, true, false, ts_smem);
         else ts_body16<true, false>(job.p, kc2, mc, true, false, ts_smem);
@@ -775,15 +1169,14 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
 
 static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     if (tb.njobs == 0) return hipSuccess;
-    const bool m16 = (g_mfma16 & 2) != 0;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[m16]) {
-        hipError_t e = m16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TS16_SMEM_BYTES)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(ts_batched_kernel<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TS_SMEM_BYTES);
+    const int mode = (g_mfma16 & 2) ? 1 : (g_ts_stagger ? 2 : 0);
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[mode]) {
+        const void *k = mode == 1 ? reinterpret_cast<const void *>(ts_batched_kernel<1>)
+                                  : mode == 2 ? reinterpret_cast<const void *>(ts_batched_kernel<2>) : reinterpret_cast<const void *>(ts_batched_kernel<0>);
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, mode == 1 ? TS16_SMEM_BYTES : TS_SMEM_BYTES);
         if (e != hipSuccess) return e;
-        attr_set[m16] = true;
+        attr_set[mode] = true;
     }
     // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
     TnBatch lb;
@@ -799,8 +1192,10 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     }
     lb.nblocks = blocks;
     lb.xcd_order = kTsXcdOrder;
-    if (m16) hipLaunchKernelGGL(ts_batched_kernel<true>, dim3(blocks), dim3(512), TS16_SMEM_BYTES, s, lb);
-    else hipLaunchKernelGGL(ts_batched_kernel<false>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
+    lb.st_min_steps = g_ts_stagger;
+    if (mode == 1) hipLaunchKernelGGL(ts_batched_kernel<1>, dim3(blocks), dim3(512), TS16_SMEM_BYTES, s, lb);
+    else if (mode == 2) hipLaunchKernelGGL(ts_batched_kernel<2>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
+    else hipLaunchKernelGGL(ts_batched_kernel<0>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
     tb.njobs = 0;
     return hipGetLastError();
 }

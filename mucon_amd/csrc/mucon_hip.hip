@@ -26,8 +26,10 @@
 #include "small_kernels.hpp"
 #include "probe.hpp"
 
-int g_mfma16 = 0;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
+int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
                               // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
+int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
+                              // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
 int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
 int g_nt_force_bm = 0;
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
@@ -66,9 +68,13 @@ long g_fs_rows = 32768;       // ... from this many rows in the batch = one 128-
                               // faster on the coarse kernel's 32-row workgroups (512 of them, two per CU)
 int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
 int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
-inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false) {
+int g_ts_layer_mc_cap = 512;  // ... and the residual layers' jobs of the batched split launch chunks of at most this many (MUCON_TS_LAYER_MC_CAP): their workgroups
+                              // stage two gradient images and replay the dropout mask, 3.1 us per 32-step tile against first_conv's 2.4 -- at 2,048 steps the
+                              // 32 of them at the finest level ran 200 us while first_conv's 128 finished after 160 and the launch (215 us) waited for them (r5: 2048 -> 512,
+                              // 0.2086 -> 0.2000 ms per launch; 1024: 0.2148, 768: 0.199, 384: 0.200, 256: 0.1975 with 8 us more slab reduction)
+inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool split = false, bool layer = false) {
     const int target = batched ? kTnBatchTarget : kTnTarget;
-    const int cap = split ? g_ts_mc_cap : kTnMcCap;
+    const int cap = split ? ((layer && batched) ? std::min(g_ts_mc_cap, g_ts_layer_mc_cap) : g_ts_mc_cap) : kTnMcCap;
     long want = ((long)B * Trows * kchunks + target - 1) / target;
     long mc = ((want + 31) / 32) * 32;
     if (mc < 128) mc = 128;
@@ -155,15 +161,15 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     // slab arena: every weight-gradient launch of a backward pass keeps its own slabs until the
     // single batched reduction at the end
     size_t sf = 0, bf = 0;
-    auto consider = [&](int Trows, int Ktot) {   // the shortest time chunk any schedule (batched or not, split or f32) would take
+    auto consider = [&](int Trows, int Ktot, bool layer = false) {   // the shortest time chunk any schedule (batched or not, split or f32) would take
         int mc = pick_mc(p.B, Trows, Ktot / 128);
-        for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(p.B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0));
+        for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(p.B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0, layer));
         const size_t nmc = (size_t)p.B * ((Trows + mc - 1) / mc);
         sf += align64(nmc * 128 * Ktot);
         bf += align64(nmc * 256);
     };
     consider(p.T, p.D);
-    for (int l = 0; l < p.L; ++l) consider(p.Tl[l], 512);
+    for (int l = 0; l < p.L; ++l) consider(p.Tl[l], 512, true);
     consider(p.Tz, 128);
     p.slab_floats = sf;
     p.bslab_floats = bf;
@@ -314,7 +320,7 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     const bool split = g_tn_split != 0;
     if (split && dual && a.nk0 % 2 == 0)   // the split kernel pairs the conv_1x1 chunk with the last tap (gemm_tn_split.hpp)
         return fail(MUCON_E_ARG, "internal: dual weight-gradient job with an even chunk count");
-    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr, split);
+    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr, split, dual);
     t.chunks_per_video = (Trows + t.MC - 1) / t.MC;
     t.slope = slope;
     t.drop = a.drop;
@@ -487,8 +493,16 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_mfma16 = atoi(e) & 3;
         return true;
     }
+    if (!strcmp(name, "MUCON_TS_STAGGER")) {
+        if (e) g_ts_stagger = atoi(e) > 0 ? atoi(e) : 0;
+        return true;
+    }
     if (!strcmp(name, "MUCON_TN_SPLIT")) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TS_LAYER_MC_CAP")) {
+        if (e && atoi(e) >= 128) g_ts_layer_mc_cap = atoi(e) / 32 * 32;
         return true;
     }
     if (!strcmp(name, "MUCON_TS_MC_CAP")) {
@@ -521,7 +535,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_MFMA16", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -547,6 +561,7 @@ int mucon_test_get_knob(const char *name) {
     mucon_abi_version();
     if (name && !strcmp(name, "MUCON_MFMA16")) return g_mfma16;
     if (name && !strcmp(name, "MUCON_TN_SPLIT")) return g_tn_split;
+    if (name && !strcmp(name, "MUCON_TS_STAGGER")) return g_ts_stagger;
     if (name && !strcmp(name, "MUCON_FIRST_CONV_SPLIT")) return g_first_conv_split;
     return -1;
 }
@@ -586,6 +601,26 @@ int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void
     if (clock_ghz_host) *clock_ghz_host = n ? (float)ghz[n / 2] : 0.f;
     if (ms_host) *ms_host = ms;
     return MUCON_OK;
+}
+int mucon_test_read_cs_stamps(long long *stamps, int32_t *info, int32_t n_slots) {
+#if CS_STAMP
+    if (!stamps || !info || n_slots < 64) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_cs_stamps), sizeof(long long) * 64 * 2 * 4 * 12) != hipSuccess) return -1;
+    const int used = g_cs_slot < 64 ? g_cs_slot : 64;
+    for (int i = 0; i < used; ++i) {
+        const CsStampInfo &c = g_cs_info[i];
+        const int v[8] = {c.bwd, c.pool, c.taps, c.one, c.rb, c.gx, c.gy, c.rows};
+        for (int k = 0; k < 8; ++k) info[i * 8 + k] = v[k];
+    }
+    g_cs_slot = 0;
+    return used;
+#else
+    (void)stamps;
+    (void)info;
+    (void)n_slots;
+    return 0;
+#endif
 }
 int mucon_test_read_clock(int32_t slot, long long *out, int32_t n) {
 #if CLK_STAMP

@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
         }
         if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
+    // A clipped group whose gradient norm is not finite (a NaN / inf gradient: a diverged step, or a kernel that reported failure by
+    // poisoning its outputs -- the eight-workgroup decoder's hand-over time-out) is NOT applied: parameters, gradients and momentum stay as
+    // they are and norms_out carries the non-finite norm, which ops.check_health() raises on at the caller's next synchronisation point.
+    // (torch would scale every gradient of the group by NaN and write NaN into every parameter; the reference has no such guard.)
+    if (mx > 0.f && !(norm < __builtin_inff())) return;   // (uniform over the workgroup)
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     auto update = [&](float g, float p, float m, float &g_out, float &p_out, float &m_out) {
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void clip_apply_kernel(const SgdTensor *tab, i
         }
         if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
-    if (coef == 1.f) return;    // torch multiplies by a clamped 1.0 too: the same bits
+    if (coef == 1.f || (mx > 0.f && !(norm < __builtin_inff()))) return;    // torch multiplies by a clamped 1.0 too: the same bits; a non-finite norm is left for check_health
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     for (long e = b0 + threadIdx.x; e < b1; e += 256) t.g[e] *= coef;
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(const AdamTensor *tab, 
         }
         if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
     }
+    if (mx > 0.f && !(norm < __builtin_inff())) return;   // non-finite norm of a clipped group: the step is not applied (see sgd_apply_kernel)
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
     const long b1 = min(t.n, b0 + SGD_CHUNK);
     // four elements per thread and round, all loads of a round issued before its arithmetic

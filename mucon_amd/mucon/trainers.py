@@ -217,6 +217,12 @@ class SimpleTrainer:
             self.optimizer.step()
         return loss, forward_out
 
+    def check_health(self):
+        """The device-side failure words of the asynchronous step (a decoder hand-over time-out, a non-finite gradient norm whose update the
+        fused optimizer skipped), read where the host waits for the device anyway; raises MuconHipError (mucon_amd/ops.py:check_health)."""
+        from .. import ops
+        ops.check_health([self.fused_step] if self.fused_step is not None else [])
+
     def train_epoch(self, epoch_num: int, shuffle_seed: Optional[int] = None):
         """Shards the (shuffled) video list over ranks; every rank takes the same number of steps."""
         self.on_start_epoch(epoch_num)
@@ -236,6 +242,9 @@ class SimpleTrainer:
                 # HIP runtime stalls for 15 - 140 ms at a time (tools/e2e_queue_probe.py: 0.875 ms per step un-synchronised, 0.750 with a
                 # synchronisation every 40 steps).  Draining every 32 steps costs one ~20 us pipeline restart per 32 steps.
                 torch.cuda.current_stream().synchronize()
+                self.check_health()
+        if steps and torch.cuda.is_available() and str(self.device).startswith("cuda"):
+            self.check_health()
         if self.scheduler is not None and not isinstance(self.scheduler, ReduceLROnPlateau):
             self.scheduler.step()
         return torch.stack(losses).tolist() if losses else []

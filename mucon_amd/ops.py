@@ -516,6 +516,34 @@ DECODER_HANDOVER_FAILED = ("mucon_decoder_fwd: a hand-over between the eight wor
                            "co-resident for about a second: the GPU is oversubscribed); n_steps = -1, the outputs of this call are invalid")
 
 
+NONFINITE_GRADIENT_NORM = ("fused clip + optimizer step: the gradient norm of clipping group {group} is {norm} -- that group's update was NOT applied "
+                           "(csrc/optim.hpp).  A non-finite gradient is a diverged step or a kernel that reported a failure by poisoning its outputs "
+                           "(the eight-workgroup decoder's hand-over time-out fills its outputs / dV with NaN)")
+_PENDING_DECODER_STATUS = []      # n_steps words (device int32 [1]) of teacher-forced decoder calls nobody has read yet
+
+
+def check_health(optimizers=()):
+    """To be called where the host synchronises anyway (SimpleTrainer.train_epoch drains the stream every 32 steps): reads the status words the
+    asynchronous training path left on the device and raises MuconHipError on
+      * a decoder launch whose eight workgroups failed a hand-over (n_steps = -1; a teacher-forced forward does not read the word itself),
+      * a fused optimizer step that met a non-finite gradient norm (`last_norms`; the device skipped that group's update, so the weights
+        are still the last good ones).
+    Synchronises.  Cheap: one small device-to-host copy per call."""
+    pend = list(_PENDING_DECODER_STATUS)
+    del _PENDING_DECODER_STATUS[:]
+    if pend:
+        if int(torch.stack([t.reshape(()) for t in pend]).min().item()) < 0:
+            raise _lib.MuconHipError(DECODER_HANDOVER_FAILED)
+    for opt in optimizers:
+        norms = getattr(opt, "last_norms", None)
+        if norms is None or getattr(opt, "max_norm", None) is None:
+            continue
+        host = norms.detach().cpu()
+        bad = (~torch.isfinite(host)).nonzero().flatten().tolist()
+        if bad:
+            raise _lib.MuconHipError(NONFINITE_GRADIENT_NORM.format(group=bad[0], norm=float(host[bad[0]])))
+
+
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, memory, hn, cn, tf_input, dropmask, opts, *params):
@@ -550,6 +578,12 @@ class _DecoderFn(torch.autograd.Function):
         n = int(n_steps.item()) if stop_on_eos else max_steps
         if n < 0:
             raise _lib.MuconHipError(DECODER_HANDOVER_FAILED)
+        if not stop_on_eos:
+            # a teacher-forced call does not wait for the device: its status word is read at the caller's next synchronisation point
+            # (check_health); a failed launch has filled logp / lengths with NaN meanwhile, which the fused optimizer step refuses to apply
+            _PENDING_DECODER_STATUS.append(n_steps)
+            if len(_PENDING_DECODER_STATUS) > 4096:      # nobody is calling check_health: do not grow without bound
+                check_health()
         logp, lengths = logp[:n], lengths[:n]
         ctx.cfg, ctx.n, ctx.ws, ctx.nbytes, ctx.dropmask = cfg, n, ws, nbytes, dropmask
         ctx.save_for_backward(memory, hn, cn, logp, *params)

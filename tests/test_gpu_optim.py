@@ -195,3 +195,55 @@ def test_gradient_accumulation_with_the_fused_tail_matches_torch(optimizer):
         # (Adam divides by sqrt(v): where a gradient is rounding noise the update is +-lr whatever the optimizer, so the bound is a
         # fraction of one learning-rate step, not of the parameter)
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + (5e-6 if optimizer == "Adam" else 1e-7), n
+
+
+@pytest.mark.parametrize("kind", ["sgd", "sgd_momentum", "adam"])
+def test_a_non_finite_gradient_norm_is_not_applied_and_check_health_raises(kind):
+    """A NaN gradient in one clipping group (what a failed decoder hand-over leaves behind: decoder_mw.hpp poisons its outputs): that
+    group's parameters, gradients and optimizer state stay untouched on the device, the other group steps as usual, last_norms carries the
+    NaN and ops.check_health -- the trainer's call at its stream drain -- raises.  (torch would write NaN into every parameter of the group.)"""
+    from mucon_amd import _lib, ops
+    ps, gs = _params(3, 1.0)
+    split = 4
+    if kind == "adam":
+        opt = torch.optim.Adam(ps, lr=0.01, amsgrad=True)
+        fused = ops.FusedClipAdam([ps[:split], ps[split:]], 100.0, opt)
+    else:
+        opt = torch.optim.SGD(ps, lr=0.01, weight_decay=0.005, momentum=0.9 if kind == "sgd_momentum" else 0.0)
+        fused = ops.FusedClipSGD([ps[:split], ps[split:]], 100.0, opt)
+    for p, g in zip(ps, gs):
+        p.grad = g.clone()
+    fused.step()                      # a healthy step first (creates the optimizer state)
+    ops.check_health([fused])
+    before = [p.detach().clone() for p in ps]
+    for p, g in zip(ps, gs):
+        p.grad = g.clone()
+    ps[5].grad[0, 1] = float("nan")   # group 1
+    grads_before = [p.grad.clone() for p in ps]
+    fused.step()
+    torch.cuda.synchronize()
+    for i in range(split, len(ps)):
+        assert torch.equal(ps[i].detach(), before[i]), i                                    # not applied
+        assert torch.equal(ps[i].grad.nan_to_num(7.0), grads_before[i].nan_to_num(7.0)), i   # not scaled either
+    for i in range(split):
+        assert not torch.equal(ps[i].detach(), before[i]) and torch.isfinite(ps[i]).all(), i
+    assert torch.isfinite(fused.last_norms[0]) and torch.isnan(fused.last_norms[1])
+    with pytest.raises(_lib.MuconHipError, match="gradient norm of clipping group 1"):
+        ops.check_health([fused])
+    for p, g in zip(ps, gs):          # the next healthy step goes through
+        p.grad = g.clone()
+    fused.step()
+    ops.check_health([fused])
+    assert all(torch.isfinite(p).all() for p in ps)
+
+
+def test_check_health_reads_the_teacher_forced_decoders_status_word():
+    from mucon_amd import _lib, ops
+    ops.check_health()
+    ops._PENDING_DECODER_STATUS.append(torch.tensor([7], dtype=torch.int32, device=DEV))
+    ops.check_health()
+    assert not ops._PENDING_DECODER_STATUS
+    ops._PENDING_DECODER_STATUS.extend([torch.tensor([7], dtype=torch.int32, device=DEV), torch.tensor([-1], dtype=torch.int32, device=DEV)])
+    with pytest.raises(_lib.MuconHipError, match="hand-over"):
+        ops.check_health()
+    assert not ops._PENDING_DECODER_STATUS

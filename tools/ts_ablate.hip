@@ -8,6 +8,8 @@
 #include <string.h>
 #include <math.h>
 
+int g_ts_stagger = 0;   // TS_ST=1 in the environment: the staggered schedule
+int g_mfma16 = 0;   // TS_M16=1 in the environment: the 16x16x32 instantiation (bit 1, as MUCON_MFMA16)
 #include "../mucon_amd/csrc/gemm_tn_split.hpp"
 #include "experiments/gemm_tn_ws.hpp"
 #ifndef USE_TW
@@ -29,6 +31,8 @@ __global__ void fill(float *p, long n, uint32_t seed) {
 int main(int argc, char **argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32768, K = argc > 2 ? atoi(argv[2]) : 2048;
     const int MC = argc > 3 ? atoi(argv[3]) : 2048, iters = argc > 4 ? atoi(argv[4]) : 20;
+    if (getenv("TS_M16") && atoi(getenv("TS_M16"))) g_mfma16 = 2;
+    if (getenv("TS_ST") && atoi(getenv("TS_ST"))) g_ts_stagger = 32;
     float *Y, *X, *slabs, *bslabs;
     const int nmc = (M + MC - 1) / MC;
     CK(hipMalloc(&Y, (size_t)M * 128 * 4));
