@@ -358,26 +358,35 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 // at <= 256 workgroups a launch costs the latency of its chain, not its weight bytes).  r3: at B = 8 x T = 4096 the T/4 level is 512
 // workgroups of 16 rows, two per CU, and IS bound by the 786 KB of fragments its CU streams (15-21 us per launch against 9.6 at T/8):
 // 32 rows there and 16 elsewhere is -11.5 us per step (0.7855 -> 0.774 ms, same box, twice).
-extern int g_cs_rb;   // 0 = by level size (above), 1 = 16 rows, 2 = 32 rows (MUCON_COARSE_RB; tests force both)
+extern int g_cs_rb;        // 0 = by level size (above), 1 = 16 rows, 2 = 32 rows, 4 = 64 rows forward / 32 backward (MUCON_COARSE_RB; tests force all three)
+extern int g_cs_rb4_wgs;   // forward launches take 64 rows where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never -- the A/B)
 template <bool BWD, int POOL, int TAPS, bool ONE = false, bool PRO_ACT = false>
 static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const uint16_t *W2img, int B, hipStream_t s) {
-    const int rb = g_cs_rb ? g_cs_rb : ((long)B * ((p.Trows + 15) / 16) > kCsRb2Workgroups ? 2 : 1);
+    // 64 rows (RB = 4) for the FORWARD launches of a level with more than 512 16-row workgroups (the T/2 level of the bench shape: 1,024): at RB = 2 that level
+    // is 512 workgroups, two co-resident per CU, each streaming the layer's 384 KB of fragments through the CU's one path to L2 (~70 GB/s per CU:
+    // profiles/r05_cs_kernel_phase_stamps.txt) -- 768 KB per CU, 22 us; one 64-row workgroup per CU streams them once.  (Backward launches stay at 32 rows: the
+    // un-pooling variants' second exchange would need 256 KB of LDS at RB = 4.)
+    const long wg16 = (long)B * ((p.Trows + 15) / 16);
+    int rb = g_cs_rb ? g_cs_rb : (g_cs_rb4_wgs > 0 && wg16 > g_cs_rb4_wgs && !BWD ? 4 : wg16 > kCsRb2Workgroups ? 2 : 1);
+    if (BWD && rb > 2) rb = 2;
 #if CS_STAMP
     const int slot = g_cs_slot++ & 63;
     g_cs_info[slot] = CsStampInfo{BWD, POOL, TAPS, ONE, rb, (p.Trows + 16 * rb - 1) / (16 * rb), B, p.Trows};
-    if (rb == 2) hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), dim3((p.Trows + 31) / 32, B), dim3(256), 0, s, p, W1img, W2img, slot);
-    else hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), dim3((p.Trows + 15) / 16, B), dim3(256), 0, s, p, W1img, W2img, slot);
-    return hipGetLastError();
+#define CS_SLOT_ARG , slot
 #else
-    if (rb == 2) {
-        dim3 grid((p.Trows + 31) / 32, B);
-        hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img);
-    } else {
-        dim3 grid((p.Trows + 15) / 16, B);
-        hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p, W1img, W2img);
-    }
-    return hipGetLastError();
+#define CS_SLOT_ARG
 #endif
+    const dim3 grid((p.Trows + 16 * rb - 1) / (16 * rb), B);
+    if constexpr (!BWD) {
+        if (rb == 4) {
+            hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 4>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
+            return hipGetLastError();
+        }
+    }
+    if (rb == 2) hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
+    else hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
+    return hipGetLastError();
+#undef CS_SLOT_ARG
 }
 
 // ---- chained row-local launches ---------------------------------------------------------------------------------------------

@@ -290,6 +290,15 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
     const int t0 = blockIdx.x * 128;
     const int ktt = p.Kc >> 6;                // 64-deep k-tiles per tap
     const int nS = (TAPS ? p.taps : 1) * ktt; // even (Kc is a multiple of 128)
+    // Every workgroup walks the k-tiles in a ROTATED order, starting at a tile that depends on its place in the grid: with all 256
+    // workgroups starting at k = 0 and advancing in step, every tape access of the chip at one moment is a 256-byte piece at the same
+    // offset inside an 8 KB frame -- addresses that differ by multiples of 8 KB only (NT16_ROT = 0: that order).  Depends on blockIdx.x
+    // alone among the videos of a batch: a video alone sums in the order it sums inside a batch.
+#ifndef NT16_ROT
+#define NT16_ROT 1
+#endif
+    const int rot = NT16_ROT ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nS) : 0;
+    auto phys = [&](int S) { const int q = S + rot; return q >= nS ? q - nS : q; };   // logical tile S of this workgroup's walk -> k-tile
     const int trow_raw0 = t0 + wr * 32 + r, trow_raw1 = trow_raw0 + 16;
     const float *a_vid = p.A + (long)b * p.a_bstride + 32 * g + 4 * h;
     const float *a_src0 = a_vid + (long)min(trow_raw0, p.Trows - 1) * p.lda;   // padding rows re-read a valid row
@@ -299,8 +308,9 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
     f32x4 ra[2][4];   // two k-tiles of this lane's A values in flight: [set][2 * row half + piece]
     bool rok[2][2] = {{true, true}, {true, true}};   // TAPS: the staged row exists (else zero padding; the load re-read a clamped row)
     u32x4 rws[6];     // this thread's share of the next W image
-    auto gloadA = [&](int S, auto SET) {
+    auto gloadA = [&](int Sl, auto SET) {
         constexpr int Q = decltype(SET)::value;
+        const int S = phys(Sl);
         if (TAPS) {
             const int tap = S / ktt;
             const int sh = (tap - (p.taps >> 1)) * p.tap_step;
@@ -320,7 +330,8 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
             ra[Q][3] = *reinterpret_cast<const f32x4 *>(a_src1 + 64 * S + 16);
         }
     };
-    auto gloadW = [&](int S) {
+    auto gloadW = [&](int Sl) {
+        const int S = phys(Sl);
 #pragma unroll
         for (int q = 0; q < 6; ++q) rws[q] = *reinterpret_cast<const u32x4 *>(w_src + (long)S * S2_WIMG + q * 4096);
     };

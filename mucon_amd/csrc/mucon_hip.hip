@@ -30,6 +30,7 @@ int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / laye
                               // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
 int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
+int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never)
 int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
 int g_nt_force_bm = 0;
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
@@ -477,8 +478,12 @@ static bool apply_knob(const char *name, const char *e) {
         g_fs = atoi(e) ? 1 : 0;
         return true;
     }
+    if (!strcmp(name, "MUCON_COARSE_RB4_WGS")) {
+        if (e) g_cs_rb4_wgs = atoi(e) > 0 ? atoi(e) : 0;
+        return true;
+    }
     if (!strcmp(name, "MUCON_COARSE_RB")) {
-        g_cs_rb = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 0;
+        g_cs_rb = (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4) ? atoi(e) : 0;
         return true;
     }
     if (!strcmp(name, "MUCON_COARSE_SPLIT")) {
@@ -535,7 +540,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 

@@ -469,10 +469,11 @@ def test_fused_split_layer_kernels_at_every_size():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("rb", ["1", "2"])
+@pytest.mark.parametrize("rb", ["1", "2", "4"])
 def test_coarse_split_kernel_row_blocks(rb):
-    """The coarse-level k-split kernel (csrc/gemm_coarse_split.hpp) takes 16 or 32 rows per workgroup by level size; MUCON_COARSE_RB
-    forces either at every size: goldens, oracle forward / backward, dropout replay (fresh interpreter)."""
+    """The coarse-level k-split kernel (csrc/gemm_coarse_split.hpp) takes 16, 32 or (forward launches) 64 rows per workgroup by level size;
+    MUCON_COARSE_RB forces one at every size (4: forward launches 64 rows, backward launches 32): goldens, oracle forward / backward, dropout
+    replay (fresh interpreter)."""
     import subprocess
     import sys
     env = dict(os.environ, MUCON_COARSE_RB=rb)
