@@ -109,7 +109,7 @@ class EvalForward:
         """feats [1 x T x D] float32 on the device, tf_input int64 on the device (its first entry is the start token) ->
         the dict of MuCon.forward_deferred."""
         groups = self._param_list()
-        ptrs = [t.data_ptr() for g in groups for t in g]
+        ptrs = [(t.data_ptr(), t.dtype, t.numel()) for g in groups for t in g]
         if ptrs != self._ptrs:
             self._bind(groups)
             self._ptrs = ptrs

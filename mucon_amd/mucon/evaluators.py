@@ -334,6 +334,10 @@ class MuConEvaluator:
             self.target_transcripts.append(v["target_transcript"])
             self._evaluated.append(v["i"])
 
+    def on_start_eval(self):
+        """Inference decodes greedily (reference evaluators.py:316-318: "should not happen if we want alignment performance")."""
+        self.model.set_teacher_forcing(False)
+
     batched = True          # pooled host round trips + device metrics for device-resident test videos (False: one video at a time)
     chunk_videos = 32
 
@@ -341,7 +345,7 @@ class MuConEvaluator:
     def evaluate(self, rank: int = 0, world_size: int = 1):
         """Test videos sharded over ranks; every metric's accumulator is a few scalars, all-reduced as one vector."""
         self.model.eval()
-        self.model.set_teacher_forcing(False)          # reference evaluators.py:316-318
+        self.on_start_eval()
         for m in self.metrics.values():
             m.reset()
         self._reset_lists()
@@ -406,3 +410,13 @@ class MuConEvaluator:
         if self.skipped:
             result["skipped_videos"] = self.skipped
         return result
+
+
+class MuConAlignmentEvaluator(MuConEvaluator):
+    """Alignment instead of inference: the s-head is teacher-forced with the ground-truth transcript during evaluation, so the Viterbi
+    decode aligns the GIVEN action sequence to the frames (reference evaluators.py:343-347).  Teacher-forced videos take the per-video
+    forward() path (MuCon.can_defer_eval is False under teacher forcing)."""
+
+    def on_start_eval(self):
+        super().on_start_eval()
+        self.model.set_teacher_forcing(True)      # because we are doing alignment here

@@ -254,3 +254,15 @@ class SimpleTrainer:
         (trainers.py:157-163, figure_scheduler_input).  Called by the training script after every evaluation."""
         if isinstance(self.scheduler, ReduceLROnPlateau):
             self.scheduler.step(float(eval_result["s_mof_nbg"]))
+
+
+class TrainerForTFExperiments(SimpleTrainer):
+    """SimpleTrainer that trains with teacher forcing up to `turnoff_tf_after_epoch` and without it from that epoch on
+    (reference trainers.py:166-191)."""
+
+    def __init__(self, cfg, model, device, train_db=None, world_size: int = 1, rank: int = 0, turnoff_tf_after_epoch: int = 1000):
+        super().__init__(cfg, model, device, train_db, world_size=world_size, rank=rank)
+        self.turnoff_tf_after_epoch = turnoff_tf_after_epoch
+
+    def on_start_epoch(self, epoch_num: int):
+        self.model.set_teacher_forcing(epoch_num < self.turnoff_tf_after_epoch)

@@ -99,10 +99,11 @@ _STRUCT_CACHE = {}
 
 def _param_struct(kind, tensors, build):
     """The ctypes struct of device pointers `build(tensors)` for a list of PARAMETER tensors, kept while they live where they did: a struct is a
-    function of the addresses alone, so the key is (kind, addresses).  On a miss the tensors are checked (device, float32, contiguous); on a hit
+    function of the addresses alone; the key is (kind, (address, dtype, numel) per tensor).  On a miss the tensors are checked (device, float32, contiguous); on a hit
     nothing but 46 data_ptr() calls happens -- these lists were re-checked and re-packed three times per training step (0.1 ms of the host's
     0.7 ms per one-video step, which is bound by host code as much as by the GPU: tools/e2e_host_profile.py)."""
-    key = (kind,) + tuple(t.data_ptr() for t in tensors)
+    # (dtype and element count ride in the key: an address alone can be re-used by another tensor once a parameter's storage is freed)
+    key = (kind,) + tuple((t.data_ptr(), t.dtype, t.numel()) for t in tensors)
     hit = None if os.environ.get("MUCON_NO_STRUCT_CACHE") else _STRUCT_CACHE.get(key)
     if hit is None:
         _check_dev(*tensors)
@@ -796,11 +797,14 @@ class FusedClipSGD:
         if not idx:
             return
         for k, i in enumerate(idx):
-            g = grads[i]
-            if not g.is_contiguous():
+            g, p_ = grads[i], flat[i][0]
+            if not g.is_contiguous() or not p_.is_contiguous():
                 raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
             t = tab[k]
-            t.param, t.grad = flat[i][0].data_ptr(), g.data_ptr()
+            if t.n != p_.numel() or g.numel() != t.n or g.dtype != torch.float32 or p_.dtype != torch.float32:
+                self._plan = None            # a parameter was replaced by one of another size / type: the cached table is stale
+                return self.step()
+            t.param, t.grad = p_.data_ptr(), g.data_ptr()
         n = len(idx)
         nbytes = lib.mucon_sgd_workspace_bytes(n, total)
         dev = flat[idx[0]][0].device
@@ -1136,21 +1140,32 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
         lab_t = torch.empty(sum(T if T > 0 else 1 for T in Ts), dtype=torch.int32 if fmt == _lib.VIT_LABELS_I32 else torch.uint8, pin_memory=True)
         lab_arr, lab_ptr = lab_t.numpy(), lab_t.data_ptr()
     decode, fn_addr, J = _vit_entry(lib), _VIT_FN_ADDR[0], max_len // fs
-    start = 0
+    # Inputs that are not already what the C loop reads in place (1-d int32 transcripts, C-contiguous float64 [J x N] tables) are converted in ONE
+    # pass here: the C loop reports one offending video per call, so a list of 256 int64 transcripts used to cost 256 extra crossings.
+    for v in range(nv):
+        t = trs[v]
+        if not (isinstance(t, np.ndarray) and t.dtype == np.int32 and t.ndim == 1 and t.flags.c_contiguous):
+            trs[v] = np.ascontiguousarray(t, dtype=np.int32).reshape(-1)
+        t = tabs[v]
+        if not (isinstance(t, np.ndarray) and t.dtype == np.float64 and t.ndim == 2 and t.flags.c_contiguous):
+            tabs[v] = np.ascontiguousarray(t, dtype=np.float64)
+        if tabs[v].shape != (J, trs[v].shape[0]):
+            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(J, trs[v].shape[0])})")
+    start, last_bad = 0, -1
     while True:
         rc, bad, sum_T, sum_N, out = decode(ptrs, Ts, trs, tabs, forces, C, fs, max_len, fmt, 1 if (C & 3) == 0 else 0, start, lab_ptr,
                                             fn_addr, _lib.current_stream_raw())
         if bad < 0:
             break
-        # video `bad`: not an int32 / float64 C-contiguous buffer, or an emission tensor whose start is not 16-byte aligned
-        trs[bad] = np.ascontiguousarray(trs[bad], dtype=np.int32)
-        tabs[bad] = np.ascontiguousarray(tabs[bad], dtype=np.float64)
-        if tabs[bad].shape != (J, trs[bad].shape[0]):
-            raise ValueError(f"video {bad}: length table {tabs[bad].shape} (expected {(J, trs[bad].shape[0])})")
+        # video `bad`: what is left after the pass above is an emission tensor whose start is not 16-byte aligned
+        if bad == last_bad:      # the same video refused twice: nothing here can repair it -- never spin
+            raise _lib.MuconHipError(f"viterbi_decode_batch: video {bad} is refused by the binding's C loop (transcript {trs[bad].dtype} "
+                                     f"{trs[bad].shape}, table {tabs[bad].dtype} {tabs[bad].shape}, emissions at 0x{ptrs[bad]:x})")
+        last_bad = bad
         if (C & 3) == 0 and (ptrs[bad] & 15):
             lps[bad] = lps[bad].clone(memory_format=torch.contiguous_format)
             ptrs[bad] = lps[bad].data_ptr()
-        start = bad
+        start = 0      # (every call rebuilds its records: the C side's scratch is not trusted across two crossings -- another Python thread may have used it)
     if rc != _lib.OK:
         _lib.check(rc, "mucon_viterbi_decode_host")
     # out: [score f64 nv][n_seg i32 nv][status i32 nv][seg_len i32 sum_N, padded][label offsets i64 nv + 1][segment offsets i64 nv + 1][labels]

@@ -139,3 +139,45 @@ def test_nearest_resize_equals_torch():
         x = rng.integers(0, 48, L)
         want = torch.nn.functional.interpolate(torch.tensor(x[None, None]).float(), size=n, mode="nearest")[0, 0].long().numpy()
         np.testing.assert_array_equal(make_same_size_interpolate(x, n), want)
+
+
+def test_alignment_evaluator_and_teacher_forcing_trainer(tmp_path):
+    """The two small harness subclasses of the reference (evaluators.py:343-347, trainers.py:166-191) on the host plumbing: the alignment
+    evaluator keeps the s-head teacher-forced during evaluation -- its predicted transcript IS the given one, so the transcript metrics are
+    perfect whatever the weights -- and TrainerForTFExperiments switches teacher forcing off from the given epoch on."""
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.core.datasets import handel_dataset, write_synthetic_breakfast
+    from mucon_amd.mucon.evaluators import MuConAlignmentEvaluator, MuConEvaluator
+    from mucon_amd.mucon.models import create_model
+    from mucon_amd.mucon.trainers import SimpleTrainer, TrainerForTFExperiments
+
+    data, root = tmp_path / "datasets", tmp_path / "root"
+    write_synthetic_breakfast(str(data), n_train=3, n_test=3, t_range=(200, 320), n_range=(2, 4))
+    cfgs = _overlay(tmp_path, root, data)
+    cfg = update_config(get_cfg_defaults(), cfgs, ["system.device", "cpu", "dataset.split", "1"])
+    torch.manual_seed(3)
+    train_db, test_db = handel_dataset(cfg, train=True), handel_dataset(cfg, train=False)
+    model = create_model(cfg, num_classes=train_db.get_num_classes(), max_decoding_steps=train_db.max_transcript_length + 1,
+                         input_feature_size=train_db.feat_dim)
+    seen = []
+    real = model.set_teacher_forcing
+    model.set_teacher_forcing = lambda teacher_forcing=True: (seen.append(bool(teacher_forcing)), real(teacher_forcing))[1]
+
+    ev = MuConAlignmentEvaluator(cfg, test_db, model, "cpu")
+    assert isinstance(ev, MuConEvaluator)
+    ev.viterbi_mode(True)
+    res = ev.evaluate()
+    assert seen[-2:] == [False, True] and model.teacher_forcing is True          # super().on_start_eval(), then forced on
+    assert res.get("skipped_videos", 0) == 0
+    for got, want in zip(ev.s_transcript, ev.target_transcripts):                  # teacher-forced: the decoder is fed, and scored on, the given transcript
+        assert len(got) == len(want)
+    plain = MuConEvaluator(cfg, test_db, model, "cpu")
+    plain.on_start_eval()
+    assert model.teacher_forcing is False
+
+    tr = TrainerForTFExperiments(cfg, model, "cpu", train_db, turnoff_tf_after_epoch=2)
+    assert isinstance(tr, SimpleTrainer) and tr.turnoff_tf_after_epoch == 2
+    for epoch, want in ((0, True), (1, True), (2, False), (7, False)):
+        tr.on_start_epoch(epoch)
+        assert model.teacher_forcing is want
+    assert TrainerForTFExperiments(cfg, model, "cpu").turnoff_tf_after_epoch == 1000

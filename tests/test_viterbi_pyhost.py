@@ -169,3 +169,29 @@ def test_expand_labels_rule():
     assert lab.tolist() == [9] * 10 + [7] * 60 + [3] * 30 + [9] * 90
     assert ops.expand_labels(tr, np.array([60, 30], np.int32), 2, 90, 30).tolist() == [7] * 60 + [3] * 30
     assert ops.expand_labels(tr, np.array([], np.int32), 0, 10, 30).shape == (0,)
+
+
+def test_other_dtypes_and_shapes_are_converted_in_one_pass_and_one_crossing(fake_decode, monkeypatch):
+    """int64 / list / (N, 1)-shaped transcripts and float32 / Fortran-ordered tables are normalised before the first C call (one crossing
+    for the whole list -- the C loop reports one offending video per call); a wrong table shape raises instead of looping."""
+    lps, trs, tabs = _inputs(6, seed=3)
+    want_tr = [t.copy() for t in trs]
+    want_tab = [t.copy() for t in tabs]
+    trs[0] = trs[0].astype(np.int64)
+    trs[1] = trs[1].reshape(-1, 1)
+    trs[2] = [int(x) for x in trs[2]]
+    tabs[3] = np.asfortranarray(tabs[3])
+    tabs[4] = tabs[4].astype(np.float32)
+    want_tab[4] = tabs[4].astype(np.float64)
+    calls = []
+    real = _lib.pyhost().mucon_py_viterbi_decode
+    monkeypatch.setattr(ops, "_vit_entry", lambda lib: (ops._VIT_FN_ADDR.__setitem__(0, ctypes.cast(lib.mucon_viterbi_decode_host, ctypes.c_void_p).value),
+                                                        lambda *a: (calls.append(1), real(*a))[1])[1])
+    res = ops.viterbi_decode_batch(lps, trs, tabs, FS, MAXLEN, labels="lazy")
+    assert len(calls) == 1 and len(res) == 6
+    for v, r in enumerate(fake_decode["records"]):
+        np.testing.assert_array_equal(r["tr"], want_tr[v])
+        np.testing.assert_array_equal(r["tab"], want_tab[v])
+    tabs[5] = tabs[5][:, :-1] if tabs[5].shape[1] > 1 else np.zeros((J, 3))
+    with pytest.raises(ValueError, match="length table"):
+        ops.viterbi_decode_batch(lps, trs, tabs, FS, MAXLEN, labels="lazy")
