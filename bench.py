@@ -111,7 +111,7 @@ def box_calibration(lib, dev):
     tf, ghz, ms = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
     s = _lib.current_stream_ptr()
     out = {}
-    for name, shape16 in (("32x32x16", 0), ("16x16x32", 1)):
+    for name, shape16 in (("32x32x16", 0), ("16x16x32", 1), ("32x32x16_lds", 2)):
         _lib.check(lib.mucon_test_mfma_probe(shape16, 10, 2000, _lib.ptr(scratch), scratch.numel(), ctypes.byref(tf), ctypes.byref(ghz),
                                              ctypes.byref(ms), s), "mfma_probe")            # ramp
         _lib.check(lib.mucon_test_mfma_probe(shape16, 60, 2000, _lib.ptr(scratch), scratch.numel(), ctypes.byref(tf), ctypes.byref(ghz),
@@ -133,7 +133,7 @@ def box_calibration(lib, dev):
     torch.cuda.synchronize()
     out["copy_gbs"] = round(20 * 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)     # bytes read + bytes written
     out["note"] = ("mfma_tflops / clock_ghz: 60 launches of 1,024 workgroups x 4 waves x 2,000 x 16 v_mfma_f32_32x32x16_bf16 on pseudo-random operands in registers "
-                   "(the *_16x16x32 pair: the same FLOPs on the narrower shape), HIP events; clock = delta s_memtime / delta s_memrealtime inside the last launch, "
+                   "(the *_16x16x32 pair: the same FLOPs on the narrower shape; *_32x32x16_lds: one operand of every MFMA re-read from LDS by ds_read_b128), HIP events; clock = delta s_memtime / delta s_memrealtime inside the last launch, "
                    "median over workgroups; copy_gbs: 20 x 1 GiB device-to-device torch copy, read + written bytes")
     del src, dst
     return out
@@ -336,7 +336,10 @@ def end_to_end_bench(dev, steps=40):
         torch.cuda.synchronize()
         rounds.append((time.perf_counter() - t0) / steps)
     dt = sorted(rounds)[2]
+    trainer.check_health()          # raises on a decoder hand-over failure / a non-finite gradient norm met during the timed steps
+    finite = bool(all(torch.isfinite(p_).all().item() for p_ in model.parameters()))     # (NaN operands would have run faster: see the hot-path leg)
     return {"videos_per_s": round(1.0 / dt, 1), "frames_per_s": round(T / dt, 1), "ms_per_video": round(dt * 1e3, 3),
+            "ms_per_video_rounds": [round(r * 1e3, 3) for r in rounds], "weights_finite_after_last_round": finite,
             "config": f"full MuCon train step, batch 1, T={T}, N={N}: all-HIP, graph-free: encoder, s-head (persistent LSTM / decoder), y-head, fused losses, backward, fused clip+SGD as one straight line of launches (MuCon.fused_train_step)",
             "reference_readme_it_per_s": [14.67, 16.23]}
 
@@ -810,7 +813,7 @@ def main():
                          "note": "achieved = algorithmic fp32 FLOP / launch time; peak = the kernel's own ceiling = 2.5 PFLOP/s dense bf16 MFMA / 6 "
                                  "(it issues 6 bf16 MFMA FLOP per algorithmic FLOP), so frac = frac_of_bf16_mfma_peak <= 1; "
                                  "frac_of_f32_mfma_peak prices the same FLOP against the 157.3 TFLOP/s f32-input MFMA peak a plain fp32 kernel is capped at",
-                         "rocprof_summary": "profiles/r04_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
+                         "rocprof_summary": "profiles/r05_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies

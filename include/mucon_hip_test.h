@@ -65,7 +65,8 @@ int mucon_test_get_knob(const char *name);
 int mucon_test_read_stamps(long long *out, int32_t n);
 
 /* Box calibration (bench.py `box_calibration`; csrc/probe.hpp): 1 + `launches` launches of a bare bf16 MFMA loop (1,024 workgroups of four waves,
- * `iters` x 16 v_mfma_f32_32x32x16_bf16 -- or, with shape16, the same FLOPs as 16x16x32 -- per wave, pseudo-random operands in registers) on
+ * `iters` x 16 v_mfma_f32_32x32x16_bf16 -- or, with shape16 = 1, the same FLOPs as 16x16x32; shape16 = 2: the 32x32x16 loop with one operand of every MFMA
+ * re-read from LDS by ds_read_b128 -- per wave, pseudo-random operands in registers) on
  * `stream`: *tflops_host = sustained dense bf16 TFLOP/s over the timed launches (HIP events), *clock_ghz_host = the in-kernel shader clock of the
  * last launch (delta s_memtime / delta s_memrealtime, median over workgroups), *ms_host = the timed launches' milliseconds.  `scratch`: >= 16,448
  * bytes of device memory.  Synchronises the stream. */

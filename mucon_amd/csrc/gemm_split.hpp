@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
 #ifndef NT16_ROT
 #define NT16_ROT 1
 #endif
-    const int rot = NT16_ROT ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nS) : 0;
+    const int rot = NT16_ROT ? (int)((blockIdx.x * 5u) % (unsigned)nS) : 0;
     auto phys = [&](int S) { const int q = S + rot; return q >= nS ? q - nS : q; };   // logical tile S of this workgroup's walk -> k-tile
     const int trow_raw0 = t0 + wr * 32 + r, trow_raw1 = trow_raw0 + 16;
     const float *a_vid = p.A + (long)b * p.a_bstride + 32 * g + 4 * h;

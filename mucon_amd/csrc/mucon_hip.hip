@@ -579,7 +579,8 @@ int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void
     ProbeOut *po = static_cast<ProbeOut *>(scratch);
     float *sink = reinterpret_cast<float *>(po + grid);
     auto go = [&]() {
-        if (shape16) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3(grid), dim3(256), 0, s, iters, po, sink);
+        if (shape16 == 2) hipLaunchKernelGGL(mfma_lds_probe_kernel, dim3(grid), dim3(256), 0, s, iters, po, sink);
+        else if (shape16) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3(grid), dim3(256), 0, s, iters, po, sink);
         else hipLaunchKernelGGL(mfma_probe_kernel<false>, dim3(grid), dim3(256), 0, s, iters, po, sink);
         return hipGetLastError();
     };

@@ -64,3 +64,48 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, ProbeOut *ou
     if (total == 12345.678f) sink[0] = total;   // keeps the accumulators alive
 }
 constexpr double kProbeFlopsPerIter = 16.0 * 2.0 * 32 * 32 * 16;   // per wave and loop iteration, either shape
+
+// The same loop with ONE operand of every MFMA re-read from LDS by ds_read_b128 (32x32x16 shape; 128 B/clk per CU: half the LDS peak, about what
+// the split-bf16 kernels of the path ask of it).  Devices of one pool differ more on this kind of loop than on the register-only one
+// (MI355X_MICROARCH.md, DVFS give-back item 5: 12 % across devices), and it is the kind the path's kernels are.
+__global__ __launch_bounds__(256) void mfma_lds_probe_kernel(int iters, ProbeOut *out, float *sink) {
+    __shared__ u32x4 img[4][16][64];   // 64 KB: per wave 16 fragments of 1 KB
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32x4 b[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t r = mix32(id * 64u + k * 4u + e + 0x2468aceu);
+            v[e] = (r & 0x807f807fu) | (((0x77u + (r >> 28 & 7u)) << 7) * 0x00010001u);
+        }
+        img[wave][k][lane] = v;
+        if (k < 4) b[k] = v;
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const u32x4 a = img[wave][k][lane];
+            acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[(k >> 2) & 3]), acc[k & 3], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");   // (the fragments are re-read every iteration)
+    }
+    const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) total += acc[k][0] + acc[k][15];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x].cycles = c1 - c0;
+        out[blockIdx.x].ticks = r1 - r0;
+    }
+    if (total == 12345.678f) sink[0] = total;
+}
