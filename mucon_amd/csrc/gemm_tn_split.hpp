@@ -111,6 +111,23 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         const int t0 = tbeg + tile * 32;
         return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
     };
+#ifndef TS_BRANCHFREE
+#define TS_BRANCHFREE 1   // 0: round 4's loads (interior / edge variants of the X loads and the clamp of the G rows as branches inside the tile loop)
+#endif
+#if TS_BRANCHFREE
+    // (r5) no branch between a load and its use inside the tile loop: see ts_body_st -- with the branches the compiler's wait counts made every X tile wait for
+    // the loads issued one phase ago
+    const int ldx4 = ldx * 4, xcb = (cg * 32 + xc4) * 4;
+    auto gloadX = [&](int tile, auto SET) {
+        constexpr int Q = decltype(SET)::value;
+        const int row0 = tbeg + tile * 32 + xoff;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ts = min(max(row0 + 8 * i + xrow, 0), Tx - 1);
+            rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(Xu) + (uint32_t)(ts * ldx4 + xcb));
+        }
+    };
+#else
     auto gloadX = [&](int tile, auto SET) {
         constexpr int Q = decltype(SET)::value;
         if (x_int(tile)) {
@@ -127,6 +144,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
             }
         }
     };
+#endif
     // a tile's 32 x 32 values go through the wave's own LDS tile: written as they were loaded (rows), read back by column into
     // the MFMA operand order (lane (r, h): column r, time steps 8h .. 8h + 7 of step s).  Wave-private: program order is all it needs.
     auto stageX = [&](auto SET) {
@@ -150,7 +168,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     };
     auto gloadG = [&](int tile, auto HALF) {
         constexpr int HB = decltype(HALF)::value;
-        const bool inner = g_int(tile);
+        const bool inner = TS_BRANCHFREE ? false : g_int(tile);
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
