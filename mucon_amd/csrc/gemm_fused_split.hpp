@@ -230,9 +230,11 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     auto prefetch1 = [&]() {
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
+            // (unconditional loads from a valid address, the condition on the arithmetic below: a load behind a branch makes the compiler wait for
+            //  everything in flight at the join -- eight branches with a wait each in front of the stage-1 epilogue; measured neutral here, 0.6915 = 0.6918 ms)
             if (!BWD) aux1[nb] = *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g);
-            else aux1[nb] = p.res1 ? *reinterpret_cast<const f32x4 *>(p.res1 + grow + 16 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (BWD && p.mask1) msk1[nb] = *reinterpret_cast<const f32x4 *>(p.mask1 + grow + 16 * nb);
+            else aux1[nb] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : p.A) + grow + 16 * nb);
+            if (BWD) msk1[nb] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : p.A) + grow + 16 * nb);
         }
     };
 
@@ -269,6 +271,14 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         __syncthreads();
         FS_T(3);
     };
+#ifndef FS_UNROLL
+#define FS_UNROLL 1   // 0: round 4's loop (the conditional loads of tile1 stay branches: S is a loop variable)
+#endif
+#if FS_UNROLL
+    // (r5) fully unrolled: S is a constant in every copy, so `if (S + 2 < 8) gloadW` and `if (S == 4) prefetch1()` are no branches around loads any more
+    // (a branch between a load and its use makes the compiler's wait counts conservative: gemm_tn_split.hpp)
+#pragma unroll
+#endif
     for (int S = 0; S < 6; S += 2) {
         tile1(S, 0, I0{}, I1{});
         tile1(S + 1, 1, I1{}, I0{});
@@ -280,7 +290,8 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     {
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
-            f32x4 x = acc[nb] + aux1[nb];
+            f32x4 x = acc[nb];
+            if (!BWD || p.res1) x += aux1[nb];
             if (!BWD) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = act_f(x[e], p.slope);
