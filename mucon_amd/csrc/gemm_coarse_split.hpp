@@ -96,7 +96,10 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
             ra[rb][i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
     constexpr int NP = TAPS * 8;      // (tap, channel block) pairs of stage 1, three plane fragments each
-    constexpr int D = 8;              // pairs in flight
+#ifndef CS_RING
+#define CS_RING 8
+#endif
+    constexpr int D = (CS_RING > 8 && NP % CS_RING == 0) ? CS_RING : 8;   // pairs in flight (CS_RING = 12: the experiment of profiles/r05_cs_kernel_phase_stamps.txt)
     bf16x8 wf[D][3];
     const uint16_t *w1 = W1img + (long)w * FS_WSTEP + lane * 8;      // step (tap * 4 + w): + tap * 4 * FS_WSTEP
     auto loadW1 = [&](int i, int slot) {

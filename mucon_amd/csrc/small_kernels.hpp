@@ -545,6 +545,21 @@ __global__ __launch_bounds__(256) void head_fwd_z_kernel(const HeadFwdArgs a) {
     __syncthreads();
     // the frames of these rows are contiguous: [first frame of z0, first frame of z0 + nz)
     const int fa = first_frame(z0, a.scale, a.Tz, a.Tf), fb = first_frame(z0 + nz, a.scale, a.Tz, a.Tf);
+    if ((C & 3) == 0) {
+        // (r5) 16-byte pieces: thread (frame slot tid / (C / 4), piece tid % (C / 4)); 256 / 12 = 21 frames per pass at C = 48 -- seven passes
+        // for a workgroup's ~128 frames instead of 32 passes of 4-byte stores (a wave per frame, 48 of 64 lanes)
+        const int C4 = C >> 2, slots = 256 / C4;
+        const int slot = tid / C4, c4 = (tid - slot * C4) * 4;
+        if (slot < slots) {
+            for (int i = fa + slot; i < fb; i += slots) {
+                const int zi = zmap(i, a.scale, a.Tz) - z0;
+                const long gi = ((long)b * a.Tf + i) * C + c4;
+                if (a.logits) *reinterpret_cast<f32x4 *>(a.logits + gi) = *reinterpret_cast<const f32x4 *>(Ls + zi * HEAD_MAXC + c4);
+                if (a.logp) *reinterpret_cast<f32x4 *>(a.logp + gi) = *reinterpret_cast<const f32x4 *>(Ps + zi * HEAD_MAXC + c4);
+            }
+        }
+        return;
+    }
     for (int i = fa + (tid >> 6); i < fb; i += 4) {   // a wave per frame, lane = class
         const int cc = tid & 63;
         const int zi = zmap(i, a.scale, a.Tz) - z0;
