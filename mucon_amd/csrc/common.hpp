@@ -82,6 +82,7 @@ __device__ __forceinline__ void sp_split_weights16(const float *W, uint16_t *img
 #endif
 #if CLK_STAMP
 __device__ long long g_clk[2][4096][2];
+__device__ long long g_clk_wg[4096][2];   // ts_batched_kernel: s_memrealtime at a workgroup's entry and exit (100 MHz ticks, absolute)
 #define CLK_BEGIN() const long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
 #define CLK_END(slot, wg)                                                                          \
     do {                                                                                           \

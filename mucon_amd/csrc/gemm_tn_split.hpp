@@ -1141,6 +1141,9 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
 template <int MODE>   // 0: ts_body (32x32x16, round 4's lock-step schedule), 1: ts_body16 (16x16x32), 2: ts_body_st (32x32x16, staggered blocks)
 __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+#if CLK_STAMP
+    const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: the workgroup's whole life beside its tile loop, g_clk_wg)
+#endif
     int ji = 0;
     while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
     const TnJob &job = tb.j[ji];
@@ -1183,6 +1186,13 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
         else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
         else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
     }
+#if CLK_STAMP
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_clk_wg[blockIdx.x][0] = wg_t0_;
+        g_clk_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {

@@ -630,9 +630,11 @@ int mucon_test_read_cs_stamps(long long *stamps, int32_t *info, int32_t n_slots)
 }
 int mucon_test_read_clock(int32_t slot, long long *out, int32_t n) {
 #if CLK_STAMP
-    if (!out || slot < 0 || slot > 1 || n < 2 * 4096) return -1;
+    if (!out || slot < 0 || slot > 2 || n < 2 * 4096) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 2 * 4096, sizeof(long long) * 2 * 4096 * slot) != hipSuccess) return -1;
+    if (slot == 2) {   // the weight-gradient launch's workgroups: absolute entry / exit ticks
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_wg), sizeof(long long) * 2 * 4096) != hipSuccess) return -1;
+    } else if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 2 * 4096, sizeof(long long) * 2 * 4096 * slot) != hipSuccess) return -1;
     int used = 0;
     for (int i = 0; i < 4096; ++i)
         if (out[2 * i + 1] > 0) used = i + 1;

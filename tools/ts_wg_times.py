@@ -45,3 +45,13 @@ for g0 in range(0, n, 16):
     cl = [ghz[i] for i, _ in grp]
     print(f"  blocks {g0:4d}-{g0 + 15:4d}: even {sum(ev) / max(len(ev), 1):7.1f}  odd {sum(od) / max(len(od), 1):7.1f}  max {max(u for _, u in grp):7.1f}  clock {sum(cl) / len(cl):.2f} GHz")
 print(f"longest workgroup {max(us):.1f} us; sum over workgroups / 256 CUs = {sum(us) / 256:.1f} us")
+buf2 = (ctypes.c_longlong * (2 * 4096))()
+if lib.mucon_test_read_clock(2, buf2, 2 * 4096) > 0:
+    t0 = min(buf2[2 * i] for i in range(n) if buf2[2 * i] > 0)
+    life = [(buf2[2 * i + 1] - buf2[2 * i]) / 100.0 for i in range(n)]
+    ovh = [life[i] - us[i] for i in range(n) if us[i] > 0]
+    end = max(buf2[2 * i + 1] for i in range(n))
+    print(f"workgroup life minus tile loop (prologue + slab epilogue): mean {sum(ovh) / len(ovh):.2f} us, min {min(ovh):.2f}, max {max(ovh):.2f}; "
+          f"first entry to last exit {(end - t0) / 100.0:.1f} us; sum of lives / 256 CUs = {sum(life) / 256:.1f} us")
+    starts = sorted((buf2[2 * i] - t0) / 100.0 for i in range(n))
+    print("entry times (us after the first): " + " ".join(f"{starts[k]:.0f}" for k in range(0, n, max(n // 24, 1))))
