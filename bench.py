@@ -97,7 +97,7 @@ def make_params(spec, C, dev):
 
 
 REF_LDS_PROBE_TFLOPS = 1583.0  # the LDS-fed calibration loop's rate on the reference (faster) kind of box of DESIGN.md section 5: a normalisation constant, not a peak
-LDS_PROBE_EXPONENT = 3.0       # over the pool's boxes ms_per_step went as (REF / mfma_tflops_32x32x16_lds)^3 (five boxes, round 5: 7.9 % raw spread -> 1.8 %)
+LDS_PROBE_EXPONENT = 3.0       # over the pool's boxes ms_per_step went as (REF / mfma_tflops_32x32x16_lds)^3 (five boxes, round 5: 7.9 % raw spread -> 1.8 %; three later boxes: +-2 %)
 
 
 def box_calibration(lib, dev):
@@ -861,7 +861,7 @@ def main():
             out["box_calibration"] = calib
             out["ms_per_step_at_reference_box"] = round(out["ms_per_step"] * k, 4)
             out["normalisation"] = (f"ms_per_step x (mfma_tflops_32x32x16_lds / {REF_LDS_PROBE_TFLOPS:.0f})^{LDS_PROBE_EXPONENT:.0f}: an empirical fit over five boxes of the pool "
-                                    f"(DESIGN.md section 5), good to about +-1 %; value / ms_per_step stay raw")
+                                    f"(DESIGN.md section 5), good to about +-2 % over eight boxes; value / ms_per_step stay raw")
         if rccl is not None:
             out["rccl"] = rccl
         # the single-GPU legs (CPU baseline, Viterbi, end-to-end, evaluation) belong to the N = 1 line: at N > 1 the other ranks would sit in the
