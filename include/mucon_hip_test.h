@@ -76,7 +76,8 @@ int mucon_test_mfma_probe(int32_t shape16, int32_t launches, int32_t iters, void
 /* Diagnostic builds only (MUCON_HIPCC_FLAGS=-DCLK_STAMP=1): per workgroup of the last launches of slot 0 (first_conv's split-bf16 kernel) or
  * slot 1 (the split-bf16 weight-gradient launch) the pair (shader cycles, 100 MHz ticks) spent in the kernel's main loop, [4096][2]; returns
  * the number of workgroup records (0 in a normal build, -1 on a bad argument).  In-kernel clock = cycles / ticks x 100 MHz.
- * slot 2: per workgroup of the last weight-gradient launch the absolute s_memrealtime ticks at its entry and exit. */
+ * slot 2: per workgroup of the last weight-gradient launch the absolute s_memrealtime ticks at its entry and exit; slot 3: behind its job lookup and
+ * at its first tile; slot 4: behind its last tile (second word: 1). */
 int mucon_test_read_clock(int32_t slot, long long *out, int32_t n);
 
 /* Timing builds only (MUCON_HIPCC_FLAGS=-DCS_STAMP=1): the phase stamps of the cs_kernel launches since the last call (at most 64; csrc/gemm_coarse_split.hpp):

@@ -83,6 +83,8 @@ __device__ __forceinline__ void sp_split_weights16(const float *W, uint16_t *img
 #if CLK_STAMP
 __device__ long long g_clk[2][4096][2];
 __device__ long long g_clk_wg[4096][2];   // ts_batched_kernel: s_memrealtime at a workgroup's entry and exit (100 MHz ticks, absolute)
+__device__ long long g_clk_ph[4096][2];   // ... behind its job lookup, and at the first tile (absolute)
+__device__ long long g_clk_pe[4096][2];   // ... behind its last tile (absolute; second word unused)
 #define CLK_BEGIN() const long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
 #define CLK_END(slot, wg)                                                                          \
     do {                                                                                           \
@@ -90,6 +92,11 @@ __device__ long long g_clk_wg[4096][2];   // ts_batched_kernel: s_memrealtime at
         if (threadIdx.x == 0 && (wg) < 4096) {                                                     \
             g_clk[slot][wg][0] = c1_ - clk_c0_;                                                    \
             g_clk[slot][wg][1] = r1_ - clk_r0_;                                                    \
+            if ((slot) == 1) {                                                                     \
+                g_clk_ph[wg][1] = clk_r0_;                                                         \
+                g_clk_pe[wg][0] = r1_;                                                             \
+                g_clk_pe[wg][1] = 1;                                                               \
+            }                                                                                      \
         }                                                                                          \
     } while (0)
 #else

@@ -13,6 +13,8 @@
 // LDS tiles are [32 time steps][128 channels] exactly as in HBM (512-byte rows, no padding
 // needed: the MFMA operand read is ds_read_b32 with 32 consecutive lanes on consecutive floats).
 #pragma once
+#include <climits>
+
 #include "common.hpp"
 #include "dispatch.hpp"
 
@@ -222,6 +224,7 @@ struct TnJob {
 };
 struct TnBatch {
     TnJob j[TN_MAX_BATCH];
+    int first_block[TN_MAX_BATCH];   // j[i].block0 once more, contiguous (unused entries: INT_MAX): gemm_tn_split.hpp's job lookup
     int njobs, nblocks;
     int xcd_order;        // gemm_tn_split.hpp
     int st_min_steps;     // gemm_tn_split.hpp: jobs with time chunks of at least this many steps run the staggered schedule

@@ -47,9 +47,9 @@ constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 
 constexpr int TS_XT_FLOATS = 32 * 32;                   // a wave's X tile [32 time steps][32 columns] (4 KB), transposed through LDS
 constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS_XT_FLOATS * 4;   // two buffers x two images + eight X tiles: 131,072 B
 
-template <bool TWO_G, bool DROP>
+template <bool TWO_G, bool DROP, class AfterLoop>
 __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
-                                        uint16_t *smem) {
+                                        uint16_t *smem, const int item, AfterLoop &&after_loop) {
     constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -374,7 +374,8 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         tile(mt, I0{}, I1{});
         if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
     }
-    CLK_END(1, blockIdx.x);
+    CLK_END(1, item);
+    after_loop();   // (the persistent launch draws its next item here: the ticket travels under the slab write-out)
 
 #if TS_STAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -414,9 +415,9 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
 // arithmetic with the tile re-ordered into blocks so that the two waves of a SIMD never want the same unit -- see the comment at the
 // tile loop below.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool TWO_G, bool DROP>
+template <bool TWO_G, bool DROP, class AfterLoop>
 __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
-                                        uint16_t *smem) {
+                                        uint16_t *smem, const int item, AfterLoop &&after_loop) {
     constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -741,7 +742,8 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
             if (mt + 1 < ntiles) tile2(mt + 1, I1{}, I0{}, std::false_type{});
         }
     }
-    CLK_END(1, blockIdx.x);
+    CLK_END(1, item);
+    after_loop();
 
 #if TS_STAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -1137,19 +1139,25 @@ __device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, cons
 }
 
 // All weight gradients of a backward pass in one launch (the job table of gemm_tn.hpp): a job with n 128-column chunks has
-// ceil(n / 2) workgroups per time chunk.
-template <int MODE>   // 0: ts_body (32x32x16, round 4's lock-step schedule), 1: ts_body16 (16x16x32), 2: ts_body_st (32x32x16, staggered blocks)
-__global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
-#if CLK_STAMP
-    const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: the workgroup's whole life beside its tile loop, g_clk_wg)
-#endif
-    int ji = 0;
-    while (ji + 1 < tb.njobs && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
+// ceil(n / 2) workgroups per time chunk.  ts_run_item is one such workgroup's work ("item" = its block index in the table's layout).
+template <int MODE, class AfterLoop>   // 0: ts_body (32x32x16, round 4's lock-step schedule), 1: ts_body16 (16x16x32), 2: ts_body_st (32x32x16, staggered blocks)
+__device__ __forceinline__ bool ts_run_item(const TnBatch &tb, const int item, uint16_t *ts_smem, AfterLoop &&after_loop) {
+    // which job: the number of jobs that start at or before the item -- all first blocks compared at once (walking the table job by job
+    // was a chain of dependent scalar loads, 1.0 - 1.7 us in front of a workgroup's first load: profiles/r05_weight_gradient_schedule.txt §9)
+    int ji = -1;
+#pragma unroll
+    for (int k = 0; k < TN_MAX_BATCH; ++k) ji += item >= tb.first_block[k] ? 1 : 0;
     const TnJob &job = tb.j[ji];
-    if ((int)blockIdx.x - job.block0 >= ((job.nkc + 1) >> 1) * job.nmc) return;   // padding block between two jobs
+    if (item - job.block0 >= ((job.nkc + 1) >> 1) * job.nmc) return false;   // padding block between two jobs
+#if CLK_STAMP
+    {
+        long long t_;   // (the job's words are an input of the stamp: it cannot be read before they have arrived)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(job.nkc), "s"(job.nmc));
+        if (threadIdx.x == 0 && item < 4096) g_clk_ph[item][0] = t_;
+    }
+#endif
     const int nkc2 = (job.nkc + 1) >> 1;
-    const int local = blockIdx.x - job.block0;
+    const int local = item - job.block0;
     int mc = local / nkc2, kc2 = local - mc * nkc2;
     if (tb.xcd_order) {
         // The nkc2 workgroups of a time chunk read the same gradient rows.  Workgroups are dealt round-robin over the 8 XCDs
@@ -1171,21 +1179,32 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
         // workgroups that stage two images and replay the dropout mask have twice the staging work per tile and the registers for one X
         // tile in flight only -- staggered they ran 218 us instead of 200 (profiles/r05_weight_gradient_schedule.txt).
         if (job.dual || tb.st_min_steps <= 0 || job.p.MC < tb.st_min_steps) {
-            if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
-            else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
-            else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
-        } else if (!two_g) ts_body_st<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
-        else if (job.p.drop.thresh) ts_body_st<true, true>(job.p, kc2, mc, true, false, ts_smem);
-        else ts_body_st<true, false>(job.p, kc2, mc, true, false, ts_smem);
+            if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
+            else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
+            else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
+        } else if (!two_g) ts_body_st<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
+        else if (job.p.drop.thresh) ts_body_st<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
+        else ts_body_st<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
     } else if constexpr (MODE == 1) {
         if (!two_g) ts_body16<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
         else if (job.p.drop.thresh) ts_body16<true, true>(job.p, kc2, mc, true, false, ts_smem);
         else ts_body16<true, false>(job.p, kc2, mc, true, false, ts_smem);
+        after_loop();
     } else {
-        if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
-        else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem);
-        else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem);
+        if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
+        else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
+        else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
     }
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+#if CLK_STAMP
+    const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: the workgroup's whole life beside its tile loop, g_clk_wg)
+#endif
+    if (!ts_run_item<MODE>(tb, (int)blockIdx.x, ts_smem, [] {})) return;
 #if CLK_STAMP
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -1195,25 +1214,78 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
 #endif
 }
 
-static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
+// The same items on PERSISTENT workgroups (round 5; MUCON_TS_PERSIST, default): one workgroup per CU walks the item list -- its own block
+// index first, then whatever item the launch's ticket counter hands it.  What that buys (profiles/r05_weight_gradient_schedule.txt §9): the
+// hardware dispatcher deals workgroups to the XCDs strictly round-robin, so a freed CU waited a median 1.4 us and up to 15 us (another XCD's
+// turn) for its next workgroup; the ticket is drawn behind the item's last tile and arrives under its slab write-out.  Every item computes
+// exactly what its workgroup computed (which workgroup runs it changes nothing in its sums): bitwise the same gradients.
+// `tickets` is one zeroed word of the caller's workspace (encoder_bwd's first kernel zeroes it: gn_bwd_kernel).
+template <int MODE>
+__global__ __launch_bounds__(512) void ts_persist_kernel(const TnBatch tb, unsigned *tickets) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+    int *s_next = reinterpret_cast<int *>(ts_smem + TS_SMEM_BYTES / 2);   // one word behind the tiles
+    int item = blockIdx.x;
+    while (item < tb.nblocks) {
+#if CLK_STAMP
+        const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+        unsigned drawn = 0;
+        bool have = false;
+        auto draw = [&]() {
+            if (threadIdx.x == 0) drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = true;
+        };
+        const bool ran = ts_run_item<MODE>(tb, item, ts_smem, draw);
+        if (!have) draw();   // (a padding item)
+#if CLK_STAMP
+        if (ran) {
+            __syncthreads();
+            if (threadIdx.x == 0 && item < 4096) {
+                g_clk_wg[item][0] = wg_t0_;
+                g_clk_wg[item][1] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+#endif
+        (void)ran;
+        if (threadIdx.x == 0) *s_next = (int)(gridDim.x + drawn);
+        __syncthreads();   // ... which also puts the item's last LDS reads (the bias sums) in front of the next item's first stores
+        item = __builtin_amdgcn_readfirstlane(*s_next);
+    }
+}
+
+extern int g_ts_persist;   // mucon_hip.hip (MUCON_TS_PERSIST)
+static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s, unsigned *tickets = nullptr) {
     if (tb.njobs == 0) return hipSuccess;
     const int mode = (g_mfma16 & 2) ? 1 : (g_ts_stagger ? 2 : 0);
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[mode]) {
-        const void *k = mode == 1 ? reinterpret_cast<const void *>(ts_batched_kernel<1>)
-                                  : mode == 2 ? reinterpret_cast<const void *>(ts_batched_kernel<2>) : reinterpret_cast<const void *>(ts_batched_kernel<0>);
-        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, mode == 1 ? TS16_SMEM_BYTES : TS_SMEM_BYTES);
+    const bool persist = tickets != nullptr && g_ts_persist != 0;
+    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+    static int ncu = 0;
+    const void *k = persist ? (mode == 1 ? reinterpret_cast<const void *>(ts_persist_kernel<1>)
+                                         : mode == 2 ? reinterpret_cast<const void *>(ts_persist_kernel<2>) : reinterpret_cast<const void *>(ts_persist_kernel<0>))
+                            : (mode == 1 ? reinterpret_cast<const void *>(ts_batched_kernel<1>)
+                                         : mode == 2 ? reinterpret_cast<const void *>(ts_batched_kernel<2>) : reinterpret_cast<const void *>(ts_batched_kernel<0>));
+    const int smem = (mode == 1 ? TS16_SMEM_BYTES : TS_SMEM_BYTES) + (persist ? 16 : 0);
+    if (!attr_set[persist][mode]) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        attr_set[mode] = true;
+        attr_set[persist][mode] = true;
+    }
+    if (persist && ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = prop.multiProcessorCount;
     }
     // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
     TnBatch lb;
     lb.njobs = tb.njobs;
     int blocks = 0;
+    for (int i = 0; i < TN_MAX_BATCH; ++i) lb.first_block[i] = INT_MAX;
     for (int i = 0; i < tb.njobs; ++i) {
         const TnJob &src = tb.j[tb.njobs - 1 - i];
         lb.j[i] = src;
         lb.j[i].block0 = blocks;
+        lb.first_block[i] = blocks;
         lb.j[i].nmc = src.block0;                     // block0 carried the time-chunk count while queued
         blocks += ((src.nkc + 1) / 2) * src.block0;
         if (kTsXcdOrder) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
@@ -1221,9 +1293,14 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {
     lb.nblocks = blocks;
     lb.xcd_order = kTsXcdOrder;
     lb.st_min_steps = g_ts_stagger;
-    if (mode == 1) hipLaunchKernelGGL(ts_batched_kernel<1>, dim3(blocks), dim3(512), TS16_SMEM_BYTES, s, lb);
-    else if (mode == 2) hipLaunchKernelGGL(ts_batched_kernel<2>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
-    else hipLaunchKernelGGL(ts_batched_kernel<0>, dim3(blocks), dim3(512), TS_SMEM_BYTES, s, lb);
+    if (persist) {
+        const dim3 grid(std::min(blocks, ncu));
+        if (mode == 1) hipLaunchKernelGGL(ts_persist_kernel<1>, grid, dim3(512), smem, s, lb, tickets);
+        else if (mode == 2) hipLaunchKernelGGL(ts_persist_kernel<2>, grid, dim3(512), smem, s, lb, tickets);
+        else hipLaunchKernelGGL(ts_persist_kernel<0>, grid, dim3(512), smem, s, lb, tickets);
+    } else if (mode == 1) hipLaunchKernelGGL(ts_batched_kernel<1>, dim3(blocks), dim3(512), smem, s, lb);
+    else if (mode == 2) hipLaunchKernelGGL(ts_batched_kernel<2>, dim3(blocks), dim3(512), smem, s, lb);
+    else hipLaunchKernelGGL(ts_batched_kernel<0>, dim3(blocks), dim3(512), smem, s, lb);
     tb.njobs = 0;
     return hipGetLastError();
 }

@@ -28,6 +28,7 @@
 
 int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
                               // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
+int g_ts_persist = 1;         // the batched split weight-gradient launch of encoder_bwd on persistent workgroups with a ticket counter (MUCON_TS_PERSIST; gemm_tn_split.hpp)
 int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
 int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never)
@@ -92,6 +93,7 @@ struct Plan {
     size_t Wfs;  // per layer: the four split images of gemm_fused_split.hpp (W1f, W1b, W2, W2t)
     size_t x[MUCON_MAX_LAYERS + 1], h[MUCON_MAX_LAYERS], ypre[MUCON_MAX_LAYERS];
     size_t z, gnstat, gnpart;
+    size_t sync;   // 64 words the backward's first kernel zeroes: [0] the ticket counter of the persistent weight-gradient launch
     size_t gz, g[MUCON_MAX_LAYERS + 1], dpre[MUCON_MAX_LAYERS], dyd[MUCON_MAX_LAYERS];
     size_t slabs, slab_floats, bslabs, bslab_floats;
     size_t total;  // floats
@@ -151,6 +153,7 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     p.z = take((size_t)p.B * p.Tz * 128);
     p.gnstat = take((size_t)p.B * 128 * 2);
     p.gnpart = take((size_t)p.B * 256);
+    p.sync = take(64);
     // backward buffers, one per layer (no ping-pong): the weight-gradient launches run on a second
     // stream and may still be reading a layer's tensors while the data-gradient chain moves on
     p.gz = take((size_t)p.B * p.Tz * 128);
@@ -506,6 +509,10 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
     }
+    if (!strcmp(name, "MUCON_TS_PERSIST")) {
+        if (e) g_ts_persist = atoi(e) ? 1 : 0;
+        return true;
+    }
     if (!strcmp(name, "MUCON_TS_LAYER_MC_CAP")) {
         if (e && atoi(e) >= 128) g_ts_layer_mc_cap = atoi(e) / 32 * 32;
         return true;
@@ -540,7 +547,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TS_PERSIST", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -567,6 +574,7 @@ int mucon_test_get_knob(const char *name) {
     if (name && !strcmp(name, "MUCON_MFMA16")) return g_mfma16;
     if (name && !strcmp(name, "MUCON_TN_SPLIT")) return g_tn_split;
     if (name && !strcmp(name, "MUCON_TS_STAGGER")) return g_ts_stagger;
+    if (name && !strcmp(name, "MUCON_TS_PERSIST")) return g_ts_persist;
     if (name && !strcmp(name, "MUCON_FIRST_CONV_SPLIT")) return g_first_conv_split;
     return -1;
 }
@@ -630,9 +638,13 @@ int mucon_test_read_cs_stamps(long long *stamps, int32_t *info, int32_t n_slots)
 }
 int mucon_test_read_clock(int32_t slot, long long *out, int32_t n) {
 #if CLK_STAMP
-    if (!out || slot < 0 || slot > 2 || n < 2 * 4096) return -1;
+    if (!out || slot < 0 || slot > 4 || n < 2 * 4096) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (slot == 2) {   // the weight-gradient launch's workgroups: absolute entry / exit ticks
+    if (slot == 3) {   // ... behind the job lookup / at the first tile
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_ph), sizeof(long long) * 2 * 4096) != hipSuccess) return -1;
+    } else if (slot == 4) {   // ... behind the last tile
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_pe), sizeof(long long) * 2 * 4096) != hipSuccess) return -1;
+    } else if (slot == 2) {   // the weight-gradient launch's workgroups: absolute entry / exit ticks
         if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_wg), sizeof(long long) * 2 * 4096) != hipSuccess) return -1;
     } else if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 2 * 4096, sizeof(long long) * 2 * 4096 * slot) != hipSuccess) return -1;
     int used = 0;
@@ -991,6 +1003,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
+        g.zero = reinterpret_cast<unsigned *>(ws + pl.sync);   // (the pass's first kernel: the words the later launches count in start at zero)
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
@@ -1253,7 +1266,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
         prof_mark(1, false, s);
-        HIPCHK(g_tn_split ? launch_ts_batch(tnb, s) : launch_tn_batch(tnb, s));
+        HIPCHK(g_tn_split ? launch_ts_batch(tnb, s, reinterpret_cast<unsigned *>(ws + pl.sync)) : launch_tn_batch(tnb, s));
         prof_mark(1, true, s);
     }
     HIPCHK(red.run());

@@ -294,6 +294,7 @@ struct GnBwdArgs {
     float *dz;              // [B][Tz][128]
     const float *gamma, *beta, *stats;
     float *part;            // [B][2][128]: per-video d_gamma, d_beta partials
+    unsigned *zero;         // 64 words workgroup (0, 0) zeroes (encoder_bwd's counters: this is the pass's first kernel), or null
     int Tz, G;
     int use_gn, use_relu;
     DropCfg drop;
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
     __shared__ float red[4];
     __shared__ float cred[2][4][128];   // per-channel partials [d_gamma | d_beta][wave][channel of the group]
     const int g = blockIdx.x, b = blockIdx.y;
+    if (a.zero && g == 0 && b == 0 && threadIdx.x < 64) a.zero[threadIdx.x] = 0u;
     const int cpg = 128 / a.G, lpg = cpg >> 2;
     const int nel = a.Tz * lpg;
     const float *zb = a.z + (long)b * a.Tz * 128 + g * cpg;

@@ -578,3 +578,36 @@ def test_trimmed_weight_relayout_is_bitwise_neutral(B, T, training):
         _lib.set_knob("MUCON_PACK_ALL", 0)
     for name, a_, b_ in zip(["enc"] + names, base, other):
         assert torch.equal(a_, b_), name
+
+
+@pytest.mark.parametrize("B,T,training", [(1, 2000, True), (8, 4096, True), (3, 777, False), (2, 16384, True)])
+def test_persistent_weight_gradient_launch_is_bitwise_neutral(B, T, training):
+    """(r5) encoder_bwd's batched weight-gradient launch runs on one persistent workgroup per CU that draws items from a ticket
+    counter (ts_persist_kernel, MUCON_TS_PERSIST=1: default); MUCON_TS_PERSIST=0 launches one workgroup per item as before.
+    An item's sums do not depend on which workgroup runs it: every gradient bitwise the same either way, run after run (the
+    counter is zeroed by the pass's first kernel: back-to-back passes on one workspace)."""
+    from mucon_amd import _lib, ops
+    from oracle import dense as od
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 157)
+    names = ops.param_names(spec)
+    tape = torch.tensor(synth.tape(158, B, T, 2048), device=DEV)
+    v = torch.tensor(synth.uniform_pm1(159, (B, spec.out_length(T), 128)), device=DEV)
+
+    def run():
+        P = _dev_params(params_np, names)
+        enc = ops.encoder_forward(tape, P, spec, training=training, seed=4321)
+        (v * enc).sum().backward()
+        return [p.grad.detach().clone() for p in P]
+
+    assert _lib.load().mucon_test_get_knob(b"MUCON_TS_PERSIST") == 1
+    base = run()
+    again = run()
+    try:
+        _lib.set_knob("MUCON_TS_PERSIST", 0)
+        other = run()
+    finally:
+        _lib.set_knob("MUCON_TS_PERSIST", 1)
+    for name, a_, b_, c_ in zip(names, base, again, other):
+        assert torch.equal(a_, b_), name
+        assert torch.equal(a_, c_), name

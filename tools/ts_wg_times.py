@@ -55,3 +55,26 @@ if lib.mucon_test_read_clock(2, buf2, 2 * 4096) > 0:
           f"first entry to last exit {(end - t0) / 100.0:.1f} us; sum of lives / 256 CUs = {sum(life) / 256:.1f} us")
     starts = sorted((buf2[2 * i] - t0) / 100.0 for i in range(n))
     print("entry times (us after the first): " + " ".join(f"{starts[k]:.0f}" for k in range(0, n, max(n // 24, 1))))
+
+# (r5) where a workgroup's life outside its tile loop goes: job lookup, prologue (first loads, image of tile 0), epilogue (slab write-out)
+b3 = (ctypes.c_longlong * (2 * 4096))()
+b4 = (ctypes.c_longlong * (2 * 4096))()
+if lib.mucon_test_read_clock(3, b3, 2 * 4096) > 0 and lib.mucon_test_read_clock(4, b4, 2 * 4096) > 0:
+    print("per 16 blocks (us): job lookup | rest of the prologue | epilogue   [entry time of the group after the launch's first]")
+    for g0 in range(0, n, 16):
+        rows = [i for i in range(g0, min(g0 + 16, n)) if us[i] > 0 and b3[2 * i] > 0]
+        if not rows:
+            continue
+        look = [(b3[2 * i] - buf2[2 * i]) / 100.0 for i in rows]
+        pro = [(b3[2 * i + 1] - b3[2 * i]) / 100.0 for i in rows]
+        epi = [(buf2[2 * i + 1] - b4[2 * i]) / 100.0 for i in rows]
+        ent = [(buf2[2 * i] - t0) / 100.0 for i in rows]
+        print(f"  blocks {g0:4d}-{g0 + 15:4d}: {sum(look) / len(look):5.2f} | {sum(pro) / len(pro):5.2f} | {sum(epi) / len(epi):5.2f} (max {max(epi):5.2f})   [{min(ent):6.1f} .. {max(ent):6.1f}]")
+    # how long a freed CU waits for its next workgroup: the k-th workgroup that enters late follows the k-th exit
+    exits = sorted((buf2[2 * i + 1] - t0) / 100.0 for i in range(n) if buf2[2 * i + 1] > 0)
+    late = sorted((buf2[2 * i] - t0) / 100.0 for i in range(n) if buf2[2 * i] - t0 > 100)
+    gaps = [e - x for e, x in zip(late, exits)]
+    if gaps:
+        gs = sorted(gaps)
+        print(f"exit of a workgroup -> entry of the next one on the freed CU (k-th late entry minus k-th exit), {len(gaps)} pairs: "
+              f"median {gs[len(gs) // 2]:.2f} us, p10 {gs[len(gs) // 10]:.2f}, p90 {gs[len(gs) * 9 // 10]:.2f}, min {gs[0]:.2f}, max {gs[-1]:.2f}")
