@@ -96,8 +96,6 @@ def make_params(spec, C, dev):
     return names, [sd[k].to(dev).contiguous().requires_grad_(True) for k in names]
 
 
-REF_LDS_PROBE_TFLOPS = 1583.0  # the LDS-fed calibration loop's rate on the reference (faster) kind of box of DESIGN.md section 5: a normalisation constant, not a peak
-LDS_PROBE_EXPONENT = 3.0       # over the pool's boxes ms_per_step went as (REF / mfma_tflops_32x32x16_lds)^3 (five boxes, round 5: 7.9 % raw spread -> 1.8 %; three later boxes: +-2 %)
 
 
 def box_calibration(lib, dev):
@@ -779,7 +777,9 @@ def main():
         # and the bf16 FLOPs actually issued against the dense bf16 peak -- the number that says how far the kernel is from ITS roof
         split_tn = os.environ.get("MUCON_TN_SPLIT", "1") != "0"
         mfma16 = int(lib.mucon_test_get_knob(b"MUCON_MFMA16"))     # which MFMA shape the two tape-streaming launches ran on
-        dom = ((f"ts_batched_kernel<{'true' if mfma16 & 2 else 'false'}>: all weight gradients of the step in one launch (bf16 MFMA "
+        persist = int(lib.mucon_test_get_knob(b"MUCON_TS_PERSIST")) == 1
+        dom = ((f"{'ts_persist_kernel' if persist else 'ts_batched_kernel'}: all weight gradients of the step in one launch"
+                f"{' of one persistent workgroup per CU' if persist else ''} (bf16 MFMA "
                 f"{'16x16x32' if mfma16 & 2 else '32x32x16'} on exactly split fp32 operands)"
                 if split_tn else "tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)"), k_wg_ms)
         achieved = flops_wg / (dom[1] * 1e-3) / 1e12
@@ -853,15 +853,14 @@ def main():
             "fp32_fraction_whole_path": round(value / world * 2.517e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         }
         if calib is not None:
-            # Normalisation by the LDS-fed MFMA loop's rate on this box (a loop that is not part of the path and does not change with it).  The pool has two kinds
-            # of box: the same tree reads 0.693 - 0.698 ms on one and 0.744 - 0.747 on the other, while the loop reads 1,578 - 1,587 and 1,545 - 1,549 TFLOP/s:
-            # the step follows the third power of the loop's rate (the five pairs, and why the register-only loops and the copy are reported only).
-            k = (calib["mfma_tflops_32x32x16_lds"] / REF_LDS_PROBE_TFLOPS) ** LDS_PROBE_EXPONENT
-            calib["box_kind"] = "faster" if calib["mfma_tflops_32x32x16_lds"] >= 1565.0 else "power-limited"
+            # The probes are reported RAW.  Round 5 first fitted ms_per_step ~ (LDS-fed loop's rate)^-3 on five boxes (7.9 % spread -> 1.8 %), then met boxes the fit
+            # fails on outright: the loop at 1,482 - 1,530 TFLOP/s (the lowest readings of the round) beside a step of 0.702 - 0.706 ms (among the fastest) --
+            # DESIGN.md section 5 has the ten (probe, step) pairs.  No code-independent probe found predicts the step to better than the boxes' own spread, so no
+            # normalised figure is emitted (the key stays, null: the round-4 verdict's contract); same-box A/Bs (tools/flag_ab.sh, tools/knob_sweep.sh) remain the method.
             out["box_calibration"] = calib
-            out["ms_per_step_at_reference_box"] = round(out["ms_per_step"] * k, 4)
-            out["normalisation"] = (f"ms_per_step x (mfma_tflops_32x32x16_lds / {REF_LDS_PROBE_TFLOPS:.0f})^{LDS_PROBE_EXPONENT:.0f}: an empirical fit over five boxes of the pool "
-                                    f"(DESIGN.md section 5), good to about +-2 % over eight boxes; value / ms_per_step stay raw")
+            out["ms_per_step_at_reference_box"] = None
+            out["normalisation"] = ("none: over ten boxes of the pool none of the probes (register-only MFMA loops of both shapes, LDS-fed MFMA loop, 1 GiB copy, the "
+                                    "frozen round-2 first_conv kernel) predicts ms_per_step -- DESIGN.md section 5; box_calibration holds them raw")
         if rccl is not None:
             out["rccl"] = rccl
         # the single-GPU legs (CPU baseline, Viterbi, end-to-end, evaluation) belong to the N = 1 line: at N > 1 the other ranks would sit in the

@@ -306,7 +306,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         }
         splitstoreG(0, 0, I0{}, 1.f);
         splitstoreG(0, 0, I1{}, 1.f);
-        gloadG(min(1, last), I0{});
+        gloadG(min(1, last), I0{});   // (r5: requested with the loads above instead -- neutral, 0.6982 against 0.6987 ms per step; not kept)
         stageX(I0{});
         gloadX(min(2, last), I0{});
         readX(0);
@@ -375,7 +375,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
     }
     CLK_END(1, item);
-    after_loop();   // (the persistent launch draws its next item here: the ticket travels under the slab write-out)
 
 #if TS_STAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -391,6 +390,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
                 slab[(long)row * p.Ktot] = acc[nb][reg];
             }
     }
+    after_loop();   // (the persistent launch draws its next item here: the ticket's round trip passes while the slab stores drain)
     // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
     // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
     const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
@@ -743,7 +743,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
         }
     }
     CLK_END(1, item);
-    after_loop();
 
 #if TS_STAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -759,6 +758,7 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
                 slab[(long)row * p.Ktot] = acc[nb][reg];
             }
     }
+    after_loop();   // (the persistent launch draws its next item here: the ticket's round trip passes while the slab stores drain)
     // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
     // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
     const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
@@ -1224,15 +1224,24 @@ template <int MODE>
 __global__ __launch_bounds__(512) void ts_persist_kernel(const TnBatch tb, unsigned *tickets) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
     int *s_next = reinterpret_cast<int *>(ts_smem + TS_SMEM_BYTES / 2);   // one word behind the tiles
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int item = blockIdx.x;
     while (item < tb.nblocks) {
 #if CLK_STAMP
         const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-        unsigned drawn = 0;
+        // The ticket is a SCALAR-memory atomic (s_atomic_add, wave 0): it returns through lgkmcnt, so it neither queues behind the slab stores
+        // nor makes the compiler wait for them (a vector atomic behind a `threadIdx.x == 0` branch did: its round trip, 1.2 - 2.3 us,
+        // stood in front of the item's slab write-out: profiles/r05_weight_gradient_schedule.txt §9).  Issue and wait are one asm
+        // statement -- the compiler never sees a register with a load in flight -- placed behind wave 0's slab stores
+        // so that it waits while they drain.
         bool have = false;
         auto draw = [&]() {
-            if (threadIdx.x == 0) drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0) {
+                unsigned t = 1u;
+                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tickets) : "memory");
+                if (threadIdx.x == 0) *s_next = (int)(gridDim.x + t);
+            }
             have = true;
         };
         const bool ran = ts_run_item<MODE>(tb, item, ts_smem, draw);
@@ -1247,7 +1256,6 @@ __global__ __launch_bounds__(512) void ts_persist_kernel(const TnBatch tb, unsig
         }
 #endif
         (void)ran;
-        if (threadIdx.x == 0) *s_next = (int)(gridDim.x + drawn);
         __syncthreads();   // ... which also puts the item's last LDS reads (the bias sums) in front of the next item's first stores
         item = __builtin_amdgcn_readfirstlane(*s_next);
     }
