@@ -611,3 +611,40 @@ def test_persistent_weight_gradient_launch_is_bitwise_neutral(B, T, training):
     for name, a_, b_, c_ in zip(names, base, again, other):
         assert torch.equal(a_, b_), name
         assert torch.equal(a_, c_), name
+
+
+def test_schedule_knobs_of_round_5_do_not_change_results():
+    """(r5) The schedule choices of the weight-gradient launch and of the coarse kernels at the bench shape: first_conv's items on the
+    staggered wave schedule (MUCON_TS_STAGGER=0: the lock-step body -- same sums in the same order: BITWISE equal), the layer jobs'
+    time chunks of <= 512 steps (MUCON_TS_LAYER_MC_CAP=2048: round 4's chunks -- other partial sums: equal to fp32 rounding), 64-row
+    coarse workgroups at T/2 (MUCON_COARSE_RB4_WGS beyond every grid: 32-row workgroups -- a row's sums do not depend on its
+    workgroup's height: bitwise)."""
+    from mucon_amd import _lib, ops
+    from oracle import dense as od
+    B, T = 8, 4096
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 257)
+    names = ops.param_names(spec)
+    tape = torch.tensor(synth.tape(258, B, T, 2048), device=DEV)
+    v = torch.tensor(synth.uniform_pm1(259, (B, spec.out_length(T), 128)), device=DEV)
+
+    def run():
+        P = _dev_params(params_np, names)
+        enc = ops.encoder_forward(tape, P, spec, training=True, seed=99)
+        (v * enc).sum().backward()
+        return [enc.detach().clone()] + [p.grad.detach().clone() for p in P]
+
+    base = run()
+    for knob, value, default, exact in (("MUCON_TS_STAGGER", 0, 1024, True), ("MUCON_TS_LAYER_MC_CAP", 2048, 512, False),
+                                        ("MUCON_COARSE_RB4_WGS", 1 << 30, 512, True)):
+        try:
+            _lib.set_knob(knob, value)
+            other = run()
+        finally:
+            _lib.set_knob(knob, default)
+        for name, a_, b_ in zip(["enc"] + names, base, other):
+            if exact:
+                assert torch.equal(a_, b_), (knob, name)
+            else:
+                scale = a_.abs().max().item() + 1e-20
+                assert (a_ - b_).abs().max().item() <= 2e-5 * scale, (knob, name)
