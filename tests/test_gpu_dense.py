@@ -97,7 +97,8 @@ def test_forward_matches_reference_golden(name, over):
 @pytest.mark.parametrize("B,T,over", [(2, 16, {}), (1, 33, {}),   # the shortest tapes four poolings allow (Tz = 1, 2)
                                       (2, 3500, {}),                # 6144 < frames < 8192: first_conv neither in k-chunks nor split-bf16
                                       (1, 353, {}), (3, 1201, {}), (2, 640, {"pooling_type": "sum", "leaky_relu": True}),
-                                      (1, 1500, {"last_relu": False}), (2, 333, {"last_gn_num_groups": 8})])
+                                      (1, 1500, {"last_relu": False}), (2, 333, {"last_gn_num_groups": 8}),
+                                      (1, 9000, {"last_gn_num_groups": 8})])   # (r5) GroupNorm's general loops: more than 4 elements per thread
 def test_forward_matches_oracle_f64(B, T, over):
     from mucon_amd import ops
     from oracle import dense as od
@@ -173,7 +174,8 @@ def _pattern_agrees(hip, oracle_masks, only=None, tol=2e-5, max_flips=8):
                                       (1, 16384, {}),               # BASELINE config 5's tape, dense leg
                                       (2, 500, {"pooling_type": "sum"}),
                                       (1, 900, {"leaky_relu": True}), (1, 640, {"last_gn": False}),
-                                      (1, 512, {"last_relu": False, "last_gn_num_groups": 16})])
+                                      (1, 512, {"last_relu": False, "last_gn_num_groups": 16}),
+                                      (1, 9000, {"last_gn_num_groups": 8})])   # (r5) GroupNorm's general loops (Tz = 562 rows x 4 float4 columns per group)
 def test_backward_matches_oracle_f64(B, T, over):
     """Gradients of L = sum(w*logp) + sum(u*logits) + sum(v*enc) w.r.t. every parameter.
 
