@@ -1245,7 +1245,10 @@ __global__ __launch_bounds__(512) void ts_persist_kernel(const TnBatch tb, unsig
             have = true;
         };
         const bool ran = ts_run_item<MODE>(tb, item, ts_smem, draw);
-        if (!have) draw();   // (a padding item)
+        if (!have) {         // a padding item: no barrier has been passed since the item was read -- every wave must have read it before wave 0 overwrites the word
+            __syncthreads();
+            draw();
+        }
 #if CLK_STAMP
         if (ran) {
             __syncthreads();
