@@ -582,7 +582,7 @@ def live_traffic(args):
             cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                    "--repeats", "1", "--prewarm-steps", "10", "--batch", str(args.batch), "--frames", str(args.frames), "--tapes", str(args.tapes),
                    "--no-cpu-baseline", "--no-viterbi", "--no-calibration", "--no-traffic"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
