@@ -577,7 +577,10 @@ def live_traffic(args):
         return None
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="mucon_pmc_", dir="/tmp")
+        try:
+            d = tempfile.mkdtemp(prefix="mucon_pmc_", dir="/tmp")
+        except OSError:
+            return None
         try:
             cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                    "--repeats", "1", "--prewarm-steps", "10", "--batch", str(args.batch), "--frames", str(args.frames), "--tapes", str(args.tapes),
