@@ -502,12 +502,32 @@ __global__ __launch_bounds__(256) void head_fwd_z_kernel(const HeadFwdArgs a) {
     for (int e = tid * 4; e < nz * H; e += 1024)
         *reinterpret_cast<f32x4 *>(Es + e) = *reinterpret_cast<const f32x4 *>(a.enc + ((long)b * a.Tz + z0) * H + e);
     for (int e = nz * H + tid; e < HF_Z * H; e += 256) Es[e] = 0.f;
+    // (r5) H = 128: the thread's eight pieces of W are requested in front of the barrier, beside the rows' own trip (they were a second trip behind it)
+    const float *wr = a.w + (long)min(c, C - 1) * H;
+    f32x4 wpre[8];
+#ifndef HEAD_PRE
+#define HEAD_PRE 1   // 0: round 4's order (the y-head kernels' second operands requested behind their first barrier)
+#endif
+    const bool pre = HEAD_PRE && H == 128;
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wpre[i] = *reinterpret_cast<const f32x4 *>(wr + q * 4 + 16 * i);
+    }
     __syncthreads();
     float acc[HF_Z];
 #pragma unroll
     for (int zi = 0; zi < HF_Z; ++zi) acc[zi] = 0.f;
-    if (c < C) {
-        const float *wr = a.w + (long)c * H;
+    if (c < C && pre) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = q * 4 + 16 * i;
+#pragma unroll
+            for (int zi = 0; zi < HF_Z; ++zi) {
+                const f32x4 ev = *reinterpret_cast<const f32x4 *>(Es + zi * H + k);
+                acc[zi] += (wpre[i][0] * ev[0] + wpre[i][1] * ev[1]) + (wpre[i][2] * ev[2] + wpre[i][3] * ev[3]);
+            }
+        }
+    } else if (c < C) {
         for (int k = q * 4; k < H; k += 16) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k);
 #pragma unroll
@@ -693,16 +713,19 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
             // branch costs a branch and a full wait per element)
             const float *p1 = a.dlogits ? a.dlogits : a.dlogp, *p2 = a.dlogp ? a.dlogp : a.dlogits;
             const float w1 = a.dlogits ? 1.f : 0.f, w2 = a.dlogp ? 1.f : 0.f;
-            for (int base = 0; base < nfr; base += 8) {
-                float v1[8], v2[8];
+#ifndef HB_FRAMES
+#define HB_FRAMES 16   // (r5) frames of a bin requested at once (8: round 4 -- a bin of Tf / Tz = 16 frames was two dependent round trips)
+#endif
+            for (int base = 0; base < nfr; base += HB_FRAMES) {
+                float v1[HB_FRAMES], v2[HB_FRAMES];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < HB_FRAMES; ++j) {
                     const long gi = ((long)b * a.Tf + fa + min(base + j, nfr - 1)) * C + c;
                     v1[j] = p1[gi];
                     v2[j] = p2[gi];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < HB_FRAMES; ++j) {
                     if (base + j < nfr) {
                         g1 += v1[j];
                         g2 += v2[j];
@@ -715,14 +738,23 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
         G1[zi][c] = g1;
         G2[zi][c] = g2;
     }
+    // (r5) the saved log-probabilities of this thread's two rows are requested in front of the barrier (they were a round trip behind it)
+    float lpz[HB_Z / 4];
+#pragma unroll
+    for (int i = 0; i < HB_Z / 4; ++i) {
+        const int zi = (tid >> 6) + 4 * i, c = tid & 63;
+        lpz[i] = a.logp_z[((long)b * a.Tz + z0 + min(zi, nz - 1)) * C + min(c, C - 1)];
+    }
     __syncthreads();
-    for (int zi = tid >> 6; zi < HB_Z; zi += 4) {   // a wave per row: S2 = sum_c G2, then the log-softmax backward
+#pragma unroll
+    for (int i = 0; i < HB_Z / 4; ++i) {   // a wave per row: S2 = sum_c G2, then the log-softmax backward
+        const int zi = (tid >> 6) + 4 * i;
         const int c = tid & 63;
         float s = G2[zi][c];
 #pragma unroll
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
         float d = G1[zi][c] + G2[zi][c];
-        if (zi < nz && c < C && s != 0.f) d -= expf(a.logp_z[((long)b * a.Tz + z0 + zi) * C + c]) * s;
+        if (zi < nz && c < C && s != 0.f) d -= expf(HEAD_PRE ? lpz[i] : a.logp_z[((long)b * a.Tz + z0 + zi) * C + c]) * s;
         G1[zi][c] = d;
         if (c == 0) S2[zi] = s;
     }
