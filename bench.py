@@ -597,7 +597,7 @@ def live_traffic(args):
                 k = x["Kernel_Name"]
                 if "nt_split16_kernel<true, false, false, false>" in k or "nt_split_kernel<true, false, false, false>" in k:
                     fwd.append(float(x["Counter_Value"]))
-                if "ts_persist_kernel" in k or "ts_batched_kernel" in k or "tn_batched_kernel" in k:
+                if "ts_runs_kernel" in k or "ts_batched_kernel" in k or "tn_batched_kernel" in k:
                     wg.append(float(x["Counter_Value"]))
             if not fwd or not wg:
                 return None
@@ -828,10 +828,10 @@ def main():
         # and the bf16 FLOPs actually issued against the dense bf16 peak -- the number that says how far the kernel is from ITS roof
         split_tn = os.environ.get("MUCON_TN_SPLIT", "1") != "0"
         mfma16 = int(lib.mucon_test_get_knob(b"MUCON_MFMA16"))     # which MFMA shape the two tape-streaming launches ran on
-        persist = int(lib.mucon_test_get_knob(b"MUCON_TS_PERSIST")) == 1
-        dom = ((f"{'ts_persist_kernel' if persist else 'ts_batched_kernel'}: all weight gradients of the step in one launch"
-                f"{' of one persistent workgroup per CU' if persist else ''} (bf16 MFMA "
-                f"{'16x16x32' if mfma16 & 2 else '32x32x16'} on exactly split fp32 operands)"
+        runs = int(lib.mucon_test_get_knob(b"MUCON_TS_RUNS")) == 1
+        dom = ((f"{'ts_runs_kernel' if runs else 'ts_batched_kernel'}: all weight gradients of the step in one launch"
+                f"{' of one persistent workgroup per CU, each a contiguous share of the (column, video, tile) line with its accumulators kept in registers' if runs else ''}"
+                f" (bf16 MFMA 32x32x16 on exactly split fp32 operands)"
                 if split_tn else "tn_batched_kernel<2>: all weight gradients of the step in one launch (f32 MFMA)"), k_wg_ms)
         achieved = flops_wg / (dom[1] * 1e-3) / 1e12
         # the kernel's OWN ceiling: it issues 6 bf16 MFMA FLOP per algorithmic fp32 FLOP, so 2.5 PFLOP/s dense bf16 / 6 = 416.7 TFLOP/s

@@ -293,19 +293,32 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
 //   mode 0: out[row*ncols + col]      mode 1 (conv k=3 weight, ncols = 384): col = tap*128 + i ->
 //   out[(row*128 + i)*3 + tap], the reference's [out][in][k] layout
 // ------------------------------------------------------------------------------------------
-constexpr int REDUCE_MAX_JOBS = 64;
+//   colblk >= 0 (round 6: the slabs of the static-runs weight-gradient launch, gemm_tn_split.hpp): the job's columns lie in the 256-column
+//   blocks colblk, colblk + 1, ... of the launch's column table; block c owns cols.n[c] partial tiles [128][256] from slab cols.slab0[c] of the
+//   arena on (the number differs from column to column: one per workgroup whose share touched it); a bias job reads the 256-float bias
+//   partials of ONE column the same way
+constexpr int REDUCE_MAX_JOBS = 56;
+constexpr int REDUCE_MAX_COLS = 48;     // = TS_MAX_COLS
 struct ReduceJob {
     const float *slabs;
     float *out;
     long slab_stride;
-    int nslabs, ld, coff, ncols, n_elems, mode;
-    int block0;  // first workgroup of this job
-    int vec;     // 1: ncols, coff, ld, slab_stride and n_elems are multiples of 4 (float4 path)
+    int nslabs, ld, coff, ncols, n_elems;
+    int block0;      // first workgroup of this job
+    int8_t mode;
+    int8_t vec;      // 1: ncols, coff, ld, slab_stride and n_elems are multiples of 4 (float4 path)
+    int8_t colblk;   // -1: slabs / nslabs / slab_stride / ld above
+    int8_t isbias;
+};
+struct ReduceCols {
+    uint16_t slab0[REDUCE_MAX_COLS], n[REDUCE_MAX_COLS];
+    const float *slabs, *bias;
 };
 struct ReduceBatch {
     ReduceJob j[REDUCE_MAX_JOBS];
     int first_block[REDUCE_MAX_JOBS];   // j[i].block0 once more, contiguous (unused entries: INT_MAX): see reduce_batch_kernel
     int njobs, nblocks;
+    ReduceCols cols;
 };
 
 template <int G>
@@ -340,24 +353,32 @@ __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch 
         row = e / J.ncols;
         col = e - row * J.ncols;
         const float *p = J.slabs + (long)row * J.ld + J.coff + col;
+        int nslabs = J.nslabs;
+        long stride = J.slab_stride;
+        if (J.colblk >= 0) {   // the static-runs launch's slabs: this lane's 256-column block says where they are and how many
+            const int gcol = J.coff + col, c = J.colblk + (J.isbias ? 0 : gcol >> 8);
+            nslabs = rb.cols.n[c];
+            stride = J.isbias ? 256 : 128 * 256;
+            p = (J.isbias ? rb.cols.bias + gcol : rb.cols.slabs + (long)row * 256 + (gcol & 255)) + (long)rb.cols.slab0[c] * stride;
+        }
         int i = g;
         if (G >= 16) {   // few deep jobs (the y-head's 256 slabs): sixteen loads per lane in flight -- the pass is its chain of round trips
-            for (; i + 15 * G < J.nslabs; i += 16 * G) {
+            for (; i + 15 * G < nslabs; i += 16 * G) {
                 f32x4 v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * J.slab_stride);
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * stride);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s += v[u];
             }
         }
-        for (; i + 3 * G < J.nslabs; i += 4 * G) {
+        for (; i + 3 * G < nslabs; i += 4 * G) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * J.slab_stride);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * stride);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += v[u];
         }
-        for (; i < J.nslabs; i += G) s += *reinterpret_cast<const f32x4 *>(p + (long)i * J.slab_stride);
+        for (; i < nslabs; i += G) s += *reinterpret_cast<const f32x4 *>(p + (long)i * stride);
     }
     if (G > 1) {
         part[g][lane] = s;

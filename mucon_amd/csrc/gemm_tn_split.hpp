@@ -47,20 +47,20 @@ constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 
 constexpr int TS_XT_FLOATS = 32 * 32;                   // a wave's X tile [32 time steps][32 columns] (4 KB), transposed through LDS
 constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS_XT_FLOATS * 4;   // two buffers x two images + eight X tiles: 131,072 B
 
-template <bool TWO_G, bool DROP, class AfterLoop>
-__device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
-                                        uint16_t *smem, const int item, AfterLoop &&after_loop) {
+template <bool TWO_G, bool DROP>
+__device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const int b, const int tbeg, const int tend, const bool dual, const bool x0_act,
+                                        uint16_t *smem, const int item, f32x16 (&acc)[4], float (&bsum)[2]) {
     constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    const int tid = threadIdx.x;
+    // (the thread index through an opaque asm: a run's per-lane offsets and roles are then computed inside the run -- hoisted out of the caller's run and
+    // column loops they stayed alive across every body of the kernel: spills inside the staggered body's staging blocks, 277 us per share instead of 168)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = wave >> 2, cg = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int b = mc / p.chunks_per_video;
-    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
-    const int tend = min(tbeg + p.MC, p.Trows);
     const int ntiles = (tend - tbeg + 31) >> 5;
     const int last = ntiles - 1;
     const int nch = p.nk0 + (dual ? 1 : 0);
@@ -99,9 +99,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     f32x4 rx[2][4];          // X: [set][8-row group], two tiles in flight
     float rawT[8];           // the eight time steps of this lane's column for the next MFMA step (read back from the X tile)
     float rgA[NU][4], rgB[NU][4];   // G: time slots 0-3 / 4-7 of the next image
-    float bsum[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
 
     // A tile is interior when none of its 32 rows needs a mask: inside the chunk (G) and, for this wave's tap, inside the video (X).
     // Interior tiles are loaded with wave-uniform row addresses and enter the MFMA body as they are; the others are loaded
@@ -240,11 +237,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         return P;
     };
 
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     // G fragment (step s, plane pl, channel block nb): image[s][pl][h][nb*32 + r][8]
     const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
@@ -380,34 +372,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     if (blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
 #endif
-    if (active) {
-        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                slab[(long)row * p.Ktot] = acc[nb][reg];
-            }
-    }
-    after_loop();   // (the persistent launch draws its next item here: the ticket's round trip passes while the slab stores drain)
-    // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
-    // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
-    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
-    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
-    if (bias0 || bias1) {   // workgroup-uniform
-        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
-        float own = bsum[0];
-        if (TWO_G) own += bsum[NU - 1];
-        red[(s_hi * 2 + s_lo) * 128 + sn] = own;
-        __syncthreads();
-        if (TWO_G) {
-            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
-            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
-        } else if (tid < 128 && bias0) {
-            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -415,20 +379,20 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
 // arithmetic with the tile re-ordered into blocks so that the two waves of a SIMD never want the same unit -- see the comment at the
 // tile loop below.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool TWO_G, bool DROP, class AfterLoop>
-__device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
-                                        uint16_t *smem, const int item, AfterLoop &&after_loop) {
+template <bool TWO_G, bool DROP>
+__device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, const int b, const int tbeg, const int tend, const bool dual, const bool x0_act,
+                                        uint16_t *smem, const int item, f32x16 (&acc)[4], float (&bsum)[2]) {
     constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    const int tid = threadIdx.x;
+    // (the thread index through an opaque asm: a run's per-lane offsets and roles are then computed inside the run -- hoisted out of the caller's run and
+    // column loops they stayed alive across every body of the kernel: spills inside the staggered body's staging blocks, 277 us per share instead of 168)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = wave >> 2, cg = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int b = mc / p.chunks_per_video;
-    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
-    const int tend = min(tbeg + p.MC, p.Trows);
     const int ntiles = (tend - tbeg + 31) >> 5;
     const int last = ntiles - 1;
     const int nch = p.nk0 + (dual ? 1 : 0);
@@ -468,9 +432,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     f32x4 rx[NXS][4];        // X: [set][8-row group]
     float rawT[8], rawU[8];  // the eight time steps of this lane's column for the two MFMA steps of a tile (read back from the X tile)
     float rgA[NU][4], rgB[NU][4];   // G: time slots 0-3 / 4-7 of the next image
-    float bsum[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
 
     // A tile is interior when none of its 32 rows needs a mask: inside the chunk (G) and, for this wave's tap, inside the video (X).
     // Interior tiles are loaded with wave-uniform row addresses and enter the MFMA body as they are; the others are loaded
@@ -589,11 +550,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
         return P;
     };
 
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     // G fragment (step s, plane pl, channel block nb): image[s][pl][h][nb*32 + r][8]
     const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
@@ -748,547 +704,274 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     if (blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
 #endif
-    if (active) {
-        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// What a workgroup leaves behind for one COLUMN (a job's pair of 128-column chunks kc2): its 128 x 256 partial tile and the bias
+// partials of the gradient images it staged.  `slab` = the partial's [128][ld] block at this column's first column, `bias` = 256
+// floats (image 0's column sums in the first 128 words -- written by the workgroups of column 0 only --, image 1's in the second).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TWO_G>
+__device__ __forceinline__ void ts_flush(const TnParams &p, const int kc2, const bool dual, uint16_t *smem, const f32x16 (&acc)[4], const float (&bsum)[2],
+                                         float *slab, const int ld, float *bias) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave >> 2, cg = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int nch = p.nk0 + (dual ? 1 : 0);
+    if (2 * kc2 + hf < nch) {   // (an odd chunk count leaves the last column's second half without columns)
+        float *o = slab + hf * 128 + cg * 32 + r;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                slab[(long)row * p.Ktot] = acc[nb][reg];
+                o[(long)row * ld] = acc[nb][reg];
             }
     }
-    after_loop();   // (the persistent launch draws its next item here: the ticket's round trip passes while the slab stores drain)
-    // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroup that owns chunk 0, image 1
-    // (Y1, dropout replayed) from the TWO_G workgroup.  Fixed order: a thread's own time slots, then the units.
-    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
-    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
+    // bias gradients = column sums of the staged gradient rows: image 0 (Y0) from the workgroups of column 0, image 1 (Y1, dropout
+    // replayed) from the TWO_G workgroups.  Fixed order: a thread's own time slots, then the units.
+    const bool bias0 = bias != nullptr && kc2 == 0;
+    const bool bias1 = TWO_G && bias != nullptr;
     if (bias0 || bias1) {   // workgroup-uniform
-        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
+        const int sn = tid & 127;
+        const int s_hi = wave >> 2, s_lo = (wave >> 1) & 1;
+        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the tile loop's last barrier
         float own = bsum[0];
-        if (TWO_G) own += bsum[NU - 1];
+        if (TWO_G) own += bsum[1];
         red[(s_hi * 2 + s_lo) * 128 + sn] = own;
         __syncthreads();
         if (TWO_G) {
-            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
-            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
+            if (tid < 128 && bias0) bias[tid] = red[tid] + red[128 + tid];
+            if (tid >= 128 && tid < 256 && bias1) bias[tid] = red[256 + sn] + red[384 + sn];
         } else if (tid < 128 && bias0) {
-            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            bias[tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
         }
+        __syncthreads();   // ... and the next column's first image must not land under these reads
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same workgroup on v_mfma_f32_16x16x32_bf16 (round 5: MUCON_MFMA16 bit 1; why a second shape: gemm_split.hpp, and
-// profiles/r05_mfma_shape.txt for the A/B).  Lane (r = lane & 15, h = lane >> 4) holds 8 consecutive TIME steps 8h .. 8h + 7 of a
-// 32-step tile, for channel r of a 16-channel block (G) or column r of a 16-column half (X): a tile is ONE 32-deep step of
-// 8 channel blocks x 2 column halves x 6 products = 96 MFMAs (32x32x16: 2 steps x 4 x 6 = 48 of twice the cycles).
-//   * G image per 32 steps: [plane 3][time group 4][channel 128][8 steps] -- the same 24 KB, staged by the same thread roles
-//     (unit (s, h) of the wide shape is time group 2s + h), conflict-free ds_read_b128 / ds_write_b64.
-//   * a tile runs as two phases of four channel blocks each, both column halves in every phase: every G fragment is read from
-//     LDS once (12 per phase, as before).  The operand planes of BOTH column halves of a tile are complete when it starts; the
-//     split of the next tile's column half 0 / 1 is woven into phase 0 / 1, so the wave's X tile in LDS holds tile mt + 1
-//     while tile mt multiplies (one tile further ahead than the wide shape; the register sets hold tiles mt + 2, mt + 3).
-//   * the X tile is [32 steps][32] floats with columns 0-15 and 16-31 exchanged in the odd groups of 8 steps: ds_read_b32 serves
-//     lanes 0-31 and 32-63 as two groups over 32 banks, a group's two time groups (h = 0, 1 / 2, 3) then sit in different bank halves
-//     (plain row-major would collide 2-way).
-//   * accumulators: [column half][channel block] float4 = channels 16 cb + 4 h + e of column 16 c + r.
-// Summation order differs from the wide shape's (K = 32 per MFMA instead of 16): the gradients of the two shapes agree to
-// fp32 rounding, not bitwise; each shape is bitwise repeatable and batch independent by itself.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int TS16_XT_FLOATS = 32 * 32;
-constexpr int TS16_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS16_XT_FLOATS * 4;   // 131,072 B
-
-template <bool TWO_G, bool DROP>
-__device__ __forceinline__ void ts_body16(const TnParams &p, const int kc2, const int mc, const bool dual, const bool x0_act,
-                                          uint16_t *smem) {
-    constexpr int NU = TWO_G ? 2 : 1;   // staging units (8 time steps of one channel) per thread and tile
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hf = wave >> 2, cg = wave & 3;
-    const int r = lane & 15, h = lane >> 4;
-    const int b = mc / p.chunks_per_video;
-    const int tbeg = (mc - b * p.chunks_per_video) * p.MC;
-    const int tend = min(tbeg + p.MC, p.Trows);
-    const int ntiles = (tend - tbeg + 31) >> 5;
-    const int last = ntiles - 1;
-    const int nch = p.nk0 + (dual ? 1 : 0);
-    const int kc_raw = 2 * kc2 + hf;
-    const bool active = kc_raw < nch;
-    const int kc = active ? kc_raw : 2 * kc2;
-    const bool second = dual && kc >= p.nk0;
-    const int xoff = (!second && p.taps == 3) ? (kc - 1) * p.tap_step : 0;
-    const int xcol = (second || p.taps == 3) ? 0 : kc * 128;
-    const int ldx = second ? 128 : p.ldx;
-    const int Tx = second ? p.Trows : p.Tx;
-    const float *Xu = second ? p.X1 + (long)b * p.Trows * 128 : p.X0 + (long)b * p.x_bstride + xcol;   // wave-uniform
-    const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
-    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;
-    float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS16_XT_FLOATS;
-
-    const int sn = tid & 127;
-    const int s_hi = wave >> 2, s_lo = (wave >> 1) & 1;
-    const int s_img = TWO_G ? s_hi : 0;
-    const int s_s = TWO_G ? s_lo : s_hi;
-    const float *Yu = ((TWO_G && s_img) ? p.Y1 : p.Y0) + (long)b * p.Trows * 128;   // wave-uniform
-    const uint32_t y_lane = (uint32_t)sn * 4u;
-    auto unit_h = [&](int u) { return TWO_G ? u : s_lo; };
-    DropCfg dcfg = p.drop;
-    dcfg.thresh = s_img ? dcfg.thresh : 0u;
-    dcfg.scale = s_img ? dcfg.scale : 1.f;
-    auto ld_su = [](const float *ubase, uint32_t lane_bytes) {
-        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + lane_bytes);
-    };
-
-    f32x4 rx[2][4];
-    float rawT[8];
-    float rgA[NU][4], rgB[NU][4];
-    float bsum[NU];
+// One RUN = time steps [tbeg, tend) of video b for column (job, kc2), added to the accumulators the caller keeps.  The staggered
+// schedule (ts_body_st) is taken by the single-image columns of jobs without a second gradient set (first_conv's: 128 workgroups x 64 tiles
+// at the bench shape, 155-160 -> 136-141 us each); the residual layers' columns keep the lock-step body: the ones that stage two images and
+// replay the dropout mask have twice the staging work per tile and the registers for one X tile in flight only -- staggered they ran 218 us
+// instead of 200 (profiles/r05_weight_gradient_schedule.txt).  The two bodies are bit-identical.
+__device__ __forceinline__ void ts_run(const TnJob &job, const int kc2, const int b, const int tbeg, const int tend, const bool stagger,
+                                       uint16_t *ts_smem, const int item, f32x16 (&acc)[4], float (&bsum)[2]) {
+    const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
+    if (!two_g) {
+        if (stagger && !job.dual) ts_body_st<false, false>(job.p, kc2, b, tbeg, tend, false, job.x0_act != 0, ts_smem, item, acc, bsum);
+        else ts_body<false, false>(job.p, kc2, b, tbeg, tend, job.dual != 0, job.x0_act != 0, ts_smem, item, acc, bsum);
+    } else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, b, tbeg, tend, true, false, ts_smem, item, acc, bsum);
+    else ts_body<true, false>(job.p, kc2, b, tbeg, tend, true, false, ts_smem, item, acc, bsum);
+}
+__device__ __forceinline__ void ts_zero(f32x16 (&acc)[4], float (&bsum)[2]) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
-
-    auto g_int = [&](int tile) { return tbeg + tile * 32 + 32 <= tend; };
-    auto x_int = [&](int tile) {
-        const int t0 = tbeg + tile * 32;
-        return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
-    };
-    auto gloadX = [&](int tile, auto SET) {
-        constexpr int Q = decltype(SET)::value;
-        if (x_int(tile)) {
-            const float *ub = Xu + (long)(tbeg + tile * 32 + xoff) * ldx;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ub + (long)(8 * i) * ldx) + x_lane);
-        } else {
-            const int row0 = tbeg + tile * 32 + xrow + xoff;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ts = min(max(row0 + 8 * i, 0), Tx - 1);
-                rx[Q][i] = *reinterpret_cast<const f32x4 *>(Xu + (long)ts * ldx + cg * 32 + xc4);
-            }
-        }
-    };
-    // wave-private X tile: rows as loaded (the odd groups of 8 steps with the two 16-column halves exchanged), read back by column
-    auto stageX = [&](auto SET) {
-        constexpr int Q = decltype(SET)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xT + (8 * i + xrow) * 32 + (xc4 ^ (16 * (i & 1)))) = rx[Q][i];
-    };
-    auto readX = [&](int c) {   // column 16 c + r, steps 8h .. 8h + 7
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rawT[j] = xT[(8 * h + j) * 32 + ((16 * c + r) ^ (16 * (h & 1)))];
-    };
-    auto fixX = [&](float (&raw)[8], int tile) {   // non-linearity of the last_conv job, zero padding, chunk end
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = tbeg + tile * 32 + 8 * h + j;
-            const int ts = t + xoff;
-            float x = raw[j];
-            if (x0_act) x = act_f(x, p.slope);
-            raw[j] = (t < tend && ts >= 0 && ts < Tx) ? x : 0.f;
-        }
-    };
-    auto gloadG = [&](int tile, auto HALF) {
-        constexpr int HB = decltype(HALF)::value;
-        const bool inner = g_int(tile);
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;   // wave-uniform
-                if (!inner) t = min(t, p.Trows - 1);
-                const float v = ld_su(Yu + (long)t * 128, y_lane);
-                if constexpr (HB) rgB[u][jj] = v;
-                else rgA[u][jj] = v;
-            }
-    };
-    auto fixG = [&](int tile, auto HALF) {
-        constexpr int HB = decltype(HALF)::value;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
-                if constexpr (HB) rgB[u][jj] = t < tend ? rgB[u][jj] : 0.f;
-                else rgA[u][jj] = t < tend ? rgA[u][jj] : 0.f;
-            }
-    };
-    auto splitstoreG = [&](int tile, int buf, auto HALF, float bw) {
-        constexpr int HB = decltype(HALF)::value;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            float v[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                v[jj] = HB ? rgB[u][jj] : rgA[u][jj];
-                if (DROP) {
-                    const int t = tbeg + tile * 32 + 16 * s_s + 8 * unit_h(u) + 4 * HB + jj;
-                    v[jj] *= drop_mul(dcfg, (uint32_t)(b * p.Trows + t) * 128u + (uint32_t)sn);
-                }
-                bsum[u] = fmaf(v[jj], bw, bsum[u]);
-            }
-            uint32_t a0, m0, l0, a1, m1, l1;
-            sp_split2(v[0], v[1], a0, m0, l0);
-            sp_split2(v[2], v[3], a1, m1, l1);
-            // image [plane 3][time group 4][channel 128][8]: this unit is time group 2 s + h
-            uint16_t *dst = smem + (buf * 2 + s_img) * TS_IMG + ((2 * s_s + unit_h(u)) * 128 + sn) * 8 + 4 * HB;
-            *reinterpret_cast<u32x2 *>(dst) = u32x2{a0, a1};
-            *reinterpret_cast<u32x2 *>(dst + 4 * 128 * 8) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2 *>(dst + 8 * 128 * 8) = u32x2{l0, l1};
-        }
-    };
-    struct Planes { bf16x8 pl[3]; };
-    auto convertX = [&](const float (&x)[8]) {
-        u32x4 hh, mm, ll;
-        uint32_t a, bb, c;
-        sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
-        sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
-        sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
-        sp_split2(x[6], x[7], a, bb, c); hh[3] = a; mm[3] = bb; ll[3] = c;
-        Planes P;
-        P.pl[0] = __builtin_bit_cast(bf16x8, hh);
-        P.pl[1] = __builtin_bit_cast(bf16x8, mm);
-        P.pl[2] = __builtin_bit_cast(bf16x8, ll);
-        return P;
-    };
-
-    f32x4 acc[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // G fragment (plane pl, channel block cb): image[pl][h][cb*16 + r][8]
-    const int g_off = (TWO_G ? hf : 0) * TS_IMG + (h * 128 + r) * 8;
-    auto mfma_phase = [&](int buf, auto HALF, const Planes &X0, const Planes &X1) {
-        constexpr int CB0 = 4 * decltype(HALF)::value;
-        const uint16_t *base = smem + buf * 2 * TS_IMG + g_off + CB0 * 16 * 8;
-        bf16x8 w[4][3];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w[cb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (4 * 128 * 8) + cb * 16 * 8);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {   // small terms first; all six land in the same fp32 accumulator
-                const Planes &X = c ? X1 : X0;
-                f32x4 a = acc[c][CB0 + cb];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], X.pl[1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][2], X.pl[0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[2], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], X.pl[0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], X.pl[0], a, 0, 0, 0);
-                acc[c][CB0 + cb] = a;
-            }
-    };
-    // 48 MFMAs: the first two channel blocks' fragments in front, the other six under the first 12 MFMAs (a fragment read issued four
-    // 16-cycle MFMAs ahead of its use still exposed its latency); 2 * VPM vector instructions behind every pair of MFMAs (an MFMA
-    // holds the SIMD's issue for 8 of its 16 cycles), the LDS stores in the second half
-    constexpr int VPM = DROP ? 7 : (TWO_G ? 4 : 3);
-    auto weave = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-        for (int i = 0; i < 48; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 12 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (i & 1) __builtin_amdgcn_sched_group_barrier(0x002, VPM - VPM / 2, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x002, VPM / 2, 0);
-            if (i >= 24 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-    };
-
-    auto pin = [](auto &arr) {
-#pragma unroll
-        for (auto &v : arr) asm volatile("" : "+v"(v));
-    };
-    auto use = [](const Planes &P) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
-    };
-    Planes cur0, cur1;
-    {   // prologue: image of tile 0; X tiles 0 .. 3 requested, tile 0 split into both operands, tile 1 staged; first half of image 1 requested
-        gloadG(0, I0{});
-        gloadG(0, I1{});
-        gloadX(0, I0{});
-        gloadX(min(1, last), I1{});
-        if (!g_int(0)) {
-            fixG(0, I0{});
-            fixG(0, I1{});
-        }
-        splitstoreG(0, 0, I0{}, 1.f);
-        splitstoreG(0, 0, I1{}, 1.f);
-        gloadG(min(1, last), I0{});
-        stageX(I0{});
-        gloadX(min(2, last), I0{});
-        readX(0);
-        if (!x_int(0)) fixX(rawT, 0);
-        cur0 = convertX(rawT);
-        readX(1);
-        if (!x_int(0)) fixX(rawT, 0);
-        cur1 = convertX(rawT);
-        stageX(I1{});
-        gloadX(min(3, last), I1{});
-        __syncthreads();
-    }
-
-    // tile mt (image in buffer Q; operands cur0 / cur1; the wave's X tile holds tile mt+1; set Q holds tile mt+2, set O tile mt+3 on its way):
-    //   { second half of image mt+1 requested; X (mt+1, columns 0-15) read back }
-    //   { MFMAs of channel blocks 0-3 | split of X (mt+1, columns 0-15), first half of image mt+1 -> buffer O }
-    //   { X (mt+1, columns 16-31) read back; X tile <- tile mt+2 (set Q), set Q <- tile mt+4 requested; first half of image mt+2 requested }
-    //   { MFMAs of channel blocks 4-7 | split of X (mt+1, columns 16-31), second half of image mt+1 }
-#if TS_STAMP
-    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-    long long st_prev = __builtin_amdgcn_s_memtime();
-#endif
-    auto tile = [&](int mt, auto SET, auto OTHER) {
-        constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
-        TS_T(5);
-        const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n4 = min(mt + 4, last);
-        const float bw = mt < last ? 1.f : 0.f;
-        gloadG(n1, I1{});
-        readX(0);
-        if (!x_int(n1)) {
-            asm volatile("");   // (keeps the fix-up a branch: if-converted it is ~80 selects on every tile)
-            fixX(rawT, n1);
-        }
-        if (!g_int(n1)) {
-            asm volatile("");
-            fixG(n1, I0{});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        TS_T(0);
-        pin(rawT);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) pin(rgA[u]);
-        mfma_phase(Q, I0{}, cur0, cur1);
-        Planes nxt0 = convertX(rawT);
-        splitstoreG(n1, O, I0{}, bw);
-        weave();
-        use(nxt0);
-        __builtin_amdgcn_sched_barrier(0);
-        TS_T(1);
-        readX(1);
-        stageX(SET);
-        gloadG(n2, I0{});
-        gloadX(n4, SET);
-        if (!x_int(n1)) {
-            asm volatile("");
-            fixX(rawT, n1);
-        }
-        if (!g_int(n1)) {
-            asm volatile("");
-            fixG(n1, I1{});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        TS_T(2);
-        pin(rawT);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) pin(rgB[u]);
-        mfma_phase(Q, I1{}, cur0, cur1);
-        Planes nxt1 = convertX(rawT);
-        splitstoreG(n1, O, I1{}, bw);
-        weave();
-        use(nxt1);
-        __builtin_amdgcn_sched_barrier(0);
-        TS_T(3);
-        cur0 = nxt0;
-        cur1 = nxt1;
-        __syncthreads();
-        TS_T(4);
-    };
-    CLK_BEGIN();
-    for (int mt = 0; mt < ntiles; mt += 2) {
-        tile(mt, I0{}, I1{});
-        if (mt + 1 < ntiles) tile(mt + 1, I1{}, I0{});
-    }
-    CLK_END(1, blockIdx.x);
-
-#if TS_STAMP
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
-#endif
-    if (active) {
-        float *slab = p.slabs + (long)mc * 128 * p.Ktot + kc_raw * 128 + cg * 32 + r;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) slab[(long)(cb * 16 + 4 * h + e) * p.Ktot + 16 * c] = acc[c][cb][e];
-    }
-    const bool bias0 = p.bias_slabs != nullptr && kc2 == 0;
-    const bool bias1 = TWO_G && p.bias_slabs != nullptr;
-    if (bias0 || bias1) {   // workgroup-uniform
-        float *red = reinterpret_cast<float *>(smem);   // the images are dead after the loop's last barrier
-        float own = bsum[0];
-        if (TWO_G) own += bsum[NU - 1];
-        red[(s_hi * 2 + s_lo) * 128 + sn] = own;
-        __syncthreads();
-        if (TWO_G) {
-            if (tid < 128 && bias0) p.bias_slabs[(long)mc * 256 + tid] = red[tid] + red[128 + tid];
-            if (tid >= 128 && tid < 256 && bias1) p.bias_slabs[(long)mc * 256 + tid] = red[256 + sn] + red[384 + sn];
-        } else if (tid < 128 && bias0) {
-            p.bias_slabs[(long)mc * 256 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-        }
-    }
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bsum[0] = bsum[1] = 0.f;
 }
 
-// All weight gradients of a backward pass in one launch (the job table of gemm_tn.hpp): a job with n 128-column chunks has
-// ceil(n / 2) workgroups per time chunk.  ts_run_item is one such workgroup's work ("item" = its block index in the table's layout).
-template <int MODE, class AfterLoop>   // 0: ts_body (32x32x16, round 4's lock-step schedule), 1: ts_body16 (16x16x32), 2: ts_body_st (32x32x16, staggered blocks)
-__device__ __forceinline__ bool ts_run_item(const TnBatch &tb, const int item, uint16_t *ts_smem, AfterLoop &&after_loop) {
-    // which job: the number of jobs that start at or before the item -- all first blocks compared at once (walking the table job by job
-    // was a chain of dependent scalar loads, 1.0 - 1.7 us in front of a workgroup's first load: profiles/r05_weight_gradient_schedule.txt §9)
+// ---- one workgroup per ITEM (= column x time chunk of p.MC steps; slabs [time chunk][128][Ktot]): the form of the stand-alone entry points
+// (mucon_linear_bwd, mucon_conv128_wgrad) and, under MUCON_TS_RUNS=0, of the batched launch -- the tests' second schedule of the same sums
+__global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+    const int item = blockIdx.x;
     int ji = -1;
 #pragma unroll
     for (int k = 0; k < TN_MAX_BATCH; ++k) ji += item >= tb.first_block[k] ? 1 : 0;
     const TnJob &job = tb.j[ji];
-    if (item - job.block0 >= ((job.nkc + 1) >> 1) * job.nmc) return false;   // padding block between two jobs
-#if CLK_STAMP
-    {
-        long long t_;   // (the job's words are an input of the stamp: it cannot be read before they have arrived)
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(job.nkc), "s"(job.nmc));
-        if (threadIdx.x == 0 && item < 4096) g_clk_ph[item][0] = t_;
-    }
-#endif
     const int nkc2 = (job.nkc + 1) >> 1;
     const int local = item - job.block0;
-    int mc = local / nkc2, kc2 = local - mc * nkc2;
-    if (tb.xcd_order) {
-        // The nkc2 workgroups of a time chunk read the same gradient rows.  Workgroups are dealt round-robin over the 8 XCDs
-        // (block b and b + 8 share one -- observed, used for speed only), so inside every run of 8 * nkc2 blocks the chunk is
-        // the block index mod 8: the workgroups that share rows share an L2 (4 MB per XCD; first_conv's 1 MB of rows per chunk
-        // is fetched from the Infinity Cache once instead of eight times).
-        const int nmc = job.nmc, grp = 8 * nkc2;
-        const int G = local / grp;
-        if ((G + 1) * 8 <= nmc) {
-            const int in = local - G * grp;
-            mc = G * 8 + (in & 7);
-            kc2 = in >> 3;
+    if (local >= nkc2 * job.nmc) return;   // padding block between two jobs
+    const int mc = local / nkc2, kc2 = local - mc * nkc2;
+    const int b = mc / job.p.chunks_per_video;
+    const int tbeg = (mc - b * job.p.chunks_per_video) * job.p.MC;
+    const int tend = min(tbeg + job.p.MC, job.p.Trows);
+    f32x16 acc[4];
+    float bsum[2];
+    ts_zero(acc, bsum);
+    ts_run(job, kc2, b, tbeg, tend, tb.st_min_steps > 0 && job.p.MC >= tb.st_min_steps, ts_smem, item, acc, bsum);
+    float *slab = job.p.slabs + (long)mc * 128 * job.p.Ktot + kc2 * 256;
+    float *bias = job.p.bias_slabs ? job.p.bias_slabs + (long)mc * 256 : nullptr;
+    if (job.dual && 2 * kc2 + 1 == job.p.nk0) ts_flush<true>(job.p, kc2, true, ts_smem, acc, bsum, slab, job.p.Ktot, bias);
+    else ts_flush<false>(job.p, kc2, job.dual != 0, ts_smem, acc, bsum, slab, job.p.Ktot, bias);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// STATIC RUNS (round 6; the batched launch of encoder_bwd): every weight gradient of the pass on G persistent workgroups, each of which
+// takes ONE contiguous share of the pass's work and keeps its accumulators in registers for as long as it stays inside a column.
+//
+// Round 5's persistent launch handed out (column, <= 512-step chunk) items by ticket: 720 items, each with its own 128 KB partial
+// tile -- 96 MB of slabs written and read back per step (HBM traffic 1.35 x the algorithmic bytes, a 20-us reduction pass behind the launch),
+// and every item paid ~6.5 us of prologue / slab epilogue (2.8 items per CU).  Longer chunks lose under a ticket (it balances whole
+// items: profiles/r06_same_box_abs.txt section 1).  Here the pass is ONE line of work: the columns (job, kc2) in launch order, inside a
+// column video after video, tile after tile, priced in cost units (a 32-step tile of the column's kind + a fixed cost per video a run
+// enters); workgroup w takes [w S, (w + 1) S) of it, S = ceil(W / G) ("stream-K" over the reduction dimension).  A share is cut into
+// runs at video ends (the taps' zero padding and the chunk masks are per video) and into columns where the column changes; one partial
+// tile is written per (workgroup, column): G + columns - 1 slabs at most (290 x 128 KB = 37 MB at the bench shape).  The schedule is a pure
+// function of the job shapes and G -- no ticket, no atomics: the same sums in the same order run after run.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TS_MAX_COLS = 48;
+struct TsCol {
+    uint32_t pos0;      // where the column starts on the line of work (cost units); unused entries: 0xffffffff
+    uint32_t vcost;     // cost of one video of the column = ovh + tiles per video * tcost
+    uint16_t tcost;     // cost of a 32-step tile
+    uint16_t wfirst;    // first workgroup whose share touches the column: workgroup w writes the column's slab w - wfirst
+    uint16_t slab0;     // index of the column's first slab in the launch's slab arena (units of 128 x 256 floats; bias partials: of 256 floats)
+    uint8_t job;
+    uint8_t kc2;        // bit 7: FLAT -- a job without taps over contiguous videos (first_conv, last_conv) is ONE video of B * Trows rows: no run ends inside its columns
+};
+struct TsRuns {
+    TsCol c[TS_MAX_COLS + 1];   // [ncols]: the end of the line (pos0 = W)
+    uint32_t W, S, ovh;         // length of the line, share per workgroup, fixed cost of entering a video
+    int ncols, B;
+    float *slabs, *bias;        // arenas: [slab][128][256], [slab][256]
+};
+// position inside a column -> tile index on the column's own line (video-major): the SAME function gives a share's end and the next share's start
+__device__ __host__ __forceinline__ uint32_t ts_qmap(const TsCol &C, const uint32_t ovh, const uint32_t tv, const uint32_t off) {
+    const uint32_t b = off / C.vcost, rem = off - b * C.vcost;
+    const uint32_t t = rem <= ovh ? 0u : (rem - ovh) / C.tcost;
+    return b * tv + (t < tv ? t : tv);
+}
+__global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const TsRuns rs) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
+    const uint32_t w = blockIdx.x;
+    const uint32_t lo = min(w * rs.S, rs.W), hi = min(lo + rs.S, rs.W);
+    if (lo >= hi) return;
+#if CLK_STAMP
+    const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: a workgroup's whole life, g_clk_wg; tools/ts_runs_times.py)
+#endif
+    int col = -1;   // the column `lo` lies in: all starts compared at once (independent scalar loads)
+#pragma unroll
+    for (int k = 0; k < TS_MAX_COLS; ++k) col += lo >= rs.c[k].pos0 ? 1 : 0;
+    for (; col < rs.ncols && rs.c[col].pos0 < hi; ++col) {
+        const TsCol &C = rs.c[col];
+        const TnJob &job = tb.j[C.job];
+        const int kc2 = C.kc2 & 127;
+        const bool flat = (C.kc2 & 128) != 0;
+        const int rows = flat ? rs.B * job.p.Trows : job.p.Trows;
+        const uint32_t tv = (uint32_t)(rows + 31) >> 5, end = rs.c[col + 1].pos0;
+        const uint32_t q0 = lo > C.pos0 ? ts_qmap(C, rs.ovh, tv, lo - C.pos0) : 0u;
+        const uint32_t q1 = hi >= end ? (flat ? 1u : (uint32_t)rs.B) * tv : ts_qmap(C, rs.ovh, tv, hi - C.pos0);
+        // (a share that touches the column without holding one of its tiles still writes its -- zero -- slab: the reduction reads wfirst .. wlast)
+        const long si = (long)C.slab0 + (long)(w - C.wfirst);
+        float *slab = rs.slabs + si * (128 * 256);
+        float *bias = rs.bias ? rs.bias + si * 256 : nullptr;
+        using T = std::true_type;
+        using F = std::false_type;
+        if (flat && tv >= 8 && tb.st_min_steps > 0 && !job.x0_act) {
+            // ONE run on the staggered schedule, the accumulators zeroed in front of it: with accumulators that are alive through the body's
+            // prologue (a second run of a column) the compiler spilled the X tiles in flight -- loads waited for and parked in scratch inside
+            // the tile loop, 277 us per share instead of 168 (tools/ts_runs_times.py; the schedule prices these columns at the staggered tile cost)
+            TnParams pf = job.p;
+            pf.Trows = pf.Tx = rows;
+            f32x16 acc[4];
+            float bsum[2];
+            ts_zero(acc, bsum);
+            if (q0 < q1) ts_body_st<false, false>(pf, kc2, 0, (int)q0 * 32, min((int)q1 * 32, rows), false, job.x0_act != 0, ts_smem, (int)w, acc, bsum);
+            ts_flush<false>(pf, kc2, false, ts_smem, acc, bsum, slab, 256, bias);
+            continue;
+        }
+        // the lock-step body, chosen per COLUMN, each choice its own zero / runs / write-out sequence (one loop around all bodies kept the
+        // accumulators alive across the ones that do not run: 162 spilled registers)
+        auto column = [&](auto TWO, auto DRP) {
+            constexpr bool TWO_G = decltype(TWO)::value, DROP = decltype(DRP)::value;
+            TnParams pf = job.p;
+            if (flat) pf.Trows = pf.Tx = rows;
+            f32x16 acc[4];
+            float bsum[2];
+            ts_zero(acc, bsum);
+            for (uint32_t q = q0; q < q1;) {
+                const uint32_t b = q / tv, t0 = q - b * tv, t1 = min(tv, t0 + (q1 - q));
+                ts_body<TWO_G, DROP>(pf, kc2, (int)b, (int)t0 * 32, min((int)t1 * 32, rows), job.dual != 0, !TWO_G && job.x0_act != 0, ts_smem, (int)w, acc, bsum);
+                q += t1 - t0;
+            }
+            ts_flush<TWO_G>(pf, kc2, job.dual != 0, ts_smem, acc, bsum, slab, 256, bias);
+        };
+        if (job.dual && 2 * kc2 + 1 == job.p.nk0) {
+            if (job.p.drop.thresh) column(T{}, T{});
+            else column(T{}, F{});
+        } else column(F{}, F{});
+    }
+#if CLK_STAMP
+    __syncthreads();
+    if (threadIdx.x == 0 && w < 4096) {
+        g_clk_wg[w][0] = wg_t0_;
+        g_clk_wg[w][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// Cost units (1/32 us; MUCON_TS_COSTS = "staggered,plain,two-image,video"): a 32-step tile of a staggered single-image column (first_conv's), of a
+// lock-step single-image column, of a column that stages two gradient images and replays the dropout mask, and what a run pays for entering a video
+// (prologue: one memory round trip + the first image + the first X tile through LDS) -- the least-squares fit of the 256 shares' lives at the bench
+// shape (tools/ts_runs_times.py, profiles/r06_weight_gradient_runs.txt: 2.14 / 2.32 / 2.97 us per tile, 3.4 us per run)
+extern int g_ts_cost[4];
+// The line of work of a queued batch for G workgroups.  Host only; the reduction's column table (gemm_tn.hpp: ReduceCols) is filled from the same numbers.
+struct TsSchedule {
+    TsRuns rs;
+    int G;
+    int nslabs;                    // slabs the launch writes
+    int col0[TN_MAX_BATCH];        // first column of job i (launch order)
+    int nslab_col[TS_MAX_COLS];    // slabs of a column
+};
+static bool ts_make_schedule(const TnBatch &lb, int B, int maxG, TsSchedule &sc) {
+    TsRuns &rs = sc.rs;
+    memset(&rs, 0, sizeof(rs));
+    rs.ovh = (uint32_t)g_ts_cost[3];
+    rs.B = B;
+    int nc = 0;
+    uint64_t pos = 0, tiles = 0;
+    for (int i = 0; i < lb.njobs; ++i) {
+        const TnJob &job = lb.j[i];
+        const int nkc2 = (job.nkc + 1) >> 1;
+        // no taps, one gradient set, videos back to back in both operands: the batch is one video of B * Trows rows
+        const bool flat = !job.dual && job.p.taps != 3 && job.p.Tx == job.p.Trows && job.p.x_bstride == (long)job.p.Tx * job.p.ldx &&
+                          (long)B * job.p.Trows < (1L << 30) && nkc2 < 128;
+        const uint32_t nvid = flat ? 1u : (uint32_t)B;
+        const uint32_t tv = (uint32_t)((flat ? B : 1) * (long)job.p.Trows + 31) >> 5;
+        sc.col0[i] = nc;
+        for (int k = 0; k < nkc2; ++k) {
+            if (nc >= TS_MAX_COLS || k >= 128) return false;
+            const bool two_g = job.dual && 2 * k + 1 == job.p.nk0;
+            TsCol &C = rs.c[nc++];
+            C.job = (uint8_t)i;
+            C.kc2 = (uint8_t)(k | (flat ? 128 : 0));
+            // (a column with the non-linearity on its X operand -- last_conv's -- masks every tile: 2.7 us per tile on either body, priced like a two-image column)
+            C.tcost = (uint16_t)((two_g || job.x0_act) ? g_ts_cost[2] : (flat && tv >= 8 && lb.st_min_steps > 0) ? g_ts_cost[0] : g_ts_cost[1]);
+            C.vcost = rs.ovh + tv * C.tcost;
+            C.pos0 = (uint32_t)pos;
+            pos += (uint64_t)nvid * C.vcost;
+            tiles += (uint64_t)nvid * tv;
+            if (pos >= 0xf0000000ull) return false;   // (33 M frames x 16 columns fit; anything longer takes the per-item launch)
         }
     }
-    const bool two_g = job.dual && 2 * kc2 + 1 == job.p.nk0;
-    if constexpr (MODE == 2) {
-        // The staggered schedule is taken by the jobs with ONE gradient image and time chunks of at least tb.st_min_steps steps (first_conv's:
-        // 128 workgroups of 64 tiles at the bench shape, 155-160 -> 136-141 us each).  The residual layers' jobs keep round 4's body: their
-        // workgroups that stage two images and replay the dropout mask have twice the staging work per tile and the registers for one X
-        // tile in flight only -- staggered they ran 218 us instead of 200 (profiles/r05_weight_gradient_schedule.txt).
-        if (job.dual || tb.st_min_steps <= 0 || job.p.MC < tb.st_min_steps) {
-            if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
-            else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
-            else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
-        } else if (!two_g) ts_body_st<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
-        else if (job.p.drop.thresh) ts_body_st<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
-        else ts_body_st<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
-    } else if constexpr (MODE == 1) {
-        if (!two_g) ts_body16<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem);
-        else if (job.p.drop.thresh) ts_body16<true, true>(job.p, kc2, mc, true, false, ts_smem);
-        else ts_body16<true, false>(job.p, kc2, mc, true, false, ts_smem);
-        after_loop();
-    } else {
-        if (!two_g) ts_body<false, false>(job.p, kc2, mc, job.dual != 0, job.x0_act != 0, ts_smem, item, after_loop);
-        else if (job.p.drop.thresh) ts_body<true, true>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
-        else ts_body<true, false>(job.p, kc2, mc, true, false, ts_smem, item, after_loop);
+    rs.ncols = nc;
+    rs.W = (uint32_t)pos;
+    for (int k = nc; k <= TS_MAX_COLS; ++k) rs.c[k].pos0 = k == nc ? rs.W : 0xffffffffu;
+    // at least four tiles per share (a share pays ~6 us of prologue and write-out whatever its length)
+    int G = (int)std::min<uint64_t>((uint64_t)maxG, std::max<uint64_t>(1, tiles / 4));
+    if (G > 65535) G = 65535;
+    rs.S = (uint32_t)((pos + G - 1) / G);
+    sc.G = G;
+    int ns = 0;
+    for (int k = 0; k < nc; ++k) {
+        const uint32_t wf = rs.c[k].pos0 / rs.S, wl = (rs.c[k + 1].pos0 - 1) / rs.S;
+        rs.c[k].wfirst = (uint16_t)wf;
+        rs.c[k].slab0 = (uint16_t)ns;
+        sc.nslab_col[k] = (int)(wl - wf + 1);
+        ns += sc.nslab_col[k];
+        if (ns > 65535) return false;
     }
+    sc.nslabs = ns;
     return true;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
-#if CLK_STAMP
-    const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: the workgroup's whole life beside its tile loop, g_clk_wg)
-#endif
-    if (!ts_run_item<MODE>(tb, (int)blockIdx.x, ts_smem, [] {})) return;
-#if CLK_STAMP
-    __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        g_clk_wg[blockIdx.x][0] = wg_t0_;
-        g_clk_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-}
-
-// The same items on PERSISTENT workgroups (round 5; MUCON_TS_PERSIST, default): one workgroup per CU walks the item list -- its own block
-// index first, then whatever item the launch's ticket counter hands it.  What that buys (profiles/r05_weight_gradient_schedule.txt §9): the
-// hardware dispatcher deals workgroups to the XCDs strictly round-robin, so a freed CU waited a median 1.4 us and up to 15 us (another XCD's
-// turn) for its next workgroup; the ticket is drawn behind the item's last tile and arrives under its slab write-out.  Every item computes
-// exactly what its workgroup computed (which workgroup runs it changes nothing in its sums): bitwise the same gradients.
-// `tickets` is one zeroed word of the caller's workspace (encoder_bwd's first kernel zeroes it: gn_bwd_kernel).
-template <int MODE>
-__global__ __launch_bounds__(512) void ts_persist_kernel(const TnBatch tb, unsigned *tickets) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
-    int *s_next = reinterpret_cast<int *>(ts_smem + TS_SMEM_BYTES / 2);   // one word behind the tiles
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int item = blockIdx.x;
-    while (item < tb.nblocks) {
-#if CLK_STAMP
-        const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();
-#endif
-        // The ticket is a SCALAR-memory atomic (s_atomic_add, wave 0): it returns through lgkmcnt, so it neither queues behind the slab stores
-        // nor makes the compiler wait for them (a vector atomic behind a `threadIdx.x == 0` branch did: its round trip, 1.2 - 2.3 us,
-        // stood in front of the item's slab write-out: profiles/r05_weight_gradient_schedule.txt §9).  Issue and wait are one asm
-        // statement -- the compiler never sees a register with a load in flight -- placed behind wave 0's slab stores
-        // so that it waits while they drain.
-        bool have = false;
-        auto draw = [&]() {
-            if (wave == 0) {
-                unsigned t = 1u;
-                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tickets) : "memory");
-                if (threadIdx.x == 0) *s_next = (int)(gridDim.x + t);
-            }
-            have = true;
-        };
-        const bool ran = ts_run_item<MODE>(tb, item, ts_smem, draw);
-        if (!have) {         // a padding item: no barrier has been passed since the item was read -- every wave must have read it before wave 0 overwrites the word
-            __syncthreads();
-            draw();
-        }
-#if CLK_STAMP
-        if (ran) {
-            __syncthreads();
-            if (threadIdx.x == 0 && item < 4096) {
-                g_clk_wg[item][0] = wg_t0_;
-                g_clk_wg[item][1] = __builtin_amdgcn_s_memrealtime();
-            }
-        }
-#endif
-        (void)ran;
-        __syncthreads();   // ... which also puts the item's last LDS reads (the bias sums) in front of the next item's first stores
-        item = __builtin_amdgcn_readfirstlane(*s_next);
-    }
-}
-
-extern int g_ts_persist;   // mucon_hip.hip (MUCON_TS_PERSIST)
-static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s, unsigned *tickets = nullptr) {
-    if (tb.njobs == 0) return hipSuccess;
-    const int mode = (g_mfma16 & 2) ? 1 : (g_ts_stagger ? 2 : 0);
-    const bool persist = tickets != nullptr && g_ts_persist != 0;
-    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
-    static int ncu = 0;
-    const void *k = persist ? (mode == 1 ? reinterpret_cast<const void *>(ts_persist_kernel<1>)
-                                         : mode == 2 ? reinterpret_cast<const void *>(ts_persist_kernel<2>) : reinterpret_cast<const void *>(ts_persist_kernel<0>))
-                            : (mode == 1 ? reinterpret_cast<const void *>(ts_batched_kernel<1>)
-                                         : mode == 2 ? reinterpret_cast<const void *>(ts_batched_kernel<2>) : reinterpret_cast<const void *>(ts_batched_kernel<0>));
-    const int smem = (mode == 1 ? TS16_SMEM_BYTES : TS_SMEM_BYTES) + (persist ? 16 : 0);
-    if (!attr_set[persist][mode]) {
-        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set[persist][mode] = true;
-    }
-    if (persist && ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = prop.multiProcessorCount;
-    }
-    // jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
-    TnBatch lb;
+// jobs were queued coarse levels first; the fine levels have the longest workgroups: lay them out first
+static void ts_layout(const TnBatch &tb, TnBatch &lb) {
     lb.njobs = tb.njobs;
     int blocks = 0;
     for (int i = 0; i < TN_MAX_BATCH; ++i) lb.first_block[i] = INT_MAX;
@@ -1299,19 +982,32 @@ static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s, unsigned *tickets 
         lb.first_block[i] = blocks;
         lb.j[i].nmc = src.block0;                     // block0 carried the time-chunk count while queued
         blocks += ((src.nkc + 1) / 2) * src.block0;
-        if (kTsXcdOrder) blocks = (blocks + 7) & ~7;     // every job starts on a multiple of 8 (the padding blocks exit at once)
     }
     lb.nblocks = blocks;
-    lb.xcd_order = kTsXcdOrder;
+    lb.xcd_order = 0;
     lb.st_min_steps = g_ts_stagger;
-    if (persist) {
-        const dim3 grid(std::min(blocks, ncu));
-        if (mode == 1) hipLaunchKernelGGL(ts_persist_kernel<1>, grid, dim3(512), smem, s, lb, tickets);
-        else if (mode == 2) hipLaunchKernelGGL(ts_persist_kernel<2>, grid, dim3(512), smem, s, lb, tickets);
-        else hipLaunchKernelGGL(ts_persist_kernel<0>, grid, dim3(512), smem, s, lb, tickets);
-    } else if (mode == 1) hipLaunchKernelGGL(ts_batched_kernel<1>, dim3(blocks), dim3(512), smem, s, lb);
-    else if (mode == 2) hipLaunchKernelGGL(ts_batched_kernel<2>, dim3(blocks), dim3(512), smem, s, lb);
-    else hipLaunchKernelGGL(ts_batched_kernel<0>, dim3(blocks), dim3(512), smem, s, lb);
+}
+static hipError_t ts_smem_attr(const void *k, bool &done) {
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, TS_SMEM_BYTES);
+    done = e == hipSuccess;
+    return e;
+}
+static hipError_t launch_ts_batch(TnBatch &tb, hipStream_t s) {   // one workgroup per item
+    if (tb.njobs == 0) return hipSuccess;
+    static bool attr = false;
+    hipError_t e = ts_smem_attr(reinterpret_cast<const void *>(ts_batched_kernel), attr);
+    if (e != hipSuccess) return e;
+    TnBatch lb;
+    ts_layout(tb, lb);
+    hipLaunchKernelGGL(ts_batched_kernel, dim3(lb.nblocks), dim3(512), TS_SMEM_BYTES, s, lb);
     tb.njobs = 0;
+    return hipGetLastError();
+}
+static hipError_t launch_ts_runs(const TnBatch &lb, const TsSchedule &sc, hipStream_t s) {
+    static bool attr = false;
+    hipError_t e = ts_smem_attr(reinterpret_cast<const void *>(ts_runs_kernel), attr);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ts_runs_kernel, dim3(sc.G), dim3(512), TS_SMEM_BYTES, s, lb, sc.rs);
     return hipGetLastError();
 }

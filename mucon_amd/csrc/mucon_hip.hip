@@ -28,7 +28,9 @@
 
 int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
                               // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
-int g_ts_persist = 1;         // the batched split weight-gradient launch of encoder_bwd on persistent workgroups with a ticket counter (MUCON_TS_PERSIST; gemm_tn_split.hpp)
+int g_ts_runs = 1;            // the batched split weight-gradient launch of encoder_bwd as static runs on persistent workgroups (MUCON_TS_RUNS; gemm_tn_split.hpp); 0: one workgroup per item
+int g_ts_cost[4] = {69, 74, 95, 109};   // ... its cost units (1/32 us): tile of a staggered / lock-step / two-image column, a run's fixed cost per video (MUCON_TS_COSTS=a,b,c,d)
+int g_ts_max_wg = 0;          // ... on at most this many workgroups (MUCON_TS_MAX_WG; 0 = one per CU)
 int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
 int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never)
@@ -82,6 +84,18 @@ inline int pick_mc(int B, int Trows, int kchunks, bool batched = false, bool spl
     if (mc < 128) mc = 128;
     if (mc > cap) mc = cap;
     return (int)mc;
+}
+
+// slab / bias-partial floats ONE weight-gradient job needs under every schedule it can take: one workgroup per (column, time chunk) item
+// (the shortest chunk any of those launches would pick), or static runs (one 128 x 256 partial per workgroup and column: gemm_tn_split.hpp)
+inline void one_job_arena(int B, int Trows, int Ktot, bool layer, size_t &sf, size_t &bf) {
+    int mc = pick_mc(B, Trows, Ktot / 128);
+    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0, layer));
+    const size_t nmc = (size_t)B * ((Trows + mc - 1) / mc);
+    const size_t ncols = ((size_t)Ktot / 128 + 1) / 2, tiles = ncols * B * (((size_t)Trows + 31) / 32);
+    const size_t nsl = std::min<size_t>(kTsMaxWorkgroups, (tiles + 3) / 4) + ncols;   // (rounded up: the bounds of a batch's jobs add up to the bound of the batch)
+    sf = std::max(align64(nmc * 128 * Ktot), align64(nsl * 128 * 256));
+    bf = std::max(align64(nmc * 256), align64(nsl * 256));
 }
 
 struct Plan {
@@ -166,11 +180,10 @@ void make_plan(const mucon_encoder_cfg *c, Plan &p) {
     // single batched reduction at the end
     size_t sf = 0, bf = 0;
     auto consider = [&](int Trows, int Ktot, bool layer = false) {   // the shortest time chunk any schedule (batched or not, split or f32) would take
-        int mc = pick_mc(p.B, Trows, Ktot / 128);
-        for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(p.B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0, layer));
-        const size_t nmc = (size_t)p.B * ((Trows + mc - 1) / mc);
-        sf += align64(nmc * 128 * Ktot);
-        bf += align64(nmc * 256);
+        size_t s1, b1;
+        one_job_arena(p.B, Trows, Ktot, layer, s1, b1);
+        sf += s1;
+        bf += b1;
     };
     consider(p.T, p.D);
     for (int l = 0; l < p.L; ++l) consider(p.Tl[l], 512, true);
@@ -260,7 +273,9 @@ struct Reducer {
         j.coff = coff;
         j.ncols = ncols;
         j.n_elems = nrows * ncols;
-        j.mode = mode;
+        j.mode = (int8_t)mode;
+        j.colblk = -1;
+        j.isbias = 0;
         j.vec = ((ncols | coff | ld | j.n_elems) % 4 == 0 && slab_stride % 4 == 0) ? 1 : 0;
         j.block0 = rb.nblocks;
         max_slabs = rb.njobs == 1 ? nslabs : std::max(max_slabs, nslabs);
@@ -270,7 +285,21 @@ struct Reducer {
         rb.nblocks += (j.n_elems + 255) / 256;
         return true;
     }
+    bool cols_used = false;   // rb.cols holds the table of a static-runs launch whose jobs are queued
+    // a job over the slabs of the static-runs launch: columns coff .. coff + ncols of the 256-column blocks from `col0` on (bias: the 256-float partials of column col0)
+    bool add_cols(int col0, bool isbias, int coff, int nrows, int ncols, float *out, int mode) {
+        if (!add(nullptr, 1, 0, 256, coff, nrows, ncols, out, mode)) return false;
+        ReduceJob &j = rb.j[rb.njobs - 1];
+        j.colblk = (int8_t)col0;
+        j.isbias = isbias ? 1 : 0;
+        cols_used = true;
+        int deepest = 0;
+        for (int c = col0 + (isbias ? 0 : coff / 256); c <= col0 + (isbias ? 0 : (coff + ncols - 1) / 256); ++c) deepest = std::max(deepest, (int)rb.cols.n[c]);
+        max_slabs = std::max(max_slabs, deepest);
+        return j.vec == 1;
+    }
     hipError_t run() {
+        cols_used = false;
         if (rb.njobs == 0) return hipSuccess;
         // few, deep jobs (the y-head's 256 slabs of 6 K elements: 25 workgroups) want many slab lanes: the chain of dependent
         // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
@@ -304,8 +333,13 @@ struct WgradArgs {
     int mode0;
     DropCfg drop;
 };
-int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, const WgradArgs &a, float slope,
-          Reducer &red, hipStream_t s, int prof_slot = -1, TnBatch *batch = nullptr) {
+// The weight-gradient jobs of a backward pass, queued for ONE launch behind the data-gradient chain (flush_wgrads).
+struct WgradQueue {
+    TnBatch tb;
+    WgradArgs out[TN_MAX_BATCH];
+    WgradQueue() { tb.njobs = 0; }
+};
+static TnParams wgrad_params(const Plan &pl, int Trows, const WgradArgs &a, float slope, bool batched) {
     const bool dual = a.Y1 != nullptr;
     TnParams t;
     memset(&t, 0, sizeof(t));
@@ -321,13 +355,15 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     t.Y1 = a.Y1;
     t.X1 = a.X1;
     t.Ktot = 128 * (a.nk0 + (dual ? 1 : 0));
-    const bool split = g_tn_split != 0;
-    if (split && dual && a.nk0 % 2 == 0)   // the split kernel pairs the conv_1x1 chunk with the last tap (gemm_tn_split.hpp)
-        return fail(MUCON_E_ARG, "internal: dual weight-gradient job with an even chunk count");
-    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batch != nullptr, split, dual);
+    t.MC = pick_mc(pl.B, Trows, t.Ktot / 128, batched, g_tn_split != 0, dual);
     t.chunks_per_video = (Trows + t.MC - 1) / t.MC;
     t.slope = slope;
     t.drop = a.drop;
+    return t;
+}
+// slabs [time chunk][128][Ktot] for a job of the per-item launches, carved from the arena at arena / barena (floats, advanced); reductions queued on `red`
+static int wgrad_slabs(const Plan &pl, float *ws, size_t &arena, size_t &barena, TnParams &t, const WgradArgs &a, Reducer &red) {
+    const bool dual = a.Y1 != nullptr;
     const int nmc = pl.B * t.chunks_per_video;
     const size_t need = align64((size_t)nmc * 128 * t.Ktot), bneed = align64((size_t)nmc * 256);
     if (arena + need > pl.slab_floats || barena + bneed > pl.bslab_floats)
@@ -336,42 +372,6 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
     t.bias_slabs = ws + pl.bslabs + barena;
     arena += need;
     barena += bneed;
-    if (batch) {
-        if (batch->njobs >= TN_MAX_BATCH) HIPCHK(g_tn_split ? launch_ts_batch(*batch, s) : launch_tn_batch(*batch, s));
-        TnJob &jb = batch->j[batch->njobs++];
-        jb.p = t;
-        jb.nkc = t.Ktot / 128;
-        jb.block0 = nmc;   // time-chunk count while queued; launch_tn_batch turns it into the block offset
-        jb.x0_act = a.x0_act ? 1 : 0;
-        jb.dual = dual ? 1 : 0;
-    } else if (split) {
-        TnBatch one;
-        one.njobs = 1;
-        one.j[0].p = t;
-        one.j[0].nkc = t.Ktot / 128;
-        one.j[0].block0 = nmc;
-        one.j[0].nmc = nmc;
-        one.j[0].x0_act = a.x0_act ? 1 : 0;
-        one.j[0].dual = dual ? 1 : 0;
-        if (prof_slot >= 0) prof_mark(prof_slot, false, s);
-        HIPCHK(launch_ts_batch(one, s));
-        if (prof_slot >= 0) prof_mark(prof_slot, true, s);
-    } else {
-    if (prof_slot >= 0) prof_mark(prof_slot, false, s);
-    // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
-    const bool ks2 = kTnKs == 2 || (kTnKs == 0 && dual);
-    if (dual) {
-        if (ks2) HIPCHK((launch_tn<false, true, 2>(t, pl.B, s)));
-        else HIPCHK((launch_tn<false, true, 1>(t, pl.B, s)));
-    } else if (a.x0_act) {
-        if (ks2) HIPCHK((launch_tn<true, false, 2>(t, pl.B, s)));
-        else HIPCHK((launch_tn<true, false, 1>(t, pl.B, s)));
-    } else {
-        if (ks2) HIPCHK((launch_tn<false, false, 2>(t, pl.B, s)));
-        else HIPCHK((launch_tn<false, false, 1>(t, pl.B, s)));
-    }
-    if (prof_slot >= 0) prof_mark(prof_slot, true, s);
-    }
     const long ss = (long)128 * t.Ktot;
     bool ok = red.add(t.slabs, nmc, ss, t.Ktot, 0, 128, a.nk0 * 128, a.out_w0, a.mode0);
     if (a.out_b0) ok = ok && red.add(t.bias_slabs, nmc, 256, 256, 0, 1, 128, a.out_b0, 0);
@@ -380,6 +380,123 @@ int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, c
         if (a.out_b1) ok = ok && red.add(t.bias_slabs, nmc, 256, 256, 128, 1, 128, a.out_b1, 0);
     }
     if (!ok) return fail(MUCON_E_ARG, "internal: too many reduction jobs");
+    return MUCON_OK;
+}
+static int device_cus() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        ncu = prop.multiProcessorCount;
+    }
+    return ncu;
+}
+// Launches what is queued.  Default: the static-runs launch (gemm_tn_split.hpp) -- the schedule and the reduction's column table come from the
+// same numbers; MUCON_TS_RUNS=0 (or a batch the schedule does not take): one workgroup per (column, time chunk) item; MUCON_TN_SPLIT=0: the f32 kernels.
+static int flush_wgrads(const Plan &pl, float *ws, size_t &arena, size_t &barena, WgradQueue &q, Reducer &red, hipStream_t s) {
+    TnBatch &tb = q.tb;
+    if (tb.njobs == 0) return MUCON_OK;
+    if (g_tn_split && g_ts_runs) {
+        const int ncu = device_cus();
+        if (ncu <= 0) return fail(MUCON_E_ARG, "internal: device properties unavailable");
+        TnBatch lb;
+        ts_layout(tb, lb);
+        TsSchedule sc;
+        const int maxg = std::min(kTsMaxWorkgroups, g_ts_max_wg > 0 ? std::min(g_ts_max_wg, ncu) : ncu);
+        if (ts_make_schedule(lb, pl.B, maxg, sc)) {
+            const size_t need = (size_t)sc.nslabs * 128 * 256, bneed = (size_t)sc.nslabs * 256;
+            if (arena + need > pl.slab_floats || barena + bneed > pl.bslab_floats) return fail(MUCON_E_WORKSPACE, "internal: slab arena too small");
+            if (red.rb.njobs > 0 && red.cols_used && red.run() != hipSuccess) return fail(MUCON_E_ARG, "internal: slab reduction failed");
+            sc.rs.slabs = ws + pl.slabs + arena;
+            sc.rs.bias = ws + pl.bslabs + barena;
+            arena += align64(need);
+            barena += align64(bneed);
+            red.cols_used = true;
+            red.rb.cols.slabs = sc.rs.slabs;
+            red.rb.cols.bias = sc.rs.bias;
+            for (int c = 0; c < sc.rs.ncols; ++c) {
+                red.rb.cols.slab0[c] = sc.rs.c[c].slab0;
+                red.rb.cols.n[c] = (uint16_t)sc.nslab_col[c];
+            }
+            bool ok = true;
+            for (int i = 0; i < lb.njobs; ++i) {
+                const WgradArgs &a = q.out[tb.njobs - 1 - i];   // (ts_layout reverses the queue)
+                const int c0 = sc.col0[i], nk0 = lb.j[i].p.nk0;
+                ok = ok && red.add_cols(c0, false, 0, 128, nk0 * 128, a.out_w0, a.mode0);
+                if (a.out_b0) ok = ok && red.add_cols(c0, true, 0, 1, 128, a.out_b0, 0);
+                if (lb.j[i].dual) {
+                    ok = ok && red.add_cols(c0, false, nk0 * 128, 128, 128, a.out_w1, 0);
+                    if (a.out_b1) ok = ok && red.add_cols(c0 + nk0 / 2, true, 128, 1, 128, a.out_b1, 0);
+                }
+            }
+            if (!ok) return fail(MUCON_E_ARG, "internal: too many reduction jobs");
+            HIPCHK(launch_ts_runs(lb, sc, s));
+            tb.njobs = 0;
+            return MUCON_OK;
+        }
+    }
+    for (int i = 0; i < tb.njobs; ++i) {
+        int rc = wgrad_slabs(pl, ws, arena, barena, tb.j[i].p, q.out[i], red);
+        if (rc != MUCON_OK) return rc;
+    }
+    HIPCHK(g_tn_split ? launch_ts_batch(tb, s) : launch_tn_batch(tb, s));
+    return MUCON_OK;
+}
+
+// One weight-gradient job through the TN core: queued on `q` (encoder_bwd), or launched at once.
+//   set 0: Y0 x X0 (taps / column chunks) -> out_w0 (mode0: 0 = [128][nk0*128], 1 = conv3 layout), out_b0
+//   set 1 (dual): (Y1 * dropout) x X1    -> out_w1 [128][128], out_b1
+int wgrad(const Plan &pl, float *ws, size_t &arena, size_t &barena, int Trows, const WgradArgs &a, float slope,
+          Reducer &red, hipStream_t s, int prof_slot = -1, WgradQueue *q = nullptr) {
+    const bool dual = a.Y1 != nullptr;
+    const bool split = g_tn_split != 0;
+    if (split && dual && a.nk0 % 2 == 0)   // the split kernel pairs the conv_1x1 chunk with the last tap (gemm_tn_split.hpp)
+        return fail(MUCON_E_ARG, "internal: dual weight-gradient job with an even chunk count");
+    TnParams t = wgrad_params(pl, Trows, a, slope, q != nullptr);
+    auto enqueue = [&](WgradQueue &wq) {
+        wq.out[wq.tb.njobs] = a;
+        TnJob &jb = wq.tb.j[wq.tb.njobs++];
+        jb.p = t;
+        jb.nkc = t.Ktot / 128;
+        jb.block0 = pl.B * t.chunks_per_video;   // time-chunk count while queued; the launch turns it into the block offset
+        jb.x0_act = a.x0_act ? 1 : 0;
+        jb.dual = dual ? 1 : 0;
+    };
+    if (q) {
+        if (q->tb.njobs >= TN_MAX_BATCH) {
+            int rc = flush_wgrads(pl, ws, arena, barena, *q, red, s);
+            if (rc != MUCON_OK) return rc;
+        }
+        enqueue(*q);
+        return MUCON_OK;
+    }
+    if (split) {   // a queue of one
+        WgradQueue one;
+        enqueue(one);
+        if (prof_slot >= 0) prof_mark(prof_slot, false, s);
+        int rc = flush_wgrads(pl, ws, arena, barena, one, red, s);
+        if (prof_slot >= 0) prof_mark(prof_slot, true, s);
+        return rc;
+    }
+    int rc = wgrad_slabs(pl, ws, arena, barena, t, a, red);
+    if (rc != MUCON_OK) return rc;
+    if (prof_slot >= 0) prof_mark(prof_slot, false, s);
+    {
+        // layer launches run one workgroup per CU: two waves per SIMD (KS = 2); first_conv's has two workgroups per CU
+        const bool ks2 = kTnKs == 2 || (kTnKs == 0 && dual);
+        if (dual) {
+            if (ks2) HIPCHK((launch_tn<false, true, 2>(t, pl.B, s)));
+            else HIPCHK((launch_tn<false, true, 1>(t, pl.B, s)));
+        } else if (a.x0_act) {
+            if (ks2) HIPCHK((launch_tn<true, false, 2>(t, pl.B, s)));
+            else HIPCHK((launch_tn<true, false, 1>(t, pl.B, s)));
+        } else {
+            if (ks2) HIPCHK((launch_tn<false, false, 2>(t, pl.B, s)));
+            else HIPCHK((launch_tn<false, false, 1>(t, pl.B, s)));
+        }
+    }
+    if (prof_slot >= 0) prof_mark(prof_slot, true, s);
     return MUCON_OK;
 }
 
@@ -509,8 +626,18 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_tn_split = atoi(e) ? 1 : 0;
         return true;
     }
-    if (!strcmp(name, "MUCON_TS_PERSIST")) {
-        if (e) g_ts_persist = atoi(e) ? 1 : 0;
+    if (!strcmp(name, "MUCON_TS_RUNS")) {
+        if (e) g_ts_runs = atoi(e) ? 1 : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TS_MAX_WG")) {
+        if (e) g_ts_max_wg = atoi(e) > 0 ? atoi(e) : 0;
+        return true;
+    }
+    if (!strcmp(name, "MUCON_TS_COSTS")) {
+        int v[4];
+        if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] >= 0 && v[0] < 4096 && v[1] < 4096 && v[2] < 4096)
+            for (int k = 0; k < 4; ++k) g_ts_cost[k] = v[k];
         return true;
     }
     if (!strcmp(name, "MUCON_TS_LAYER_MC_CAP")) {
@@ -547,7 +674,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TS_PERSIST", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TS_RUNS", "MUCON_TS_MAX_WG", "MUCON_TS_COSTS", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -574,7 +701,7 @@ int mucon_test_get_knob(const char *name) {
     if (name && !strcmp(name, "MUCON_MFMA16")) return g_mfma16;
     if (name && !strcmp(name, "MUCON_TN_SPLIT")) return g_tn_split;
     if (name && !strcmp(name, "MUCON_TS_STAGGER")) return g_ts_stagger;
-    if (name && !strcmp(name, "MUCON_TS_PERSIST")) return g_ts_persist;
+    if (name && !strcmp(name, "MUCON_TS_RUNS")) return g_ts_runs;
     if (name && !strcmp(name, "MUCON_FIRST_CONV_SPLIT")) return g_first_conv_split;
     return -1;
 }
@@ -985,9 +1112,8 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     Reducer red(s);
     size_t arena = 0, barena = 0;
     float *gz = ws + pl.gz;
-    TnBatch tnb;
-    tnb.njobs = 0;
-    TnBatch *batch = &tnb;   // every weight gradient of the pass is queued for ONE launch after the data-gradient chain
+    WgradQueue wq;
+    WgradQueue *batch = &wq;   // every weight gradient of the pass is queued for ONE launch after the data-gradient chain
 
     {   // GroupNorm / ReLU / Dropout backward -> dz
         GnBwdArgs g;
@@ -1266,7 +1392,8 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     }
     {   // ... first_conv's included (its workgroups first): profile slot 1 times this launch
         prof_mark(1, false, s);
-        HIPCHK(g_tn_split ? launch_ts_batch(tnb, s, reinterpret_cast<unsigned *>(ws + pl.sync)) : launch_tn_batch(tnb, s));
+        rc = flush_wgrads(pl, ws, arena, barena, wq, red, s);
+        if (rc != MUCON_OK) return rc;
         prof_mark(1, true, s);
     }
     HIPCHK(red.run());
@@ -1373,19 +1500,15 @@ bool linear_plan(int B, int T, int D, LinearPlan &lp) {
     if (B < 1 || T < 1 || D < 128 || D % 128 != 0) return false;
     memset(&lp.pl, 0, sizeof(lp.pl));
     lp.pl.B = B;
-    int mc = pick_mc(B, T, D / 128);
-    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, T, D / 128, (v & 1) != 0, (v & 2) != 0));
-    const size_t nmc = (size_t)B * ((T + mc - 1) / mc);
     size_t o = 0;
     lp.planes = o;
     o += align64((size_t)3 * 128 * D / 2);
     lp.slabs = o;
     lp.pl.slabs = o;
-    lp.pl.slab_floats = align64(nmc * 128 * D);
+    one_job_arena(B, T, D, false, lp.pl.slab_floats, lp.pl.bslab_floats);
     o += lp.pl.slab_floats;
     lp.bslabs = o;
     lp.pl.bslabs = o;
-    lp.pl.bslab_floats = align64(nmc * 256);
     o += lp.pl.bslab_floats;
     lp.total = o;
     return true;
@@ -1454,13 +1577,9 @@ bool conv128_plan(int B, int T, int taps, Plan &pl) {
     if (B < 1 || T < 1 || (taps != 1 && taps != 3)) return false;
     memset(&pl, 0, sizeof(pl));
     pl.B = B;
-    int mc = pick_mc(B, T, taps);
-    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, T, taps, (v & 1) != 0, (v & 2) != 0));
-    const size_t nmc = (size_t)B * ((T + mc - 1) / mc);
     pl.slabs = 0;
-    pl.slab_floats = align64(nmc * 128 * 128 * taps);
+    one_job_arena(B, T, 128 * taps, false, pl.slab_floats, pl.bslab_floats);
     pl.bslabs = pl.slab_floats;
-    pl.bslab_floats = align64(nmc * 256);
     return true;
 }
 }  // namespace
@@ -1577,13 +1696,9 @@ int mucon_test_gemm_tn(const float *Y, const float *X, float *out, int32_t M, in
     Plan pl;
     memset(&pl, 0, sizeof(pl));
     pl.B = 1;
-    int mc = pick_mc(1, M, K / 128);
-    for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(1, M, K / 128, (v & 1) != 0, (v & 2) != 0));
-    const size_t nmc = (M + mc - 1) / mc;
     pl.slabs = 0;
-    pl.slab_floats = align64(nmc * 128 * K);
+    one_job_arena(1, M, K, false, pl.slab_floats, pl.bslab_floats);
     pl.bslabs = pl.slab_floats;
-    pl.bslab_floats = align64(nmc * 256);
     if (workspace_bytes < (pl.slab_floats + pl.bslab_floats) * sizeof(float)) return fail(MUCON_E_WORKSPACE, "test_gemm_tn workspace");
     WgradArgs a;
     memset(&a, 0, sizeof(a));

@@ -20,17 +20,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=[0, 2], ids=["mfma32x32x16", "mfma16x16x32"])
-def mfma_shape(request):
-    """Every test of this file runs on both instantiations of the kernel: ts_batched_kernel<false> (v_mfma_f32_32x32x16_bf16) and
-    ts_batched_kernel<true> (16x16x32; MUCON_MFMA16 bit 1).  The shipped default is restored afterwards."""
+@pytest.fixture(autouse=True, params=[1, 0], ids=["static-runs", "workgroup-per-item"])
+def launch_form(request):
+    """Every test of this file runs on both launch forms of the split kernel: ts_runs_kernel (persistent workgroups, each one contiguous
+    share of the (column, tile) line; the default) and ts_batched_kernel (one workgroup per (column, time chunk) item; MUCON_TS_RUNS=0)."""
     from mucon_amd import _lib
-    default = _lib.mfma16_default()
-    _lib.set_knob("MUCON_MFMA16", (default & ~2) | request.param)
+    _lib.set_knob("MUCON_TS_RUNS", request.param)
     try:
         yield request.param
     finally:
-        _lib.set_knob("MUCON_MFMA16", default)
+        _lib.set_knob("MUCON_TS_RUNS", 1)
 
 
 def _tn(Y, X):
