@@ -242,19 +242,28 @@ def viterbi_bench(dev, C=48):
             per.append((time.perf_counter() - t0) / reps)
         return sorted(per)[len(per) // 2]
 
+    from mucon_amd.core.viterbi import poisson_params_for_many
+
+    def decoder(tr, mu):
+        """ops.viterbi_decode_batch as the evaluator calls it since round 6 (mucon/evaluators.py): the PoissonModel's [3, N] parameter block per
+        video + the shared log-factorial row, the length scores built on the device (ABI 7) -- and the host-built [J, N] table form beside it."""
+        pp = poisson_params_for_many([mu], [tr], fs, max_len)[0]
+        return (lambda lps, **kw: ops.viterbi_decode_batch(lps, [tr] * len(lps), [pp.params] * len(lps), fs, max_len, log_fact=pp.log_fact, **kw),
+                PoissonModel(mu).rows_for(tr, fs))
+
     # a Breakfast-typical video first (T ~ 2000 frames, 6 actions), single stream
     T, N = 2000, 6
     tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
     mu = np.ones(C)
     mu[np.unique(tr)] = T / N
-    P = PoissonModel(mu).rows_for(tr, fs)
+    dec, P = decoder(tr, mu)
     lp = torch.log_softmax(3 * torch.randn(T, C, generator=g), dim=1).to(dev)
     for _ in range(3):
-        ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len)
-    out["ms_per_video_T2000_N6_single"] = round(timed(lambda: ops.viterbi_decode_batch([lp], [tr], [P], fs, max_len), 20) * 1e3, 4)
+        dec([lp])
+    out["ms_per_video_T2000_N6_single"] = round(timed(lambda: dec([lp]), 20) * 1e3, 4)
     lps256 = [torch.log_softmax(3 * torch.randn(T, C, device=dev), dim=1) for _ in range(256)]   # 256 videos in flight
-    ops.viterbi_decode_batch(lps256, [tr] * 256, [P] * 256, fs, max_len)
-    out["ms_per_video_T2000_N6_batch256"] = round(timed(lambda: ops.viterbi_decode_batch(lps256, [tr] * 256, [P] * 256, fs, max_len), 2) / 256 * 1e3, 5)
+    dec(lps256)
+    out["ms_per_video_T2000_N6_batch256"] = round(timed(lambda: dec(lps256), 2) / 256 * 1e3, 5)
     del lps256
     lp_h = lp.cpu().numpy()
     best = float("inf")
@@ -267,11 +276,24 @@ def viterbi_bench(dev, C=48):
     out["reference_python_ms_per_video_T2000_N6"] = 68.0   # measured in the build container, context only
     bytes_small = T * C * 4 + T * 4
 
+    # BASELINE.md section 3's two other planned decodes, 64 in flight each
+    for (Tq, Nq) in ((6000, 10), (10000, 30)):
+        trq = torch.randint(0, C, (Nq,), generator=g).numpy().astype(np.int32)
+        muq = np.ones(C)
+        muq[np.unique(trq)] = Tq / Nq
+        decq, _ = decoder(trq, muq)
+        lpq = [torch.log_softmax(3 * torch.randn(Tq, C, device=dev), dim=1) for _ in range(64)]
+        decq(lpq)
+        out[f"ms_per_video_T{Tq}_N{Nq}_batch64"] = round(timed(lambda: decq(lpq), 2, 3) / 64 * 1e3, 5)
+        decq(lpq[:1])
+        out[f"ms_per_video_T{Tq}_N{Nq}_single"] = round(timed(lambda: decq(lpq[:1]), 10, 3) * 1e3, 4)
+        del lpq
+
     T, N = 16384, 64
     tr = torch.randint(0, C, (N,), generator=g).numpy().astype(np.int32)
     mu = np.ones(C)
     mu[np.unique(tr)] = T / N
-    P = PoissonModel(mu).rows_for(tr, fs)
+    dec, P = decoder(tr, mu)
     lp = torch.log_softmax(3 * torch.randn(T, C, generator=g), dim=1).to(dev)
     for label, nv, reps in (("single", 1, 5), ("batch64", 64, 2), ("batch256", 256, 1)):
         if nv == 1:
@@ -280,17 +302,18 @@ def viterbi_bench(dev, C=48):
             lps = base64 = [torch.log_softmax(3 * torch.randn(T, C, device=dev), dim=1) for _ in range(64)]
         else:
             lps = base64 * (nv // 64)          # 256 videos in flight (the 64 emission tensors four times over)
-        ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)  # warm-up
-        out[f"ms_per_video_{label}"] = round(timed(lambda: ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len), reps, 3) / nv * 1e3, 4)
+        dec(lps)  # warm-up
+        out[f"ms_per_video_{label}"] = round(timed(lambda: dec(lps), reps, 3) / nv * 1e3, 4)
         if nv > 1:
-            # the same call with the per-frame labels leaving the GPU (uint8 / the reference's int32, written by the kernels into pinned
+            # the same call with host-built [J, N] length tables (rounds 1-5: 66 doubles per transcript state over PCIe instead of 3)
+            ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)
+            out[f"ms_per_video_{label}_host_tables"] = round(timed(lambda: ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len), reps, 3) / nv * 1e3, 4)
+            # ... with the per-frame labels leaving the GPU (uint8 / the reference's int32, written by the kernels into pinned
             # host memory), and with the segments expanded to int32 labels on the host for EVERY video (ViterbiResult.labels)
             for fmt in ("uint8", "int32"):
-                ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len, labels=fmt)
-                out[f"ms_per_video_{label}_{fmt}_labels"] = round(
-                    timed(lambda: ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len, labels=fmt), reps, 3) / nv * 1e3, 4)
-            out[f"ms_per_video_{label}_expanded_on_host"] = round(
-                timed(lambda: [r.labels for r in ops.viterbi_decode_batch(lps, [tr] * nv, [P] * nv, fs, max_len)], reps, 3) / nv * 1e3, 4)
+                dec(lps, labels=fmt)
+                out[f"ms_per_video_{label}_{fmt}_labels"] = round(timed(lambda: dec(lps, labels=fmt), reps, 3) / nv * 1e3, 4)
+            out[f"ms_per_video_{label}_expanded_on_host"] = round(timed(lambda: [r.labels for r in dec(lps)], reps, 3) / nv * 1e3, 4)
     lp_h = lp.cpu().numpy()
     best = float("inf")
     for _ in range(3):
@@ -300,7 +323,7 @@ def viterbi_bench(dev, C=48):
     out["cpu_oracle_ms_per_video"] = round(best * 1e3, 3)
     out["cpu_oracle_all_cores_ms_per_video"] = round(_cpu_viterbi_all_cores(lp_h, tr, P, fs, max_len, 4 * cores, cores), 4)
     out["config"] = (f"ms_per_video_single/batch64/batch256 and cpu_oracle_*: BASELINE config 5, T={T}, N={N}, C={C}, fs={fs} "
-                     f"(K=546 columns, 64x66 hypotheses); every GPU timing is the whole ops.viterbi_decode_batch call: job table / transcripts / length tables read by the kernels from pinned host memory, results written there (no copy calls).  "
+                     f"(K=546 columns, 64x66 hypotheses); every GPU timing is the whole ops.viterbi_decode_batch call: job table / transcripts / the PoissonModel's [3, N] parameter blocks read by the kernels from pinned host memory (the length scores are built on the device, bit for bit: ABI 7; *_host_tables: the [J, N] tables built on the host as in rounds 1-5), results written there (no copy calls).  "
                      f"The decode's result is the segmentation (score, segment lengths): ms_per_video_* without a suffix is that call (label format 'lazy': no per-frame labels leave the GPU, ViterbiResult.labels expands the segments on access); "
                      f"*_uint8_labels / *_int32_labels: the kernels also write the per-frame labels (T or 4 T bytes per video over PCIe); *_expanded_on_host: the lazy call plus the int32 expansion of every video on the host; "
                      f"cpu_oracle_all_cores_*: {cores} threads, one video each, {cores} physical cores")
@@ -784,7 +807,7 @@ def main():
     if dist is not None and not args.no_viterbi:
         # BASELINE.json's metric names "Viterbi ms/video at 1/2/4/8 GPU": at N > 1 (and with MUCON_BENCH_FORCE_DIST=1) every rank runs the
         # decode and evaluation legs on its own shard of videos; no collective on the data path, max-over-ranks timing as for the step
-        from mucon_amd.core.viterbi import PoissonModel
+        from mucon_amd.core.viterbi import poisson_params_for_many
 
         def allmax(x):
             t_ = torch.tensor([x], device=dev, dtype=torch.float64)
@@ -798,12 +821,13 @@ def main():
             tr = torch.randint(0, C, (Nv,), generator=gc).numpy().astype(np.int32)
             mu = np.ones(C)
             mu[np.unique(tr)] = Tv / Nv
-            P = PoissonModel(mu).rows_for(tr, 30)
+            P = poisson_params_for_many([mu], [tr], 30, 2000)[0].params      # [3, N]: the length scores are built on the device (ABI 7)
             distinct = min(videos, 64 if kind == "config5" else videos)      # config 5: 64 emission tensors (3.1 MB each), each used videos / 64 times
             base = [torch.log_softmax(3 * torch.randn(Tv, C, device=dev, generator=gd), dim=1) for _ in range(distinct)]
             return (base * (videos // distinct + 1))[:videos], [tr] * videos, [P] * videos
 
-        sharded = {"viterbi": viterbi_bench_sharded(rank, world, sync, allmax, lambda a, b_, c: ops.viterbi_decode_batch(a, b_, c, 30, 2000), make_videos),
+        log_fact = poisson_params_for_many([np.ones(C)], [[0]], 30, 2000)[0].log_fact
+        sharded = {"viterbi": viterbi_bench_sharded(rank, world, sync, allmax, lambda a, b_, c: ops.viterbi_decode_batch(a, b_, c, 30, 2000, log_fact=log_fact), make_videos),
                    "evaluation": eval_bench(dev, 32, rank, world, sync, allmax)}
 
     if rank == 0:

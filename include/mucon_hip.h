@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 6   /* 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 7   /* 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -269,6 +269,26 @@ int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *video
                               int32_t max_len, double *score, int32_t *n_seg, int32_t *status,
                               void *labels, int32_t label_format, int32_t *seg_len, void *stream);
 
+/* ABI 7: the same two decodes with the PoissonModel's length scores BUILT ON THE DEVICE (reference src/core/viterbi/length_model.py:65-71:
+ * `self.poisson[l, :] = l * np.log(self.mean_lengths) - self.mean_lengths - logFak - self.norms`, read at l = (j + 1) fs; >= max_len: -inf, :76-80).
+ * Per transcript state n the caller passes the three numbers of that expression that depend on the class c = a_n -- the rows
+ * [0][n] = np.log(mu_c), [1][n] = mu_c, [2][n] = norms_c of a [3][N] block (NumPy's log and the norms' sums stay on the host: length_model.py:54-63)
+ * -- and ONE shared row log_fact [J], log_fact[j] = the reference's running `logFak` at l = (j + 1) fs.  The kernels evaluate
+ * ((l * [0][n] - [1][n]) - log_fact[j]) - [2][n] left to right as four single IEEE double operations (csrc/viterbi.hip is built with
+ * -ffp-contract=off): bit for bit the table the host would have sent (tests/test_gpu_viterbi.py::test_device_built_length_rows, incl.
+ * mu < 0.5 -> NaN).  3 doubles per state cross PCIe instead of J = 66: 8.6 MB -> 0.4 MB for a 256-video call of BASELINE config 5.
+ *   mucon_viterbi_decode_host_poisson:  videos[v].table = HOST [3][N] parameter block (instead of [J][N]); log_fact HOST [J].
+ *   mucon_viterbi_decode_batch_poisson: jobs[v].p_off = double offset of the video's [3][N] block inside poisson_params (DEVICE); log_fact DEVICE [J].
+ * Everything else as mucon_viterbi_decode_host / mucon_viterbi_decode_batch. */
+int mucon_viterbi_decode_host_poisson(int32_t n_videos, const mucon_viterbi_video *videos, const double *log_fact, int32_t C, int32_t fs,
+                                      int32_t max_len, double *score, int32_t *n_seg, int32_t *status,
+                                      void *labels, int32_t label_format, int32_t *seg_len, void *stream);
+int mucon_viterbi_decode_batch_poisson(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C,
+                                       int32_t fs, int32_t max_len, int32_t max_N,
+                                       const int32_t *transcripts, const double *poisson_params, const double *log_fact,
+                                       void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg,
+                                       double *score, int32_t *status, void *workspace, void *stream);
+
 /* Viterbi.decode of a decoder built with a finite max_hypotheses (reference src/core/viterbi/viterbi.py:34; prune(), :74-79, after
  * every column :57-61): the beam search, bit for bit -- which hypothesis wins a tie depends on the iteration order of the reference's
  * hypothesis dict and on Python's tuple order of prune()'s (score, key) pairs; both are reproduced (csrc/viterbi_beam.hip).
@@ -400,7 +420,11 @@ int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmentation, con
  * Per clipping group g: norm_g = ||all gradients of the group||_2, coef = min(max_norm[g] / (norm_g + 1e-6), 1)
  * (max_norm[g] <= 0: no clipping); then per element  grad *= coef (written back),  u = grad + weight_decay * param,
  * buf = momentum * buf + u and u = buf (when momentum != 0),  param -= lr * u.   `tensors` is a HOST array;
- * the pointers in it are device pointers.  group_norms [n_groups] (device, may be NULL) receives the norms. */
+ * the pointers in it are device pointers.  group_norms [2 * n_groups] (device, may be NULL): [g] receives the norm of group g; a clipped
+ * group whose norm is not finite is NOT applied (parameters, gradients, momentum untouched -- torch would write NaN into every parameter)
+ * and [n_groups + g] is incremented: a STICKY count of skipped steps the library never clears (the caller zeroes the buffer once and
+ * reads / resets the counts where it synchronises anyway: ops.check_health).  (ABI 7: the buffer was [n_groups] and the only trace of a
+ * skipped step was its norm, which the next healthy step overwrote.)  The same holds for mucon_clip_grads and mucon_adam_clip_step. */
 typedef struct mucon_sgd_tensor {
     float *param;
     float *grad;

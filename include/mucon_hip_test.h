@@ -90,6 +90,11 @@ int mucon_test_read_cs_stamps(long long *stamps, int32_t *info, int32_t n_slots)
  * [2] waiting for the device (flag spin or stream synchronisation), [3] copying the results out of the pinned output buffer. */
 int mucon_test_vit_host_phases(double *us4);
 
+/* The length rows the Viterbi kernels build from a [3][N] PoissonModel parameter block and the shared log-factorial row [J]
+ * (include/mucon_hip.h, mucon_viterbi_decode_host_poisson): out [J][N] f64.  All pointers DEVICE. */
+int mucon_test_vit_rows(const double *poisson_params, const double *log_fact, int32_t N, int32_t J, int32_t fs, int32_t max_len,
+                        double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 METRICS_MAX_RUNS = 1024   # MUCON_METRICS_MAX_RUNS
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
@@ -124,11 +124,14 @@ SYMBOLS = {
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_viterbi_decode_host": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "mucon_viterbi_decode_host_poisson": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "mucon_viterbi_decode_batch_poisson": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_viterbi_decode_beam": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mucon_encoder_saved_view": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), _i32, _i32, ctypes.POINTER(ctypes.c_size_t),
                                                 ctypes.POINTER(ctypes.c_int32)]),
     "mucon_test_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mucon_test_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "mucon_test_vit_rows": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mucon_test_dropout_mask": (ctypes.c_int, [_vp, _i64, ctypes.c_uint64, _i32, ctypes.c_float, _vp]),
     "mucon_test_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "mucon_test_get_knob": (ctypes.c_int, [ctypes.c_char_p]),
@@ -185,7 +188,7 @@ def pyhost():
         lib = ctypes.PyDLL(PYHOST_PATH)
         po = ctypes.py_object
         lib.mucon_py_viterbi_decode.restype = po
-        lib.mucon_py_viterbi_decode.argtypes = [po, po, po, po, po] + [ctypes.c_long] * 6 + [ctypes.c_ulonglong] * 3
+        lib.mucon_py_viterbi_decode.argtypes = [po, po, po, po, po, po] + [ctypes.c_long] * 6 + [ctypes.c_ulonglong] * 3
         _pyhost = lib
     return _pyhost
 

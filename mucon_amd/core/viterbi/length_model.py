@@ -149,3 +149,69 @@ def poisson_rows_for_many(mean_lengths, transcripts, frame_sampling: int, max_le
         out.append(np.ascontiguousarray(P[:, at: at + n]))
         at += n
     return out
+
+
+class PoissonParams(LengthModel):
+    """A PoissonModel reduced to what the DEVICE needs to build the decoder's rows itself (csrc/viterbi.hip: VitTab; include/mucon_hip.h,
+    mucon_viterbi_decode_host_poisson): per transcript state n the three numbers of `l * np.log(mu) - mu - logFak - norms` that depend on the
+    class -- params[0, n] = np.log(mu_c), params[1, n] = mu_c, params[2, n] = norms_c for c = a_n (reference length_model.py:54-71; NumPy's log,
+    computed here on the host) -- and the shared running log-factorial at the lengths the decoder reads, log_fact[j] = logFak((j + 1) * fs).
+    3 doubles per state cross PCIe instead of J = 66.  rows_for() builds the same rows on the host, bit for bit what PoissonModel.rows_for gives."""
+
+    def __init__(self, params: np.ndarray, log_fact: np.ndarray, max_length: int, frame_sampling: int):
+        self.params, self.log_fact, self.max_len, self.frame_sampling = params, log_fact, int(max_length), int(frame_sampling)
+
+    def max_length(self):
+        return self.max_len
+
+    def row(self, j: int) -> np.ndarray:
+        """P[j, :] (float64 [N]): the reference's expression, left to right; lengths >= max_length score -inf (length_model.py:76-80)."""
+        length = (j + 1) * self.frame_sampling
+        if length >= self.max_len:
+            return np.full(self.params.shape[1], -np.inf)
+        with np.errstate(all="ignore"):
+            return length * self.params[0] - self.params[1] - self.log_fact[j] - self.params[2]
+
+    def rows_for(self, transcript, frame_sampling):
+        if int(frame_sampling) != self.frame_sampling or self.params.shape[1] != len(transcript):
+            raise ValueError("PoissonParams was built for another transcript / frame_sampling")
+        J = self.max_len // self.frame_sampling
+        return np.ascontiguousarray(np.stack([self.row(j) for j in range(J)])) if J else np.zeros((0, len(transcript)))
+
+    def score(self, length, label):
+        raise NotImplementedError("PoissonParams holds one transcript's parameters only; build a PoissonModel for single scores")
+
+
+def poisson_params_for_many(mean_lengths, transcripts, frame_sampling: int, max_length: int = 2000):
+    """[PoissonParams of PoissonModel(mu) for the transcript tr, for mu, tr in zip(mean_lengths, transcripts)]: the norms and logs of
+    poisson_rows_for_many (same element-wise expressions, reference length_model.py:43-63), without the J x N tables -- those are built on the
+    device (bit for bit: tests/test_gpu_viterbi.py::test_device_built_length_rows).  All models share one log_fact array."""
+    nv = len(transcripts)
+    if nv == 0:
+        return []
+    mu = np.asarray(mean_lengths, dtype=np.float64).reshape(nv, -1)
+    max_len, fs = int(max_length), int(frame_sampling)
+    J = max_len // fs
+    trs = [np.asarray(t, dtype=np.int64) for t in transcripts]
+    counts = [len(t) for t in trs]
+    vid = np.repeat(np.arange(nv), counts)
+    cls = np.concatenate(trs) if sum(counts) else np.zeros(0, np.int64)
+    with np.errstate(all="ignore"):
+        lf = _log_factorials(max(max_len, 2))
+        r = np.round(mu)
+        norms = r * np.log(r) - r
+        finite = np.where(np.isfinite(mu), mu, 0)
+        kmax = int(np.nanmax(finite)) if mu.size else 0
+        lf2 = np.concatenate(([0.0, 0.0], np.cumsum(np.log(np.arange(2, max(kmax + 1, 3))))))     # sum_{k=2..m} log k: a prefix of it is a video's own
+        m = finite.astype(np.int64)
+        norms = norms - np.where(m >= 2, lf2[np.clip(m, 0, len(lf2) - 1)], 0)
+        logmu = np.log(mu)
+    lengths = (np.arange(J, dtype=np.int64) + 1) * fs
+    log_fact = np.ascontiguousarray(lf[np.minimum(lengths, len(lf) - 1)])
+    log_fact.setflags(write=False)
+    flat = np.stack([logmu[vid, cls], mu[vid, cls], norms[vid, cls]])          # [3, sum N]
+    out, at = [], 0
+    for n in counts:
+        out.append(PoissonParams(np.ascontiguousarray(flat[:, at: at + n]), log_fact, max_len, fs))
+        at += n
+    return out

@@ -25,6 +25,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from .grammar import SingleTranscriptGrammar
+from .length_model import PoissonParams
 
 
 def last_in_dict_order(K: int, J: int, n_lim: int) -> Optional[Tuple[int, int]]:
@@ -116,12 +117,23 @@ class Viterbi(object):
             raise NoHypothesisError("'NoneType' object has no attribute 'label'")  # empty transcript: no hypothesis
         if T < fs:
             raise ShortSequenceError(f"index {fs - 1} is out of bounds for axis 0 with size {T}")
-        P = self._table(tr)
-        J = P.shape[0]
+        lm, P = self.length_model, None
+        if isinstance(lm, PoissonParams) and lm.frame_sampling == fs and lm.params.shape[1] == N:
+            # The rows are built on the device (csrc/viterbi.hip: VitTab).  What this function needs of them is which states' scores are NaN
+            # (a mean length < 0.5: the reference's norms are NaN, length_model.py:56-58).  The length enters a score only through `l * log(mu)`
+            # with l > 0, so a column is NaN in every row or in none -- as long as no row is cut off at -inf by max_length.
+            J = lm.max_len // fs
+            if J >= 1 and J * fs < lm.max_len:
+                first, last = np.isnan(lm.row(0)), np.isnan(lm.row(J - 1))
+                if (first == last).all():
+                    P, nan_cols = lm.params, first
+        if P is None:
+            P = self._table(tr)
+            J = P.shape[0]
+            nan_cols = np.isnan(P).any(axis=0)
+            if nan_cols.any() and not (np.isnan(P).all(axis=0) == nan_cols).all():
+                raise NotImplementedError("length table with partially-NaN columns")
         K = T // fs
-        nan_cols = np.isnan(P).any(axis=0)
-        if nan_cols.any() and not (np.isnan(P).all(axis=0) == nan_cols).all():
-            raise NotImplementedError("length table with partially-NaN columns")
         n_lim = int(np.argmax(nan_cols)) if nan_cols.any() else N
         force = None
         if n_lim < N or K < N:
@@ -194,9 +206,11 @@ class Viterbi(object):
                     out.append(e)
             return out
         lps, trs, tabs, forces, slots, beams = [], [], [], [], [], []
+        log_facts = []      # per queued video: the shared log-factorial row of its PoissonParams, or None (a host-built table)
         out: List = [None] * len(log_frame_probs)
         max_len = None
-        for i, (lp, tr, lm) in enumerate(zip(log_frame_probs, transcripts, length_models)):
+        length_models_by_slot = list(length_models)
+        for i, (lp, tr, lm) in enumerate(zip(log_frame_probs, transcripts, length_models_by_slot)):
             if isinstance(lp, np.ndarray):
                 lp = torch.from_numpy(np.ascontiguousarray(lp, dtype=np.float32)).cuda()
             v = Viterbi(SingleTranscriptGrammar(tr, lp.shape[1]), lm, fs, self.max_hypotheses)
@@ -218,9 +232,16 @@ class Viterbi(object):
             lps.append(lp)
             trs.append(t)
             tabs.append(P)
+            log_facts.append(lm.log_fact if (isinstance(lm, PoissonParams) and P is lm.params) else None)
             forces.append(force)
             slots.append(i)
-        res = list(ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces)) if lps else []
+        lf = None
+        if lps:
+            if all(f is not None for f in log_facts) and all(f is log_facts[0] or np.array_equal(f, log_facts[0]) for f in log_facts):
+                lf = log_facts[0]          # every video's scores are built on the device from [3, N] parameters
+            else:                          # a mixed batch: the parameter blocks become host-built tables
+                tabs = [length_models_by_slot[i].rows_for(t, fs) if f is not None else P for i, t, P, f in zip(slots, trs, tabs, log_facts)]
+        res = list(ops.viterbi_decode_batch(lps, trs, tabs, fs, max_len, forces, log_fact=lf)) if lps else []
         if beams:      # the reference's beam search (max_hypotheses below N * J): csrc/viterbi_beam.hip, one call per max_length
             for ml in sorted({b[4] for b in beams}):
                 grp = [b for b in beams if b[4] == ml]

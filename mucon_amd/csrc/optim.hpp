@@ -142,11 +142,17 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const SgdTensor *tab, in
         } else if (threadIdx.x == 0) {
             for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
         }
-        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) {
+            norms_out[t.group] = norm;
+            // STICKY: the count of steps of this group that were skipped for a non-finite norm, never cleared by the library -- the next healthy
+            // step overwrites the norm above, not this (one writer per group and launch, launches ordered by the stream: no atomic needed)
+            if (mx > 0.f && !(norm < __builtin_inff())) norms_out[h.ngroups + t.group] += 1.f;
+        }
     }
     // A clipped group whose gradient norm is not finite (a NaN / inf gradient: a diverged step, or a kernel that reported failure by
     // poisoning its outputs -- the eight-workgroup decoder's hand-over time-out) is NOT applied: parameters, gradients and momentum stay as
-    // they are and norms_out carries the non-finite norm, which ops.check_health() raises on at the caller's next synchronisation point.
+    // they are, norms_out[group] carries the non-finite norm and norms_out[ngroups + group] counts the skipped step (sticky: later healthy steps do
+    // not clear it), which ops.check_health() raises on at the caller's next synchronisation point.
     // (torch would scale every gradient of the group by NaN and write NaN into every parameter; the reference has no such guard.)
     if (mx > 0.f && !(norm < __builtin_inff())) return;   // (uniform over the workgroup)
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
@@ -223,7 +229,12 @@ __global__ __launch_bounds__(256) void clip_apply_kernel(const SgdTensor *tab, i
         } else if (threadIdx.x == 0) {
             for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
         }
-        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) {
+            norms_out[t.group] = norm;
+            // STICKY: the count of steps of this group that were skipped for a non-finite norm, never cleared by the library -- the next healthy
+            // step overwrites the norm above, not this (one writer per group and launch, launches ordered by the stream: no atomic needed)
+            if (mx > 0.f && !(norm < __builtin_inff())) norms_out[h.ngroups + t.group] += 1.f;
+        }
     }
     if (coef == 1.f || (mx > 0.f && !(norm < __builtin_inff()))) return;    // torch multiplies by a clamped 1.0 too: the same bits; a non-finite norm is left for check_health
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;
@@ -266,7 +277,12 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(const AdamTensor *tab, 
         } else if (threadIdx.x == 0) {
             for (int i = 0; i < nt && tab[i].block0 < t.block0; ++i) earlier |= tab[i].group == t.group;
         }
-        if (!__syncthreads_or(earlier) && threadIdx.x == 0) norms_out[t.group] = norm;
+        if (!__syncthreads_or(earlier) && threadIdx.x == 0) {
+            norms_out[t.group] = norm;
+            // STICKY: the count of steps of this group that were skipped for a non-finite norm, never cleared by the library -- the next healthy
+            // step overwrites the norm above, not this (one writer per group and launch, launches ordered by the stream: no atomic needed)
+            if (mx > 0.f && !(norm < __builtin_inff())) norms_out[h.ngroups + t.group] += 1.f;
+        }
     }
     if (mx > 0.f && !(norm < __builtin_inff())) return;   // non-finite norm of a clipped group: the step is not applied (see sgd_apply_kernel)
     const long b0 = (long)(blockIdx.x - t.block0) * SGD_CHUNK;

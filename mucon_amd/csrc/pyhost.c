@@ -23,6 +23,8 @@ static int is_format(const char *fmt, char want) {
 
 typedef int (*decode_host_fn)(int32_t, const mucon_viterbi_video *, int32_t, int32_t, int32_t, double *, int32_t *, int32_t *, void *, int32_t,
                               int32_t *, void *);
+typedef int (*decode_host_poisson_fn)(int32_t, const mucon_viterbi_video *, const double *, int32_t, int32_t, int32_t, double *, int32_t *, int32_t *,
+                                      void *, int32_t, int32_t *, void *);
 
 static mucon_viterbi_video *g_rec = NULL;   /* record scratch, grown on demand (one Python thread calls at a time: the GIL) */
 static Py_ssize_t g_rec_cap = 0;
@@ -34,7 +36,8 @@ static size_t up8(size_t n) { return (n + 7) & ~(size_t)7; }
  *   lp_ptrs      list[int]   device pointers of the emission tensors (contiguous float32 [T, C])
  *   Ts           list[int]   their frame counts
  *   transcripts  list        C-contiguous int32 buffers [N]      (NumPy arrays; anything else: see `bad` below)
- *   tables       list        C-contiguous float64 buffers [J, N]
+ *   tables       list        C-contiguous float64 buffers [J, N] -- or, with log_fact, the [3, N] PoissonModel parameter blocks (include/mucon_hip.h, ABI 7)
+ *   log_fact     None, or a C-contiguous float64 buffer [J]: the length scores are built on the device, `decode_fn` is mucon_viterbi_decode_host_poisson
  *   forces       None, or list of None | (n, j)
  * (the arrays' memory is only pointed at: the caller keeps the lists alive), calls mucon_viterbi_decode_host (its address in
  * `decode_fn`: this library does not link against libmucon_hip.so), and returns
@@ -45,7 +48,7 @@ static size_t up8(size_t n) { return (n + 7) & ~(size_t)7; }
  * bad >= 0 (rc = 0, out = None, nothing decoded): video `bad` has a transcript / table that is not such a buffer, or an emission
  * pointer that is not 16-byte aligned while need_align is set -- the caller converts / copies that one and calls again with
  * start = bad (records below `start` are kept). */
-PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *transcripts, PyObject *tables, PyObject *forces, long C,
+PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *transcripts, PyObject *tables, PyObject *forces, PyObject *log_fact, long C,
                                   long fs, long max_len, long label_format, long need_align, long start,
                                   unsigned long long labels_addr, unsigned long long decode_fn, unsigned long long stream) {
     if (!PyList_Check(lp_ptrs) || !PyList_Check(Ts) || !PyList_Check(transcripts) || !PyList_Check(tables)) {
@@ -76,6 +79,21 @@ PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *tra
         }
     }
     const long J = max_len / fs;
+    const double *lf_ptr = NULL;
+    Py_buffer blf;
+    int have_lf = 0;
+    if (log_fact != Py_None) {
+        if (PyObject_GetBuffer(log_fact, &blf, PyBUF_FORMAT | PyBUF_ND | PyBUF_C_CONTIGUOUS) != 0) return NULL;
+        if (!(blf.ndim == 1 && blf.itemsize == 8 && is_format(blf.format, 'd') && blf.shape[0] == J)) {
+            PyBuffer_Release(&blf);
+            PyErr_Format(PyExc_ValueError, "mucon_py_viterbi_decode: log_fact must be a C-contiguous float64 array [%ld]", J);
+            return NULL;
+        }
+        lf_ptr = (const double *)blf.buf;     /* (the caller keeps the array alive across the call) */
+        PyBuffer_Release(&blf);
+        have_lf = 1;
+    }
+    const long tab_rows = have_lf ? 3 : J;
     mucon_viterbi_video *rec = g_rec;
     long long sum_T = 0, sum_N = 0;
     for (Py_ssize_t v = 0; v < nv; ++v) {
@@ -99,8 +117,8 @@ PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *tra
                     return Py_BuildValue("inLLO", 0, v, 0LL, 0LL, Py_None);
                 }
                 ok = bp.ndim == 2 && bp.itemsize == 8 && is_format(bp.format, 'd');
-                if (ok && (bp.shape[0] != J || bp.shape[1] != N)) {
-                    PyErr_Format(PyExc_ValueError, "video %zd: length table [%zd, %zd], expected [%ld, %ld]", v, bp.shape[0], bp.shape[1], J, N);
+                if (ok && (bp.shape[0] != tab_rows || bp.shape[1] != N)) {
+                    PyErr_Format(PyExc_ValueError, "video %zd: length table [%zd, %zd], expected [%ld, %ld]", v, bp.shape[0], bp.shape[1], tab_rows, N);
                     PyBuffer_Release(&bp);
                     return NULL;
                 }
@@ -150,9 +168,12 @@ PyObject *mucon_py_viterbi_decode(PyObject *lp_ptrs, PyObject *Ts, PyObject *tra
     void *labels = lab_elem ? (labels_addr ? (void *)(uintptr_t)labels_addr : (void *)(b + o_lab)) : NULL;
     /* (the GIL stays held: the library keeps per-device staging state and this file a record scratch, both written for ONE host thread
      * per process -- include/mucon_hip.h; a second Python thread entering here during a 0.05 - 0.9 ms decode would share them) */
-    const int rc = ((decode_host_fn)(uintptr_t)decode_fn)((int32_t)nv, rec, (int32_t)C, (int32_t)fs, (int32_t)max_len, (double *)b,
-                                                          (int32_t *)(b + o_nseg), (int32_t *)(b + o_stat), labels, (int32_t)label_format,
-                                                          (int32_t *)(b + o_seg), (void *)(uintptr_t)stream);
+    const int rc = have_lf ? ((decode_host_poisson_fn)(uintptr_t)decode_fn)((int32_t)nv, rec, lf_ptr, (int32_t)C, (int32_t)fs, (int32_t)max_len, (double *)b,
+                                                                            (int32_t *)(b + o_nseg), (int32_t *)(b + o_stat), labels, (int32_t)label_format,
+                                                                            (int32_t *)(b + o_seg), (void *)(uintptr_t)stream)
+                           : ((decode_host_fn)(uintptr_t)decode_fn)((int32_t)nv, rec, (int32_t)C, (int32_t)fs, (int32_t)max_len, (double *)b,
+                                                                    (int32_t *)(b + o_nseg), (int32_t *)(b + o_stat), labels, (int32_t)label_format,
+                                                                    (int32_t *)(b + o_seg), (void *)(uintptr_t)stream);
     PyObject *res = Py_BuildValue("inLLO", rc, (Py_ssize_t)-1, sum_T, sum_N, out);
     Py_DECREF(out);
     return res;

@@ -606,6 +606,26 @@ __device__ __forceinline__ double hand_up_f64(double v) {
 }
 
 // The decoding lanes' registers and one column of the DP (see the comment above).  Lane dl = n * G + g of the NW decoding waves.
+// The length scores P[j][n] = length_model.score((j + 1) fs, a_n) of a video, two forms:
+//   * lf == nullptr: a host-built table [J][N] at double offset p_off (mucon_viterbi_decode_host / _batch);
+//   * lf != nullptr (ABI 7, the *_poisson entries): p_off points at the transcript's PoissonModel parameters [3][N] = (ln mu, mu, norm) of the
+//     classes a_n, lf[j] is the reference's running log-factorial at length (j + 1) fs, and the score is built here exactly as reference
+//     src/core/viterbi/length_model.py:65-71 builds it -- `l * np.log(mu) - mu - logFak - norms`, left to right: four single IEEE double
+//     operations (this translation unit is compiled with -ffp-contract=off: no fused multiply-add), NumPy's `log` stays on the host.
+//     Lengths >= max_len score -inf (length_model.py:76-80).  3 doubles per transcript state cross PCIe instead of J = 66.
+struct VitTab {
+    const double *t;
+    const double *lf;
+    int fs, max_len;
+    __device__ __forceinline__ double at(const int64_t p_off, const int j, const int n, const int N) const {
+        if (lf == nullptr) return t[p_off + (size_t)j * N + n];
+        const double *q = t + p_off;
+        const long l = (long)(j + 1) * fs;
+        const double v = (((double)l * q[n] - q[N + n]) - lf[j]) - q[2 * N + n];
+        return l < max_len ? v : -INFINITY;
+    }
+};
+
 template <int G, int JG>
 struct VitLanes {
     static_assert(G * JG >= 67 && (G == 4 || G == 8), "slots 0..66 over the G lanes of a state");
@@ -618,7 +638,7 @@ struct VitLanes {
     bool is_n1;       // a lane of state 1 (its entry comes from state 0's side chain, not from the hand-over)
 
     // the loads that do not depend on the frame scores (issued early; `dl` = decoding lane index)
-    __device__ __forceinline__ void load(const mucon_viterbi_job &job, const double *tables, const int dl, const int J) {
+    __device__ __forceinline__ void load(const mucon_viterbi_job &job, const VitTab &tables, const int dl, const int J) {
         const int N = job.N;
         n = dl / G;
         g = dl - n * G;
@@ -628,7 +648,7 @@ struct VitLanes {
 #pragma unroll
         for (int i = 0; i < JG; ++i) {
             const int sidx = g * JG + i;
-            PlS[i] = (state_on && sidx >= 1 && sidx <= J) ? tables[job.p_off + (size_t)(sidx - 1) * N + n] : NEG;
+            PlS[i] = (state_on && sidx >= 1 && sidx <= J) ? tables.at(job.p_off, sidx - 1, n, N) : NEG;
             S[i] = NEG;
         }
         zmask = (state_on && n == 1 && g == 0) ? 0.0 : NEG;
@@ -757,7 +777,7 @@ __device__ __forceinline__ void vit_lanes_finalize(const VitLanes<G, JG> &L, con
 template <int G, int JG, int NW>
 __device__ __forceinline__ void viterbi_dp_lanes_body(
     const mucon_viterbi_job &job, const int vid, const float *F, uint8_t *bp, uint8_t *bp_l, const bool bp_lds, const int32_t *transcripts,
-    const double *tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
+    const VitTab tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, int C, int fs, int J,
     const unsigned long long *progress = nullptr, const uint32_t seq = 0, const int live_threads = 0) {
     // progress != nullptr (pair kernel): the frame scores are being written by another workgroup, which publishes
     // (seq << 32 | columns done) there; live_threads: the workgroup's threads that run this body (the others have left)
@@ -797,7 +817,7 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
         a[tid] = tid < N ? transcripts[job.tr_off + tid] : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            if (tid + u * NL < 128) Pl0[tid + u * NL] = tid + u * NL < J ? tables[job.p_off + (size_t)(tid + u * NL) * N] : NEG;
+            if (tid + u * NL < 128) Pl0[tid + u * NL] = tid + u * NL < J ? tables.at(job.p_off, tid + u * NL, 0, N) : NEG;
     }
     __syncthreads();
 
@@ -890,7 +910,7 @@ __device__ __forceinline__ void viterbi_dp_lanes_body(
 
 template <int G, int JG, int NW>
 __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lanes_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const VitTab tables, const VitLabels labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J, int bp_lds_bytes,
     volatile int32_t *done_flag, int32_t done_value) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vl_bp[];   // [K][N] back-pointers when they fit (bp_lds_bytes of them)
@@ -914,7 +934,7 @@ __global__ __launch_bounds__(NW == 1 ? VL_THREADS : 64 * NW) void viterbi_dp_lan
 // (T = 16,384 / N = 64: 0.44 -> 0.34 ms).  For latency calls (vit_launch: <= 8 videos).
 template <int G, int JG, int NW, bool W4>
 __global__ __launch_bounds__(FSC_THREADS) void viterbi_pair_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const VitTab tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
     double *score, int32_t *status, char *ws, int C, int fs, int J, int cols, int bp_lds_bytes, volatile int32_t *done_flag,
     int32_t done_value, unsigned long long *progress_words, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
@@ -954,7 +974,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_pair_kernel(
 // (r2, two launches + copies: 0.100 ms for T = 2,000 / N = 6; r3: 0.050 ms.)
 template <int G, int JG, bool W4>
 __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_viterbi_job job, const int32_t *transcripts,
-                                                                    const double *tables, const VitLabels labels, int32_t *seg_len,
+                                                                    const VitTab tables, const VitLabels labels, int32_t *seg_len,
                                                                     int32_t *n_seg, double *score, int32_t *status, int C,
                                                                     int fs, int J, int cols, int dyn_floats, volatile int32_t *done_flag,
                                                                     int32_t done_value) {
@@ -995,7 +1015,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_
             an = transcripts[job.tr_off + (L.n < N ? L.n : 0)];
             a_own = dl < N ? transcripts[job.tr_off + dl] : 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) pl0r[u] = dl + 64 * u < J ? tables[job.p_off + (size_t)(dl + 64 * u) * N] : -INFINITY;
+            for (int u = 0; u < 2; ++u) pl0r[u] = dl + 64 * u < J ? tables.at(job.p_off, dl + 64 * u, 0, N) : -INFINITY;
         }
         framescore_cols_body<W4, 6, false>(job.lp, F, K, C, fs, cols, fs_smem, [&](const int k_lo, const int k_hi) {
             int k = k_lo;
@@ -1048,7 +1068,7 @@ __global__ __launch_bounds__(FSC_THREADS) void viterbi_fused_kernel(const mucon_
 // DPP reductions, then the writes -- so that the LDS and DPP latencies of the states overlap instead of adding up.
 template <int SPW>
 __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
-    const mucon_viterbi_job *jobs, const int32_t *transcripts, const double *tables, const VitLabels labels,
+    const mucon_viterbi_job *jobs, const int32_t *transcripts, const VitTab tables, const VitLabels labels,
     int32_t *seg_len, int32_t *n_seg, double *score, int32_t *status, char *ws, int C, int fs, int J) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mucon_viterbi_job job = jobs[blockIdx.x];
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_dp_kernel(
     for (int e = tid; e < N; e += nthreads) a[e] = transcripts[job.tr_off + e];
     for (int e = tid; e < N * J; e += nthreads) {
         const int n = e / J, j = e - n * J;
-        Pl[e] = tables[job.p_off + (size_t)j * N + n];
+        Pl[e] = tables.at(job.p_off, j, n, N);
     }
     // frame-score chunks 0 and 1
     for (int e = tid; e < 2 * VIT_FCHUNK * C; e += nthreads) {
@@ -1295,7 +1315,7 @@ extern "C" size_t mucon_viterbi_job_workspace_bytes(int32_t T, int32_t C, int32_
 
 // Launches of one decode: `fused` = the one-launch kernel (one short video, <= 16 states), else frame scores + DP.
 static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs, int32_t max_len, int32_t max_N,
-                      const int32_t *transcripts, const double *length_tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
+                      const int32_t *transcripts, const VitTab length_tables, const VitLabels labels, int32_t *seg_len, int32_t *n_seg,
                       double *score, int32_t *status, void *workspace, hipStream_t s, bool fused, int max_K, bool cols_ok,
                       volatile int32_t *done_flag, int32_t done_value, const mucon_viterbi_job *host_jobs,
                       unsigned long long *progress_words = nullptr, hipEvent_t tables_ready = nullptr) {
@@ -1509,10 +1529,10 @@ static int vit_launch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C
     return MUCON_OK;
 }
 
-extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
-                                          int32_t max_len, int32_t max_N, const int32_t *transcripts, const double *length_tables,
-                                          void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg, double *score,
-                                          int32_t *status, void *workspace, void *stream) {
+static int vit_decode_batch_impl(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
+                                 int32_t max_len, int32_t max_N, const int32_t *transcripts, const VitTab length_tables,
+                                 void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg, double *score,
+                                 int32_t *status, void *workspace, void *stream) {
     if (n_videos <= 0) return MUCON_OK;
     if (label_format < MUCON_VIT_LABELS_I32 || label_format > MUCON_VIT_LABELS_NONE || (!labels && label_format != MUCON_VIT_LABELS_NONE)) {
         snprintf(g_err, sizeof(g_err), "viterbi: label_format %d / labels %s", label_format, labels ? "given" : "NULL");
@@ -1524,6 +1544,24 @@ extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_
     const int rc = vit_launch(n_videos, jobs, C, fs, max_len, max_N, transcripts, length_tables, VitLabels{labels, label_format}, seg_len, n_seg, score, status,
                               workspace, static_cast<hipStream_t>(stream), false, 0, (C & 3) == 0, nullptr, 0, nullptr);
     return rc > 0 ? MUCON_OK : rc;
+}
+extern "C" int mucon_viterbi_decode_batch(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
+                                          int32_t max_len, int32_t max_N, const int32_t *transcripts, const double *length_tables,
+                                          void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg, double *score,
+                                          int32_t *status, void *workspace, void *stream) {
+    return vit_decode_batch_impl(n_videos, jobs, C, fs, max_len, max_N, transcripts, VitTab{length_tables, nullptr, fs, max_len}, labels, label_format,
+                                 seg_len, n_seg, score, status, workspace, stream);
+}
+extern "C" int mucon_viterbi_decode_batch_poisson(int32_t n_videos, const mucon_viterbi_job *jobs, int32_t C, int32_t fs,
+                                                  int32_t max_len, int32_t max_N, const int32_t *transcripts, const double *poisson_params,
+                                                  const double *log_fact, void *labels, int32_t label_format, int32_t *seg_len, int32_t *n_seg,
+                                                  double *score, int32_t *status, void *workspace, void *stream) {
+    if (!poisson_params || !log_fact) {
+        snprintf(g_err, sizeof(g_err), "viterbi: null Poisson parameters / log-factorial row");
+        VIT_FAIL(MUCON_E_ARG);
+    }
+    return vit_decode_batch_impl(n_videos, jobs, C, fs, max_len, max_N, transcripts, VitTab{poisson_params, log_fact, fs, max_len}, labels, label_format,
+                                 seg_len, n_seg, score, status, workspace, stream);
 }
 
 // ---- decode with host-side inputs and outputs (what Viterbi.decode is: numpy in, Python objects out) -------------------------
@@ -1569,9 +1607,10 @@ extern "C" int mucon_test_vit_host_phases(double *us4) {
     return MUCON_OK;
 }
 
-extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
-                                         double *score, int32_t *n_seg, int32_t *status, void *labels, int32_t label_format,
-                                         int32_t *seg_len, void *stream) {
+// log_fact != nullptr: videos[v].table is the video's [3][N] PoissonModel parameter rows, the length scores are built on the device (VitTab)
+static int vit_decode_host_impl(int32_t n_videos, const mucon_viterbi_video *videos, const double *log_fact, int32_t C, int32_t fs, int32_t max_len,
+                                double *score, int32_t *n_seg, int32_t *status, void *labels, int32_t label_format,
+                                int32_t *seg_len, void *stream) {
     if (n_videos <= 0) return MUCON_OK;
     const double t_begin = vh_now_us();
     if (label_format < MUCON_VIT_LABELS_I32 || label_format > MUCON_VIT_LABELS_NONE) {
@@ -1607,7 +1646,8 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
         aligned = aligned && (reinterpret_cast<uintptr_t>(q.lp) & 15) == 0;   // the pipelined frame-score kernel loads 16 bytes per lane
     }
     // input staging: [jobs][length tables][transcripts]; output staging: [flag, 64 B][score][n_seg][status][seg_len][labels]
-    const size_t o_tab = up16(sizeof(mucon_viterbi_job) * n_videos), o_tr = o_tab + up16(sizeof(double) * J * sum_N);
+    const size_t tab_rows = log_fact ? 3 : (size_t)J;   // doubles per transcript state in the staging buffer; parameter form: + the shared lf[J] behind them
+    const size_t o_tab = up16(sizeof(mucon_viterbi_job) * n_videos), o_tr = o_tab + up16(sizeof(double) * (tab_rows * sum_N + (log_fact ? (size_t)J : 0)));
     const size_t in_bytes = o_tr + up16(sizeof(int32_t) * sum_N);
     const size_t o_score = 64, o_nseg = o_score + up16(8 * (size_t)n_videos), o_stat = o_nseg + up16(4 * (size_t)n_videos);
     // `labels` is by far the largest output (4 T bytes per video).  When the caller's array is itself pinned host memory the kernels
@@ -1644,7 +1684,7 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
         mucon_viterbi_job &j = jobs[v];
         j.lp = q.lp;
         j.tr_off = (int64_t)tr_off;
-        j.p_off = (int64_t)tr_off * J;
+        j.p_off = (int64_t)(tr_off * tab_rows);
         j.label_off = (int64_t)lab_off;
         j.seg_off = (int64_t)tr_off;
         j.ws_off = (int64_t)ws_off;
@@ -1652,12 +1692,13 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
         j.N = q.N;
         j.force_n = q.force_n;
         j.force_j = q.force_j;
-        memcpy(tabs + tr_off * J, q.table, sizeof(double) * (size_t)J * q.N);
+        memcpy(tabs + tr_off * tab_rows, q.table, sizeof(double) * tab_rows * q.N);
         memcpy(trs + tr_off, q.transcript, sizeof(int32_t) * (size_t)q.N);
         tr_off += (size_t)q.N;
         lab_off += (size_t)(q.T > 0 ? q.T : 1);
         ws_off += (mucon_viterbi_job_workspace_bytes(q.T, C, q.N, fs) + 255) & ~(size_t)255;
     }
+    if (log_fact) memcpy(tabs + tab_rows * sum_N, log_fact, sizeof(double) * (size_t)J);
     char *din = nullptr, *dout = nullptr;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&din), st.pin_in, 0) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&dout), st.pin_out, 0) != hipSuccess) {
@@ -1693,7 +1734,9 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     // latency path: a handful of short videos in ONE launch each; throughput path: two launches whose second packs many per CU
     const bool want_fused = n_videos == 1;
     const int rc = vit_launch(n_videos, reinterpret_cast<const mucon_viterbi_job *>(din), C, fs, max_len, max_N,
-                              reinterpret_cast<const int32_t *>(tab_base + o_tr), reinterpret_cast<const double *>(tab_base + o_tab),
+                              reinterpret_cast<const int32_t *>(tab_base + o_tr),
+                              VitTab{reinterpret_cast<const double *>(tab_base + o_tab),
+                                     log_fact ? reinterpret_cast<const double *>(tab_base + o_tab) + tab_rows * sum_N : nullptr, fs, max_len},
                               VitLabels{labels_dev ? labels_dev : static_cast<void *>(dout + o_lab), label_format}, reinterpret_cast<int32_t *>(dout + o_seg),
                               reinterpret_cast<int32_t *>(dout + o_nseg), reinterpret_cast<double *>(dout + o_score),
                               reinterpret_cast<int32_t *>(dout + o_stat), st.ws, s, want_fused, max_K, aligned,
@@ -1724,5 +1767,39 @@ extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_v
     g_vh_phase_us[1] = t_launched - t_staged;
     g_vh_phase_us[2] = t_waited - t_launched;
     g_vh_phase_us[3] = vh_now_us() - t_waited;
+    return MUCON_OK;
+}
+
+extern "C" int mucon_viterbi_decode_host(int32_t n_videos, const mucon_viterbi_video *videos, int32_t C, int32_t fs, int32_t max_len,
+                                         double *score, int32_t *n_seg, int32_t *status, void *labels, int32_t label_format,
+                                         int32_t *seg_len, void *stream) {
+    return vit_decode_host_impl(n_videos, videos, nullptr, C, fs, max_len, score, n_seg, status, labels, label_format, seg_len, stream);
+}
+extern "C" int mucon_viterbi_decode_host_poisson(int32_t n_videos, const mucon_viterbi_video *videos, const double *log_fact, int32_t C, int32_t fs,
+                                                 int32_t max_len, double *score, int32_t *n_seg, int32_t *status, void *labels,
+                                                 int32_t label_format, int32_t *seg_len, void *stream) {
+    if (!log_fact) {
+        snprintf(g_err, sizeof(g_err), "viterbi: null log-factorial row");
+        VIT_FAIL(MUCON_E_ARG);
+    }
+    return vit_decode_host_impl(n_videos, videos, log_fact, C, fs, max_len, score, n_seg, status, labels, label_format, seg_len, stream);
+}
+
+// Test hook (include/mucon_hip_test.h): the length rows the kernels build from a [3][N] parameter block -- out[j][n] = VitTab::at -- so that a test can hold
+// them against PoissonModel.rows_for bit for bit.  All pointers DEVICE.
+__global__ void vit_rows_probe_kernel(const VitTab tab, int N, int J, double *out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * J; e += gridDim.x * blockDim.x) out[e] = tab.at(0, e / N, e % N, N);
+}
+extern "C" int mucon_test_vit_rows(const double *poisson_params, const double *log_fact, int32_t N, int32_t J, int32_t fs, int32_t max_len,
+                                   double *out, void *stream) {
+    if (!poisson_params || !log_fact || !out || N < 1 || J < 1 || fs < 1) {
+        snprintf(g_err, sizeof(g_err), "test_vit_rows: bad arguments");
+        VIT_FAIL(MUCON_E_ARG);
+    }
+    hipLaunchKernelGGL(vit_rows_probe_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), VitTab{poisson_params, log_fact, fs, max_len}, N, J, out);
+    if (hipGetLastError() != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "test_vit_rows: launch failed");
+        VIT_FAIL(MUCON_E_HIP);
+    }
     return MUCON_OK;
 }

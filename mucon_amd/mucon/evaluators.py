@@ -12,8 +12,8 @@ import torch
 from .models import EmptyTranscriptError
 from ..core.metrics import (AbsLenDiffMetric, Edit, F1Score, IoDMetric, IoUMetric, MatchingScoreMetric,  # noqa: F401
                             MoFAccuracyMetric)
-from ..core.viterbi import (NoHypothesisError, PoissonModel, PoissonRows, ShortSequenceError, SingleTranscriptGrammar, Viterbi,
-                            poisson_rows_for_many)
+from ..core.viterbi import (NoHypothesisError, PoissonModel, ShortSequenceError, SingleTranscriptGrammar, Viterbi,
+                            poisson_params_for_many)
 
 
 def one_hot(a: np.ndarray, num_classes: int) -> np.ndarray:
@@ -262,8 +262,8 @@ class MuConEvaluator:
             # the chunk's length tables in one go (PoissonModel(lengths).rows_for(transcript, fs) per video, bit for bit: poisson_rows_for_many)
             fs = self.vi_decoder.frame_sampling
             mus = [mean_lengths_from_s_head(v["rel"], v["transcript"][:-1], int(v["out"]["logp"].shape[0]), C) for v in alive]
-            rows = poisson_rows_for_many(mus, [v["transcript"][:-1] for v in alive], fs, 2000)      # (2000: PoissonModel's default max_length, evaluators.py:167)
-            lms = [PoissonRows(r, 2000, fs) for r in rows]
+            # (r6) ... as [3, N] parameter blocks: the rows themselves are built on the device, bit for bit (core/viterbi/length_model.py: PoissonParams)
+            lms = poisson_params_for_many(mus, [v["transcript"][:-1] for v in alive], fs, 2000)      # (2000: PoissonModel's default max_length, evaluators.py:167)
             res = self.vi_decoder.decode_batch([v["out"]["logp"] for v in alive], [v["transcript"][:-1] for v in alive], lms,
                                                return_exceptions=True, labels_as_arrays=True)
             kept = []

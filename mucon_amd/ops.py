@@ -517,7 +517,8 @@ DECODER_HANDOVER_FAILED = ("mucon_decoder_fwd: a hand-over between the eight wor
                            "co-resident for about a second: the GPU is oversubscribed); n_steps = -1, the outputs of this call are invalid")
 
 
-NONFINITE_GRADIENT_NORM = ("fused clip + optimizer step: the gradient norm of clipping group {group} is {norm} -- that group's update was NOT applied "
+NONFINITE_GRADIENT_NORM = ("fused clip + optimizer step: clipping group {group} met a non-finite gradient norm in {skipped} step(s) since the last check "
+                           "(norm of the latest step: {norm}) -- those updates were NOT applied "
                            "(csrc/optim.hpp).  A non-finite gradient is a diverged step or a kernel that reported a failure by poisoning its outputs "
                            "(the eight-workgroup decoder's hand-over time-out fills its outputs / dV with NaN)")
 _PENDING_DECODER_STATUS = []      # n_steps words (device int32 [1]) of teacher-forced decoder calls nobody has read yet
@@ -536,13 +537,26 @@ def check_health(optimizers=()):
         if int(torch.stack([t.reshape(()) for t in pend]).min().item()) < 0:
             raise _lib.MuconHipError(DECODER_HANDOVER_FAILED)
     for opt in optimizers:
-        norms = getattr(opt, "last_norms", None)
-        if norms is None or getattr(opt, "max_norm", None) is None:
+        buf = getattr(opt, "_norms_buf", None)
+        if buf is None or getattr(opt, "max_norm", None) is None:
             continue
-        host = norms.detach().cpu()
-        bad = (~torch.isfinite(host)).nonzero().flatten().tolist()
+        host = buf.detach().cpu()
+        n = host.numel() // 2
+        skipped = host[n:]
+        bad = ((~torch.isfinite(host[:n])) | (skipped > 0)).nonzero().flatten().tolist()
         if bad:
-            raise _lib.MuconHipError(NONFINITE_GRADIENT_NORM.format(group=bad[0], norm=float(host[bad[0]])))
+            buf[n:].zero_()     # the counts are sticky on the device: reported once, then cleared here
+            raise _lib.MuconHipError(NONFINITE_GRADIENT_NORM.format(group=bad[0], norm=float(host[bad[0]]), skipped=int(skipped[bad[0]])))
+
+
+def _norms_for(holder, n_groups, dev):
+    """The [2 * n_groups] device buffer of a fused optimizer's launches (include/mucon_hip.h): norms, then the STICKY counts of skipped steps.
+    `holder.last_norms` is a view of the first half."""
+    buf = getattr(holder, "_norms_buf", None)
+    if buf is None or buf.device != dev or buf.numel() != 2 * n_groups:
+        buf = holder._norms_buf = torch.zeros(2 * n_groups, dtype=torch.float32, device=dev)
+        holder.last_norms = buf[:n_groups]
+    return buf
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -758,7 +772,7 @@ class FusedClipSGD:
         """An iteration of a gradient-accumulation group that does not step: the clipping alone."""
         fused_clip_only(self.groups, self.max_norm, self)
 
-    def step(self):
+    def step(self, _retry=False):
         lib = _lib.load()
         pg = self.optimizer.param_groups[0]
         lr, wd, mom = float(pg["lr"]), float(pg["weight_decay"]), float(pg["momentum"])
@@ -802,17 +816,25 @@ class FusedClipSGD:
                 raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
             t = tab[k]
             if t.n != p_.numel() or g.numel() != t.n or g.dtype != torch.float32 or p_.dtype != torch.float32:
-                self._plan = None            # a parameter was replaced by one of another size / type: the cached table is stale
-                return self.step()
+                # a parameter's storage was replaced by one of another size / type: the cached table is stale -- and so is every momentum buffer
+                # that no longer matches its parameter (id(p) is unchanged: the table would point the kernel at the old, smaller buffer)
+                if _retry:
+                    raise _lib.MuconHipError("FusedClipSGD: parameter / gradient sizes do not match after rebuilding the table")
+                self._plan = None
+                for q, _ in flat:
+                    b = self._mom.get(id(q))
+                    if b is not None and (b.shape != q.shape or b.dtype != q.dtype or b.device != q.device):
+                        del self._mom[id(q)]
+                return self.step(_retry=True)
             t.param, t.grad = p_.data_ptr(), g.data_ptr()
         n = len(idx)
         nbytes = lib.mucon_sgd_workspace_bytes(n, total)
         dev = flat[idx[0]][0].device
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.last_norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
+        norms = _norms_for(self, len(self.groups), dev)
         mx = (ctypes.c_float * len(self.groups))(*[float(self.max_norm) if self.max_norm is not None else 0.0] * len(self.groups))
-        _lib.check(lib.mucon_sgd_clip_step(n, tab, len(self.groups), mx, lr, wd, mom, _lib.ptr(self.last_norms),
+        _lib.check(lib.mucon_sgd_clip_step(n, tab, len(self.groups), mx, lr, wd, mom, _lib.ptr(norms),
                                            _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream_ptr()),
                    "mucon_sgd_clip_step")
         # this call stands in for optimizer.step(): tell torch's schedulers so (they warn about the call order otherwise)
@@ -843,10 +865,9 @@ def fused_clip_only(groups, max_norm, holder):
     dev = entries[0][0].device
     if getattr(holder, "_clip_ws", None) is None or holder._clip_ws.numel() < nbytes or holder._clip_ws.device != dev:
         holder._clip_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if holder.last_norms is None or holder.last_norms.device != dev:
-        holder.last_norms = torch.zeros(len(groups), dtype=torch.float32, device=dev)
+    norms = _norms_for(holder, len(groups), dev)
     mx = (ctypes.c_float * len(groups))(*[float(max_norm)] * len(groups))
-    _lib.check(lib.mucon_clip_grads(n, tab, len(groups), mx, _lib.ptr(holder.last_norms), _lib.ptr(holder._clip_ws),
+    _lib.check(lib.mucon_clip_grads(n, tab, len(groups), mx, _lib.ptr(norms), _lib.ptr(holder._clip_ws),
                                     holder._clip_ws.numel(), _lib.current_stream_ptr()), "mucon_clip_grads")
 
 
@@ -911,11 +932,11 @@ class FusedClipAdam:
         dev = entries[0][0].device
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.last_norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
+        norms = _norms_for(self, len(self.groups), dev)
         mx = (ctypes.c_float * len(self.groups))(*[float(self.max_norm) if self.max_norm is not None else 0.0] * len(self.groups))
         b1, b2 = pg["betas"]
         _lib.check(lib.mucon_adam_clip_step(n, tab, len(self.groups), mx, float(pg["lr"]), float(b1), float(b2), float(pg["eps"]),
-                                            float(pg["weight_decay"]), steps.pop(), _lib.ptr(self.last_norms), _lib.ptr(self._ws),
+                                            float(pg["weight_decay"]), steps.pop(), _lib.ptr(norms), _lib.ptr(self._ws),
                                             self._ws.numel(), _lib.current_stream_ptr()), "mucon_adam_clip_step")
         if isinstance(self.optimizer, torch.optim.Optimizer):
             self.optimizer._opt_called = True
@@ -1098,7 +1119,8 @@ class ViterbiBatchResult(collections.abc.Sequence):
 
 def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray],
                          tables: Sequence[np.ndarray], fs: int, max_len: int,
-                         forces: Optional[Sequence[Optional[tuple]]] = None, labels: str = "lazy") -> ViterbiBatchResult:
+                         forces: Optional[Sequence[Optional[tuple]]] = None, labels: str = "lazy",
+                         log_fact: Optional[np.ndarray] = None) -> ViterbiBatchResult:
     """Decode a batch of videos (one workgroup per video) through mucon_viterbi_decode_host.
 
     lps[v]: device float32 [T_v, C] log-probs (they stay where they are: every video is decoded in place, nothing is
@@ -1106,6 +1128,10 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
     forces[v]: None or (n, j) -- finalize on that hypothesis with score -inf (host-resolved degenerate outcomes of the
     reference).  The library reads the small inputs from and writes the results to its own pinned host buffers; a single
     short video is one launch whose completion the host sees through a flag (no copy calls, no stream synchronisation).
+
+    log_fact (float64 [J]): the PoissonModel's length scores are BUILT ON THE DEVICE (mucon_viterbi_decode_host_poisson, ABI 7); tables[v] is
+    then the video's float64 [3, N_v] parameter block (core/viterbi/length_model.py: PoissonParams.params, .log_fact) -- 3 doubles per
+    transcript state over PCIe instead of J.
 
     labels: the form the per-frame labels leave the GPU in (include/mucon_hip.h, MUCON_VIT_LABELS_*): "int32" (the reference's
     ints, 4 T bytes per video over PCIe), "uint8" (T bytes) or "lazy" (default: none -- the kernels write the segmentation only and
@@ -1139,7 +1165,11 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
         # torch's caching host allocator; below that the results come through the library's own staging buffer anyway.
         lab_t = torch.empty(sum(T if T > 0 else 1 for T in Ts), dtype=torch.int32 if fmt == _lib.VIT_LABELS_I32 else torch.uint8, pin_memory=True)
         lab_arr, lab_ptr = lab_t.numpy(), lab_t.data_ptr()
-    decode, fn_addr, J = _vit_entry(lib), _VIT_FN_ADDR[0], max_len // fs
+    decode, J = _vit_entry(lib), max_len // fs
+    fn_addr = _VIT_FN_ADDR[1 if log_fact is not None else 0]
+    rows = 3 if log_fact is not None else J
+    if log_fact is not None and not (isinstance(log_fact, np.ndarray) and log_fact.dtype == np.float64 and log_fact.shape == (J,) and log_fact.flags.c_contiguous):
+        log_fact = np.ascontiguousarray(log_fact, dtype=np.float64).reshape(J)
     # Inputs that are not already what the C loop reads in place (1-d int32 transcripts, C-contiguous float64 [J x N] tables) are converted in ONE
     # pass here: the C loop reports one offending video per call, so a list of 256 int64 transcripts used to cost 256 extra crossings.
     for v in range(nv):
@@ -1149,11 +1179,11 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
         t = tabs[v]
         if not (isinstance(t, np.ndarray) and t.dtype == np.float64 and t.ndim == 2 and t.flags.c_contiguous):
             tabs[v] = np.ascontiguousarray(t, dtype=np.float64)
-        if tabs[v].shape != (J, trs[v].shape[0]):
-            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(J, trs[v].shape[0])})")
+        if tabs[v].shape != (rows, trs[v].shape[0]):
+            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(rows, trs[v].shape[0])})")
     start, last_bad = 0, -1
     while True:
-        rc, bad, sum_T, sum_N, out = decode(ptrs, Ts, trs, tabs, forces, C, fs, max_len, fmt, 1 if (C & 3) == 0 else 0, start, lab_ptr,
+        rc, bad, sum_T, sum_N, out = decode(ptrs, Ts, trs, tabs, forces, log_fact, C, fs, max_len, fmt, 1 if (C & 3) == 0 else 0, start, lab_ptr,
                                             fn_addr, _lib.current_stream_raw())
         if bad < 0:
             break
@@ -1179,13 +1209,14 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
                               i64[n_off: n_off + nv + 1], i64[n_off + nv + 1: n_off + 2 * nv + 2], Ts, trs, fs, (lps, tabs))
 
 
-_VIT_FN_ADDR = [0]
+_VIT_FN_ADDR = [0, 0]
 
 
 def _vit_entry(lib):
-    """(pyhost's decode function; the address of mucon_viterbi_decode_host is cached in _VIT_FN_ADDR)"""
+    """(pyhost's decode function; the addresses of mucon_viterbi_decode_host / _host_poisson are cached in _VIT_FN_ADDR)"""
     if not _VIT_FN_ADDR[0]:
         _VIT_FN_ADDR[0] = ctypes.cast(lib.mucon_viterbi_decode_host, ctypes.c_void_p).value
+        _VIT_FN_ADDR[1] = ctypes.cast(lib.mucon_viterbi_decode_host_poisson, ctypes.c_void_p).value
     return _lib.pyhost().mucon_py_viterbi_decode
 
 
@@ -1198,11 +1229,12 @@ class ViterbiDeviceResult:
 
 def viterbi_decode_batch_device(lps: Sequence[torch.Tensor], transcripts: Sequence[np.ndarray], tables: Sequence[np.ndarray],
                                 fs: int, max_len: int, forces: Optional[Sequence[Optional[tuple]]] = None,
-                                label_dtype: Optional[torch.dtype] = torch.uint8) -> ViterbiDeviceResult:
+                                label_dtype: Optional[torch.dtype] = torch.uint8, log_fact: Optional[np.ndarray] = None) -> ViterbiDeviceResult:
     """The all-device decode, mucon_viterbi_decode_batch: nothing comes back to the host and the call does not synchronise --
     the job table, transcripts and length tables go up in ONE pinned copy on the current stream, the two launches (frame scores,
     DP) follow, the results stay in HBM for whatever consumes them there (device metrics, a later gather).  Arguments as
-    viterbi_decode_batch; label_dtype: torch.uint8 (default), torch.int32 or None (segments only)."""
+    viterbi_decode_batch (log_fact given: tables[v] is the [3, N] PoissonModel parameter block and the length scores are built on the device,
+    mucon_viterbi_decode_batch_poisson); label_dtype: torch.uint8 (default), torch.int32 or None (segments only)."""
     lib = _lib.load()
     nv = len(lps)
     if nv == 0:
@@ -1216,16 +1248,17 @@ def viterbi_decode_batch_device(lps: Sequence[torch.Tensor], transcripts: Sequen
     tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
     Ts = np.array([lp.shape[0] for lp in lps], dtype=np.int64)
     Ns = np.array([t.shape[0] for t in trs], dtype=np.int64)
+    R = 3 if log_fact is not None else J       # doubles per transcript state
     for v in range(nv):
-        if tabs[v].shape != (J, Ns[v]) or lps[v].shape[1] != C:
-            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(J, int(Ns[v]))}) / {lps[v].shape[1]} classes (expected {C})")
+        if tabs[v].shape != (R, Ns[v]) or lps[v].shape[1] != C:
+            raise ValueError(f"video {v}: length table {tabs[v].shape} (expected {(R, int(Ns[v]))}) / {lps[v].shape[1]} classes (expected {C})")
     tr_off = np.concatenate(([0], np.cumsum(Ns)))
     lab_off = np.concatenate(([0], np.cumsum(np.maximum(Ts, 1))))
     ws_each = np.array([(lib.mucon_viterbi_job_workspace_bytes(int(T), C, int(N), fs) + 255) & ~255 for T, N in zip(Ts, Ns)], dtype=np.int64)
     ws_off = np.concatenate(([0], np.cumsum(ws_each)))
     jobs = np.zeros(nv, dtype=_VITERBI_JOB_DTYPE)
     jobs["lp"] = [lp.data_ptr() for lp in lps]
-    jobs["tr_off"], jobs["p_off"], jobs["label_off"], jobs["seg_off"], jobs["ws_off"] = tr_off[:-1], tr_off[:-1] * J, lab_off[:-1], tr_off[:-1], ws_off[:-1]
+    jobs["tr_off"], jobs["p_off"], jobs["label_off"], jobs["seg_off"], jobs["ws_off"] = tr_off[:-1], tr_off[:-1] * R, lab_off[:-1], tr_off[:-1], ws_off[:-1]
     jobs["T"], jobs["N"] = Ts, Ns
     if forces is None:
         jobs["force_n"] = jobs["force_j"] = -1
@@ -1235,15 +1268,18 @@ def viterbi_decode_batch_device(lps: Sequence[torch.Tensor], transcripts: Sequen
     # one pinned staging tensor [jobs | length tables f64 | transcripts i32] -> one H2D copy
     sum_N = int(tr_off[-1])
     o_tab = (jobs.nbytes + 15) & ~15
-    o_tr = o_tab + 8 * J * sum_N
+    o_lf = o_tab + 8 * R * sum_N                   # (parameter form: the shared log-factorial row [J] behind the blocks)
+    o_tr = o_lf + (8 * J if log_fact is not None else 0)
     total = (o_tr + 4 * sum_N + 15) & ~15
     stage = torch.empty(total, dtype=torch.uint8, pin_memory=True)
     sn = stage.numpy()
     sn[:jobs.nbytes] = jobs.view(np.uint8)
-    tab_v = sn[o_tab:o_tr].view(np.float64)
+    tab_v = sn[o_tab:o_lf].view(np.float64)
     tr_v = sn[o_tr:o_tr + 4 * sum_N].view(np.int32)
+    if log_fact is not None:
+        sn[o_lf:o_tr].view(np.float64)[:] = np.asarray(log_fact, dtype=np.float64).reshape(J)
     for v in range(nv):
-        tab_v[tr_off[v] * J: tr_off[v + 1] * J] = tabs[v].reshape(-1)
+        tab_v[tr_off[v] * R: tr_off[v + 1] * R] = tabs[v].reshape(-1)
         tr_v[tr_off[v]: tr_off[v + 1]] = trs[v]
     up = stage.to(dev, non_blocking=True)
     r = ViterbiDeviceResult()
@@ -1256,8 +1292,14 @@ def viterbi_decode_batch_device(lps: Sequence[torch.Tensor], transcripts: Sequen
     r.label_off, r.seg_off, r.T, r.N = lab_off, tr_off, Ts, Ns
     r._keep = (lps, up, ws, stage)
     base = up.data_ptr()
-    _lib.check(lib.mucon_viterbi_decode_batch(nv, base, C, fs, max_len, int(Ns.max()), base + o_tr, base + o_tab,
-                                              _lib.ptr(r.labels), fmt, _lib.ptr(r.seg_len), _lib.ptr(r.n_seg), _lib.ptr(r.score),
-                                              _lib.ptr(r.status), _lib.ptr(ws), _lib.current_stream_ptr()),
-               "mucon_viterbi_decode_batch")
+    if log_fact is not None:
+        _lib.check(lib.mucon_viterbi_decode_batch_poisson(nv, base, C, fs, max_len, int(Ns.max()), base + o_tr, base + o_tab, base + o_lf,
+                                                          _lib.ptr(r.labels), fmt, _lib.ptr(r.seg_len), _lib.ptr(r.n_seg), _lib.ptr(r.score),
+                                                          _lib.ptr(r.status), _lib.ptr(ws), _lib.current_stream_ptr()),
+                   "mucon_viterbi_decode_batch_poisson")
+    else:
+        _lib.check(lib.mucon_viterbi_decode_batch(nv, base, C, fs, max_len, int(Ns.max()), base + o_tr, base + o_tab,
+                                                  _lib.ptr(r.labels), fmt, _lib.ptr(r.seg_len), _lib.ptr(r.n_seg), _lib.ptr(r.score),
+                                                  _lib.ptr(r.status), _lib.ptr(ws), _lib.current_stream_ptr()),
+                   "mucon_viterbi_decode_batch")
     return r

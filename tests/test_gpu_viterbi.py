@@ -312,3 +312,137 @@ def test_beam_entry_argument_checks():
     q.T = 20
     assert lib.mucon_viterbi_decode_beam(1, vids, C, FS, MAXLEN, 10, *args) == _lib.OK and st[0] == _lib.VIT_INDEX_ERROR
     del ctypes
+
+
+# ---- (r6, ABI 7) the PoissonModel's length scores built ON THE DEVICE from [3][N] parameters (mucon_viterbi_decode_host_poisson) ----------------
+def _device_rows(params, log_fact, J, fs, max_len):
+    from mucon_amd import _lib
+    lib = _lib.load()
+    N = params.shape[1]
+    p_d, lf_d = torch.from_numpy(np.ascontiguousarray(params)).cuda(), torch.from_numpy(np.ascontiguousarray(log_fact)).cuda()
+    out = torch.full((J, N), 123.0, dtype=torch.float64, device="cuda")
+    _lib.check(lib.mucon_test_vit_rows(_lib.ptr(p_d), _lib.ptr(lf_d), N, J, fs, max_len, _lib.ptr(out), _lib.current_stream_ptr()), "test_vit_rows")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _same_rows(got, want):
+    """bit for bit -- except that a NaN only has to be a NaN: x86 and gfx950 generate different default NaNs (sign bit) for inf - inf / 0 * inf, and
+    no comparison or arg-max of the decode can tell two NaNs apart"""
+    nan = np.isnan(want)
+    return got.shape == want.shape and (np.isnan(got) == nan).all() and (got.view(np.int64)[~nan] == want.view(np.int64)[~nan]).all()
+
+
+def test_device_built_length_rows():
+    """The rows the kernels build -- ((l * ln mu - mu) - logFak_l) - norm as four single IEEE double operations on host-computed ln mu, mu, norm
+    and the shared log-factorial row -- equal, BIT FOR BIT, (a) the rows the reference's own PoissonModel produced for every golden case
+    (tests/golden: `__P`, generated by importing the reference) and (b) PoissonModel.rows_for of this package, incl. a mean length < 0.5 (the
+    reference's norms are NaN, length_model.py:56-58: NaN rows), mu = 0 and inf, and lengths cut off by max_length (-inf, :76-80)."""
+    from mucon_amd.core.viterbi import PoissonModel, poisson_params_for_many
+    n = 0
+    for cs in META["cases"]:
+        nm = cs["name"]
+        if cs["kind"] != "poisson" or f"{nm}__mu" not in Z.files:
+            continue
+        mu, tr, P_ref = Z[f"{nm}__mu"], Z[f"{nm}__transcript"], Z[f"{nm}__P"]
+        pp = poisson_params_for_many([mu], [tr], FS, MAXLEN)[0]
+        got = _device_rows(pp.params, pp.log_fact, MAXLEN // FS, FS, MAXLEN)
+        assert _same_rows(got, P_ref), nm
+        n += 1
+    assert n >= 30
+    rng = np.random.default_rng(5)
+    for fs, max_len in ((30, 2000), (30, 1980), (1, 7), (3, 20), (50, 6400), (10, 500)):
+        mus = [rng.uniform(0.05, 1200.0, C) for _ in range(6)]
+        mus[1][:8] = [0.3, 0.49999, 0.5, 0.0, np.inf, 1e-300, 1999.7, 2.5]
+        trs = [rng.integers(0, C, int(rng.integers(1, 65))) for _ in range(6)]
+        trs[1] = np.arange(16) % 8
+        with np.errstate(all="ignore"):
+            for mu, tr, pp in zip(mus, trs, poisson_params_for_many(mus, trs, fs, max_len)):
+                want = PoissonModel(mu, max_length=max_len).rows_for(tr, fs)
+                got = _device_rows(pp.params, pp.log_fact, max_len // fs, fs, max_len)
+                assert _same_rows(got, want), (fs, max_len)
+                assert _same_rows(pp.rows_for(tr, fs), want)
+        if max_len % fs == 0:
+            assert np.isneginf(got[-1]).all()       # the row at l = max_len
+
+
+def _decode_params(lp, tr, mu, fs=FS, max_len=MAXLEN):
+    from mucon_amd.core.viterbi import SingleTranscriptGrammar, Viterbi, poisson_params_for_many
+    with np.errstate(all="ignore"):
+        pp = poisson_params_for_many([mu], [tr], fs, max_len)[0]
+    v = Viterbi(SingleTranscriptGrammar([int(x) for x in tr], lp.shape[1]), pp, frame_sampling=fs)
+    return v.decode(lp)
+
+
+@pytest.mark.parametrize("cs", [c for c in META["cases"] if c["kind"] == "poisson"], ids=[c["name"] for c in META["cases"] if c["kind"] == "poisson"])
+def test_decode_with_device_built_rows_matches_reference_golden(cs):
+    nm = cs["name"]
+    lp = viterbi_case_inputs(Z, cs)
+    got = _decode_params(torch.from_numpy(lp).cuda(), Z[f"{nm}__transcript"], Z[f"{nm}__mu"])
+    _check(got, Z[f"{nm}__score"][0], Z[f"{nm}__labels"], Z[f"{nm}__seg_label"], Z[f"{nm}__seg_len"])
+
+
+@pytest.mark.parametrize("er", META["errors"], ids=[e["name"] for e in META["errors"]])
+def test_error_behaviour_with_device_built_rows(er):
+    lp = torch.from_numpy(synth.emissions(er["seed"], er["T"], C)).cuda()
+    mu = np.full(C, 300.0)
+    if er["mu_small"]:
+        mu[er["transcript"][0]] = 0.3
+    with pytest.raises({"IndexError": IndexError, "AttributeError": AttributeError}[er["exception"]]):
+        _decode_params(lp, np.asarray(er["transcript"]), mu)
+
+
+def test_batched_decodes_with_device_built_rows_against_oracle():
+    """64 ragged videos (every kernel family: the latency kernels of 1..8 videos, the throughput launches), a NaN-norm state in the middle of
+    a transcript (the host resolves the truncated outcome from the parameters alone), BASELINE config 5 x 12 -- parameter form == the oracle,
+    == the host-table form; and the all-device entry (mucon_viterbi_decode_batch_poisson)."""
+    from mucon_amd import ops
+    from mucon_amd.core.viterbi import PoissonModel, Viterbi, poisson_params_for_many
+    lps, trs, mus, wants = [], [], [], []
+    for i in range(64):
+        T = 200 + int(synth.integers(900 + i, 1, 0, 3800)[0])
+        N = 1 + int(synth.integers(901 + i, 1, 0, 12)[0])
+        N = max(min(N, T // 30), -(-(T // 30) // 66))
+        tr = synth.transcript(902 + i, N, C)
+        lp = synth.emissions(903 + i, T, C, labels=synth.segment_labels(904 + i, T, tr))
+        mu = np.full(C, float(T) / N)
+        if i % 9 == 4 and N >= 3:
+            mu[tr[N // 2]] = 0.3          # NaN norms from that state on
+        wants.append(mu)
+        lps.append(torch.from_numpy(lp).cuda())
+        trs.append([int(x) for x in tr])
+        mus.append(mu)
+    dec = Viterbi(None, None, frame_sampling=FS)
+    with np.errstate(all="ignore"):
+        pps = poisson_params_for_many(mus, trs, FS, MAXLEN)
+        ref = dec.decode_batch(lps, trs, [PoissonModel(mu) for mu in mus], return_exceptions=True)
+    for nv in (64, 1, 3, 8):
+        got = dec.decode_batch(lps[:nv], trs[:nv], pps[:nv], return_exceptions=True)
+        for g, r in zip(got, ref[:nv]):
+            if isinstance(r, Exception):
+                assert type(g) is type(r)
+            else:
+                _check(g, r[0], np.asarray(r[1], dtype=np.int32), np.asarray([s.label for s in r[2]], dtype=np.int32), np.asarray([s.length for s in r[2]], dtype=np.int32))
+    # against the literal oracle on the healthy ones
+    for i in (0, 7, 21, 40, 63):
+        if np.isfinite(mus[i]).all() and (mus[i] >= 0.5).all():
+            lp = lps[i].cpu().numpy()
+            _check(dec.decode_batch([lps[i]], [trs[i]], [pps[i]])[0], *oracle.viterbi_decode(lp, np.asarray(trs[i], dtype=np.int32), mus[i], FS, MAXLEN))
+    # BASELINE config 5 x 12 through both host entries and the all-device entry
+    T, N = 16384, 64
+    tr = synth.transcript(11, N, C)
+    mu = np.ones(C)
+    mu[np.unique(tr)] = T / N
+    lp5 = [torch.from_numpy(synth.emissions(300 + k, T, C, labels=synth.segment_labels(13, T, tr))).cuda() for k in range(12)]
+    pp = poisson_params_for_many([mu] * 12, [tr] * 12, FS, MAXLEN)
+    a = dec.decode_batch(lp5, [tr] * 12, pp)
+    b = dec.decode_batch(lp5, [tr] * 12, [PoissonModel(mu)] * 12)
+    for x, y in zip(a, b):
+        assert f64_bits(x[0]) == f64_bits(y[0]) and x[1] == y[1]
+    _check(a[0], *oracle.viterbi_decode(lp5[0].cpu().numpy(), tr, mu, FS, MAXLEN))
+    P = PoissonModel(mu).rows_for(tr, FS)
+    d_par = ops.viterbi_decode_batch_device(lp5, [tr] * 12, [p.params for p in pp], FS, MAXLEN, log_fact=pp[0].log_fact)
+    d_tab = ops.viterbi_decode_batch_device(lp5, [tr] * 12, [P] * 12, FS, MAXLEN)
+    torch.cuda.synchronize()
+    assert torch.equal(d_par.score.view(torch.int64), d_tab.score.view(torch.int64)) and torch.equal(d_par.seg_len, d_tab.seg_len)
+    assert torch.equal(d_par.labels, d_tab.labels) and torch.equal(d_par.status, d_tab.status)

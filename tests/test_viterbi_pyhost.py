@@ -32,6 +32,8 @@ class FakeTensor:
 
 PROTO = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.POINTER(_lib.ViterbiVideo), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
+PROTO_POISSON = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.POINTER(_lib.ViterbiVideo), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
 
 
 @pytest.fixture
@@ -40,7 +42,12 @@ def fake_decode(monkeypatch):
     (the last one takes the remainder), score = -(v + 1), labels written in the asked format."""
     seen = {}
 
-    def decode(nv, vids, Cc, fs, max_len, score, n_seg, status, labels, fmt, seg, stream):
+    def decode_poisson(nv, vids, log_fact, Cc, fs, max_len, score, n_seg, status, labels, fmt, seg, stream):
+        seen["log_fact"] = np.ctypeslib.as_array((ctypes.c_double * (max_len // fs)).from_address(log_fact)).copy()
+        seen["log_fact_ptr"] = log_fact
+        return decode(nv, vids, Cc, fs, max_len, score, n_seg, status, labels, fmt, seg, stream, rows=3)
+
+    def decode(nv, vids, Cc, fs, max_len, score, n_seg, status, labels, fmt, seg, stream, rows=J):
         seen.update(nv=nv, C=Cc, fs=fs, max_len=max_len, fmt=fmt, records=[], labels_null=not labels)
         sc = (ctypes.c_double * nv).from_address(score)
         ns = (ctypes.c_int32 * nv).from_address(n_seg)
@@ -49,7 +56,7 @@ def fake_decode(monkeypatch):
         for v in range(nv):
             q = vids[v]
             tr = np.ctypeslib.as_array((ctypes.c_int32 * q.N).from_address(q.transcript)).copy()
-            tab = np.ctypeslib.as_array((ctypes.c_double * (J * q.N)).from_address(q.table)).reshape(J, q.N).copy()
+            tab = np.ctypeslib.as_array((ctypes.c_double * (rows * q.N)).from_address(q.table)).reshape(rows, q.N).copy()
             seen["records"].append(dict(lp=q.lp, T=q.T, N=q.N, tr=tr, tab=tab, tr_ptr=q.transcript, tab_ptr=q.table, force=(q.force_n, q.force_j)))
             sg = (ctypes.c_int32 * q.N).from_address(seg + 4 * seg_off)
             if q.T < fs:
@@ -72,12 +79,14 @@ def fake_decode(monkeypatch):
         return 0
 
     cb = PROTO(decode)
+    cb_p = PROTO_POISSON(decode_poisson)
 
     class Lib:
         mucon_viterbi_decode_host = cb
+        mucon_viterbi_decode_host_poisson = cb_p
 
     monkeypatch.setattr(_lib, "load", lambda *a, **k: Lib)
-    monkeypatch.setattr(ops, "_VIT_FN_ADDR", [0])
+    monkeypatch.setattr(ops, "_VIT_FN_ADDR", [0, 0])
 
     monkeypatch.setattr(_lib, "current_stream_raw", lambda: 0x1234)
     return seen
@@ -186,7 +195,8 @@ def test_other_dtypes_and_shapes_are_converted_in_one_pass_and_one_crossing(fake
     calls = []
     real = _lib.pyhost().mucon_py_viterbi_decode
     monkeypatch.setattr(ops, "_vit_entry", lambda lib: (ops._VIT_FN_ADDR.__setitem__(0, ctypes.cast(lib.mucon_viterbi_decode_host, ctypes.c_void_p).value),
-                                                        lambda *a: (calls.append(1), real(*a))[1])[1])
+                                                        ops._VIT_FN_ADDR.__setitem__(1, ctypes.cast(lib.mucon_viterbi_decode_host_poisson, ctypes.c_void_p).value),
+                                                        lambda *a: (calls.append(1), real(*a))[1])[2])
     res = ops.viterbi_decode_batch(lps, trs, tabs, FS, MAXLEN, labels="lazy")
     assert len(calls) == 1 and len(res) == 6
     for v, r in enumerate(fake_decode["records"]):
@@ -195,3 +205,22 @@ def test_other_dtypes_and_shapes_are_converted_in_one_pass_and_one_crossing(fake
     tabs[5] = tabs[5][:, :-1] if tabs[5].shape[1] > 1 else np.zeros((J, 3))
     with pytest.raises(ValueError, match="length table"):
         ops.viterbi_decode_batch(lps, trs, tabs, FS, MAXLEN, labels="lazy")
+
+
+@pytest.mark.parametrize("nv", [1, 9])
+def test_poisson_parameter_form_hands_over_parameter_blocks_and_the_shared_row(fake_decode, nv):
+    """(ABI 7) log_fact given: the records point at the callers' [3, N] parameter blocks (not copied), the entry called is
+    mucon_viterbi_decode_host_poisson and it receives the shared log-factorial row; a [J, N] table is refused then."""
+    from mucon_amd.core.viterbi import poisson_params_for_many
+    lps, trs, _ = _inputs(nv, seed=4)
+    rng = np.random.default_rng(9)
+    pps = poisson_params_for_many([rng.uniform(1.0, 500.0, C) for _ in range(nv)], trs, FS, MAXLEN)
+    lf = pps[0].log_fact
+    res = ops.viterbi_decode_batch(lps, trs, [p.params for p in pps], FS, MAXLEN, labels="lazy", log_fact=lf)
+    assert len(res) == nv and fake_decode["log_fact_ptr"] == lf.ctypes.data
+    np.testing.assert_array_equal(fake_decode["log_fact"], lf)
+    for v, r in enumerate(fake_decode["records"]):
+        assert r["tab_ptr"] == pps[v].params.ctypes.data and r["tab"].shape == (3, len(trs[v]))
+        np.testing.assert_array_equal(r["tab"], pps[v].params)
+    with pytest.raises(ValueError, match="length table"):
+        ops.viterbi_decode_batch(lps, trs, [p.rows_for(t, FS) for p, t in zip(pps, trs)], FS, MAXLEN, labels="lazy", log_fact=lf)
