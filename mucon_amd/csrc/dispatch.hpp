@@ -15,7 +15,7 @@ constexpr int kTnTarget = 256;          // ... and per stand-alone launch (mucon
 constexpr int kTnMcCap = 2048;          // longest time chunk of an f32 weight-gradient workgroup
 constexpr int kTnBatchKs = 2;           // the f32 batched launch runs 8-wave workgroups (waves 4-7: second half of every 32-step tile)
 constexpr int kTnKs = 0;                // stand-alone f32 launches: 0 = k-split 2 for layer jobs, 1 for first_conv's
-constexpr int kTsMaxWorkgroups = 512;    // static-runs launch: persistent workgroups = min(CUs, this); the slab arena is sized for it
+constexpr int kTsMaxWorkgroups = 256;    // static-runs launch: persistent workgroups = min(CUs, this); the slab arena is sized for it
 constexpr int kReduceLanes = 4;         // slab lanes per workgroup of the batched slab reduction
 
 // ---- NT / two-stage layer kernels ---------------------------------------------------------------------------------------

@@ -293,12 +293,79 @@ static hipError_t launch_tn(const TnParams &p, int B, hipStream_t s) {
 //   mode 0: out[row*ncols + col]      mode 1 (conv k=3 weight, ncols = 384): col = tap*128 + i ->
 //   out[(row*128 + i)*3 + tap], the reference's [out][in][k] layout
 // ------------------------------------------------------------------------------------------
-//   colblk >= 0 (round 6: the slabs of the static-runs weight-gradient launch, gemm_tn_split.hpp): the job's columns lie in the 256-column
-//   blocks colblk, colblk + 1, ... of the launch's column table; block c owns cols.n[c] partial tiles [128][256] from slab cols.slab0[c] of the
-//   arena on (the number differs from column to column: one per workgroup whose share touched it); a bias job reads the 256-float bias
-//   partials of ONE column the same way
+//   sched >= 0 (round 6: the partial tiles of the static-runs weight-gradient launch, gemm_tn_split.hpp): the job's columns lie in the 256-column
+//   blocks of job `sched` of the launch's line of work (TsLine); block cb of group g was visited by the shares floor(unit start / S) ..
+//   floor((unit end - 1) / S), each of which left one partial tile [128][256] (a bias job: 256 floats); a column's visits take consecutive
+//   slabs (TsColTab: first slab and count per column)
 constexpr int REDUCE_MAX_JOBS = 56;
-constexpr int REDUCE_MAX_COLS = 48;     // = TS_MAX_COLS
+
+// ---- the line of work of the static-runs launch (gemm_tn_split.hpp), shared with the reduction --------------------------------------------
+// A job's work is cut into UNITS = (group g, column c): a group is a stretch of time -- `vg` whole videos, or for a job without taps over
+// back-to-back videos (flat: first_conv, last_conv) a panel of `gt` 32-step tiles of the batch taken as one long video -- and a column is a
+// pair of 128-column chunks kc2.  The line runs job by job, inside a job group by group, inside a group column by column: the columns of a
+// group read the SAME gradient rows (and, for the taps of a residual layer, the same input rows), so the shares that work on them at the same time
+// sit next to each other on the line -- and on one XCD (ts_share_of: eight consecutive shares per XCD), where the second reader hits the L2.
+// (Column-major lines -- a column through all videos, then the next -- re-read every shared operand from memory: 800 MB of HBM traffic per
+// launch for 531 MB of operands, profiles/r06_traffic.json first cut.)
+struct TsJobLine {
+    uint32_t pos0;          // start of the job on the line (cost units)
+    uint32_t ngroups;
+    uint32_t gcost;         // cost of a group = (ncols - 1) * ucost + ucost_last
+    uint32_t ucost;         // cost of a unit of a plain column = nvid * (ovh + gt * tc)
+    uint32_t ucost_last;    // ... of the job's last column (a residual layer's: two gradient images, dropout replay)
+    uint32_t gt;            // tiles per video of a unit (flat: per panel)
+    uint32_t tiles;         // flat: tiles of the whole batch (the last panel may be short)
+    uint16_t tc, tc_last;   // cost of a 32-step tile
+    uint8_t ncols, flat, vg, aligned;   // aligned: every unit of the job is exactly one share (gemm_tn_split.hpp: ts_make_schedule)
+};
+constexpr int TS_MAX_JOBS = 16;   // = TN_MAX_BATCH
+constexpr int TS_MAX_NCOLS = 16;  // columns of a job (first_conv at D = 2048: 8)
+// where the partial tiles of a column lie: its visits (group by group, inside a group share by share) take consecutive slabs from slab0 on
+struct TsColTab {
+    uint16_t slab0[TS_MAX_JOBS][TS_MAX_NCOLS], n[TS_MAX_JOBS][TS_MAX_NCOLS];
+    float *slabs, *bias;            // arenas: [slab][128][256], [slab][256]
+};
+struct TsLine {
+    TsJobLine j[TS_MAX_JOBS + 1];   // [njobs].pos0 = W: the end of the line; unused: 0xffffffff
+    uint32_t W, S, ovh;             // length of the line, share per workgroup, fixed cost of entering a video
+    int njobs, G;
+    TsColTab ct;
+};
+// share -> workgroup: eight consecutive shares on one XCD (workgroups are dealt to the 8 XCDs round-robin: block b and b + 8 share one --
+// observed, used for speed only), while every run of 64 workgroups still covers 64 consecutive shares
+__device__ __host__ __forceinline__ uint32_t ts_share_of(const uint32_t w, const uint32_t G) {
+    if (w >= (G & ~63u)) return w;
+    return (w & ~63u) | ((w & 7u) << 3) | ((w >> 3) & 7u);
+}
+// unit (g, c) of a job: [start, end) on the line
+__device__ __host__ __forceinline__ void ts_unit_span(const TsJobLine &J, const uint32_t g, const uint32_t c, uint32_t &u0, uint32_t &u1) {
+    u0 = J.pos0 + g * J.gcost + c * J.ucost;
+    u1 = u0 + (c + 1 == J.ncols ? J.ucost_last : J.ucost);
+}
+// visits of unit (g, c): the shares floor(start / S) .. floor((end - 1) / S)
+__device__ __host__ __forceinline__ void ts_unit_visitors(const TsJobLine &J, const uint32_t S, const uint32_t g, const uint32_t c, uint32_t &wf, uint32_t &wl) {
+    uint32_t u0, u1;
+    ts_unit_span(J, g, c, u0, u1);
+    wf = u0 / S;
+    wl = (u1 - 1) / S;
+}
+// the slab share `sh` leaves for unit (g, c) of job ji: the column's visits in line order (an aligned job: one visit per group)
+__device__ __host__ __forceinline__ uint32_t ts_slab_index(const TsLine &ln, const int ji, const uint32_t g, const uint32_t c, const uint32_t sh) {
+    const TsJobLine &J = ln.j[ji];
+    uint32_t v = g;
+    if (!J.aligned) {
+        v = 0;
+        uint32_t wf, wl;
+        for (uint32_t gg = 0; gg < g; ++gg) {
+            ts_unit_visitors(J, ln.S, gg, c, wf, wl);
+            v += wl - wf + 1;
+        }
+        ts_unit_visitors(J, ln.S, g, c, wf, wl);
+        v += sh - wf;
+    }
+    return (uint32_t)ln.ct.slab0[ji][c] + v;
+}
+
 struct ReduceJob {
     const float *slabs;
     float *out;
@@ -307,18 +374,15 @@ struct ReduceJob {
     int block0;      // first workgroup of this job
     int8_t mode;
     int8_t vec;      // 1: ncols, coff, ld, slab_stride and n_elems are multiples of 4 (float4 path)
-    int8_t colblk;   // -1: slabs / nslabs / slab_stride / ld above
-    int8_t isbias;
-};
-struct ReduceCols {
-    uint16_t slab0[REDUCE_MAX_COLS], n[REDUCE_MAX_COLS];
-    const float *slabs, *bias;
+    int8_t sched;    // -1: slabs / nslabs / slab_stride / ld above; else the job of `line`
+    int8_t isbias;   // ... the 256-float bias partials of column `bcol`
+    int8_t bcol;
 };
 struct ReduceBatch {
     ReduceJob j[REDUCE_MAX_JOBS];
     int first_block[REDUCE_MAX_JOBS];   // j[i].block0 once more, contiguous (unused entries: INT_MAX): see reduce_batch_kernel
     int njobs, nblocks;
-    ReduceCols cols;
+    TsColTab ct;                        // the static-runs launch's columns (jobs with sched >= 0)
 };
 
 template <int G>
@@ -355,11 +419,11 @@ __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch 
         const float *p = J.slabs + (long)row * J.ld + J.coff + col;
         int nslabs = J.nslabs;
         long stride = J.slab_stride;
-        if (J.colblk >= 0) {   // the static-runs launch's slabs: this lane's 256-column block says where they are and how many
-            const int gcol = J.coff + col, c = J.colblk + (J.isbias ? 0 : gcol >> 8);
-            nslabs = rb.cols.n[c];
+        if (J.sched >= 0) {   // the static-runs launch's partial tiles: this lane's 256-column block of the job says where they are and how many
+            const int gcol = J.coff + col, cb = J.isbias ? (int)J.bcol : gcol >> 8;
+            nslabs = rb.ct.n[J.sched][cb];
             stride = J.isbias ? 256 : 128 * 256;
-            p = (J.isbias ? rb.cols.bias + gcol : rb.cols.slabs + (long)row * 256 + (gcol & 255)) + (long)rb.cols.slab0[c] * stride;
+            p = (J.isbias ? rb.ct.bias + gcol : rb.ct.slabs + (long)row * 256 + (gcol & 255)) + (long)rb.ct.slab0[J.sched][cb] * stride;
         }
         int i = g;
         if (G >= 16) {   // few deep jobs (the y-head's 256 slabs): sixteen loads per lane in flight -- the pass is its chain of round trips

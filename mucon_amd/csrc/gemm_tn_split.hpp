@@ -802,105 +802,110 @@ __global__ __launch_bounds__(512) void ts_batched_kernel(const TnBatch tb) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // STATIC RUNS (round 6; the batched launch of encoder_bwd): every weight gradient of the pass on G persistent workgroups, each of which
-// takes ONE contiguous share of the pass's work and keeps its accumulators in registers for as long as it stays inside a column.
+// takes ONE contiguous share of the pass's work and keeps its accumulators in registers for as long as it stays inside a unit.
 //
 // Round 5's persistent launch handed out (column, <= 512-step chunk) items by ticket: 720 items, each with its own 128 KB partial
 // tile -- 96 MB of slabs written and read back per step (HBM traffic 1.35 x the algorithmic bytes, a 20-us reduction pass behind the launch),
 // and every item paid ~6.5 us of prologue / slab epilogue (2.8 items per CU).  Longer chunks lose under a ticket (it balances whole
-// items: profiles/r06_same_box_abs.txt section 1).  Here the pass is ONE line of work: the columns (job, kc2) in launch order, inside a
-// column video after video, tile after tile, priced in cost units (a 32-step tile of the column's kind + a fixed cost per video a run
-// enters); workgroup w takes [w S, (w + 1) S) of it, S = ceil(W / G) ("stream-K" over the reduction dimension).  A share is cut into
-// runs at video ends (the taps' zero padding and the chunk masks are per video) and into columns where the column changes; one partial
-// tile is written per (workgroup, column): G + columns - 1 slabs at most (290 x 128 KB = 37 MB at the bench shape).  The schedule is a pure
-// function of the job shapes and G -- no ticket, no atomics: the same sums in the same order run after run.
+// items: profiles/r06_same_box_abs.txt section 1).  Here the pass is ONE line of work (gemm_tn.hpp: TsLine -- jobs in launch order, a job's
+// groups of videos / panels, a group's columns), priced in cost units (a 32-step tile of the column's kind + a fixed cost per video a run
+// enters); share s is [s S, (s + 1) S) of it, S = ceil(W / G) ("stream-K" over the reduction dimension), run by workgroup ts_share_of^-1(s).
+// A share is cut into runs at video ends (the taps' zero padding and the chunk masks are per video) and into units where the column or the
+// group changes; one partial tile is written per (share, unit).  The schedule is a pure function of the job shapes and G -- no ticket, no
+// atomics: the same sums in the same order run after run.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TS_MAX_COLS = 48;
-struct TsCol {
-    uint32_t pos0;      // where the column starts on the line of work (cost units); unused entries: 0xffffffff
-    uint32_t vcost;     // cost of one video of the column = ovh + tiles per video * tcost
-    uint16_t tcost;     // cost of a 32-step tile
-    uint16_t wfirst;    // first workgroup whose share touches the column: workgroup w writes the column's slab w - wfirst
-    uint16_t slab0;     // index of the column's first slab in the launch's slab arena (units of 128 x 256 floats; bias partials: of 256 floats)
-    uint8_t job;
-    uint8_t kc2;        // bit 7: FLAT -- a job without taps over contiguous videos (first_conv, last_conv) is ONE video of B * Trows rows: no run ends inside its columns
-};
-struct TsRuns {
-    TsCol c[TS_MAX_COLS + 1];   // [ncols]: the end of the line (pos0 = W)
-    uint32_t W, S, ovh;         // length of the line, share per workgroup, fixed cost of entering a video
-    int ncols, B;
-    float *slabs, *bias;        // arenas: [slab][128][256], [slab][256]
-};
-// position inside a column -> tile index on the column's own line (video-major): the SAME function gives a share's end and the next share's start
-__device__ __host__ __forceinline__ uint32_t ts_qmap(const TsCol &C, const uint32_t ovh, const uint32_t tv, const uint32_t off) {
-    const uint32_t b = off / C.vcost, rem = off - b * C.vcost;
-    const uint32_t t = rem <= ovh ? 0u : (rem - ovh) / C.tcost;
+// position inside a unit -> tile index on the unit's own line (video-major): the SAME function gives a share's end and the next share's start
+__device__ __host__ __forceinline__ uint32_t ts_qmap(const uint32_t vcost, const uint32_t tcost, const uint32_t ovh, const uint32_t tv, const uint32_t off) {
+    const uint32_t b = off / vcost, rem = off - b * vcost;
+    const uint32_t t = rem <= ovh ? 0u : (rem - ovh) / tcost;
     return b * tv + (t < tv ? t : tv);
 }
-__global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const TsRuns rs) {
+__global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const TsLine ln) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ts_smem[];
     const uint32_t w = blockIdx.x;
-    const uint32_t lo = min(w * rs.S, rs.W), hi = min(lo + rs.S, rs.W);
+    const uint32_t sh = ts_share_of(w, (uint32_t)ln.G);
+    const uint32_t lo = min(sh * ln.S, ln.W), hi = min(lo + ln.S, ln.W);
     if (lo >= hi) return;
 #if CLK_STAMP
     const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: a workgroup's whole life, g_clk_wg; tools/ts_runs_times.py)
 #endif
-    int col = -1;   // the column `lo` lies in: all starts compared at once (independent scalar loads)
+    int ji = -1;   // the job `lo` lies in: all starts compared at once (independent scalar loads)
 #pragma unroll
-    for (int k = 0; k < TS_MAX_COLS; ++k) col += lo >= rs.c[k].pos0 ? 1 : 0;
-    for (; col < rs.ncols && rs.c[col].pos0 < hi; ++col) {
-        const TsCol &C = rs.c[col];
-        const TnJob &job = tb.j[C.job];
-        const int kc2 = C.kc2 & 127;
-        const bool flat = (C.kc2 & 128) != 0;
-        const int rows = flat ? rs.B * job.p.Trows : job.p.Trows;
-        const uint32_t tv = (uint32_t)(rows + 31) >> 5, end = rs.c[col + 1].pos0;
-        const uint32_t q0 = lo > C.pos0 ? ts_qmap(C, rs.ovh, tv, lo - C.pos0) : 0u;
-        const uint32_t q1 = hi >= end ? (flat ? 1u : (uint32_t)rs.B) * tv : ts_qmap(C, rs.ovh, tv, hi - C.pos0);
-        // (a share that touches the column without holding one of its tiles still writes its -- zero -- slab: the reduction reads wfirst .. wlast)
-        const long si = (long)C.slab0 + (long)(w - C.wfirst);
-        float *slab = rs.slabs + si * (128 * 256);
-        float *bias = rs.bias ? rs.bias + si * 256 : nullptr;
-        using T = std::true_type;
-        using F = std::false_type;
-        if (flat && tv >= 8 && tb.st_min_steps > 0 && !job.x0_act) {
-            // ONE run on the staggered schedule, the accumulators zeroed in front of it: with accumulators that are alive through the body's
-            // prologue (a second run of a column) the compiler spilled the X tiles in flight -- loads waited for and parked in scratch inside
-            // the tile loop, 277 us per share instead of 168 (tools/ts_runs_times.py; the schedule prices these columns at the staggered tile cost)
-            TnParams pf = job.p;
-            pf.Trows = pf.Tx = rows;
-            f32x16 acc[4];
-            float bsum[2];
-            ts_zero(acc, bsum);
-            if (q0 < q1) ts_body_st<false, false>(pf, kc2, 0, (int)q0 * 32, min((int)q1 * 32, rows), false, job.x0_act != 0, ts_smem, (int)w, acc, bsum);
-            ts_flush<false>(pf, kc2, false, ts_smem, acc, bsum, slab, 256, bias);
+    for (int k = 0; k < TS_MAX_JOBS; ++k) ji += lo >= ln.j[k].pos0 ? 1 : 0;
+    uint32_t pos = lo;
+    while (pos < hi) {
+        if (pos >= ln.j[ji + 1].pos0) {
+            ++ji;
             continue;
         }
-        // the lock-step body, chosen per COLUMN, each choice its own zero / runs / write-out sequence (one loop around all bodies kept the
-        // accumulators alive across the ones that do not run: 162 spilled registers)
-        auto column = [&](auto TWO, auto DRP) {
-            constexpr bool TWO_G = decltype(TWO)::value, DROP = decltype(DRP)::value;
+        const TsJobLine &L = ln.j[ji];
+        const TnJob &job = tb.j[ji];
+        const uint32_t off = pos - L.pos0, g = off / L.gcost, r = off - g * L.gcost;
+        const uint32_t col = min(r / L.ucost, (uint32_t)L.ncols - 1u);
+        uint32_t u0, u1;
+        ts_unit_span(L, g, col, u0, u1);
+        const bool lastc = col + 1 == L.ncols;
+        const uint32_t tc = lastc ? L.tc_last : L.tc, vcost = ln.ovh + L.gt * tc;
+        const uint32_t nvid = L.flat ? 1u : (uint32_t)L.vg;
+        // tiles of the unit on its own line: [q0, q1) of nvid x gt (a flat job's last panel may be short: its missing tiles are priced, not run).
+        // An ALIGNED unit (pad) is exactly one share: whoever holds any of it holds all of it.
+        const uint32_t q0 = (pos > u0 && !L.aligned) ? ts_qmap(vcost, tc, ln.ovh, L.gt, pos - u0) : 0u;
+        const uint32_t q1 = (hi >= u1 || L.aligned) ? nvid * L.gt : ts_qmap(vcost, tc, ln.ovh, L.gt, hi - u0);
+        // (a share that touches the unit without holding one of its tiles still writes its -- zero -- slab: the reduction reads every visitor's)
+        const long si = (long)ts_slab_index(ln, ji, g, col, sh);
+        float *slab = ln.ct.slabs + si * (128 * 256);
+        float *bias = ln.ct.bias ? ln.ct.bias + si * 256 : nullptr;
+        const int kc2 = (int)col;
+        using T = std::true_type;
+        using F = std::false_type;
+        if (L.flat) {
+            // ONE run: the batch as one long video (no taps: no padding at the video ends), rows [panel start + q0, + q1)
+            const int flat_rows = (int)L.vg * job.p.Trows;                   // (vg = B for a flat job)
+            const uint32_t t0 = g * L.gt + q0, t1 = min(g * L.gt + q1, L.tiles);
             TnParams pf = job.p;
-            if (flat) pf.Trows = pf.Tx = rows;
+            pf.Trows = pf.Tx = flat_rows;
             f32x16 acc[4];
             float bsum[2];
             ts_zero(acc, bsum);
-            for (uint32_t q = q0; q < q1;) {
-                const uint32_t b = q / tv, t0 = q - b * tv, t1 = min(tv, t0 + (q1 - q));
-                ts_body<TWO_G, DROP>(pf, kc2, (int)b, (int)t0 * 32, min((int)t1 * 32, rows), job.dual != 0, !TWO_G && job.x0_act != 0, ts_smem, (int)w, acc, bsum);
-                q += t1 - t0;
+            if (t0 < t1) {
+                // the staggered schedule with the accumulators zeroed in front of it: with accumulators that are alive through the body's prologue (a
+                // second run of a unit) the compiler spilled the X tiles in flight -- loads waited for and parked in scratch inside the tile
+                // loop, 277 us per share instead of 168 (tools/ts_runs_times.py; the schedule prices these columns at the staggered tile cost)
+                if (t1 - t0 >= 8 && tb.st_min_steps > 0 && !job.x0_act)
+                    ts_body_st<false, false>(pf, kc2, 0, (int)t0 * 32, min((int)t1 * 32, flat_rows), false, false, ts_smem, (int)w, acc, bsum);
+                else
+                    ts_body<false, false>(pf, kc2, 0, (int)t0 * 32, min((int)t1 * 32, flat_rows), false, job.x0_act != 0, ts_smem, (int)w, acc, bsum);
             }
-            ts_flush<TWO_G>(pf, kc2, job.dual != 0, ts_smem, acc, bsum, slab, 256, bias);
-        };
-        if (job.dual && 2 * kc2 + 1 == job.p.nk0) {
-            if (job.p.drop.thresh) column(T{}, T{});
-            else column(T{}, F{});
-        } else column(F{}, F{});
+            ts_flush<false>(pf, kc2, false, ts_smem, acc, bsum, slab, 256, bias);
+        } else {
+            // the lock-step body, chosen per unit, each choice its own zero / runs / write-out sequence (one loop around all bodies kept the
+            // accumulators alive across the ones that do not run: 162 spilled registers)
+            const uint32_t tv = L.gt, b0 = g * L.vg;
+            auto unit = [&](auto TWO, auto DRP) {
+                constexpr bool TWO_G = decltype(TWO)::value, DROP = decltype(DRP)::value;
+                f32x16 acc[4];
+                float bsum[2];
+                ts_zero(acc, bsum);
+                for (uint32_t q = q0; q < q1;) {
+                    const uint32_t b = q / tv, t0 = q - b * tv, t1 = min(tv, t0 + (q1 - q));
+                    ts_body<TWO_G, DROP>(job.p, kc2, (int)(b0 + b), (int)t0 * 32, min((int)t1 * 32, job.p.Trows), job.dual != 0, !TWO_G && job.x0_act != 0,
+                                         ts_smem, (int)w, acc, bsum);
+                    q += t1 - t0;
+                }
+                ts_flush<TWO_G>(job.p, kc2, job.dual != 0, ts_smem, acc, bsum, slab, 256, bias);
+            };
+            if (job.dual && 2 * kc2 + 1 == job.p.nk0) {
+                if (job.p.drop.thresh) unit(T{}, T{});
+                else unit(T{}, F{});
+            } else unit(F{}, F{});
+        }
+        pos = u1;
     }
 #if CLK_STAMP
     __syncthreads();
-    if (threadIdx.x == 0 && w < 4096) {
-        g_clk_wg[w][0] = wg_t0_;
-        g_clk_wg[w][1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && sh < 4096) {
+        g_clk_wg[sh][0] = wg_t0_;
+        g_clk_wg[sh][1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -910,63 +915,118 @@ __global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const Ts
 // (prologue: one memory round trip + the first image + the first X tile through LDS) -- the least-squares fit of the 256 shares' lives at the bench
 // shape (tools/ts_runs_times.py, profiles/r06_weight_gradient_runs.txt: 2.14 / 2.32 / 2.97 us per tile, 3.4 us per run)
 extern int g_ts_cost[4];
-// The line of work of a queued batch for G workgroups.  Host only; the reduction's column table (gemm_tn.hpp: ReduceCols) is filled from the same numbers.
+extern int g_ts_group_rows;   // a residual layer's groups are single videos when a video has at least this many rows, else the whole batch (MUCON_TS_GROUP_ROWS)
+// The line of work of a queued batch for at most maxG workgroups.  Host only.
 struct TsSchedule {
-    TsRuns rs;
-    int G;
-    int nslabs;                    // slabs the launch writes
-    int col0[TN_MAX_BATCH];        // first column of job i (launch order)
-    int nslab_col[TS_MAX_COLS];    // slabs of a column
+    TsLine ln;
+    int nslabs;   // slabs the launch writes
 };
 static bool ts_make_schedule(const TnBatch &lb, int B, int maxG, TsSchedule &sc) {
-    TsRuns &rs = sc.rs;
-    memset(&rs, 0, sizeof(rs));
-    rs.ovh = (uint32_t)g_ts_cost[3];
-    rs.B = B;
-    int nc = 0;
-    uint64_t pos = 0, tiles = 0;
+    TsLine &ln = sc.ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.ovh = (uint32_t)g_ts_cost[3];
+    ln.njobs = lb.njobs;
+    if (lb.njobs > TS_MAX_JOBS || B > 255) return false;
+    // pass 1: tiles and tile costs (the panel length of the flat jobs wants the share, the share wants the line: estimated without the run overheads)
+    uint64_t tiles = 0, work = 0;
     for (int i = 0; i < lb.njobs; ++i) {
         const TnJob &job = lb.j[i];
         const int nkc2 = (job.nkc + 1) >> 1;
+        if (nkc2 > 255) return false;
+        TsJobLine &L = ln.j[i];
         // no taps, one gradient set, videos back to back in both operands: the batch is one video of B * Trows rows
-        const bool flat = !job.dual && job.p.taps != 3 && job.p.Tx == job.p.Trows && job.p.x_bstride == (long)job.p.Tx * job.p.ldx &&
-                          (long)B * job.p.Trows < (1L << 30) && nkc2 < 128;
-        const uint32_t nvid = flat ? 1u : (uint32_t)B;
-        const uint32_t tv = (uint32_t)((flat ? B : 1) * (long)job.p.Trows + 31) >> 5;
-        sc.col0[i] = nc;
-        for (int k = 0; k < nkc2; ++k) {
-            if (nc >= TS_MAX_COLS || k >= 128) return false;
-            const bool two_g = job.dual && 2 * k + 1 == job.p.nk0;
-            TsCol &C = rs.c[nc++];
-            C.job = (uint8_t)i;
-            C.kc2 = (uint8_t)(k | (flat ? 128 : 0));
-            // (a column with the non-linearity on its X operand -- last_conv's -- masks every tile: 2.7 us per tile on either body, priced like a two-image column)
-            C.tcost = (uint16_t)((two_g || job.x0_act) ? g_ts_cost[2] : (flat && tv >= 8 && lb.st_min_steps > 0) ? g_ts_cost[0] : g_ts_cost[1]);
-            C.vcost = rs.ovh + tv * C.tcost;
-            C.pos0 = (uint32_t)pos;
-            pos += (uint64_t)nvid * C.vcost;
-            tiles += (uint64_t)nvid * tv;
-            if (pos >= 0xf0000000ull) return false;   // (33 M frames x 16 columns fit; anything longer takes the per-item launch)
-        }
+        L.flat = (!job.dual && job.p.taps != 3 && job.p.Tx == job.p.Trows && job.p.x_bstride == (long)job.p.Tx * job.p.ldx &&
+                  (long)B * job.p.Trows < (1L << 30)) ? 1 : 0;
+        L.ncols = (uint8_t)nkc2;
+        const uint32_t tv = (uint32_t)(((L.flat ? B : 1) * (long)job.p.Trows + 31) >> 5);
+        L.tiles = tv;
+        // (a column with the non-linearity on its X operand -- last_conv's -- masks every tile: 2.7 us per tile on either body, priced like a two-image column)
+        const bool stag = L.flat && tv >= 8 && lb.st_min_steps > 0 && !job.x0_act;
+        L.tc = (uint16_t)(job.x0_act ? g_ts_cost[2] : stag ? g_ts_cost[0] : g_ts_cost[1]);
+        L.tc_last = (uint16_t)(job.dual ? g_ts_cost[2] : L.tc);
+        const uint64_t nv = L.flat ? 1 : B;
+        tiles += nv * tv * nkc2;
+        work += nv * tv * ((uint64_t)(nkc2 - 1) * L.tc + L.tc_last);
     }
-    rs.ncols = nc;
-    rs.W = (uint32_t)pos;
-    for (int k = nc; k <= TS_MAX_COLS; ++k) rs.c[k].pos0 = k == nc ? rs.W : 0xffffffffu;
     // at least four tiles per share (a share pays ~6 us of prologue and write-out whatever its length)
     int G = (int)std::min<uint64_t>((uint64_t)maxG, std::max<uint64_t>(1, tiles / 4));
-    if (G > 65535) G = 65535;
-    rs.S = (uint32_t)((pos + G - 1) / G);
-    sc.G = G;
-    int ns = 0;
-    for (int k = 0; k < nc; ++k) {
-        const uint32_t wf = rs.c[k].pos0 / rs.S, wl = (rs.c[k + 1].pos0 - 1) / rs.S;
-        rs.c[k].wfirst = (uint16_t)wf;
-        rs.c[k].slab0 = (uint16_t)ns;
-        sc.nslab_col[k] = (int)(wl - wf + 1);
-        ns += sc.nslab_col[k];
-        if (ns > 65535) return false;
+    // pass 2: groups, unit costs, positions.  A multi-column flat job at the head of the line (first_conv: 8 columns that all read the same gradient
+    // rows, 128 B of them per 2 KB of tape) is ALIGNED: its units are exactly one share each -- panel p, column c = share p * ncols + c -- so the
+    // columns of a panel start together on neighbouring shares of one XCD (ts_share_of) and walk the panel's gradient rows in step: one fetch
+    // serves all of them.  (Units that drift against the shares desynchronise within a few panels: a share's rows are ~1.2 MB, an XCD's L2 turns over
+    // every ~10 us.)  The share S is then what the REST of the line needs: S = rest / (G - aligned shares), and an aligned unit is PRICED at S.
+    uint64_t aligned_shares = 0, aligned_work = 0;
+    for (int i = 0; i < lb.njobs; ++i) {
+        TsJobLine &L = ln.j[i];
+        if (i == 0 && L.flat && L.ncols > 1 && G >= 64) {
+            const uint64_t w_i = (uint64_t)L.tiles * L.ncols * L.tc;
+            uint64_t panels = (w_i * G / std::max<uint64_t>(work, 1) + L.ncols / 2) / L.ncols;     // shares this job deserves / columns, rounded
+            panels = std::min<uint64_t>(std::max<uint64_t>(panels, 1), (uint64_t)(G - 1) / L.ncols);
+            if (panels >= 1 && L.tiles / panels >= 8) {
+                L.ngroups = (uint32_t)panels;
+                L.gt = (uint32_t)((L.tiles + panels - 1) / panels);
+                L.aligned = 1;   // aligned
+                aligned_shares = panels * L.ncols;
+                aligned_work = w_i;
+            }
+        }
     }
-    sc.nslabs = ns;
+    const uint64_t s_est = std::max<uint64_t>(1, (work - aligned_work) / std::max<uint64_t>(1, (uint64_t)G - aligned_shares));
+    uint64_t pos = 0, rest = 0;
+    for (int pass = 0; pass < 2; ++pass) {   // (first the rest of the line -> S, then the positions)
+        pos = 0;
+        for (int i = 0; i < lb.njobs; ++i) {
+            const TnJob &job = lb.j[i];
+            TsJobLine &L = ln.j[i];
+            if (L.aligned) {                    // aligned: a unit = a share
+                L.vg = (uint8_t)B;
+                L.ucost = L.ucost_last = pass ? ln.S : 0;
+            } else if (L.flat) {
+                // a panel = about what one share holds of ONE column
+                const uint64_t gt = std::max<uint64_t>(8, std::min<uint64_t>(L.tiles, s_est > ln.ovh ? (s_est - ln.ovh) / L.tc : 8));
+                L.gt = (uint32_t)gt;
+                L.ngroups = (uint32_t)((L.tiles + gt - 1) / gt);
+                L.vg = (uint8_t)B;   // (the batch: the kernel's row count of the flat video)
+                L.ucost = ln.ovh + L.gt * L.tc;
+                L.ucost_last = ln.ovh + L.gt * L.tc_last;
+            } else {
+                L.gt = L.tiles;
+                L.vg = (uint8_t)((job.p.Trows >= g_ts_group_rows || B == 1) ? 1 : B);
+                L.ngroups = (uint32_t)(B / L.vg);
+                L.ucost = L.vg * (ln.ovh + L.gt * L.tc);
+                L.ucost_last = L.vg * (ln.ovh + L.gt * L.tc_last);
+            }
+            L.gcost = (uint32_t)(L.ncols - 1) * L.ucost + L.ucost_last;
+            L.pos0 = (uint32_t)pos;
+            pos += (uint64_t)L.ngroups * L.gcost;
+            if (pos >= 0xf0000000ull) return false;   // (33 M frames x 16 columns fit; anything longer takes the per-item launch)
+        }
+        if (pass == 0) {
+            rest = pos;
+            ln.S = (uint32_t)std::max<uint64_t>(1, (rest + (G - aligned_shares) - 1) / ((uint64_t)G - aligned_shares));
+        }
+    }
+    ln.W = (uint32_t)pos;
+    for (int k = lb.njobs; k <= TS_MAX_JOBS; ++k) ln.j[k].pos0 = k == lb.njobs ? ln.W : 0xffffffffu;
+    ln.G = G;
+    if (aligned_shares == 0) ln.S = (uint32_t)((pos + G - 1) / G);
+    uint32_t ns = 0;   // a column's visits take consecutive slabs
+    for (int i = 0; i < lb.njobs; ++i) {
+        const TsJobLine &L = ln.j[i];
+        if (L.ncols > TS_MAX_NCOLS) return false;
+        for (uint32_t c = 0; c < L.ncols; ++c) {
+            uint32_t n = 0, wf, wl;
+            for (uint32_t g = 0; g < L.ngroups; ++g) {
+                ts_unit_visitors(L, ln.S, g, c, wf, wl);
+                n += wl - wf + 1;
+            }
+            if (ns + n > 65000) return false;
+            ln.ct.slab0[i][c] = (uint16_t)ns;
+            ln.ct.n[i][c] = (uint16_t)n;
+            ns += n;
+        }
+    }
+    sc.nslabs = (int)ns;
     return true;
 }
 
@@ -1008,6 +1068,6 @@ static hipError_t launch_ts_runs(const TnBatch &lb, const TsSchedule &sc, hipStr
     static bool attr = false;
     hipError_t e = ts_smem_attr(reinterpret_cast<const void *>(ts_runs_kernel), attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ts_runs_kernel, dim3(sc.G), dim3(512), TS_SMEM_BYTES, s, lb, sc.rs);
+    hipLaunchKernelGGL(ts_runs_kernel, dim3(sc.ln.G), dim3(512), TS_SMEM_BYTES, s, lb, sc.ln);
     return hipGetLastError();
 }

@@ -31,6 +31,7 @@ int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / laye
 int g_ts_runs = 1;            // the batched split weight-gradient launch of encoder_bwd as static runs on persistent workgroups (MUCON_TS_RUNS; gemm_tn_split.hpp); 0: one workgroup per item
 int g_ts_cost[4] = {69, 74, 95, 109};   // ... its cost units (1/32 us): tile of a staggered / lock-step / two-image column, a run's fixed cost per video (MUCON_TS_COSTS=a,b,c,d)
 int g_ts_max_wg = 0;          // ... on at most this many workgroups (MUCON_TS_MAX_WG; 0 = one per CU)
+int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (MUCON_TS_GROUP_ROWS)
 int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
 int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never)
@@ -92,8 +93,11 @@ inline void one_job_arena(int B, int Trows, int Ktot, bool layer, size_t &sf, si
     int mc = pick_mc(B, Trows, Ktot / 128);
     for (int v = 1; v < 4; ++v) mc = std::min(mc, pick_mc(B, Trows, Ktot / 128, (v & 1) != 0, (v & 2) != 0, layer));
     const size_t nmc = (size_t)B * ((Trows + mc - 1) / mc);
+    // static runs: one partial per (share, unit) = at most shares + units + 1 of them; units = groups x columns, groups <= B videos or, for a job
+    // taken as one long video, panels of about a share each (<= shares + 1); + the launch's copy of its line behind the bias partials
     const size_t ncols = ((size_t)Ktot / 128 + 1) / 2, tiles = ncols * B * (((size_t)Trows + 31) / 32);
-    const size_t nsl = std::min<size_t>(kTsMaxWorkgroups, (tiles + 3) / 4) + ncols;   // (rounded up: the bounds of a batch's jobs add up to the bound of the batch)
+    const size_t shares = std::min<size_t>(kTsMaxWorkgroups, (tiles + 3) / 4);
+    const size_t nsl = shares + ncols * std::max<size_t>((size_t)B, shares / ncols + 2) + 2;
     sf = std::max(align64(nmc * 128 * Ktot), align64(nsl * 128 * 256));
     bf = std::max(align64(nmc * 256), align64(nsl * 256));
 }
@@ -274,8 +278,9 @@ struct Reducer {
         j.ncols = ncols;
         j.n_elems = nrows * ncols;
         j.mode = (int8_t)mode;
-        j.colblk = -1;
+        j.sched = -1;
         j.isbias = 0;
+        j.bcol = 0;
         j.vec = ((ncols | coff | ld | j.n_elems) % 4 == 0 && slab_stride % 4 == 0) ? 1 : 0;
         j.block0 = rb.nblocks;
         max_slabs = rb.njobs == 1 ? nslabs : std::max(max_slabs, nslabs);
@@ -285,21 +290,21 @@ struct Reducer {
         rb.nblocks += (j.n_elems + 255) / 256;
         return true;
     }
-    bool cols_used = false;   // rb.cols holds the table of a static-runs launch whose jobs are queued
-    // a job over the slabs of the static-runs launch: columns coff .. coff + ncols of the 256-column blocks from `col0` on (bias: the 256-float partials of column col0)
-    bool add_cols(int col0, bool isbias, int coff, int nrows, int ncols, float *out, int mode) {
+    bool line_used = false;   // rb.ct holds the column table of a static-runs launch whose jobs are queued
+    // a job over the partial tiles of the static-runs launch: columns coff .. coff + ncols of job `sched` of the line (bias: the 256-float partials of its column bcol)
+    bool add_sched(int sched, const TsJobLine &L, bool isbias, int bcol, int coff, int nrows, int ncols, float *out, int mode) {
         if (!add(nullptr, 1, 0, 256, coff, nrows, ncols, out, mode)) return false;
         ReduceJob &j = rb.j[rb.njobs - 1];
-        j.colblk = (int8_t)col0;
+        j.sched = (int8_t)sched;
         j.isbias = isbias ? 1 : 0;
-        cols_used = true;
-        int deepest = 0;
-        for (int c = col0 + (isbias ? 0 : coff / 256); c <= col0 + (isbias ? 0 : (coff + ncols - 1) / 256); ++c) deepest = std::max(deepest, (int)rb.cols.n[c]);
-        max_slabs = std::max(max_slabs, deepest);
+        j.bcol = (int8_t)bcol;
+        line_used = true;
+        for (int c = isbias ? bcol : coff / 256; c <= (isbias ? bcol : (coff + ncols - 1) / 256); ++c) max_slabs = std::max(max_slabs, (int)rb.ct.n[sched][c]);
+        (void)L;
         return j.vec == 1;
     }
     hipError_t run() {
-        cols_used = false;
+        line_used = false;
         if (rb.njobs == 0) return hipSuccess;
         // few, deep jobs (the y-head's 256 slabs of 6 K elements: 25 workgroups) want many slab lanes: the chain of dependent
         // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
@@ -407,27 +412,22 @@ static int flush_wgrads(const Plan &pl, float *ws, size_t &arena, size_t &barena
         if (ts_make_schedule(lb, pl.B, maxg, sc)) {
             const size_t need = (size_t)sc.nslabs * 128 * 256, bneed = (size_t)sc.nslabs * 256;
             if (arena + need > pl.slab_floats || barena + bneed > pl.bslab_floats) return fail(MUCON_E_WORKSPACE, "internal: slab arena too small");
-            if (red.rb.njobs > 0 && red.cols_used && red.run() != hipSuccess) return fail(MUCON_E_ARG, "internal: slab reduction failed");
-            sc.rs.slabs = ws + pl.slabs + arena;
-            sc.rs.bias = ws + pl.bslabs + barena;
+            if (red.rb.njobs > 0 && red.line_used && red.run() != hipSuccess) return fail(MUCON_E_ARG, "internal: slab reduction failed");
+            sc.ln.ct.slabs = ws + pl.slabs + arena;
+            sc.ln.ct.bias = ws + pl.bslabs + barena;
             arena += align64(need);
             barena += align64(bneed);
-            red.cols_used = true;
-            red.rb.cols.slabs = sc.rs.slabs;
-            red.rb.cols.bias = sc.rs.bias;
-            for (int c = 0; c < sc.rs.ncols; ++c) {
-                red.rb.cols.slab0[c] = sc.rs.c[c].slab0;
-                red.rb.cols.n[c] = (uint16_t)sc.nslab_col[c];
-            }
+            red.rb.ct = sc.ln.ct;
             bool ok = true;
             for (int i = 0; i < lb.njobs; ++i) {
                 const WgradArgs &a = q.out[tb.njobs - 1 - i];   // (ts_layout reverses the queue)
-                const int c0 = sc.col0[i], nk0 = lb.j[i].p.nk0;
-                ok = ok && red.add_cols(c0, false, 0, 128, nk0 * 128, a.out_w0, a.mode0);
-                if (a.out_b0) ok = ok && red.add_cols(c0, true, 0, 1, 128, a.out_b0, 0);
+                const TsJobLine &L = sc.ln.j[i];
+                const int nk0 = lb.j[i].p.nk0;
+                ok = ok && red.add_sched(i, L, false, 0, 0, 128, nk0 * 128, a.out_w0, a.mode0);
+                if (a.out_b0) ok = ok && red.add_sched(i, L, true, 0, 0, 1, 128, a.out_b0, 0);
                 if (lb.j[i].dual) {
-                    ok = ok && red.add_cols(c0, false, nk0 * 128, 128, 128, a.out_w1, 0);
-                    if (a.out_b1) ok = ok && red.add_cols(c0 + nk0 / 2, true, 128, 1, 128, a.out_b1, 0);
+                    ok = ok && red.add_sched(i, L, false, 0, nk0 * 128, 128, 128, a.out_w1, 0);
+                    if (a.out_b1) ok = ok && red.add_sched(i, L, true, nk0 / 2, 128, 1, 128, a.out_b1, 0);
                 }
             }
             if (!ok) return fail(MUCON_E_ARG, "internal: too many reduction jobs");
@@ -630,6 +630,10 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_ts_runs = atoi(e) ? 1 : 0;
         return true;
     }
+    if (!strcmp(name, "MUCON_TS_GROUP_ROWS")) {
+        if (e && atoi(e) >= 0) g_ts_group_rows = atoi(e);
+        return true;
+    }
     if (!strcmp(name, "MUCON_TS_MAX_WG")) {
         if (e) g_ts_max_wg = atoi(e) > 0 ? atoi(e) : 0;
         return true;
@@ -674,7 +678,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TS_RUNS", "MUCON_TS_MAX_WG", "MUCON_TS_COSTS", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TS_RUNS", "MUCON_TS_MAX_WG", "MUCON_TS_GROUP_ROWS", "MUCON_TS_COSTS", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
