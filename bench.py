@@ -633,6 +633,60 @@ def live_traffic(args):
             "launches_sampled": min(sums["FETCH_SIZE"][2], sums["WRITE_SIZE"][2])}
 
 
+def batch1_dense_legs(dev, spec, C, params, with_cpu=True):
+    """BASELINE.md section 3's dense legs at batch 1 -- the hot path (encoder + y-head, fwd+bwd+SGD, training mode) on ONE video of T = 2,000
+    (Breakfast-typical) and T = 16,384 (BASELINE config 5's dense half: 'HBM roofline point') --, tapes resident in HBM and rotated past the
+    256 MiB Infinity Cache, each with its own roofline sub-record (16,768 algorithmic bytes per frame) and the CPU module graph at
+    the same shape.  Outside the headline's timed regions; the weights are the random-init ones (restored by the caller afterwards)."""
+    import types
+    from mucon_amd import ops
+    enc_params, wc, bc = params[:-2], params[-2], params[-1]
+    wc2 = wc.reshape(wc.shape[0], wc.shape[1]) if wc.dim() == 3 else wc
+    sgd = ops.FusedClipSGD([params], None, types.SimpleNamespace(param_groups=[{"lr": 0.01, "weight_decay": 0.005, "momentum": 0.0}]))
+    out = {}
+    for T, steps in ((2000, 60), (16384, 30)):
+        n_tapes = max(2, -(-(320 << 20) // (T * spec.in_dim * 4)))          # > 256 MiB of distinct tape between two reads of the same one
+        g = torch.Generator(device=dev).manual_seed(4000 + T)
+        tapes = [torch.randn(1, T, spec.in_dim, device=dev, generator=g) for _ in range(n_tapes)]
+        dlogp = torch.randn(1, T, C, device=dev, generator=g) / T
+
+        def step(i):
+            enc, c_enc = ops.run_forward(ops._EncoderFn, tapes[i % n_tapes], spec, True, int(i), *enc_params)
+            (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
+            d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
+            wc.grad, bc.grad = d_w.view_as(wc), d_b
+            for p_, g_ in zip(enc_params, ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]):
+                p_.grad = g_
+            sgd.step()
+
+        for i in range(8):
+            step(i)
+        per = []
+        for r in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(8 + r * steps + i)
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / steps)
+        ms = sorted(per)[1] * 1e3
+        fps = T / (ms * 1e-3)
+        leg = {"ms_per_step": round(ms, 4), "frames_per_s": round(fps, 1), "ms_per_step_repeats": [round(x * 1e3, 4) for x in per],
+               "tapes_rotated": n_tapes, "tape_bytes_resident": n_tapes * T * spec.in_dim * 4,
+               "roofline": {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": round(fps * BYTES_PER_FRAME_FWD_BWD / 1e9, 1),
+                            "frac": round(fps * BYTES_PER_FRAME_FWD_BWD / 1e9 / PEAK_HBM_GBS, 5),
+                            "note": "whole step against the HBM roofline (16,768 algorithmic bytes per frame): a batch-1 step is ~50 launches of 16 - 128 "
+                                    "workgroups -- latency-bound, not bandwidth-bound; the B = 8 x T = 4096 line is the throughput figure"}}
+        if with_cpu:
+            cb = cpu_baseline(spec, C, T, B=1)
+            leg["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind")}
+            leg["cpu_baseline"]["sample"] = f"oracle/dense.py:module_graph fwd+bwd fp32, B=1 x T={T} x D={spec.in_dim}, best of 3 after one warm-up"
+        out[f"B1_T{T}"] = leg
+        del tapes, dlogp
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -954,6 +1008,10 @@ def main():
                                                                            "achieved": round(gbs, 3), "frac": round(gbs / PEAK_HBM_GBS, 6)}}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spec, C, T)
+        if world == 1 and not args.no_viterbi:
+            restore_init()
+            out["dense_batch1"] = batch1_dense_legs(dev, spec, C, params, with_cpu=not args.no_cpu_baseline)
+            restore_init()
         if not args.no_viterbi and world == 1 and sharded is None:
             out["viterbi"] = viterbi_bench(dev, C)
             out["roofline_viterbi"] = viterbi_roofline(out["viterbi"])
