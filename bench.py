@@ -1012,6 +1012,15 @@ def main():
             restore_init()
             out["dense_batch1"] = batch1_dense_legs(dev, spec, C, params, with_cpu=not args.no_cpu_baseline)
             restore_init()
+        if world == 1 and not (args.no_viterbi or args.no_calibration):
+            # box-independent: shader cycles counted inside the four kernel families, from the stamped library variant in a CHILD process (one extra
+            # step outside every timed region; tools/kernel_cycles.py).  Boxes differ by 8 % in clock; a cycle count only moves with the code.
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_cycles.py")], capture_output=True, text=True, timeout=240)
+                out["kernel_cycles"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+            except (OSError, subprocess.SubprocessError, ValueError, IndexError) as e:
+                out["kernel_cycles"] = {"error": str(e)[:300]}
         if not args.no_viterbi and world == 1 and sharded is None:
             out["viterbi"] = viterbi_bench(dev, C)
             out["roofline_viterbi"] = viterbi_roofline(out["viterbi"])

@@ -203,13 +203,19 @@ def load(build_if_missing: bool = True):
         return _lib
     import torch  # noqa: F401  (loads torch's libamdhip64 before ours resolves its DT_NEEDED)
 
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("MUCON_LIB_VARIANT") == "stamp":
+        # the timing build with the in-kernel stamps compiled in (mucon_amd/build.py: build_stamp): tools/kernel_cycles.py only -- never the product path
+        path = os.path.join(os.path.dirname(LIB_PATH), "libmucon_hip_stamp.so")
+        if not os.path.exists(path):
+            raise MuconHipError(f"{path} is missing: run `python -m mucon_amd.build --stamp`")
+    elif not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise MuconHipError(f"{LIB_PATH} is missing: run `python -m mucon_amd.build`")
         from . import build as _build
 
         _build.build()
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -115,5 +115,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+STAMP_LIB = os.path.join(HERE, "libmucon_hip_stamp.so")
+STAMP_FLAGS = ["-DCLK_STAMP=1", "-DCS_STAMP=1", "-DFS_STAMP=1"]
+
+
+def build_stamp(force: bool = False, verbose: bool = False) -> str:
+    """libmucon_hip_stamp.so: the same library with the in-kernel s_memtime stamps of the four kernel families compiled in (mucon_hip.hip under
+    STAMP_FLAGS; the other translation units are the shipped objects).  Never loaded by the product path: bench.py's `kernel_cycles` child
+    (tools/kernel_cycles.py, MUCON_LIB_VARIANT=stamp) reads box-independent cycle counts from it in ONE extra step outside every timed region."""
+    build(force, verbose)
+    src, extra = SOURCES[0]
+    obj = os.path.join(HERE, "build", "mucon_hip_stamp.o")
+    deps = _deps_of(src) or []
+    newest = max([os.path.getmtime(f) for f in deps + [os.path.join(CSRC, src)]] or [0])
+    if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest or not os.path.exists(STAMP_LIB) or os.path.getmtime(STAMP_LIB) < os.path.getmtime(LIB):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+               "-c", os.path.join(CSRC, src), "-o", obj] + extra + STAMP_FLAGS
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs = [obj] + [_obj(s_) for s_, _ in SOURCES[1:]]
+        subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", STAMP_LIB] + objs)
+    return STAMP_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamp" in sys.argv:
+        print(build_stamp(force="--force" in sys.argv, verbose=True))

@@ -828,6 +828,7 @@ __global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const Ts
     if (lo >= hi) return;
 #if CLK_STAMP
     const long long wg_t0_ = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: a workgroup's whole life, g_clk_wg; tools/ts_runs_times.py)
+    const long long wg_c0_ = __builtin_amdgcn_s_memtime();       // ... and in shader cycles (g_clk_ph[share][0]: tools/kernel_cycles.py)
 #endif
     int ji = -1;   // the job `lo` lies in: all starts compared at once (independent scalar loads)
 #pragma unroll
@@ -906,6 +907,8 @@ __global__ __launch_bounds__(512) void ts_runs_kernel(const TnBatch tb, const Ts
     if (threadIdx.x == 0 && sh < 4096) {
         g_clk_wg[sh][0] = wg_t0_;
         g_clk_wg[sh][1] = __builtin_amdgcn_s_memrealtime();
+        g_clk_ph[sh][0] = __builtin_amdgcn_s_memtime() - wg_c0_;
+        g_clk_ph[sh][1] = 1;
     }
 #endif
 }
