@@ -740,6 +740,15 @@ def main():
     rank_key = (rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF          # every rank draws its own dropout masks
 
     wc2 = wc.reshape(wc.shape[0], wc.shape[1]) if wc.dim() == 3 else wc
+    # N > 1 (or MUCON_BENCH_FORCE_DIST=1), MUCON_BENCH_OVERLAP=1: the gradient exchange in two parts, the larger one under first_conv's weight-gradient
+    # launch.  Built, tested (tests/test_gpu_dense.py::test_data_parallel_overlap_hook_*) and measured at world size 1, where it can only lose: 0.783 ms per
+    # step against 0.7345 with the one collective behind the backward and 0.711 without RCCL (profiles/r06_same_box_abs.txt section 4) -- two collectives'
+    # stream hand-offs (+25 us), two weight-gradient + reduction launches instead of one (+10), 248 instead of 256 workgroups.  It pays once the 4 MB
+    # all-reduce takes more than ~65 us; no box here has a second GPU to say whether it does, so the DEFAULT stays the one collective.  The N = 1 step is untouched.
+    overlap = dist is not None and os.environ.get("MUCON_BENCH_OVERLAP", "0") == "1" and os.environ.get("MUCON_BENCH_COALESCE") != "1"
+    if overlap:
+        ov_event, ov_side = torch.cuda.Event(), torch.cuda.Stream(device=dev)
+        ov_max_wg = max(8, torch.cuda.get_device_properties(dev).multi_processor_count - 8)
 
     def step(i):
         # forward and backward of the hot path as direct calls of the autograd Functions (the same C entry points in the
@@ -752,10 +761,26 @@ def main():
         wc.grad, bc.grad = d_w.view_as(wc), d_b
         if dist is not None and os.environ.get("MUCON_BENCH_COALESCE") != "1":
             c_enc.flat_extra = d_w.numel() + d_b.numel()          # room for the y-head's gradients behind the encoder's
+        if overlap:
+            # (r6) the exchange in two parts: everything but first_conv's gradients is final BEFORE the tape's second pass (first_conv's weight
+            # gradient, the last ~85 us of the backward) -- the library records ov_event there and runs its weight-gradient launches on
+            # ncu - 8 workgroups, so RCCL's kernel has CUs while that part travels on the side stream
+            c_enc.dp_overlap = (ov_event, ov_max_wg)
         g_enc = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
         for p_, g_ in zip(enc_params, g_enc):
             p_.grad = g_
-        if dist is not None:
+        if overlap:
+            buf = ops.flat_grad_buffers(enc_params)[0]
+            off = c_enc.flat_rest_off
+            ov_side.wait_event(ov_event)
+            with torch.cuda.stream(ov_side):
+                dist.all_reduce(buf[off:], op=dist.ReduceOp.AVG)                      # 3 of the 4 MB, under first_conv's launch
+            tail = c_enc.flat_tail
+            torch.cat([d_w.reshape(-1), d_b.reshape(-1)], out=tail)
+            wc.grad, bc.grad = tail[:d_w.numel()].view_as(wc), tail[d_w.numel():]
+            dist.all_reduce(buf[:off], op=dist.ReduceOp.AVG)                          # first_conv's gradients + the y-head's: what only the pass's end has
+            torch.cuda.current_stream().wait_stream(ov_side)
+        elif dist is not None:
             # the one exchange step: ONE all-reduce per optimizer step.  The encoder's gradients are views of one flat buffer;
             # the two y-head tensors are appended to a copy of it (every RCCL call costs ~25 us of stream hand-offs even at
             # world size 1: three calls were +75 us per step, one packed call +37, one in-place call on the shared buffer less).  (Splitting the buffer so that all but first_conv's
@@ -851,7 +876,9 @@ def main():
         t = torch.tensor([ar[len(ar) // 2]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rccl = {"world": world, "backend": dist.get_backend(), "bytes_per_step": int(buf.numel() * 4),
-                "allreduce_ms": round(float(t.item()), 4), "collectives_per_step": 1,
+                "allreduce_ms": round(float(t.item()), 4), "collectives_per_step": 2 if overlap else 1,
+                "overlap": ("all but first_conv's gradients (3 of 4 MB) all-reduced on a side stream behind an event the backward records in front of first_conv's "
+                            "weight-gradient launch, which runs on ncu - 8 workgroups; first_conv's + the y-head's part behind the pass (MUCON_BENCH_OVERLAP=0: one collective)") if overlap else None,
                 "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
                 "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
                 "note": "median of 20 all-reduces of the step's flat gradient buffer (encoder + y-head), HIP events on the step's stream, "

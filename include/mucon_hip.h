@@ -94,6 +94,17 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
                       const float *tape, const float *d_enc, void *workspace,
                       size_t workspace_bytes, const mucon_encoder_params *grads, void *stream);
 
+/* Data-parallel training (no reference counterpart: reference src/core/config.py:16 has one device string; BASELINE.json's north_star names the
+ * 1/2/4/8-GPU curve).  One-shot options of the NEXT mucon_encoder_bwd call on this thread:
+ *   event_after_layers  a hipEvent_t (NULL: none) the pass records on its stream once every gradient EXCEPT first_conv.weight / .bias is final
+ *                       (the residual layers', last_conv's and GroupNorm's: 3 of the hot path's 4 MB).  The caller's all-reduce of that part of
+ *                       its flat gradient buffer, issued on another stream behind the event, then travels UNDER first_conv's weight-gradient
+ *                       launch (the tape's second pass, ~85 us at B = 8 x T = 4096) instead of behind the whole backward;
+ *   max_workgroups      > 0: the weight-gradient launches of that pass use at most this many persistent workgroups (one per CU by default):
+ *                       the CUs left free are where RCCL's kernel runs meanwhile.  0: no cap.
+ * Both are cleared when the pass has been enqueued.  The gradients are the same sums cut into other shares: equal to fp32 rounding. */
+int mucon_encoder_bwd_overlap(void *event_after_layers, int32_t max_workgroups);
+
 /* ------------------------------------------------------------------------------------------
  * Encoder variant "noft": no temporal modelling, one position-wise linear map of the tape
  * ---------------------------------------------------------------------------------------- */

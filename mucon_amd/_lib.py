@@ -101,6 +101,7 @@ class AdamTensor(ctypes.Structure):
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 SYMBOLS = {
     "mucon_abi_version": (ctypes.c_int, []),
+    "mucon_encoder_bwd_overlap": (ctypes.c_int, [_vp, _i32]),
     "mucon_last_error": (ctypes.c_char_p, []),
     "mucon_encoder_out_length": (_i32, [ctypes.POINTER(EncoderCfg)]),
     "mucon_encoder_workspace_bytes": (_sz, [ctypes.POINTER(EncoderCfg)]),

@@ -31,6 +31,10 @@ int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / laye
 int g_ts_runs = 1;            // the batched split weight-gradient launch of encoder_bwd as static runs on persistent workgroups (MUCON_TS_RUNS; gemm_tn_split.hpp); 0: one workgroup per item
 int g_ts_cost[4] = {69, 74, 95, 109};   // ... its cost units (1/32 us): tile of a staggered / lock-step / two-image column, a run's fixed cost per video (MUCON_TS_COSTS=a,b,c,d)
 int g_ts_max_wg = 0;          // ... on at most this many workgroups (MUCON_TS_MAX_WG; 0 = one per CU)
+// One-shot options of the NEXT mucon_encoder_bwd call (mucon_encoder_bwd_overlap; data-parallel training): an event to record on the pass's stream
+// once every gradient EXCEPT first_conv's is final, and a cap on the workgroups of the weight-gradient launches (CUs left free for RCCL's kernel)
+hipEvent_t g_bwd_event = nullptr;
+int g_bwd_max_wg = 0;
 int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (MUCON_TS_GROUP_ROWS)
 int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
@@ -408,7 +412,8 @@ static int flush_wgrads(const Plan &pl, float *ws, size_t &arena, size_t &barena
         TnBatch lb;
         ts_layout(tb, lb);
         TsSchedule sc;
-        const int maxg = std::min(kTsMaxWorkgroups, g_ts_max_wg > 0 ? std::min(g_ts_max_wg, ncu) : ncu);
+        int maxg = std::min(kTsMaxWorkgroups, g_ts_max_wg > 0 ? std::min(g_ts_max_wg, ncu) : ncu);
+        if (g_bwd_max_wg > 0) maxg = std::max(1, std::min(maxg, g_bwd_max_wg));
         if (ts_make_schedule(lb, pl.B, maxg, sc)) {
             const size_t need = (size_t)sc.nslabs * 128 * 256, bneed = (size_t)sc.nslabs * 256;
             if (arena + need > pl.slab_floats || barena + bneed > pl.bslab_floats) return fail(MUCON_E_WORKSPACE, "internal: slab arena too small");
@@ -1378,6 +1383,16 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             }
         }
     }
+    const hipEvent_t overlap_ev = g_bwd_event;
+    if (overlap_ev) {
+        // data-parallel step (mucon_encoder_bwd_overlap): every gradient except first_conv's is made final HERE -- the residual layers', last_conv's
+        // and GroupNorm's jobs launched and reduced -- and the caller's event recorded: its all-reduce of that part of the flat buffer (3 of the 4 MB)
+        // travels under first_conv's weight-gradient launch, which follows on fewer workgroups (g_bwd_max_wg)
+        rc = flush_wgrads(pl, ws, arena, barena, wq, red, s);
+        if (rc != MUCON_OK) return rc;
+        HIPCHK(red.run());
+        HIPCHK(hipEventRecord(overlap_ev, s));
+    }
     {   // first_conv: the tape needs no gradient; its weight gradient streams the tape once more
         WgradArgs a;
         memset(&a, 0, sizeof(a));
@@ -1401,6 +1416,15 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         prof_mark(1, true, s);
     }
     HIPCHK(red.run());
+    g_bwd_event = nullptr;   // one-shot
+    g_bwd_max_wg = 0;
+    return MUCON_OK;
+}
+
+int mucon_encoder_bwd_overlap(void *event_after_layers, int32_t max_workgroups) {
+    if (max_workgroups < 0) return fail(MUCON_E_ARG, "encoder_bwd_overlap: max_workgroups %d", max_workgroups);
+    g_bwd_event = static_cast<hipEvent_t>(event_after_layers);
+    g_bwd_max_wg = max_workgroups;
     return MUCON_OK;
 }
 

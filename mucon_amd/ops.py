@@ -174,12 +174,27 @@ class _EncoderFn(torch.autograd.Function):
         # one buffer reduces everything, with no gather copy)
         extra = int(getattr(ctx, "flat_extra", 0))
         flat = torch.empty(sum(sizes) + extra, dtype=torch.float32, device=tape.device)
-        ctx.flat_tail = flat[sum(sizes):]
+        ov = getattr(ctx, "dp_overlap", None)
+        # layout: [every parameter][extra] -- or, for the overlapped data-parallel step, [first_conv.weight, .bias][extra][the rest]: what is
+        # final only at the pass's end (first_conv's gradients, the caller's tail) is one contiguous range, what is final at the event the other
+        head = sizes[0] + sizes[1]
+        tail_at = head if ov is not None else sum(sizes)
+        ctx.flat_tail = flat[tail_at: tail_at + extra]
+        ctx.flat_rest_off = head + extra if ov is not None else 0
         grads, off = [], 0
-        for p, n in zip(params, sizes):
+        for k, (p, n) in enumerate(zip(params, sizes)):
+            if ov is not None and k == 2:
+                off += extra
             grads.append(flat[off: off + p.numel()].view(p.shape))
             off += n
         cp, cg = _param_struct(("enc", len(ctx.spec.stages)), params, lambda ts: _pack_params(ctx.spec, ts)), _pack_params(ctx.spec, grads)
+        if ov is not None:
+            # data-parallel step: (torch.cuda.Event, max workgroups) -- the event is recorded once every gradient but first_conv's is final, the
+            # weight-gradient launches leave CUs free for RCCL (include/mucon_hip.h: mucon_encoder_bwd_overlap).  flat[ctx.flat_rest_off:] is what is
+            # final at the event.
+            ev, max_wg = ov
+            ev.record()            # (materialises the event's handle; recorded again, in its place, by the library)
+            _lib.check(lib.mucon_encoder_bwd_overlap(ev.cuda_event, int(max_wg)), "mucon_encoder_bwd_overlap")
         _lib.check(lib.mucon_encoder_bwd(ctypes.byref(ctx.cfg), ctypes.byref(cp), _lib.ptr(tape), _lib.ptr(d_enc),
                                          _lib.ptr(ctx.ws), ctx.nbytes, ctypes.byref(cg), _lib.current_stream_ptr()),
                    "mucon_encoder_bwd")

@@ -655,3 +655,49 @@ def test_schedule_knobs_of_round_5_do_not_change_results():
             else:
                 scale = a_.abs().max().item() + 1e-20
                 assert (a_ - b_).abs().max().item() <= 2e-5 * scale, (knob, name)
+
+
+def test_data_parallel_overlap_hook_gradients_final_at_the_event():
+    """(r6, N > 1 readiness) mucon_encoder_bwd_overlap: the backward records the caller's event once every gradient EXCEPT first_conv's is final and
+    caps its weight-gradient launches (CUs left for RCCL).  A side stream behind the event snapshots flat[rest:] while first_conv's launch is still
+    running on the main stream: the snapshot must equal the finished buffer bit for bit; all gradients equal the plain pass's to fp32 rounding (the
+    same sums, other shares); the options are one-shot (the next pass is the plain one again, bitwise)."""
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T = 8, 4096
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 357)
+    names = ops.param_names(spec)
+    tape = torch.tensor(synth.tape(358, B, T, 2048), device=DEV)
+    v = torch.tensor(synth.uniform_pm1(359, (B, spec.out_length(T), 128)), device=DEV)
+
+    def run(overlap):
+        P = [p.detach() for p in _dev_params(params_np, names)]
+        enc, ctx = ops.run_forward(ops._EncoderFn, tape, spec, True, 77, *P)
+        snap = None
+        if overlap:
+            ev, side = torch.cuda.Event(), torch.cuda.Stream()
+            ctx.dp_overlap = (ev, 200)
+            ctx.flat_extra = 6272
+        grads = ops.run_backward(ops._EncoderFn, ctx, v)[4:]
+        if overlap:
+            for p_, g_ in zip(P, grads):
+                p_.grad = g_
+            buf = ops.flat_grad_buffers(P)[0]
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                snap = buf[ctx.flat_rest_off:].clone()
+            torch.cuda.synchronize()
+            assert ctx.flat_rest_off == 128 * 2048 + 128 + 6272 and ctx.flat_tail.numel() == 6272
+            assert torch.equal(snap, buf[ctx.flat_rest_off:])          # final at the event
+            assert grads[0].data_ptr() == buf.data_ptr() and grads[2].data_ptr() == buf.data_ptr() + 4 * ctx.flat_rest_off
+        torch.cuda.synchronize()
+        return [g.clone() for g in grads]
+
+    base = run(False)
+    over = run(True)
+    again = run(False)
+    for name, a_, b_, c_ in zip(names, base, over, again):
+        scale = a_.abs().max().item() + 1e-20
+        assert (a_ - b_).abs().max().item() <= 2e-5 * scale, name
+        assert torch.equal(a_, c_), name
