@@ -591,19 +591,23 @@ def live_traffic(args):
     this script's hot-path leg under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters alone, as MI355X_MICROARCH.md prescribes --,
     started as CHILD processes before this process touches the GPU.  Per launch of the dominant kernel and of first_conv's forward: HBM bytes = 2 x FETCH_SIZE KiB
     (the gfx950 correction of the guide: the counter reports half the bytes) + WRITE_SIZE KiB.  None when rocprofv3 is missing, this process is itself being profiled, or
-    a pass fails (the committed profile's constant is reported then, labelled)."""
+    a pass fails (the committed profile's constant is reported then, `traffic_measured: false` with the reason).  -> (result or None, reason or None).
+    (r6: the passes run BEHIND the timed regions -- in front of them they heated the box the regions were then timed on.)"""
     import csv, glob, shutil, subprocess, tempfile
-    if args.no_traffic or any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None
+    if args.no_traffic:
+        return None, "--no-traffic"
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(tool):
-        return None
+        return None, "rocprofv3 not found"
+    norm = lambda k: "".join(k.split())        # (kernel names compared with all whitespace stripped: rocprofv3's demangled spelling is not a contract)
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         try:
             d = tempfile.mkdtemp(prefix="mucon_pmc_", dir="/tmp")
-        except OSError:
-            return None
+        except OSError as e:
+            return None, f"no scratch directory: {e}"
         try:
             cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                    "--repeats", "1", "--prewarm-steps", "10", "--batch", str(args.batch), "--frames", str(args.frames), "--tapes", str(args.tapes),
@@ -611,26 +615,26 @@ def live_traffic(args):
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
             rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x["Dispatch_Id"]))
             fwd, wg = [], []
             for x in rows:
                 if x["Counter_Name"] != counter:
                     continue
-                k = x["Kernel_Name"]
-                if "nt_split16_kernel<true, false, false, false>" in k or "nt_split_kernel<true, false, false, false>" in k:
+                k = norm(x["Kernel_Name"])
+                if "nt_split16_kernel<true,false,false,false>" in k or "nt_split_kernel<true,false,false,false>" in k:
                     fwd.append(float(x["Counter_Value"]))
                 if "ts_runs_kernel" in k or "ts_batched_kernel" in k or "tn_batched_kernel" in k:
                     wg.append(float(x["Counter_Value"]))
             if not fwd or not wg:
-                return None
+                return None, f"the {counter} pass holds no launch of first_conv forward / the weight-gradient kernel"
             sums[counter] = (sum(fwd) / len(fwd) * 1024.0, sum(wg) / len(wg) * 1024.0, len(wg))      # counter unit: KiB
-        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-            return None
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            return None, f"{type(e).__name__}: {e}"[:200]
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return {"first_conv_fwd": 2.0 * sums["FETCH_SIZE"][0] + sums["WRITE_SIZE"][0], "weight_gradients": 2.0 * sums["FETCH_SIZE"][1] + sums["WRITE_SIZE"][1],
-            "launches_sampled": min(sums["FETCH_SIZE"][2], sums["WRITE_SIZE"][2])}
+            "launches_sampled": min(sums["FETCH_SIZE"][2], sums["WRITE_SIZE"][2])}, None
 
 
 def batch1_dense_legs(dev, spec, C, params, with_cpu=True):
@@ -699,7 +703,6 @@ def main():
     if os.environ.get("MUCON_BENCH_STUB") == "1":
         return stub_main(args, rank, world)
     # (child processes, before this one touches the GPU; the whole-line runs only: a run with a leg switched off -- the A/B tools' -- reports the profile's constant)
-    live = live_traffic(args) if world == 1 and "WORLD_SIZE" not in os.environ and not (args.no_viterbi or args.no_cpu_baseline or args.no_calibration) else None
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -954,9 +957,12 @@ def main():
         except (OSError, ValueError, IndexError):
             pass
         traffic_note = (f"committed profile, builder's box ({traffic_src}): a constant of the profile run, not measured in this run") if traffic_src else None
+        # (child processes of the whole-line runs only: a run with a leg switched off -- the A/B tools' -- reports the profile's constant)
+        live, live_why = (live_traffic(args) if world == 1 and not (args.no_viterbi or args.no_cpu_baseline or args.no_calibration)
+                          else (None, "a leg of the line is switched off (A/B run)" if world == 1 else "N > 1"))
         if live is not None:
             traffic, traffic_fwd = live["weight_gradients"], live["first_conv_fwd"]
-            traffic_note = (f"measured on this box in front of the timed run: two child runs of the hot-path leg under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+            traffic_note = (f"measured on this box behind the timed regions: two child runs of the hot-path leg under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
                             f"{live['launches_sampled']} launches; HBM bytes = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB")
         bytes_fwd = B * T * (spec.in_dim + spec.hidden) * 4.0
         out = {
@@ -981,7 +987,7 @@ def main():
             "tape_batches_rotated": len(tapes), "tape_bytes_resident": len(tapes) * B * T * spec.in_dim * 4,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(peak_own, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_own, 4), "traffic": traffic,
-                         "traffic_source": traffic_note,
+                         "traffic_source": traffic_note, "traffic_measured": live is not None, "traffic_not_measured_because": live_why,
                          "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "algorithmic_bytes_per_launch": bytes_wg, "avg_launch_ms": round(dom[1], 4),
                          "flops_per_launch": flops_wg, "launches_timed": int(cnt[1]),

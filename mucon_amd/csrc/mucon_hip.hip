@@ -242,8 +242,19 @@ PackDecision pack_decision(const mucon_encoder_cfg *cfg, const mucon_encoder_par
     d.img16 = g_mfma16 & 1;
     return d;
 }
+// workspace -> what its last forward wrote, and for which problem (a workspace that was freed and re-allocated at the same address for another
+// shape does not pass as "a forward was run on this workspace").  Bounded: the entries of workspaces that no longer exist are dropped wholesale
+// when the table grows past kFwdRecordMax (the next forward of a live workspace simply records again).
+struct FwdRecord {
+    PackDecision d;
+    uint64_t shape;   // B, T, D, L folded together
+};
+constexpr size_t kFwdRecordMax = 256;
 std::mutex g_fwd_mu;
-std::unordered_map<const void *, PackDecision> g_fwd_record;   // workspace -> what its last forward wrote
+std::unordered_map<const void *, FwdRecord> g_fwd_record;
+inline uint64_t fwd_shape_key(const Plan &pl) {
+    return ((uint64_t)(uint32_t)pl.B << 48) ^ ((uint64_t)(uint32_t)pl.T << 20) ^ ((uint64_t)(uint32_t)pl.D << 6) ^ (uint64_t)(uint32_t)pl.L;
+}
 inline const uint16_t *fs_img(const float *ws, const Plan &pl, int l, int mat) {   // mat: 0 W1f, 1 W1b, 2 W2, 3 W2t, 4 / 5 centre taps of W1f / W1b in accumulator order
     const long off = mat == 0 ? 0 : (mat == 1 ? FS_IMG_K384 : 2L * FS_IMG_K384 + (long)(mat - 2) * FS_IMG_K128);
     return reinterpret_cast<const uint16_t *>(ws + pl.Wfs) + (long)l * FS_LAYER_ELEMS + off;
@@ -884,7 +895,8 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
     const PackDecision dec = pack_decision(cfg, prm, pl);
     {
         std::lock_guard<std::mutex> lk(g_fwd_mu);
-        g_fwd_record[workspace] = dec;
+        if (g_fwd_record.size() >= kFwdRecordMax && g_fwd_record.find(workspace) == g_fwd_record.end()) g_fwd_record.clear();
+        g_fwd_record[workspace] = FwdRecord{dec, fwd_shape_key(pl)};
     }
     const bool need_f32 = dec.need_f32, split_first = dec.split_first, split_dgrad0 = dec.split_dgrad0;
     pa.W1f = need_f32 ? ws + pl.W1f : nullptr;
@@ -1110,12 +1122,13 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         const PackDecision now = pack_decision(cfg, prm, pl);
         std::lock_guard<std::mutex> lk(g_fwd_mu);
         auto it = g_fwd_record.find(workspace);
-        if (it == g_fwd_record.end()) return fail(MUCON_E_ARG, "encoder_bwd: no forward pass was run on this workspace");
-        if (!(it->second == now))
+        if (it == g_fwd_record.end() || it->second.shape != fwd_shape_key(pl))
+            return fail(MUCON_E_ARG, "encoder_bwd: no forward pass of this problem (B=%d T=%d D=%d L=%d) was run on this workspace", pl.B, pl.T, pl.D, pl.L);
+        if (!(it->second.d == now))
             return fail(MUCON_E_ARG, "encoder_bwd: the forward pass wrote other weight layouts than this pass would read (f32 layouts %d/%d, "
                         "first_conv image %d/%d, layer-0 data-gradient image %d/%d, 16x16x32 order %d/%d): a tuning knob or the parameter "
-                        "set changed between the two calls", (int)it->second.need_f32, (int)now.need_f32, (int)it->second.split_first,
-                        (int)now.split_first, (int)it->second.split_dgrad0, (int)now.split_dgrad0, it->second.img16, now.img16);
+                        "set changed between the two calls", (int)it->second.d.need_f32, (int)now.need_f32, (int)it->second.d.split_first,
+                        (int)now.split_first, (int)it->second.d.split_dgrad0, (int)now.split_dgrad0, it->second.d.img16, now.img16);
     }
 
     Reducer red(s);

@@ -382,6 +382,12 @@ class MuConEvaluator:
                 self.skipped += 1
         if chunk:
             self._evaluate_chunk(chunk)
+        if on_cuda:
+            # the status words the teacher-forced decoder launches of this evaluation left on the device (ops._PENDING_DECODER_STATUS: the alignment
+            # evaluator appends one per video and nothing else reads them): read here, where the host has the results anyway -- a failed hand-over
+            # raises from ITS evaluation, not from an unrelated forward 4096 videos later
+            from .. import ops
+            ops.check_health()
         if world_size > 1:
             import torch.distributed as dist
             keys = sorted(self.metrics)

@@ -1169,6 +1169,12 @@ def viterbi_decode_batch(lps: Sequence[torch.Tensor], transcripts: Sequence[np.n
             raise ValueError(f"video {v}: {lp.shape[1]} classes (expected {C})")
         if not lp.is_contiguous():
             lps[v] = lp.contiguous()
+    if (C & 3) == 0:
+        # the pipelined frame-score kernel loads 16 bytes per lane: an emission tensor that does not start on a 16-byte boundary (a slice, a view) is
+        # copied here, once, for the whole list -- the C loop reports ONE offending video per crossing (a batch of n such views cost n crossings)
+        for v, lp in enumerate(lps):
+            if lp.data_ptr() & 15:
+                lps[v] = lp.clone(memory_format=torch.contiguous_format)
     ptrs = [lp.data_ptr() for lp in lps]
     Ts = [lp.shape[0] for lp in lps]
     trs, tabs = list(transcripts), list(tables)
