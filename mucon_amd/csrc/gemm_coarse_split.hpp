@@ -96,10 +96,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
             ra[rb][i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
     constexpr int NP = TAPS * 8;      // (tap, channel block) pairs of stage 1, three plane fragments each
-#ifndef CS_RING
-#define CS_RING 8
-#endif
-    constexpr int D = (CS_RING > 8 && NP % CS_RING == 0) ? CS_RING : 8;   // pairs in flight (CS_RING = 12: the experiment of profiles/r05_cs_kernel_phase_stamps.txt)
+    constexpr int D = 8;              // pairs in flight (12: neutral, profiles/r05_cs_kernel_phase_stamps.txt)
     bf16x8 wf[D][3];
     const uint16_t *w1 = W1img + (long)w * FS_WSTEP + lane * 8;      // step (tap * 4 + w): + tap * 4 * FS_WSTEP
     auto loadW1 = [&](int i, int slot) {
@@ -198,9 +195,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
         else if (!ONE) loadW2(i + D - NP, i % D);      // NP is a multiple of D: slots line up
         // (pins every refill behind the MFMAs that free its slot: left to itself the scheduler sinks the loads towards their
         // use, eight pairs later, and the ring degenerates to one or two fragments in flight -- s_waitcnt vmcnt(1..6) in the loop)
-#ifndef CS_NO_PIN
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 
     CS_T(3);

@@ -271,14 +271,9 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
         __syncthreads();
         FS_T(3);
     };
-#ifndef FS_UNROLL
-#define FS_UNROLL 1   // 0: round 4's loop (the conditional loads of tile1 stay branches: S is a loop variable)
-#endif
-#if FS_UNROLL
     // (r5) fully unrolled: S is a constant in every copy, so `if (S + 2 < 8) gloadW` and `if (S == 4) prefetch1()` are no branches around loads any more
     // (a branch between a load and its use makes the compiler's wait counts conservative: gemm_tn_split.hpp)
 #pragma unroll
-#endif
     for (int S = 0; S < 6; S += 2) {
         tile1(S, 0, I0{}, I1{});
         tile1(S + 1, 1, I1{}, I0{});

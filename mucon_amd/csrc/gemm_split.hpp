@@ -92,15 +92,6 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
     auto convert = [&](f32x4 v0, f32x4 v1, bool ok) {
         u32x4 hh, mm, ll;
         uint32_t a, bb, c;
-#ifdef S2_ABL_NOSPLIT    // (timing ablation: the operands without the split arithmetic)
-        {
-            Planes P0;
-            P0.pl[0] = __builtin_bit_cast(bf16x8, v0);
-            P0.pl[1] = __builtin_bit_cast(bf16x8, v1);
-            P0.pl[2] = __builtin_bit_cast(bf16x8, v0);
-            return P0;
-        }
-#endif
         if (TAPS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -134,18 +125,8 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-#ifdef S2_ABL_NOW        // (timing ablation, tools/abl_first_conv.sh -- wrong results: no fragment reads)
-                w[nb][pl] = A.pl[pl];
-                continue;
-#endif
                 w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
             }
-#ifdef S2_ABL_NOMFMA     // (timing ablation: one MFMA per column block instead of six; the condition keeps the loads and the split alive)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.pl[0], w[nb][0], acc[nb], 0, 0, 0);
-        if (w[0][1][0] == 12345 && w[1][2][0] == 777 && A.pl[1][0] == 3 && A.pl[2][0] == 5) acc[0][0] += 1.f;
-        return;
-#endif
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.pl[1], w[nb][1], acc[nb], 0, 0, 0);
@@ -183,9 +164,7 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef S2_ABL_NOA       // (timing ablation: the tape is loaded for the first two k-tiles only)
         gloadA(min(S + 2, nS - 1), SET);   // the tail re-loads the last tile; nobody uses it
-#endif
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(buf, 2 * g + 1, nxt);
         cur = convert(ra[O][0], ra[O][1], rok[O]);
@@ -292,12 +271,9 @@ __global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const
     const int nS = (TAPS ? p.taps : 1) * ktt; // even (Kc is a multiple of 128)
     // Every workgroup walks the k-tiles in a ROTATED order, starting at a tile that depends on its place in the grid: with all 256
     // workgroups starting at k = 0 and advancing in step, every tape access of the chip at one moment is a 256-byte piece at the same
-    // offset inside an 8 KB frame -- addresses that differ by multiples of 8 KB only (NT16_ROT = 0: that order).  Depends on blockIdx.x
+    // offset inside an 8 KB frame -- addresses that differ by multiples of 8 KB only.  Depends on blockIdx.x
     // alone among the videos of a batch: a video alone sums in the order it sums inside a batch.
-#ifndef NT16_ROT
-#define NT16_ROT 1
-#endif
-    const int rot = NT16_ROT ? (int)((blockIdx.x * 5u) % (unsigned)nS) : 0;
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)nS);
     auto phys = [&](int S) { const int q = S + rot; return q >= nS ? q - nS : q; };   // logical tile S of this workgroup's walk -> k-tile
     const int trow_raw0 = t0 + wr * 32 + r, trow_raw1 = trow_raw0 + 16;
     const float *a_vid = p.A + (long)b * p.a_bstride + 32 * g + 4 * h;

@@ -31,18 +31,6 @@
 extern int g_mfma16;       // mucon_hip.hip (MUCON_MFMA16): bit 1 = this header's launch on v_mfma_f32_16x16x32_bf16
 extern int g_ts_stagger;   // mucon_hip.hip (MUCON_TS_STAGGER): single-image jobs with time chunks of at least this many steps take the staggered schedule ts_body_st (0: none)
 
-#ifndef TS_ABL
-#define TS_ABL 0   // tools/ts_ablate.hip: 1 no MFMAs, 2 no X split, 4 no G split / LDS stores, 8 no global loads in the loop (timing only)
-#endif
-#ifndef TS_STAMP
-#define TS_STAMP 0   // tools/ts_ablate.hip: 1 = s_memtime stamps around the phases of a tile (block 0 publishes per-wave sums; timing builds only)
-#endif
-#if TS_STAMP
-__device__ long long g_ts_stamps[8 * 8];
-#define TS_T(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#else
-#define TS_T(k) do { } while (0)
-#endif
 constexpr int TS_IMG = 2 * 3 * 2 * 128 * 8;             // bf16 elements of one 32-step G image (24,576 B)
 constexpr int TS_XT_FLOATS = 32 * 32;                   // a wave's X tile [32 time steps][32 columns] (4 KB), transposed through LDS
 constexpr int TS_SMEM_BYTES = 2 * 2 * TS_IMG * 2 + 8 * TS_XT_FLOATS * 4;   // two buffers x two images + eight X tiles: 131,072 B
@@ -76,7 +64,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     // X is fetched in 16-byte pieces: lane -> (row lane >> 3 of 8, columns 4 (lane & 7) .. + 3), four instructions per 32-step tile
     // (a 4-byte load per element costs the memory pipeline as much per instruction: 16 of them per tile were its bottleneck)
     const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
-    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;                              // per-lane byte offset
     float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS_XT_FLOATS;               // this wave's transposition tile
 
     // staging role: SAME image -> unit (s, h) = (wave >> 2, (wave >> 1) & 1); TWO_G -> image wave >> 2, s = (wave >> 1) & 1, units h = 0, 1
@@ -108,10 +95,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         const int t0 = tbeg + tile * 32;
         return !x0_act && t0 + 32 <= tend && t0 + xoff >= 0 && t0 + 31 + xoff < Tx;
     };
-#ifndef TS_BRANCHFREE
-#define TS_BRANCHFREE 1   // 0: round 4's loads (interior / edge variants of the X loads and the clamp of the G rows as branches inside the tile loop)
-#endif
-#if TS_BRANCHFREE
     // (r5) no branch between a load and its use inside the tile loop: see ts_body_st -- with the branches the compiler's wait counts made every X tile wait for
     // the loads issued one phase ago
     const int ldx4 = ldx * 4, xcb = (cg * 32 + xc4) * 4;
@@ -124,24 +107,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
             rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(Xu) + (uint32_t)(ts * ldx4 + xcb));
         }
     };
-#else
-    auto gloadX = [&](int tile, auto SET) {
-        constexpr int Q = decltype(SET)::value;
-        if (x_int(tile)) {
-            const float *ub = Xu + (long)(tbeg + tile * 32 + xoff) * ldx;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rx[Q][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ub + (long)(8 * i) * ldx) + x_lane);
-        } else {
-            const int row0 = tbeg + tile * 32 + xrow + xoff;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ts = min(max(row0 + 8 * i, 0), Tx - 1);
-                rx[Q][i] = *reinterpret_cast<const f32x4 *>(Xu + (long)ts * ldx + cg * 32 + xc4);
-            }
-        }
-    };
-#endif
     // a tile's 32 x 32 values go through the wave's own LDS tile: written as they were loaded (rows), read back by column into
     // the MFMA operand order (lane (r, h): column r, time steps 8h .. 8h + 7 of step s).  Wave-private: program order is all it needs.
     auto stageX = [&](auto SET) {
@@ -165,7 +130,7 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     };
     auto gloadG = [&](int tile, auto HALF) {
         constexpr int HB = decltype(HALF)::value;
-        const bool inner = TS_BRANCHFREE ? false : g_int(tile);
+        const bool inner = false;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -217,15 +182,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     auto convertX = [&](const float (&x)[8]) {
         u32x4 hh, mm, ll;
         uint32_t a, bb, c;
-        if (TS_ABL & 2) {
-            Planes P;
-            hh = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-            mm = u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-            P.pl[0] = __builtin_bit_cast(bf16x8, hh);
-            P.pl[1] = __builtin_bit_cast(bf16x8, mm);
-            P.pl[2] = __builtin_bit_cast(bf16x8, hh);
-            return P;
-        }
         sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
         sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
         sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
@@ -247,13 +203,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
-        if (TS_ABL & 1) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, w[nb][pl])));
-            return;
-        }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[1], acc[nb], 0, 0, 0);
@@ -312,54 +261,42 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     //   { MFMAs of step 0 | split of X step 1, first half of image mt+1 -> buffer O }
     //   { X tile <- tile mt+1 (set O), set O <- tile mt+3 requested; first half of image mt+2 requested; X (mt+1, step 0) read back }
     //   { MFMAs of step 1 | split of X (mt+1, step 0), second half of image mt+1 }
-#if TS_STAMP
-    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-    long long st_prev = __builtin_amdgcn_s_memtime();
-#endif
     auto tile = [&](int mt, auto SET, auto OTHER) {
         constexpr int Q = decltype(SET)::value, O = decltype(OTHER)::value;
         (void)Q;
-        TS_T(5);
         const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n3 = min(mt + 3, last);
         const float bw = mt < last ? 1.f : 0.f;
-        if (!(TS_ABL & 8)) gloadG(n1, I1{});
+        gloadG(n1, I1{});
         readX(1);
         if (!x_int(mt)) fixX(rawT, mt, 1);
         if (!g_int(n1)) fixG(n1, I0{});
         __builtin_amdgcn_sched_barrier(0);
-        TS_T(0);
         pin(rawT);   // (keeps the splits below in this block: without it they are duplicated into the fix-up branches, outside the weave)
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgA[u]);
         mfma_step(Q, 0, cur);
         Planes nxt = convertX(rawT);
-        if (!(TS_ABL & 4)) splitstoreG(n1, O, I0{}, bw);
+        splitstoreG(n1, O, I0{}, bw);
         weave();
         use(nxt);   // (a use inside the phase: otherwise the split is sunk behind the branches below, out of the weave)
         __builtin_amdgcn_sched_barrier(0);
-        TS_T(1);
         stageX(OTHER);
-        if (!(TS_ABL & 8)) {
-            gloadG(n2, I0{});
-            gloadX(n3, OTHER);
-        }
+        gloadG(n2, I0{});
+        gloadX(n3, OTHER);
         readX(0);
         if (!x_int(n1)) fixX(rawT, n1, 0);
         if (!g_int(n1)) fixG(n1, I1{});
         __builtin_amdgcn_sched_barrier(0);
-        TS_T(2);
         pin(rawT);
 #pragma unroll
         for (int u = 0; u < NU; ++u) pin(rgB[u]);
         mfma_step(Q, 1, nxt);
         cur = convertX(rawT);
-        if (!(TS_ABL & 4)) splitstoreG(n1, O, I1{}, bw);
+        splitstoreG(n1, O, I1{}, bw);
         weave();
         use(cur);
         __builtin_amdgcn_sched_barrier(0);
-        TS_T(3);
         __syncthreads();
-        TS_T(4);
     };
     CLK_BEGIN();
     for (int mt = 0; mt < ntiles; mt += 2) {
@@ -368,10 +305,6 @@ __device__ __forceinline__ void ts_body(const TnParams &p, const int kc2, const 
     }
     CLK_END(1, item);
 
-#if TS_STAMP
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -408,7 +341,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     // X is fetched in 16-byte pieces: lane -> (row lane >> 3 of 8, columns 4 (lane & 7) .. + 3), four instructions per 32-step tile
     // (a 4-byte load per element costs the memory pipeline as much per instruction: 16 of them per tile were its bottleneck)
     const int xrow = lane >> 3, xc4 = (lane & 7) * 4;
-    const uint32_t x_lane = (uint32_t)(xrow * ldx + cg * 32 + xc4) * 4u;                              // per-lane byte offset
     float *xT = reinterpret_cast<float *>(smem + 2 * 2 * TS_IMG) + wave * TS_XT_FLOATS;               // this wave's transposition tile
 
     // staging role: SAME image -> unit (s, h) = (wave >> 2, (wave >> 1) & 1); TWO_G -> image wave >> 2, s = (wave >> 1) & 1, units h = 0, 1
@@ -530,15 +462,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     auto convertX = [&](const float (&x)[8]) {
         u32x4 hh, mm, ll;
         uint32_t a, bb, c;
-        if (TS_ABL & 2) {
-            Planes P;
-            hh = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-            mm = u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-            P.pl[0] = __builtin_bit_cast(bf16x8, hh);
-            P.pl[1] = __builtin_bit_cast(bf16x8, mm);
-            P.pl[2] = __builtin_bit_cast(bf16x8, hh);
-            return P;
-        }
         sp_split2(x[0], x[1], a, bb, c); hh[0] = a; mm[0] = bb; ll[0] = c;
         sp_split2(x[2], x[3], a, bb, c); hh[1] = a; mm[1] = bb; ll[1] = c;
         sp_split2(x[4], x[5], a, bb, c); hh[2] = a; mm[2] = bb; ll[2] = c;
@@ -560,13 +483,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) w[nb][pl] = *reinterpret_cast<const bf16x8 *>(base + pl * (2 * 128 * 8) + nb * 32 * 8);
-        if (TS_ABL & 1) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, w[nb][pl])));
-            return;
-        }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {   // small terms first; all six land in the same fp32 accumulator
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][1], X.pl[1], acc[nb], 0, 0, 0);
@@ -576,14 +492,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[1], acc[nb], 0, 0, 0);
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][0], X.pl[0], acc[nb], 0, 0, 0);
         }
-    };
-    auto pin = [](auto &arr) {
-#pragma unroll
-        for (auto &v : arr) asm volatile("" : "+v"(v));
-    };
-    auto use = [](const Planes &P) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, P.pl[pl])));
     };
     Planes P0, P1;   // the operands of the two MFMA steps of the tile this wave multiplies next
     // One 32-step tile is two BLOCKS per wave: an MFMA block (both steps: 48 MFMAs, 24 fragment reads, nothing else) and a staging block
@@ -599,17 +507,9 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     //                X tile u (register set u & 1) -> LDS tile -> read back by column -> split into the operands of both steps, then
     //                X tile u + 2 requested into the freed set.
     //   waves 0-3, tile mt:  MFMAs(mt) | stage(mt + 1, mt + 1)        waves 4-7, tile mt:  stage(mt + 1, mt) | MFMAs(mt)
-#if TS_STAMP
-    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-    long long st_prev = __builtin_amdgcn_s_memtime();
-#endif
-#ifndef TS_ST_PRIO
-#define TS_ST_PRIO 0   // 1: s_setprio around the blocks (experiment)
-#endif
     auto mfma_block = [&](int buf) {
         __builtin_amdgcn_sched_barrier(0);
-        // (TS_ST_PRIO: the multiplying wave at priority 0, the staging wave at 2 -- measured without effect, 230.4 against 230.0 us; off)
-        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(0);
+        // (s_setprio around the blocks -- the multiplying wave at priority 0, the staging wave at 2 -- measured without effect: 230.4 against 230.0 us)
         mfma_step(buf, 0, P0);
         mfma_step(buf, 1, P1);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -621,24 +521,18 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
         __builtin_amdgcn_sched_barrier(0);
     };
     auto stageG = [&](int g, int buf, float bw, int gnext, auto EDGE) {   // (buf given, not g & 1: past the chunk's end the last image is staged again, into the idle buffer)
-        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(2);
         if (decltype(EDGE)::value && !g_int(g)) {
             fixG(g, I0{});
             fixG(g, I1{});
         }
-        if (!(TS_ABL & 4)) {
-            splitstoreG(g, buf, I0{}, bw);
-            splitstoreG(g, buf, I1{}, bw);
-        }
-        if (!(TS_ABL & 8)) {
-            gloadG(gnext, I0{});
-            gloadG(gnext, I1{});
-        }
+        splitstoreG(g, buf, I0{}, bw);
+        splitstoreG(g, buf, I1{}, bw);
+        gloadG(gnext, I0{});
+        gloadG(gnext, I1{});
     };
     auto stageXops = [&](int u, int unext, auto XSET, auto EDGE) {
-        if (TS_ST_PRIO) __builtin_amdgcn_s_setprio(2);
         stageX(XSET);
-        if (!(TS_ABL & 8)) gloadX(unext, XSET);
+        gloadX(unext, XSET);
         readX();
         if (decltype(EDGE)::value && !x_int(u)) {
             fixX(rawT, u, 0);
@@ -659,7 +553,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     //  the tiles that need a fix-up -- a video edge under a tap, the chunk's partial last tile, the non-linearity of the last_conv job --
     //  take a second copy of the tile body with the masks applied unconditionally: the interior copy is one straight line)
     auto tile = [&](int mt, auto SET, auto OTHER, auto LEAD, auto EDGE) {
-        TS_T(5);
         const int n1 = min(mt + 1, last), n2 = min(mt + 2, last), n3 = min(mt + 3, last);
         const float bw = mt < last ? 1.f : 0.f;
         // (G before X inside a staging block: the gradient rows requested at the end of stageG have the rest of the block, the barrier and the
@@ -667,23 +560,16 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
         // then never makes the X tile requested two blocks ago wait for anything younger than itself)
         if constexpr (decltype(LEAD)::value) {
             mfma_block(mt & 1);
-            TS_T(0);
             stageG(n1, (mt + 1) & 1, bw, n2, EDGE);
-            TS_T(2);
             if constexpr (NXS == 2) stageXops(n1, n3, OTHER, EDGE);
             else stageXops(n1, n2, I0{}, EDGE);
-            TS_T(1);
         } else {
             stageG(n1, (mt + 1) & 1, bw, n2, EDGE);
-            TS_T(2);
             if constexpr (NXS == 2) stageXops(mt, n2, SET, EDGE);
             else stageXops(mt, n1, I0{}, EDGE);
-            TS_T(1);
             mfma_block(mt & 1);
-            TS_T(0);
         }
         __syncthreads();
-        TS_T(4);
     };
     auto tile2 = [&](int mt, auto SET, auto OTHER, auto LEAD) { tile(mt, SET, OTHER, LEAD, std::true_type{}); };
     CLK_BEGIN();
@@ -700,10 +586,6 @@ __device__ __forceinline__ void ts_body_st(const TnParams &p, const int kc2, con
     }
     CLK_END(1, item);
 
-#if TS_STAMP
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 6; ++k) g_ts_stamps[wave * 8 + k] = st_acc[k];
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

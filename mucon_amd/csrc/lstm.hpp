@@ -17,9 +17,6 @@
 #pragma once
 #include "common.hpp"
 
-#ifndef LSTM_ABL
-#define LSTM_ABL 0   // timing builds of the forward recurrence (tools/abl_lstm.sh; 1 is wrong by construction): 1 no mat-vec FMAs,
-#endif               // 3 plain v_fma_f32 instead of v_pk_fma_f32
 constexpr int LSTM_H = 128;
 constexpr int LSTM_G = 4 * LSTM_H;  // 512 gate rows
 
@@ -151,19 +148,6 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) hv[c4] = *reinterpret_cast<const f32x4 *>(&hs[cur][16 * c4 + 4 * p]);
         __builtin_amdgcn_sched_barrier(0);
-#if LSTM_ABL == 1
-        a[0][0] = hv[0][0] + hv[1][1] + hv[2][2] + hv[3][3] + hv[4][0] + hv[5][1] + hv[6][2] + hv[7][3];
-#elif LSTM_ABL == 3
-        float b4[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int c4 = 0; c4 < 8; ++c4)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(b4[q][e & 1]) : "v"(wr[q][c4 * 4 + e]), "v"(hv[c4][e]));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = f32x2{b4[q][0], b4[q][1]};
-#else
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
 #pragma unroll
@@ -172,7 +156,6 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
                 a[q] = f32x2{wr[q][c4 * 4 + 2], wr[q][c4 * 4 + 3]} * f32x2{hv[c4][2], hv[c4][3]} + a[q];
             }
         }
-#endif
         float pre[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pre[q] = quad_sum(a[q][0] + a[q][1]);

@@ -29,16 +29,16 @@
 int g_mfma16 = 1;             // MUCON_MFMA16: bit 0 = first_conv forward / layer 0's data gradient (gemm_split.hpp), bit 1 = the weight gradients
                               // (gemm_tn_split.hpp) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (profiles/r05_mfma_shape.txt: the A/B)
 int g_ts_runs = 1;            // the batched split weight-gradient launch of encoder_bwd as static runs on persistent workgroups (MUCON_TS_RUNS; gemm_tn_split.hpp); 0: one workgroup per item
-int g_ts_cost[4] = {69, 74, 95, 109};   // ... its cost units (1/32 us): tile of a staggered / lock-step / two-image column, a run's fixed cost per video (MUCON_TS_COSTS=a,b,c,d)
-int g_ts_max_wg = 0;          // ... on at most this many workgroups (MUCON_TS_MAX_WG; 0 = one per CU)
+int g_ts_cost[4] = {69, 74, 95, 109};   // ... its cost units (1/32 us): tile of a staggered / lock-step / two-image column, a run's fixed cost per video (fixed since r6: was the knob TS_COSTS=a,b,c,d)
+int g_ts_max_wg = 0;          // ... on at most this many workgroups (fixed since r6: was the knob TS_MAX_WG; 0 = one per CU)
 // One-shot options of the NEXT mucon_encoder_bwd call (mucon_encoder_bwd_overlap; data-parallel training): an event to record on the pass's stream
 // once every gradient EXCEPT first_conv's is final, and a cap on the workgroups of the weight-gradient launches (CUs left free for RCCL's kernel)
 hipEvent_t g_bwd_event = nullptr;
 int g_bwd_max_wg = 0;
-int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (MUCON_TS_GROUP_ROWS)
-int g_ts_stagger = 1024;      // MUCON_TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
+int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (fixed since r6: was the knob TS_GROUP_ROWS)
+int g_ts_stagger = 1024;      // fixed since r6: was the knob TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
-int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (MUCON_COARSE_RB4_WGS; 0: never)
+int g_cs_rb4_wgs = 512;       // forward launches of the coarse kernel take 64 rows per workgroup where 16-row workgroups would number more than this (fixed since r6: was the knob COARSE_RB4_WGS; 0: never)
 int g_cs_rb = 0;              // row blocks (16 rows each) per workgroup of the coarse-level split kernel: 0 = by level size (MUCON_COARSE_RB)
 int g_nt_force_bm = 0;
 long g_nt_bm16_rows = 8193;   // see nt_pick_bm (MUCON_NT_BM16_ROWS; 0 = never use 16-row tiles)
@@ -66,18 +66,18 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }  // in floats
 
 // time-chunk length for a weight-gradient launch: ~256 workgroups, but never fewer than 4 m-tiles (128
 // time steps) per workgroup -- every workgroup writes a 64 KB partial tile that has to be summed later
-int g_first_conv_ksplit = 1;           // first_conv of small launches in four k-chunks (MUCON_FIRST_CONV_KSPLIT)
-long g_first_conv_ksplit_rows = 6144;  // ... up to this many frames per launch (MUCON_FIRST_CONV_KSPLIT_ROWS; measured: 65 -> 47 us at 5,000, even at 8,000)
-int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (MUCON_FIRST_CONV_SPLIT)
+int g_first_conv_ksplit = 1;           // first_conv of small launches in four k-chunks (fixed since r6: was the knob FIRST_CONV_KSPLIT)
+long g_first_conv_ksplit_rows = 6144;  // ... up to this many frames per launch (fixed since r6: was the knob FIRST_CONV_KSPLIT_ROWS; measured: 65 -> 47 us at 5,000, even at 8,000)
+int g_first_conv_split = 1;            // first_conv forward on the bf16 MFMA, operands split exactly in three (fixed since r6: was the knob FIRST_CONV_SPLIT)
 long g_first_conv_split_rows = 8192;   // ... for launches of at least this many frames (MUCON_FIRST_CONV_SPLIT_ROWS)
 int g_cs = 1;                 // residual layers of the other (coarse, latency-bound) levels on the k-split split-bf16 kernel (gemm_coarse_split.hpp; MUCON_COARSE_SPLIT=0: f32 MFMA)
-int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; MUCON_FUSED_SPLIT=0: f32 MFMA)
+int g_fs = 1;                 // residual layers of chip-filling levels on the split-bf16 two-stage kernel (gemm_fused_split.hpp; fixed since r6: was the knob FUSED_SPLIT=0: f32 MFMA)
 long g_fs_rows = 32768;       // ... from this many rows in the batch = one 128-row workgroup per CU (MUCON_FUSED_SPLIT_ROWS).  r3: 16,384 -> 32,768: at
                               // B = 8 x T = 4096 the T/2 level (16,384 rows: 256 workgroups of 64 rows on the 4-wave variant) is 3.7 us per step
                               // faster on the coarse kernel's 32-row workgroups (512 of them, two per CU)
 int g_tn_split = 1;           // weight gradients on the bf16 MFMA with exactly split operands (gemm_tn_split.hpp; MUCON_TN_SPLIT=0: f32 MFMA)
-int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (MUCON_TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
-int g_ts_layer_mc_cap = 512;  // ... and the residual layers' jobs of the batched split launch chunks of at most this many (MUCON_TS_LAYER_MC_CAP): their workgroups
+int g_ts_mc_cap = 2048;       // ... whose workgroups (256 columns each) take time chunks of at most this many steps (fixed since r6: was the knob TS_MC_CAP; measured 2048: 209 us, 1024: 218, 512: 229 at B=8 x T=4096)
+int g_ts_layer_mc_cap = 512;  // ... and the residual layers' jobs of the batched split launch chunks of at most this many (fixed since r6: was the knob TS_LAYER_MC_CAP): their workgroups
                               // stage two gradient images and replay the dropout mask, 3.1 us per 32-step tile against first_conv's 2.4 -- at 2,048 steps the
                               // 32 of them at the finest level ran 200 us while first_conv's 128 finished after 160 and the launch (215 us) waited for them (r5: 2048 -> 512,
                               // 0.2086 -> 0.2000 ms per launch; 1024: 0.2148, 768: 0.199, 384: 0.200, 256: 0.1975 with 8 us more slab reduction)
@@ -210,7 +210,7 @@ inline bool fs_level(const mucon_encoder_cfg *cfg, const Plan &pl, int l) {
     return g_fs && !g_no_fuse && l >= 0 && l < pl.L && (long)pl.B * pl.Tl[l] >= g_fs_rows && cfg->dilation[l] < pl.Tl[l];
 }
 inline bool cs_on() { return g_cs && !g_no_fuse; }
-int g_pack_f32 = 0;     // MUCON_PACK_ALL=1: every weight re-layout is written whether or not a launch of the pass reads it (A/B of the r4 trimming; tests)
+int g_pack_f32 = 0;     // fixed since r6: was the knob PACK_ALL=1: every weight re-layout is written whether or not a launch of the pass reads it (A/B of the r4 trimming; tests)
 int g_tail_chain = 1;   // MUCON_TAIL_CHAIN=0: the row-local launches at the coarsest level one by one (cs_kernel) instead of chained (ct_kernel)
 
 // Which weight re-layouts a forward pass writes.  The backward pass reads them, decides from the same predicates, and refuses to run when
@@ -594,28 +594,12 @@ static bool apply_knob(const char *name, const char *e) {
         if (e) g_tail_chain = atoi(e);
         return true;
     }
-    if (!strcmp(name, "MUCON_PACK_ALL")) {
-        if (e) g_pack_f32 = atoi(e) ? 1 : 0;
-        return true;
-    }
     if (!strcmp(name, "MUCON_VIT_LANES")) {
         if (e) g_vit_lanes = atoi(e);
         return true;
     }
     if (!strcmp(name, "MUCON_DEC_MW")) {
         if (e) g_dec_mw = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_NT_BM")) {
-        if (e) g_nt_force_bm = atoi(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FUSED_SPLIT")) {
-        g_fs = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_COARSE_RB4_WGS")) {
-        if (e) g_cs_rb4_wgs = atoi(e) > 0 ? atoi(e) : 0;
         return true;
     }
     if (!strcmp(name, "MUCON_COARSE_RB")) {
@@ -631,11 +615,7 @@ static bool apply_knob(const char *name, const char *e) {
         return true;
     }
     if (!strcmp(name, "MUCON_MFMA16")) {
-        if (e) g_mfma16 = atoi(e) & 3;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_STAGGER")) {
-        if (e) g_ts_stagger = atoi(e) > 0 ? atoi(e) : 0;
+        if (e) g_mfma16 = atoi(e) & 1;
         return true;
     }
     if (!strcmp(name, "MUCON_TN_SPLIT")) {
@@ -644,40 +624,6 @@ static bool apply_knob(const char *name, const char *e) {
     }
     if (!strcmp(name, "MUCON_TS_RUNS")) {
         if (e) g_ts_runs = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_GROUP_ROWS")) {
-        if (e && atoi(e) >= 0) g_ts_group_rows = atoi(e);
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_MAX_WG")) {
-        if (e) g_ts_max_wg = atoi(e) > 0 ? atoi(e) : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_COSTS")) {
-        int v[4];
-        if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] >= 0 && v[0] < 4096 && v[1] < 4096 && v[2] < 4096)
-            for (int k = 0; k < 4; ++k) g_ts_cost[k] = v[k];
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_LAYER_MC_CAP")) {
-        if (e && atoi(e) >= 128) g_ts_layer_mc_cap = atoi(e) / 32 * 32;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_TS_MC_CAP")) {
-        if (e && atoi(e) >= 128) g_ts_mc_cap = atoi(e) / 32 * 32;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT")) {
-        if (e) g_first_conv_split = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FIRST_CONV_KSPLIT")) {
-        if (e) g_first_conv_ksplit = atoi(e) ? 1 : 0;
-        return true;
-    }
-    if (!strcmp(name, "MUCON_FIRST_CONV_KSPLIT_ROWS")) {
-        if (e) g_first_conv_ksplit_rows = atol(e);
         return true;
     }
     if (!strcmp(name, "MUCON_FIRST_CONV_SPLIT_ROWS")) {
@@ -694,7 +640,7 @@ static bool apply_knob(const char *name, const char *e) {
     }
     return false;
 }
-static const char *const kKnobs[] = {"MUCON_TS_RUNS", "MUCON_TS_MAX_WG", "MUCON_TS_GROUP_ROWS", "MUCON_TS_COSTS", "MUCON_COARSE_RB4_WGS", "MUCON_MFMA16", "MUCON_TS_STAGGER", "MUCON_TS_LAYER_MC_CAP", "MUCON_TAIL_CHAIN", "MUCON_PACK_ALL", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_NT_BM", "MUCON_TN_SPLIT", "MUCON_TS_MC_CAP", "MUCON_FIRST_CONV_SPLIT", "MUCON_FIRST_CONV_KSPLIT", "MUCON_FIRST_CONV_KSPLIT_ROWS", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
+static const char *const kKnobs[] = {"MUCON_TS_RUNS", "MUCON_MFMA16", "MUCON_TAIL_CHAIN", "MUCON_DEC_MW", "MUCON_VIT_LANES", "MUCON_COARSE_RB", "MUCON_COARSE_SPLIT", "MUCON_FUSED_SPLIT_ROWS", "MUCON_TN_SPLIT", "MUCON_FIRST_CONV_SPLIT_ROWS", "MUCON_NT_BM16_ROWS", "MUCON_FUSE"};
 
 void mucon_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
@@ -720,7 +666,6 @@ int mucon_test_get_knob(const char *name) {
     mucon_abi_version();
     if (name && !strcmp(name, "MUCON_MFMA16")) return g_mfma16;
     if (name && !strcmp(name, "MUCON_TN_SPLIT")) return g_tn_split;
-    if (name && !strcmp(name, "MUCON_TS_STAGGER")) return g_ts_stagger;
     if (name && !strcmp(name, "MUCON_TS_RUNS")) return g_ts_runs;
     if (name && !strcmp(name, "MUCON_FIRST_CONV_SPLIT")) return g_first_conv_split;
     return -1;

@@ -505,10 +505,7 @@ __global__ __launch_bounds__(256) void head_fwd_z_kernel(const HeadFwdArgs a) {
     // (r5) H = 128: the thread's eight pieces of W are requested in front of the barrier, beside the rows' own trip (they were a second trip behind it)
     const float *wr = a.w + (long)min(c, C - 1) * H;
     f32x4 wpre[8];
-#ifndef HEAD_PRE
-#define HEAD_PRE 1   // 0: round 4's order (the y-head kernels' second operands requested behind their first barrier)
-#endif
-    const bool pre = HEAD_PRE && H == 128;
+    const bool pre = H == 128;
     if (pre) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) wpre[i] = *reinterpret_cast<const f32x4 *>(wr + q * 4 + 16 * i);
@@ -713,9 +710,7 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
             // branch costs a branch and a full wait per element)
             const float *p1 = a.dlogits ? a.dlogits : a.dlogp, *p2 = a.dlogp ? a.dlogp : a.dlogits;
             const float w1 = a.dlogits ? 1.f : 0.f, w2 = a.dlogp ? 1.f : 0.f;
-#ifndef HB_FRAMES
-#define HB_FRAMES 16   // (r5) frames of a bin requested at once (8: round 4 -- a bin of Tf / Tz = 16 frames was two dependent round trips)
-#endif
+            constexpr int HB_FRAMES = 16;   // (r5) frames of a bin requested at once (8: round 4 -- a bin of Tf / Tz = 16 frames was two dependent round trips)
             for (int base = 0; base < nfr; base += HB_FRAMES) {
                 float v1[HB_FRAMES], v2[HB_FRAMES];
 #pragma unroll
@@ -754,7 +749,7 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
 #pragma unroll
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
         float d = G1[zi][c] + G2[zi][c];
-        if (zi < nz && c < C && s != 0.f) d -= expf(HEAD_PRE ? lpz[i] : a.logp_z[((long)b * a.Tz + z0 + zi) * C + c]) * s;
+        if (zi < nz && c < C && s != 0.f) d -= expf(lpz[i]) * s;
         G1[zi][c] = d;
         if (c == 0) S2[zi] = s;
     }

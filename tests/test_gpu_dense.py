@@ -487,11 +487,11 @@ def test_coarse_split_kernel_row_blocks(rb):
 
 
 def test_f32_fused_layer_kernels_at_every_size():
-    """MUCON_COARSE_SPLIT=0 MUCON_FUSED_SPLIT=0 keeps every level on the f32-MFMA two-stage kernels (csrc/gemm_fused.hpp), which
+    """MUCON_COARSE_SPLIT=0 and MUCON_FUSED_SPLIT_ROWS beyond every batch keep every level on the f32-MFMA two-stage kernels (csrc/gemm_fused.hpp), which
     by default only the configurations the split kernels do not take still reach: goldens, oracle forward / backward, dropout."""
     import subprocess
     import sys
-    env = dict(os.environ, MUCON_COARSE_SPLIT="0", MUCON_FUSED_SPLIT="0")
+    env = dict(os.environ, MUCON_COARSE_SPLIT="0", MUCON_FUSED_SPLIT_ROWS="1099511627776")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "golden or oracle_f64 or dropout"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -500,10 +500,10 @@ def test_f32_fused_layer_kernels_at_every_size():
 
 
 def test_f32_layer_kernels_at_full_size():
-    """... and MUCON_FUSED_SPLIT=0 keeps the f32-MFMA two-stage kernels on the chip-filling levels: the full-size checks under it."""
+    """... and with MUCON_COARSE_SPLIT=0 too the chip-filling levels of the FULL-SIZE batch stay on the f32-MFMA two-stage kernels: the full-size checks under it."""
     import subprocess
     import sys
-    env = dict(os.environ, MUCON_FUSED_SPLIT="0")
+    env = dict(os.environ, MUCON_COARSE_SPLIT="0", MUCON_FUSED_SPLIT_ROWS="1099511627776")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "full_size_batch_properties or full_size_training"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -553,43 +553,14 @@ def test_unchained_coarsest_level():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("B,T,training", [(1, 2000, False), (8, 4096, True), (2, 777, True)])
-def test_trimmed_weight_relayout_is_bitwise_neutral(B, T, training):
-    """Since r4 the weight re-layout at the head of a forward pass (pack_all_kernel) leaves out the f32 operand layouts and layer 0's
-    data-gradient planes when no launch of the pass and its backward reads them (the default configuration); MUCON_PACK_ALL=1
-    writes everything as before.  The encoder output and every parameter gradient must be bitwise the same either way."""
-    from mucon_amd import _lib, ops
-    from oracle import dense as od
-    spec, ocfg = _spec({}), _ocfg({})
-    params_np = od.seeded_params(ocfg, 57)
-    names = ops.param_names(spec)
-    tape = torch.tensor(synth.tape(58, B, T, 2048), device=DEV)
-    v = torch.tensor(synth.uniform_pm1(59, (B, spec.out_length(T), 128)), device=DEV)
-
-    def run():
-        P = _dev_params(params_np, names)
-        enc = ops.encoder_forward(tape, P, spec, training=training, seed=1234)
-        (v * enc).sum().backward()
-        return [enc.detach().clone()] + [p.grad.detach().clone() for p in P]
-
-    base = run()
-    try:
-        _lib.set_knob("MUCON_PACK_ALL", 1)
-        other = run()
-    finally:
-        _lib.set_knob("MUCON_PACK_ALL", 0)
-    for name, a_, b_ in zip(["enc"] + names, base, other):
-        assert torch.equal(a_, b_), name
-
-
 @pytest.mark.parametrize("B,T,training", [(1, 2000, True), (8, 4096, True), (3, 777, False), (2, 16384, True), (1, 130, True), (5, 64, False)])
 def test_static_runs_weight_gradient_launch(B, T, training):
     """(r6) encoder_bwd's batched weight-gradient launch runs as STATIC RUNS (ts_runs_kernel, MUCON_TS_RUNS=1: default): every
     persistent workgroup takes one contiguous share of the pass's (column, video, tile) line and keeps its accumulators in
     registers while it stays inside a column -- one partial tile per (workgroup, column) instead of one per 512-step item.
     The schedule is a pure function of the shapes and the workgroup count: BITWISE the same gradients run after run
-    (back-to-back passes on one workspace).  Other cuts of the same sums -- one workgroup per item (MUCON_TS_RUNS=0), another
-    workgroup count, other cost units -- agree to fp32 rounding (2e-5 of a tensor's largest entry)."""
+    (back-to-back passes on one workspace).  Other cuts of the same sums -- one workgroup per item (MUCON_TS_RUNS=0), 97 workgroups, one
+    workgroup -- agree to fp32 rounding (2e-5 of a tensor's largest entry)."""
     from mucon_amd import _lib, ops
     from oracle import dense as od
     spec, ocfg = _spec({}), _ocfg({})
@@ -609,24 +580,31 @@ def test_static_runs_weight_gradient_launch(B, T, training):
     again = run()
     for name, a_, b_ in zip(names, base, again):
         assert torch.equal(a_, b_), name
-    for knob, value, default in (("MUCON_TS_RUNS", 0, 1), ("MUCON_TS_MAX_WG", 97, 0), ("MUCON_TS_COSTS", "40,90,70,10", "69,74,95,109"),
-                                 ("MUCON_TS_MAX_WG", 1, 0)):
-        try:
-            _lib.set_knob(knob, value)
-            other = run()
-        finally:
-            _lib.set_knob(knob, default)
+    def other_cut(max_wg):
+        """the same pass on at most max_wg workgroups (mucon_encoder_bwd_overlap's cap: another share length, other partial sums)"""
+        P = [p.detach() for p in _dev_params(params_np, names)]
+        enc, ctx = ops.run_forward(ops._EncoderFn, tape, spec, training, 4321, *P)
+        ctx.dp_overlap = (torch.cuda.Event(), max_wg)
+        out = [g.clone() for g in ops.run_backward(ops._EncoderFn, ctx, v)[4:]]
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        _lib.set_knob("MUCON_TS_RUNS", 0)
+        others = [run()]
+    finally:
+        _lib.set_knob("MUCON_TS_RUNS", 1)
+    others += [other_cut(97), other_cut(1)]
+    for k, other in enumerate(others):
         for name, a_, c_ in zip(names, base, other):
             scale = a_.abs().max().item() + 1e-20
-            assert (a_ - c_).abs().max().item() <= 2e-5 * scale, (knob, value, name)
+            assert (a_ - c_).abs().max().item() <= 2e-5 * scale, (k, name)
 
 
-def test_schedule_knobs_of_round_5_do_not_change_results():
-    """(r5) The schedule choices of the weight-gradient launch and of the coarse kernels at the bench shape: first_conv's items on the
-    staggered wave schedule (MUCON_TS_STAGGER=0: the lock-step body -- a tile's sums are bitwise the same, but the static-runs schedule
-    prices the tiles differently and cuts the shares elsewhere: equal to fp32 rounding), 64-row
-    coarse workgroups at T/2 (MUCON_COARSE_RB4_WGS beyond every grid: 32-row workgroups -- a row's sums do not depend on its
-    workgroup's height: bitwise)."""
+def test_coarse_row_blocks_do_not_change_results():
+    """The coarse kernel's rows per workgroup at the bench shape (by default 64 for the forward launches of the T/2 level, 32 at T/4, 16 below;
+    MUCON_COARSE_RB=1 / 2: 16 / 32 rows everywhere): a row's sums do not depend on its workgroup's height -- the encoder output and every
+    gradient BITWISE equal."""
     from mucon_amd import _lib, ops
     from oracle import dense as od
     B, T = 8, 4096
@@ -643,18 +621,14 @@ def test_schedule_knobs_of_round_5_do_not_change_results():
         return [enc.detach().clone()] + [p.grad.detach().clone() for p in P]
 
     base = run()
-    for knob, value, default, exact in (("MUCON_TS_STAGGER", 0, 1024, False), ("MUCON_COARSE_RB4_WGS", 1 << 30, 512, True)):
+    for value in (1, 2):
         try:
-            _lib.set_knob(knob, value)
+            _lib.set_knob("MUCON_COARSE_RB", value)
             other = run()
         finally:
-            _lib.set_knob(knob, default)
+            _lib.set_knob("MUCON_COARSE_RB", 0)
         for name, a_, b_ in zip(["enc"] + names, base, other):
-            if exact:
-                assert torch.equal(a_, b_), (knob, name)
-            else:
-                scale = a_.abs().max().item() + 1e-20
-                assert (a_ - b_).abs().max().item() <= 2e-5 * scale, (knob, name)
+            assert torch.equal(a_, b_), (value, name)
 
 
 def test_data_parallel_overlap_hook_gradients_final_at_the_event():

@@ -1,7 +1,7 @@
 """ON THE GPU BOX, CLK_STAMP build (MUCON_HIPCC_FLAGS=-DCLK_STAMP=1): the life of every share of the static-runs weight-gradient
 launch (ts_runs_kernel, csrc/gemm_tn_split.hpp) at the bench shape -- s_memrealtime at entry and exit (10-ns ticks) -- in groups of 16 workgroups
 along the line of work (first_conv's columns first, then the residual layers from the fine levels down): where the static shares are too long.
-    python3 tools/ts_runs_times.py [KNOB=VALUE ...]        e.g. MUCON_TS_COSTS=66,77,99,128"""
+    python3 tools/ts_runs_times.py        (prints the least-squares fit of the cost units to put into csrc/mucon_hip.hip: g_ts_cost)"""
 import ctypes
 import os
 import sys
@@ -13,7 +13,7 @@ import bench
 from mucon_amd import _lib, ops
 
 lib = _lib.load()
-for kv in sys.argv[1:]:
+for kv in sys.argv[1:]:           # (run-time knobs of the library, e.g. MUCON_TS_RUNS=...; the cost units are compile-time constants since r6)
     k, v = kv.split("=", 1)
     _lib.set_knob(k, v)
 dev = torch.device("cuda", 0)
