@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r06
-python -m pytest tests/test_gpu_dense.py tests/test_gpu_fuzz.py tests/test_gpu_model.py tests/test_gpu_trajectory.py -m gpu -q -x 2>&1 | tail -6 > gpurun_out/r06/t.txt
-bash tools/tree_ab_kernels.sh .r05_tree > gpurun_out/r06/tree_ab_kernels3.txt 2>&1
-cat gpurun_out/r06/t.txt; grep -E "cs_kernel|ct_kernel|pack_all|sum over" gpurun_out/r06/tree_ab_kernels3.txt
+bash tools/profile_round.sh r06 > gpurun_out/r06/profile_round.log 2>&1
+bash tools/pmc_mfma.sh > gpurun_out/r06/pmc_mfma.log 2>&1
+cp gpurun_out/pmc_mfma/summary.txt gpurun_out/r06/mfma_utilisation.txt
+ls gpurun_out/profile_r06 | head -30

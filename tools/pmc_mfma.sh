@@ -17,7 +17,7 @@ for r in rows:
     d[r['Counter_Name']].append(float(r['Counter_Value']))
 print(f"{'kernel':58s} {'grid':>8s} {'n':>4s} {'cycles':>6s} {'mfma%':>6s} {'wait_any%':>9s} {'wait_inst%':>10s} {'active%':>8s} {'lds_stall%':>10s}")
 for (k, g), d in per.items():
-    if 'GRBM_GUI_ACTIVE' not in d or not any(s in k for s in ('gemm', 'fused', 'batched', 'persist', 'head', 'reduce', 'gn_', 'split', 'fs_kernel', 'cs_kernel', 'ct_kernel')):
+    if 'GRBM_GUI_ACTIVE' not in d or not any(s in k for s in ('gemm', 'fused', 'batched', 'persist', 'ts_runs', 'head', 'reduce', 'gn_', 'split', 'fs_kernel', 'cs_kernel', 'ct_kernel')):
         continue
     avg = {c: sum(v) / len(v) for c, v in d.items()}
     gui = avg['GRBM_GUI_ACTIVE'] / 8.0            # summed over 8 XCDs

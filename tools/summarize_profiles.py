@@ -60,7 +60,7 @@ def pmc(pattern, counter):
         k = r["Kernel_Name"]
         if "nt_split_kernel<true, false, false, false>" in k or "nt_split16_kernel<true, false, false, false>" in k or ("nt_gemm_kernel" in k and "pack" in prev):
             fwd.append(float(r["Counter_Value"]))
-        if "tn_batched_kernel" in k or "ts_batched_kernel" in k or "ts_persist_kernel" in k:
+        if "tn_batched_kernel" in k or "ts_batched_kernel" in k or "ts_persist_kernel" in k or "ts_runs_kernel" in k:
             wg.append(float(r["Counter_Value"]))
         prev = k
     return {"first_conv_fwd": fwd, "weight_gradients": wg}
