@@ -1,5 +1,4 @@
 mkdir -p gpurun_out/r06
-bash tools/profile_round.sh r06 > gpurun_out/r06/profile_round.log 2>&1
-bash tools/pmc_mfma.sh > gpurun_out/r06/pmc_mfma.log 2>&1
-cp gpurun_out/pmc_mfma/summary.txt gpurun_out/r06/mfma_utilisation.txt
-ls gpurun_out/profile_r06 | head -30
+bash tools/knob_sweep.sh MUCON_FS_RB2 1 0 1 0 > gpurun_out/r06/fs_rb2_ab.txt 2>&1
+python -m pytest tests/test_gpu_dense.py -m gpu -q -x -k "golden or oracle_f64 or full_size_batch or full_size_training or coarse_row" 2>&1 | tail -4 > gpurun_out/r06/t.txt
+cat gpurun_out/r06/fs_rb2_ab.txt gpurun_out/r06/t.txt
