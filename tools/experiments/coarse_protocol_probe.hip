@@ -14,6 +14,11 @@
 //              consumer: sc1 poll, barrier, sc0 sc1 loads of the three tiles              (the guide's publish-large row)
 //   sc1+pf     sc1, and the first eight weight-fragment triples of the NEXT layer are requested before the wave starts to
 //              wait for its producers (weights do not depend on activations)
+//   xcd        (r6) sc1's flags and polls, but the tiles of a video are the workgroups with equal blockIdx % 8 -- ONE XCD under the observed round-robin
+//              placement -- and the producer's stores are PLAIN: they stay in that XCD's L2, where the consumer's sc1 (L1-bypassing) loads find them.  Not a
+//              placement-independent protocol: every workgroup records its HW_REG_XCC_ID and the host reports whether each video sat on one XCD; a
+//              product kernel would have to fall back to sc1 stores when a consumer's XCD differs (flags carry the producer's XCC id).
+//   xcd+pf     xcd with sc1+pf's weight request behind the publication
 // Every protocol must produce the same bits as `launches` (the stand-in arithmetic is deterministic): a stale read shows up as
 // a checksum mismatch.  Correctness never relies on workgroup -> XCD placement.
 //
@@ -59,7 +64,7 @@ struct Args {
     unsigned seq;         // value a finished tile publishes
 };
 
-enum { P_LAUNCH = 0, P_WBL2 = 1, P_SC1 = 2, P_SC1_PF = 3 };
+enum { P_LAUNCH = 0, P_WBL2 = 1, P_SC1 = 2, P_SC1_PF = 3, P_XCD = 4, P_XCD_PF = 5 };
 
 __device__ __forceinline__ f32x4 load_plain(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ f32x4 load_sc1(const float *p) {
@@ -161,7 +166,7 @@ __device__ __forceinline__ void layer_body(const Layer &L, const int tile, const
         f32x4 x = ((red[(0 * 8 + nb) * 64 + lane] + red[(1 * 8 + nb) * 64 + lane]) + red[(2 * 8 + nb) * 64 + lane]) + red[(3 * 8 + nb) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = res[j][e] + 0.001f * fmaxf(x[e], 0.f);
-        if (PROTO >= P_SC1) store_sc1(L.out + grow + 16 * nb, x);
+        if (PROTO == P_SC1 || PROTO == P_SC1_PF) store_sc1(L.out + grow + 16 * nb, x);
         else *reinterpret_cast<f32x4 *>(L.out + grow + 16 * nb) = x;
     }
     // ---- publish
@@ -176,7 +181,7 @@ __device__ __forceinline__ void layer_body(const Layer &L, const int tile, const
             __hip_atomic_store(flags_mine + video * TILES_PER_VIDEO + (tile & (TILES_PER_VIDEO - 1)), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // sc1+pf: the next layer's first ring, requested behind the publication (in front of it the drain above would wait for it)
-        if (PROTO == P_SC1_PF && next) {
+        if ((PROTO == P_SC1_PF || PROTO == P_XCD_PF) && next) {
             const uint16_t *wn = next->W + (long)w * WSTEP + lane * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) loadW(wn, i, i);
@@ -186,18 +191,26 @@ __device__ __forceinline__ void layer_body(const Layer &L, const int tile, const
     }
 }
 
+__device__ unsigned g_xcc[NT];
 template <int PROTO>
 __global__ __launch_bounds__(256) void probe_kernel(const Args a, const int only_layer) {
     __shared__ f32x4 red[4 * 8 * 64];
     bf16x8 wf[8][3];
-    const int tile = blockIdx.x, video = blockIdx.x / TILES_PER_VIDEO;
+    // xcd: video = blockIdx % 8 (the workgroups that share an XCD under round-robin placement), tile inside it = blockIdx / 8
+    const int video = PROTO >= P_XCD ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / TILES_PER_VIDEO);
+    const int tile = PROTO >= P_XCD ? video * TILES_PER_VIDEO + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (PROTO >= P_XCD && threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+        g_xcc[tile] = x;
+    }
     if (PROTO == P_LAUNCH) {
         layer_body<PROTO>(a.l[only_layer], tile, video, nullptr, nullptr, 0, true, red, wf, false, nullptr);
         return;
     }
     for (int l = 0; l < a.n; ++l)
         layer_body<PROTO>(a.l[l], tile, video, a.flags + (l ? l - 1 : 0) * NT, a.flags + l * NT, a.seq, l == 0, red, wf,
-                          PROTO == P_SC1_PF && l > 0, l + 1 < a.n ? &a.l[l + 1] : nullptr);
+                          (PROTO == P_SC1_PF || PROTO == P_XCD_PF) && l > 0, l + 1 < a.n ? &a.l[l + 1] : nullptr);
 }
 
 int main(int argc, char **argv) {
@@ -239,7 +252,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    const char *names[4] = {"launches", "wbl2", "sc1", "sc1+pf"};
+    const char *names[6] = {"launches", "wbl2", "sc1", "sc1+pf", "xcd", "xcd+pf"};
     // runs of same-level layers as the bench shape has them: T/8 = layers 5..8 (dilations 32 .. 256 rows: 2, 4, 8, 16 tiles), and a
     // two-layer run (T/4-like spacing on this grid) for the short case
     const int runs[2][5] = {{4, 2, 4, 8, 16}, {2, 1, 2, 0, 0}};
@@ -252,7 +265,7 @@ int main(int argc, char **argv) {
         for (int l = 0; l < n; ++l) a.l[l] = Layer{act[l], act[l + 1], W + (size_t)l * LAYER_ELEMS, runs[r][1 + l]};
         std::vector<float> ref(act_elems), got(act_elems);
         unsigned seq = 0;
-        for (int proto = 0; proto < 4; ++proto) {
+        for (int proto = 0; proto < 6; ++proto) {
             CHECK(hipMemsetAsync(act[n], 0, act_elems * 4, st));
             auto once = [&]() {
                 a.seq = ++seq;
@@ -262,8 +275,12 @@ int main(int argc, char **argv) {
                     hipLaunchKernelGGL(probe_kernel<P_WBL2>, dim3(NT), dim3(256), 0, st, a, 0);
                 } else if (proto == P_SC1) {
                     hipLaunchKernelGGL(probe_kernel<P_SC1>, dim3(NT), dim3(256), 0, st, a, 0);
-                } else {
+                } else if (proto == P_SC1_PF) {
                     hipLaunchKernelGGL(probe_kernel<P_SC1_PF>, dim3(NT), dim3(256), 0, st, a, 0);
+                } else if (proto == P_XCD) {
+                    hipLaunchKernelGGL(probe_kernel<P_XCD>, dim3(NT), dim3(256), 0, st, a, 0);
+                } else {
+                    hipLaunchKernelGGL(probe_kernel<P_XCD_PF>, dim3(NT), dim3(256), 0, st, a, 0);
                 }
             };
             for (int i = 0; i < 20; ++i) once();
@@ -278,8 +295,17 @@ int main(int argc, char **argv) {
             if (proto == 0) ref = got;
             size_t bad = 0;
             for (size_t i = 0; i < act_elems; ++i) bad += memcmp(&got[i], &ref[i], 4) != 0;
-            printf("run of %d layers  %-9s %7.2f us per run  %6.2f us per layer   mismatching words vs launches: %zu\n", n, names[proto],
+            printf("run of %d layers  %-9s %7.2f us per run  %6.2f us per layer   mismatching words vs launches: %zu", n, names[proto],
                    ms * 1e3 / reps, ms * 1e3 / reps / n, bad);
+            if (proto >= P_XCD) {
+                unsigned hx[NT];
+                CHECK(hipMemcpyFromSymbol(hx, HIP_SYMBOL(g_xcc), sizeof(hx)));
+                int split = 0;
+                for (int v = 0; v < VIDEOS; ++v)
+                    for (int t = 1; t < TILES_PER_VIDEO; ++t) split += hx[v * TILES_PER_VIDEO + t] != hx[v * TILES_PER_VIDEO];
+                printf("   (last run: %d of %d tiles NOT on their video's XCD; video 0..7 on XCC %u %u %u %u %u %u %u %u)", split, NT, hx[0], hx[32], hx[64], hx[96], hx[128], hx[160], hx[192], hx[224]);
+            }
+            printf("\n");
         }
     }
     return 0;
