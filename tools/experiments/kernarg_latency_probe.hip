@@ -1,7 +1,7 @@
 // How long does a wave wait for its kernel arguments, and does KERNARG PRELOAD (gfx950: the command processor writes the first <= 16 dwords of the kernel
 // arguments into SGPRs while it launches the wave; -mllvm -amdgpu-kernarg-preload-count=16, only for leading scalar / pointer arguments) remove that wait?
-//   hipcc --offload-arch=gfx950 -O3 tools/experiments/kernarg_latency_probe.hip -o /tmp/kp/plain && /tmp/kp/plain
-//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=16 tools/experiments/kernarg_latency_probe.hip -o /tmp/kp/pre && /tmp/kp/pre
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/kernarg_latency_probe.hip -o tools/build/kp_plain && tools/build/kp_plain
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=16 tools/experiments/kernarg_latency_probe.hip -o tools/build/kp_pre && tools/build/kp_pre
 // Every launch: 256 workgroups x 256 threads; wave 0 of each workgroup stamps s_memtime at entry and again once a value that depends on a kernel argument exists
 // (a pointer from the argument block, used for the store).  Two argument forms: a 200-byte struct by value in FRONT of the pointer (what cs_kernel / fs_kernel
 // take: never preloaded) and the pointer + three ints in front of the struct.  Launches are issued back to back on one stream, the argument block changes every launch.
