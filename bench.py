@@ -657,6 +657,7 @@ def batch1_dense_legs(dev, spec, C, params, with_cpu=True):
         def step(i):
             enc, c_enc = ops.run_forward(ops._EncoderFn, tapes[i % n_tapes], spec, True, int(i), *enc_params)
             (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
+            c_head.defer_reduce = os.environ.get("MUCON_BENCH_DEFER_HEAD", "1") == "1"
             d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
             wc.grad, bc.grad = d_w.view_as(wc), d_b
             for p_, g_ in zip(enc_params, ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]):
@@ -753,6 +754,8 @@ def main():
         ov_event, ov_side = torch.cuda.Event(), torch.cuda.Stream(device=dev)
         ov_max_wg = max(8, torch.cuda.get_device_properties(dev).multi_processor_count - 8)
 
+    defer_head = os.environ.get("MUCON_BENCH_DEFER_HEAD", "1") == "1"   # (A/B hook)
+
     def step(i):
         # forward and backward of the hot path as direct calls of the autograd Functions (the same C entry points in the
         # same order as logp.backward() would issue them; ops.run_forward / run_backward) -- no graph walk on the host, so
@@ -760,6 +763,7 @@ def main():
         tape = tapes[i % len(tapes)]
         enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, int(i) ^ rank_key, *enc_params)
         (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
+        c_head.defer_reduce = defer_head   # (r6) the y-head's slab sums ride in the encoder backward's first launch (mucon_head_bwd_defer): one launch fewer
         d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
         wc.grad, bc.grad = d_w.view_as(wc), d_b
         if dist is not None and os.environ.get("MUCON_BENCH_COALESCE") != "1":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 7   /* 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 8   /* 8: mucon_head_bwd_defer / mucon_head_bwd_flush (the y-head's slab reduction inside the encoder backward's first launch); 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -205,6 +205,16 @@ int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
 int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc,
                    const float *w, const float *d_logits, const float *d_logp, float *d_enc,
                    float *d_w, float *d_b, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ABI 8 (no reference counterpart: autograd runs the classifier's weight gradient as a launch of its own, reference src/mucon/trainers.py:131).
+ * One-shot option of the NEXT mucon_head_bwd call on this thread (enable != 0): that call writes d_enc as always but leaves d_w / d_b as the
+ * per-workgroup partial sums in its workspace; the NEXT mucon_encoder_bwd on the same stream adds them up in extra workgroups of its first launch
+ * (beside the GroupNorm backward: one launch fewer on the step's critical path, ~6 us at B = 8 x T = 4096) -- the same sums in the same order, bitwise the
+ * d_w / d_b of the plain call.  d_w / d_b and the workspace must stay valid until then.  If another mucon_head_bwd comes first, or
+ * mucon_head_bwd_flush is called, the pending sums are taken by a launch of their own on the stream they were left on.  Shapes the float4 sums do not
+ * cover (C not a multiple of 4) are reduced at once as if the option were off. */
+int mucon_head_bwd_defer(int32_t enable);
+int mucon_head_bwd_flush(void);
 
 /* ------------------------------------------------------------------------------------------
  * Viterbi: transcript-constrained decode with a length model

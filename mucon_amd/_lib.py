@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmucon_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 METRICS_MAX_RUNS = 1024   # MUCON_METRICS_MAX_RUNS
 
 OK, E_ARG, E_WORKSPACE, E_HIP = 0, -1, -2, -3
@@ -122,6 +122,8 @@ SYMBOLS = {
     "mucon_head_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_head_fwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mucon_head_bwd_defer": (ctypes.c_int, [_i32]),
+    "mucon_head_bwd_flush": (ctypes.c_int, []),
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mucon_viterbi_decode_batch": (ctypes.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mucon_viterbi_decode_host": (ctypes.c_int, [_i32, ctypes.POINTER(ViterbiVideo), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -35,6 +35,16 @@ int g_ts_max_wg = 0;          // ... on at most this many workgroups (fixed sinc
 // once every gradient EXCEPT first_conv's is final, and a cap on the workgroups of the weight-gradient launches (CUs left free for RCCL's kernel)
 hipEvent_t g_bwd_event = nullptr;
 int g_bwd_max_wg = 0;
+// One-shot option of the NEXT mucon_head_bwd call (mucon_head_bwd_defer), and what such a call leaves behind: the y-head's slab reduction, to be taken
+// by extra workgroups of the next mucon_encoder_bwd's first launch on the same stream (small_kernels.hpp: head_reduce_tail) -- or by mucon_head_bwd_flush
+struct HeadPending {
+    bool armed = false, pending = false;
+    const float *w_slabs = nullptr, *b_slabs = nullptr;
+    float *d_w = nullptr, *d_b = nullptr;
+    int nblk = 0, C = 0, H = 0;
+    hipStream_t stream = nullptr;
+};
+HeadPending g_head_pending;
 int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (fixed since r6: was the knob TS_GROUP_ROWS)
 int g_ts_stagger = 1024;      // fixed since r6: was the knob TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
@@ -1097,7 +1107,25 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
         g.zero = reinterpret_cast<unsigned *>(ws + pl.sync);   // (the pass's first kernel: the words the later launches count in start at zero)
-        hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g);
+        // (r6) a y-head slab reduction left pending on this stream (mucon_head_bwd_defer) rides in extra rows of this launch's grid
+        HeadReduceTail tail;
+        memset(&tail, 0, sizeof(tail));
+        int tail_rows = 0;
+        if (g_head_pending.pending && g_head_pending.stream == s) {
+            const HeadPending &hp = g_head_pending;
+            tail.slabs[0] = hp.w_slabs;
+            tail.slabs[1] = hp.b_slabs;
+            tail.out[0] = hp.d_w;
+            tail.out[1] = hp.d_b;
+            tail.stride[0] = tail.n_elems[0] = hp.C * hp.H;
+            tail.stride[1] = tail.n_elems[1] = hp.C;
+            tail.nslabs = hp.nblk;
+            tail.nblocks0 = (hp.C * hp.H + 255) / 256;
+            tail.nblocks = tail.nblocks0 + (hp.C + 255) / 256;
+            tail_rows = (tail.nblocks + g.G - 1) / g.G;
+            g_head_pending.pending = false;
+        }
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B + tail_rows), dim3(GN_THREADS), 0, s, g, tail, B);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
             red.add(ws + pl.gnpart, B, 256, 256, 0, 1, 128, gr->gn_w, 0);
@@ -1441,6 +1469,10 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     if (rc != MUCON_OK) return rc;
     if (!enc || !w || !d_enc || !d_w || !d_b || !workspace) return fail(MUCON_E_ARG, "null pointer argument");
     if (workspace_bytes < mucon_head_workspace_bytes(B, Tz, H, C)) return fail(MUCON_E_WORKSPACE, "head workspace too small");
+    if (g_head_pending.pending) {   // an earlier deferred reduction no encoder_bwd has taken: run it now, on its own stream
+        rc = mucon_head_bwd_flush();
+        if (rc != MUCON_OK) return rc;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *ws = static_cast<float *>(workspace);
     const int zblocks = H == 128 ? (Tz + HB_Z - 1) / HB_Z : (Tz + HEAD_ZC - 1) / HEAD_ZC;
@@ -1468,9 +1500,40 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
     HIPCHK(hipGetLastError());
+    const bool defer = g_head_pending.armed && (C & 3) == 0 && ((C * H) & 3) == 0;   // (the tail sums float4 columns; other shapes reduce here)
+    g_head_pending.armed = false;
+    if (defer) {
+        HeadPending &hp = g_head_pending;
+        hp.pending = true;
+        hp.w_slabs = a.w_slabs;
+        hp.b_slabs = a.b_slabs;
+        hp.d_w = d_w;
+        hp.d_b = d_b;
+        hp.nblk = (int)nblk;
+        hp.C = C;
+        hp.H = H;
+        hp.stream = s;
+        return MUCON_OK;
+    }
     Reducer red(s);
     red.add(a.w_slabs, (int)nblk, (long)C * H, C * H, 0, 1, C * H, d_w, 0);
     red.add(a.b_slabs, (int)nblk, C, C, 0, 1, C, d_b, 0);
+    HIPCHK(red.run());
+    return MUCON_OK;
+}
+
+int mucon_head_bwd_defer(int32_t enable) {
+    g_head_pending.armed = enable != 0;
+    return MUCON_OK;
+}
+
+int mucon_head_bwd_flush(void) {
+    HeadPending &hp = g_head_pending;
+    if (!hp.pending) return MUCON_OK;
+    hp.pending = false;
+    Reducer red(hp.stream);
+    red.add(hp.w_slabs, hp.nblk, (long)hp.C * hp.H, hp.C * hp.H, 0, 1, hp.C * hp.H, hp.d_w, 0);
+    red.add(hp.b_slabs, hp.nblk, hp.C, hp.C, 0, 1, hp.C, hp.d_b, 0);
     HIPCHK(red.run());
     return MUCON_OK;
 }

@@ -300,7 +300,64 @@ struct GnBwdArgs {
     DropCfg drop;
 };
 
-__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a) {
+// (r6) The y-head's DEFERRED slab reduction (mucon_head_bwd_defer): the sums reduce_batch_kernel<16> would take in a launch of its own behind
+// head_bwd_z_kernel, taken by extra workgroups of the backward pass's FIRST launch instead -- rows blockIdx.y >= B of gn_bwd_kernel's grid, which run
+// beside the GroupNorm workgroups on CUs that launch leaves idle.  Two jobs (d_w [C * H], d_b [C]); a workgroup owns 256 consecutive elements.
+// Same sums in the same order as reduce_batch_kernel<16>: slab lane g (of 16) adds slabs g, g + 16, ... in order, the sixteen lanes then add up in order --
+// here wave w runs lanes w, w + 4, w + 8, w + 12 one after the other (all their loads independent): bitwise the results of the undeferred call.
+struct HeadReduceTail {
+    const float *slabs[2];
+    float *out[2];
+    int stride[2], n_elems[2];
+    int nslabs;
+    int nblocks0;    // workgroups of job 0
+    int nblocks;     // of both jobs (0: nothing deferred)
+};
+__device__ __forceinline__ void head_reduce_tail(const HeadReduceTail &t, const int block) {
+    __shared__ f32x4 hpart[16][64];
+    const int job = block >= t.nblocks0 ? 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = ((block - (job ? t.nblocks0 : 0)) * 64 + lane) * 4;   // (n_elems, stride: multiples of 4 -- checked by the host)
+    const bool live = e < t.n_elems[job];
+    const float *p = t.slabs[job] + (live ? e : 0);
+    const long stride = t.stride[job];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = wave + 4 * q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int i = g;
+        for (; i + 15 * 16 < t.nslabs; i += 16 * 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + 16 * u) * stride);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; i + 3 * 16 < t.nslabs; i += 4 * 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + 16 * u) * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; i < t.nslabs; i += 16) s += *reinterpret_cast<const f32x4 *>(p + (long)i * stride);
+        hpart[g][lane] = s;
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+        f32x4 r = hpart[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r += hpart[k][lane];
+        *reinterpret_cast<f32x4 *>(t.out[job] + e) = r;
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a, const HeadReduceTail tail, const int B) {
+    if ((int)blockIdx.y >= B) {   // (only with a deferred y-head reduction queued: the grid has no such rows otherwise)
+        const int block = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
+        if (block < tail.nblocks) head_reduce_tail(tail, block);
+        return;
+    }
     __shared__ float red[4];
     __shared__ float cred[2][4][128];   // per-channel partials [d_gamma | d_beta][wave][channel of the group]
     const int g = blockIdx.x, b = blockIdx.y;

@@ -281,6 +281,7 @@ class MuCon(nn.Module):
         (main, parts), c_loss = F_.run_forward(F_._LossFn, seg, sx, tlogp, lens[:-1].contiguous(), self._loss_spec(), target.to(torch.int64),
                                                 batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw, self._loss_tw)
         d_seg, d_sx, d_tlogp, d_len = c_loss.saved_tensors            # d main / d input, computed with the loss itself
+        c_head.defer_reduce = True     # (r6) d_wc / d_bc are summed inside the encoder backward's first launch, which follows on this stream below
         if lc.smoothing.log_softmax_before:
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
         else:

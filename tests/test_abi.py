@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} not exported"
     lib.mucon_abi_version.restype = ctypes.c_int
-    assert lib.mucon_abi_version() == 7
+    assert lib.mucon_abi_version() == 8
 
 
 def test_host_only_queries():

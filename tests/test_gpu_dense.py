@@ -675,3 +675,62 @@ def test_data_parallel_overlap_hook_gradients_final_at_the_event():
         scale = a_.abs().max().item() + 1e-20
         assert (a_ - b_).abs().max().item() <= 2e-5 * scale, name
         assert torch.equal(a_, c_), name
+
+
+@pytest.mark.parametrize("B,T,C", [(8, 4096, 48), (1, 2000, 48), (2, 777, 12), (1, 530, 49)])
+def test_deferred_head_reduction_equals_the_plain_call(B, T, C):
+    """(r6, ABI 8) mucon_head_bwd_defer: the y-head's slab sums taken by extra workgroups of the encoder backward's first launch (beside the GroupNorm
+    backward) instead of a launch of their own -- the same sums in the same order: d_w / d_b bitwise the plain call's, the encoder's gradients untouched.
+    Also: a second head backward before any encoder backward flushes the pending sums; mucon_head_bwd_flush does; a class count the float4 sums do not
+    cover (49) is reduced at once."""
+    from mucon_amd import _lib, ops
+    from oracle import dense as od
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 911)
+    names = ops.param_names(spec)
+    P = [p.detach() for p in _dev_params(params_np, names)]
+    tape = torch.tensor(synth.tape(912, B, T, 2048), device=DEV)
+    wc = torch.tensor(synth.uniform_pm1(913, (C, 128)), device=DEV) * 0.1
+    bc = torch.tensor(synth.uniform_pm1(914, (C,)), device=DEV) * 0.1
+    dlogp = torch.tensor(synth.uniform_pm1(915, (B, T, C)), device=DEV) / (B * T)
+    lib = _lib.load()
+
+    def run(defer, between=None):
+        enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, 5, *P)
+        (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc, bc, T, False, True)
+        c_head.defer_reduce = defer
+        d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
+        if between is not None:
+            between(c_head)
+        g = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
+        torch.cuda.synchronize()
+        return [d_enc.clone(), d_w.clone(), d_b.clone()] + [x.clone() for x in g]
+
+    base = run(False)
+    deferred = run(True)
+    for k, (a_, b_) in enumerate(zip(base, deferred)):
+        assert torch.equal(a_, b_), k
+    assert torch.isfinite(deferred[1]).all() and deferred[1].abs().max() > 0
+
+    # the explicit flush, and a second head backward in front of the encoder's: both take the pending sums in a launch of their own
+    def flush(_):
+        _lib.check(lib.mucon_head_bwd_flush(), "mucon_head_bwd_flush")
+        torch.cuda.synchronize()
+
+    for k, (a_, b_) in enumerate(zip(base, run(True, flush))):
+        assert torch.equal(a_, b_), k
+    seen = {}
+
+    def second(c_head):
+        c_head.defer_reduce = True
+        seen["first"] = c_head.deferred
+        r = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]     # flushes the first pending pair, leaves its own pending
+        torch.cuda.synchronize()
+        assert torch.equal(seen["first"][0], base[1]) and torch.equal(seen["first"][1], base[2])
+        seen["second"] = r
+
+    out = run(True, second)
+    assert torch.equal(seen["second"][1], base[1]) and torch.equal(seen["second"][2], base[2])   # ... which the encoder backward then took
+    for k, (a_, b_) in enumerate(zip(base, out)):
+        assert torch.equal(a_, b_), k
+    assert lib.mucon_head_bwd_flush() == 0       # nothing pending: a no-op
