@@ -18,7 +18,9 @@ ARCH = "gfx950"
 # mucon_hip.hip: -fno-slp-vectorize -- the SLP pass packs the split's adjacent fp32 subtractions into v_pk_add_f32, which costs issue cycles
 # beside MFMAs (MI355X_MICROARCH.md: "an anti-lever beside MFMAs"); same box, alternated: 0.7571 -> 0.7545 ms per step, the 16x16x32 weight-gradient
 # kernel 236 -> 222 us (profiles/r05_mfma_shape.txt)
-SOURCES = [("mucon_hip.hip", ["-fno-slp-vectorize"]), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", []),
+# ... -amdgpu-kernarg-preload-count=16 (r6): gfx950 hands the first 16 dwords of LEADING scalar / pointer kernel arguments to a wave in SGPRs; the kernels of the
+# latency-bound chain (cs_kernel, ...) take their operand pointers that way and issue their first loads without a scalar-memory round trip (by-value structs are never preloaded)
+SOURCES = [("mucon_hip.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]), ("viterbi.hip", ["-ffp-contract=off"]), ("viterbi_beam.hip", ["-ffp-contract=off"]), ("shead.hip", ["-mllvm", "-amdgpu-kernarg-preload-count=16"]),
            ("metrics.hip", ["-ffp-contract=off"])]
 
 

@@ -44,7 +44,11 @@ static int g_cs_slot = 0;
 // TAPS = 1: a 1x1 product (a dilated conv whose dilation reaches past the sequence -- W1img then points at the centre tap's four
 // steps -- or last_conv); ONE: stage 1 only; PRO_ACT: the non-linearity on the loaded rows (last_conv's input, temporal.py:144).
 template <bool BWD, int POOL, int TAPS, bool ONE, bool PRO_ACT, int RB>
-__global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img CS_SLOT_PARAM) {
+// (r6) The arguments every wave needs in front of its first loads -- the operand pointers, the row count, the tap distance -- are LEADING SCALAR arguments: gfx950's
+// kernel-argument preload (-mllvm -amdgpu-kernarg-preload-count=16, mucon_amd/build.py) hands them over in SGPRs with the wave, so the activation and weight loads are
+// issued without the ~0.25 us scalar-memory round trip a by-value struct costs (tools/experiments/kernarg_latency_probe.hip); the rest of FusedParams arrives meanwhile.
+__global__ __launch_bounds__(256) void cs_kernel(const float *__restrict__ A_, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img, const int Trows_,
+                                                 const int tap_step_, const FusedParams p CS_SLOT_PARAM) {
     constexpr bool UNPOOL = BWD && POOL >= 3;
     constexpr int R2 = UNPOOL ? 2 : 1;
 #if CS_STAMP
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const long vbase = (long)b * p.Trows;
+    const long vbase = (long)b * Trows_;
     // RB row blocks of 16 time steps per workgroup: every weight fragment is loaded once and multiplies all of them
     int trow_raw[RB];
     bool valid[RB];
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         trow_raw[rb] = (blockIdx.x * RB + rb) * 16 + c;
-        valid[rb] = trow_raw[rb] < p.Trows;
-        const int tcl = min(trow_raw[rb], p.Trows - 1);
+        valid[rb] = trow_raw[rb] < Trows_;
+        const int tcl = min(trow_raw[rb], Trows_ - 1);
         grow[rb] = (vbase + tcl) * 128 + 4 * g;
         grow2[rb] = UNPOOL ? ((long)b * p.Tfine + 2 * tcl) * 128 + 4 * g : grow[rb];
     }
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < TAPS; ++i) {
-            const int ts = trow_raw[rb] + (i - TAPS / 2) * p.tap_step;
-            rok[rb][i] = valid[rb] && ts >= 0 && ts < p.Trows;
-            const float *src = p.A + (vbase + min(max(ts, 0), p.Trows - 1)) * 128 + 32 * w + 8 * g;
+            const int ts = trow_raw[rb] + (i - TAPS / 2) * tap_step_;
+            rok[rb][i] = valid[rb] && ts >= 0 && ts < Trows_;
+            const float *src = A_ + (vbase + min(max(ts, 0), Trows_ - 1)) * 128 + 32 * w + 8 * g;
             ra[rb][i][0] = *reinterpret_cast<const f32x4 *>(src);
             ra[rb][i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
@@ -141,12 +145,12 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
         const int nb = 2 * w + j;
         // (unconditional loads from a valid address, the condition on the arithmetic: a load behind a branch makes the compiler wait for
         // EVERYTHING in flight at the join -- here the whole weight ring, in front of the first MFMA)
-        if (!BWD) bia1[j] = *reinterpret_cast<const f32x4 *>((p.bias1 ? p.bias1 : p.A) + 16 * nb + 4 * g);
+        if (!BWD) bia1[j] = *reinterpret_cast<const f32x4 *>((p.bias1 ? p.bias1 : A_) + 16 * nb + 4 * g);
         if (!BWD && !ONE) bia2[j] = *reinterpret_cast<const f32x4 *>(p.bias2 + 16 * nb + 4 * g);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if (BWD) aux1[rb][j] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : p.A) + grow[rb] + 16 * nb);
-            if (BWD) msk1[rb][j] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : p.A) + grow[rb] + 16 * nb);
+            if (BWD) aux1[rb][j] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : A_) + grow[rb] + 16 * nb);
+            if (BWD) msk1[rb][j] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : A_) + grow[rb] + 16 * nb);
             if (!ONE) {
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
                 if (valid[rb]) {
                     *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 16 * nb) = u0;
                     *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 128 + 16 * nb) = u1;
-                    if (trow_raw[rb] == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
+                    if (trow_raw[rb] == Trows_ - 1 && 2 * Trows_ < p.Tfine) {   // odd trailing row of the fine level: no gradient
                         *reinterpret_cast<f32x4 *>(p.out1 + grow2[rb] + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<f32x4 *>(p.out2 + grow2[rb] + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -340,8 +344,8 @@ __global__ __launch_bounds__(256) void cs_kernel(const FusedParams p, const uint
                         const float o = __shfl_xor(x[e], 1);
                         y[e] = POOL == 1 ? fmaxf(x[e], o) : x[e] + o;
                     }
-                    if ((trow_raw[rb] & 1) == 0 && trow_raw[rb] + 1 < p.Trows)
-                        *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (p.Trows >> 1) + (trow_raw[rb] >> 1)) * 128 + 4 * g + 16 * nb) = y;
+                    if ((trow_raw[rb] & 1) == 0 && trow_raw[rb] + 1 < Trows_)
+                        *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (Trows_ >> 1) + (trow_raw[rb] >> 1)) * 128 + 4 * g + 16 * nb) = y;
                 }
             }
         }
@@ -377,12 +381,12 @@ static hipError_t launch_cs(const FusedParams &p, const uint16_t *W1img, const u
     const dim3 grid((p.Trows + 16 * rb - 1) / (16 * rb), B);
     if constexpr (!BWD) {
         if (rb == 4) {
-            hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 4>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
+            hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 4>), grid, dim3(256), 0, s, p.A, W1img, W2img, p.Trows, p.tap_step, p CS_SLOT_ARG);
             return hipGetLastError();
         }
     }
-    if (rb == 2) hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
-    else hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p, W1img, W2img CS_SLOT_ARG);
+    if (rb == 2) hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 2>), grid, dim3(256), 0, s, p.A, W1img, W2img, p.Trows, p.tap_step, p CS_SLOT_ARG);
+    else hipLaunchKernelGGL((cs_kernel<BWD, POOL, TAPS, ONE, PRO_ACT, 1>), grid, dim3(256), 0, s, p.A, W1img, W2img, p.Trows, p.tap_step, p CS_SLOT_ARG);
     return hipGetLastError();
 #undef CS_SLOT_ARG
 }
@@ -429,17 +433,18 @@ struct CtParams {
     CtStage st[CT_MAX_STAGES];
 };
 template <bool BWD>
-__global__ __launch_bounds__(256) void ct_kernel(const CtParams p) {
+// (r6) product 0's operand and image pointers and the row count as LEADING SCALAR arguments: preloaded into SGPRs with the wave (see cs_kernel)
+__global__ __launch_bounds__(256) void ct_kernel(const float *__restrict__ A_, const uint16_t *__restrict__ img0_, const int Trows_, const CtParams p) {
     __shared__ f32x4 red[2][4 * 8 * 64];   // the exchange of product s uses buffer s & 1: one barrier per product
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const long vbase = (long)b * p.Trows;
+    const long vbase = (long)b * Trows_;
     const int trow_raw = blockIdx.x * 16 + c;
-    const bool valid = trow_raw < p.Trows;
-    const int tcl = min(trow_raw, p.Trows - 1);
+    const bool valid = trow_raw < Trows_;
+    const int tcl = min(trow_raw, Trows_ - 1);
     const long grow = (vbase + tcl) * 128 + 4 * g;
 
     // two register sets of weight fragments: product s + 1's 24 KB per wave are requested before product s multiplies, so their
@@ -482,10 +487,10 @@ __global__ __launch_bounds__(256) void ct_kernel(const CtParams p) {
     };
 
     // product 0's operand: this wave's 32 channels of its rows, natural order
-    loadW(p.st[0].img, std::integral_constant<int, 0>{});
+    loadW(img0_, std::integral_constant<int, 0>{});
     Planes X;
     {
-        const float *src = p.A + (vbase + tcl) * 128 + 32 * w + 8 * g;
+        const float *src = A_ + (vbase + tcl) * 128 + 32 * w + 8 * g;
         const f32x4 r0 = *reinterpret_cast<const f32x4 *>(src), r1 = *reinterpret_cast<const f32x4 *>(src + 4);
         float x[8];
 #pragma unroll
@@ -565,6 +570,6 @@ __global__ __launch_bounds__(256) void ct_kernel(const CtParams p) {
 }
 template <bool BWD>
 static hipError_t launch_ct(const CtParams &p, int B, hipStream_t s) {
-    hipLaunchKernelGGL(ct_kernel<BWD>, dim3((p.Trows + 15) / 16, B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ct_kernel<BWD>, dim3((p.Trows + 15) / 16, B), dim3(256), 0, s, p.A, p.st[0].img, p.Trows, p);
     return hipGetLastError();
 }

@@ -106,7 +106,9 @@ __device__ __forceinline__ void fs_pack_body(const FsPackArgs &a, const int slot
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------
 template <bool BWD, int POOL, bool ONE = false, int NW = 8>
-__global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img) {
+// (r6) operand pointers, row count and tap distance as LEADING SCALAR arguments: preloaded into SGPRs with the wave (see cs_kernel, gemm_coarse_split.hpp)
+__global__ __launch_bounds__(64 * NW) void fs_kernel(const float *__restrict__ A_, const uint16_t *__restrict__ W1img, const uint16_t *__restrict__ W2img, const int Trows_,
+                                                     const int tap_step_, const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t fs_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     constexpr int NTHR = 64 * NW, NQ = FS_WTILE / (NTHR * 8);   // 16-byte pieces of a W tile per thread: 6 (8 waves) or 12 (4 waves)
     const int t0 = blockIdx.x * (16 * NW);
     const int trow_raw = t0 + wave * 16 + c;
-    const bool valid = trow_raw < p.Trows;
-    const long vbase = (long)b * p.Trows;
-    const float *Ab = p.A + vbase * 128 + 8 * g;
+    const bool valid = trow_raw < Trows_;
+    const long vbase = (long)b * Trows_;
+    const float *Ab = A_ + vbase * 128 + 8 * g;
 
 #if FS_STAMP
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 prologue | 1 step 0 of a tile | 2 step 1 | 3 barrier | 4 epilogue 1 | 5 stage 2 | 6 epilogue 2
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     auto gloadA = [&](int S, auto SET) {      // k-tile S of stage 1: tap S >> 1, channels 64 (S & 1) ..
         constexpr int Q = decltype(SET)::value;
         const int tap = S >> 1;
-        const int ts = trow_raw + (tap - 1) * p.tap_step;
-        rok[Q] = valid && ts >= 0 && ts < p.Trows;
-        const float *src = Ab + (long)min(max(ts, 0), p.Trows - 1) * 128 + 64 * (S & 1);
+        const int ts = trow_raw + (tap - 1) * tap_step_;
+        rok[Q] = valid && ts >= 0 && ts < Trows_;
+        const float *src = Ab + (long)min(max(ts, 0), Trows_ - 1) * 128 + 64 * (S & 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[Q][i] = *reinterpret_cast<const f32x4 *>(src + 32 * (i >> 1) + 4 * (i & 1));
     };
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
     // rows 2t, 2t + 1 stay with lane t -- writes the un-pooled gradient (out1) and feeds stage 2 twice (R2 = 2 row sets).
     constexpr bool UNPOOL = BWD && POOL >= 3;
     constexpr int R2 = UNPOOL ? 2 : 1;
-    const int tcl = min(trow_raw, p.Trows - 1);
+    const int tcl = min(trow_raw, Trows_ - 1);
     const long grow = (vbase + tcl) * 128 + 4 * g;   // this lane's row of the stage-1 level, its first channel of block 0
     const long grow2 = UNPOOL ? ((long)b * p.Tfine + 2 * tcl) * 128 + 4 * g : grow;   // first of its R2 rows of the stage-2 level
     f32x4 aux1[8], msk1[BWD ? 8 : 1];
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
             // (unconditional loads from a valid address, the condition on the arithmetic below: a load behind a branch makes the compiler wait for
             //  everything in flight at the join -- eight branches with a wait each in front of the stage-1 epilogue; measured neutral here, 0.6915 = 0.6918 ms)
             if (!BWD) aux1[nb] = *reinterpret_cast<const f32x4 *>(p.bias1 + 16 * nb + 4 * g);
-            else aux1[nb] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : p.A) + grow + 16 * nb);
-            if (BWD) msk1[nb] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : p.A) + grow + 16 * nb);
+            else aux1[nb] = *reinterpret_cast<const f32x4 *>((p.res1 ? p.res1 : A_) + grow + 16 * nb);
+            if (BWD) msk1[nb] = *reinterpret_cast<const f32x4 *>((p.mask1 ? p.mask1 : A_) + grow + 16 * nb);
         }
     };
 
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
                 if (valid) {
                     *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 16 * nb) = u0;
                     *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 128 + 16 * nb) = u1;
-                    if (trow_raw == p.Trows - 1 && 2 * p.Trows < p.Tfine) {   // odd trailing row of the fine level: no gradient
+                    if (trow_raw == Trows_ - 1 && 2 * Trows_ < p.Tfine) {   // odd trailing row of the fine level: no gradient
                         *reinterpret_cast<f32x4 *>(p.out1 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<f32x4 *>(p.out2 + grow2 + 256 + 16 * nb) = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(64 * NW) void fs_kernel(const FusedParams p, const 
                     const float o = __shfl_xor(x[e], 1);
                     y[e] = POOL == 1 ? fmaxf(x[e], o) : x[e] + o;
                 }
-                if ((trow_raw & 1) == 0 && trow_raw + 1 < p.Trows)
-                    *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (p.Trows >> 1) + (trow_raw >> 1)) * 128 + 4 * g + 16 * nb) = y;
+                if ((trow_raw & 1) == 0 && trow_raw + 1 < Trows_)
+                    *reinterpret_cast<f32x4 *>(p.out2 + ((long)b * (Trows_ >> 1) + (trow_raw >> 1)) * 128 + 4 * g + 16 * nb) = y;
             }
         }
     }
@@ -487,7 +489,7 @@ static hipError_t launch_fs_cfg(const FusedParams &p, const uint16_t *W1img, con
         attr_set = true;
     }
     dim3 grid((p.Trows + 16 * NW - 1) / (16 * NW), B);
-    hipLaunchKernelGGL(k, grid, dim3(64 * NW), FS_SMEM_BYTES, s, p, W1img, W2img);
+    hipLaunchKernelGGL(k, grid, dim3(64 * NW), FS_SMEM_BYTES, s, p.A, W1img, W2img, p.Trows, p.tap_step, p);
     return hipGetLastError();
 }
 // 128 rows per workgroup (8 waves) where that gives at least one workgroup per CU, 64 rows (4 waves, one per SIMD) below:

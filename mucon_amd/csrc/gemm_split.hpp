@@ -45,7 +45,15 @@ constexpr int S2_SMEM_BYTES = 2 * S2_WIMG * 2;        // double buffered: 98,304
 // TAPS: the k-tiles walk taps x Kc channels, A rows shifted by (tap - taps/2) * tap_step with zero padding (the dilated
 // convolutions and their data gradients); without it the one tap needs no bounds logic (first_conv).  EPI_* as in gemm_nt.hpp.
 template <bool EPI_ACT, bool EPI_RES, bool EPI_MASK, bool TAPS>
-__global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const uint16_t *__restrict__ Wimg) {
+// (r6: the tape pointer, its strides, the row count and the image pointer once more as LEADING SCALAR arguments -- preloaded into SGPRs with the wave, see cs_kernel)
+__global__ __launch_bounds__(512) void nt_split_kernel(const float *__restrict__ A_, const uint16_t *__restrict__ Wimg, const long a_bstride_, const int lda_, const int Trows_,
+                                                         const int Kc_, const NtParams p_) {
+    NtParams p = p_;
+    p.A = A_;
+    p.a_bstride = a_bstride_;
+    p.lda = lda_;
+    p.Trows = Trows_;
+    p.Kc = Kc_;
     extern __shared__ __attribute__((aligned(16))) uint16_t s2_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -258,7 +266,15 @@ __global__ __launch_bounds__(512) void nt_split_kernel(const NtParams p, const u
 //   * W image per k-tile: [k-step 2][plane 3][h 4][channel 128][slot 8] bf16 (sp_split_weights16 / pack_image_tile16), 48 KB as before.
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool EPI_ACT, bool EPI_RES, bool EPI_MASK, bool TAPS>
-__global__ __launch_bounds__(512) void nt_split16_kernel(const NtParams p, const uint16_t *__restrict__ Wimg) {
+// (r6: the tape pointer, its strides, the row count and the image pointer once more as LEADING SCALAR arguments -- preloaded into SGPRs with the wave, see cs_kernel)
+__global__ __launch_bounds__(512) void nt_split16_kernel(const float *__restrict__ A_, const uint16_t *__restrict__ Wimg, const long a_bstride_, const int lda_, const int Trows_,
+                                                         const int Kc_, const NtParams p_) {
+    NtParams p = p_;
+    p.A = A_;
+    p.a_bstride = a_bstride_;
+    p.lda = lda_;
+    p.Trows = Trows_;
+    p.Kc = Kc_;
     extern __shared__ __attribute__((aligned(16))) uint16_t s2_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -489,6 +505,6 @@ static hipError_t launch_nt_split(const NtParams &p, const uint16_t *Wimg, int B
         attr_set[g_mfma16 & 1] = true;
     }
     dim3 grid((p.Trows + 127) / 128, B);
-    hipLaunchKernelGGL(k, grid, dim3(512), S2_SMEM_BYTES, s, p, Wimg);
+    hipLaunchKernelGGL(k, grid, dim3(512), S2_SMEM_BYTES, s, p.A, Wimg, p.a_bstride, p.lda, p.Trows, p.Kc, p);
     return hipGetLastError();
 }

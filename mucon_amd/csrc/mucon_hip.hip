@@ -1052,7 +1052,7 @@ int mucon_encoder_fwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_gn = cfg->last_gn;
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
-        hipLaunchKernelGGL(gn_fwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g);
+        hipLaunchKernelGGL(gn_fwd_kernel, dim3(g.G, B), dim3(GN_THREADS), 0, s, g.z, g.enc, g.gamma, g.beta, g.stats, g.Tz, g.G, g);
         HIPCHK(hipGetLastError());
     }
     return MUCON_OK;
@@ -1125,7 +1125,7 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             tail_rows = (tail.nblocks + g.G - 1) / g.G;
             g_head_pending.pending = false;
         }
-        hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B + tail_rows), dim3(GN_THREADS), 0, s, g, tail, B);
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B + tail_rows), dim3(GN_THREADS), 0, s, g.z, g.denc, g.dz, g.stats, g.Tz, g.G, B, g, tail);
         HIPCHK(hipGetLastError());
         if (cfg->last_gn) {
             red.add(ws + pl.gnpart, B, 256, 256, 0, 1, 128, gr->gn_w, 0);
@@ -1456,7 +1456,7 @@ int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    if (H % 16 == 0) hipLaunchKernelGGL(head_fwd_z_kernel, dim3((Tz + HF_Z - 1) / HF_Z, B), dim3(256), head_fwd_z_smem_bytes(H), s, a);
+    if (H % 16 == 0) hipLaunchKernelGGL(head_fwd_z_kernel, dim3((Tz + HF_Z - 1) / HF_Z, B), dim3(256), head_fwd_z_smem_bytes(H), s, a.enc, a.w, a.b, a.logp_z, a.Tz, a.H, a.C, a);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3((Tf + HEAD_FB - 1) / HEAD_FB, B), dim3(256), smem, s, a);
     HIPCHK(hipGetLastError());
     return MUCON_OK;
@@ -1497,7 +1497,7 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a);
+    if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a.enc, a.w, a.dlogits, a.dlogp, a.logp_z, a.Tz, a.Tf, a.C, a.scale, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
     HIPCHK(hipGetLastError());
     const bool defer = g_head_pending.armed && (C & 3) == 0 && ((C * H) & 3) == 0;   // (the tail sums float4 columns; other shapes reduce here)

@@ -232,7 +232,18 @@ __device__ __forceinline__ float gn_block_sum(float v, float *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const GnArgs a) {
+// (r6: the pointers and the row count once more as LEADING SCALAR arguments -- preloaded into SGPRs with the wave, the first loads do not wait for the argument block;
+// the local copy makes every use below read them)
+__global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const float *z_, float *enc_, const float *gamma_, const float *beta_, float *stats_, const int Tz_, const int G_,
+                                                            const GnArgs a_) {
+    GnArgs a = a_;
+    a.z = z_;
+    a.enc = enc_;
+    a.gamma = gamma_;
+    a.beta = beta_;
+    a.stats = stats_;
+    a.Tz = Tz_;
+    a.G = G_;
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = 128 / a.G;           // channels per group (a multiple of 4)
@@ -352,7 +363,15 @@ __device__ __forceinline__ void head_reduce_tail(const HeadReduceTail &t, const 
     }
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const GnBwdArgs a, const HeadReduceTail tail, const int B) {
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const float *z_, const float *denc_, float *dz_, const float *stats_, const int Tz_, const int G_, const int B,
+                                                            const GnBwdArgs a_, const HeadReduceTail tail) {
+    GnBwdArgs a = a_;   // (leading scalars: see gn_fwd_kernel)
+    a.z = z_;
+    a.denc = denc_;
+    a.dz = dz_;
+    a.stats = stats_;
+    a.Tz = Tz_;
+    a.G = G_;
     if ((int)blockIdx.y >= B) {   // (only with a deferred y-head reduction queued: the grid has no such rows otherwise)
         const int block = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
         if (block < tail.nblocks) head_reduce_tail(tail, block);
@@ -545,7 +564,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
 // lanes of a class read 64 contiguous bytes per step) and multiplies it with all HF_Z rows from LDS; the quarters meet by two
 // shuffles.  No W staging pass, no divisions: 22 -> ~8 us at B=8, T=4096 against the frame-organised kernel above.
 constexpr int HF_Z = 8;
-__global__ __launch_bounds__(256) void head_fwd_z_kernel(const HeadFwdArgs a) {
+__global__ __launch_bounds__(256) void head_fwd_z_kernel(const float *enc_, const float *w_, const float *b_, float *logp_z_, const int Tz_, const int H_, const int C_,
+                                                         const HeadFwdArgs a_) {
+    HeadFwdArgs a = a_;   // (leading scalars: see gn_fwd_kernel)
+    a.enc = enc_;
+    a.w = w_;
+    a.b = b_;
+    a.logp_z = logp_z_;
+    a.Tz = Tz_;
+    a.H = H_;
+    a.C = C_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, C = a.C;
     float *Es = smem;                      // [HF_Z][H]
@@ -740,7 +768,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs a) {
 // d_enc, keeps its column of the encoding rows in registers for the weight-gradient partials, and the per-row class sums run
 // up shuffle trees.  30 -> ~14 us at B=8, T=4096.
 constexpr int HB_Z = 8;
-__global__ __launch_bounds__(256) void head_bwd_z_kernel(const HeadBwdArgs a) {
+__global__ __launch_bounds__(256) void head_bwd_z_kernel(const float *enc_, const float *w_, const float *dlogits_, const float *dlogp_, const float *logp_z_, const int Tz_,
+                                                         const int Tf_, const int C_, const float scale_, const HeadBwdArgs a_) {
+    HeadBwdArgs a = a_;   // (leading scalars: see gn_fwd_kernel)
+    a.enc = enc_;
+    a.w = w_;
+    a.dlogits = dlogits_;
+    a.dlogp = dlogp_;
+    a.logp_z = logp_z_;
+    a.Tz = Tz_;
+    a.Tf = Tf_;
+    a.C = C_;
+    a.scale = scale_;
     __shared__ __attribute__((aligned(16))) float Es[HB_Z][128];
     __shared__ float G1[HB_Z][HEAD_MAXC], G2[HB_Z][HEAD_MAXC], S2[HB_Z];
     const int C = a.C;
