@@ -773,6 +773,7 @@ def main():
             # gradient, the last ~85 us of the backward) -- the library records ov_event there and runs its weight-gradient launches on
             # ncu - 8 workgroups, so RCCL's kernel has CUs while that part travels on the side stream
             c_enc.dp_overlap = (ov_event, ov_max_wg)
+        c_enc.reuse_grads = True      # (r6) the flat gradient buffer and its views serve every step (sgd.step() below has consumed them before the next pass writes)
         g_enc = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
         for p_, g_ in zip(enc_params, g_enc):
             p_.grad = g_

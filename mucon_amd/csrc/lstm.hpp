@@ -12,8 +12,8 @@
 //   lstm_inproj_kernel      Gx[d][t][r] = W_ih[d][r] . x[t] + b_ih[d][r] + b_hh[d][r]     (all t at once)
 //   lstm_recur_fwd_kernel   the recurrence; saves gate activations and cell states for the backward
 //   lstm_recur_bwd_kernel   BPTT: a lane keeps a 32 x 4 tile of W_hh, dh_{t-1} = W_hh^T dgates_t stays in registers (DPP row sums)
-//   lstm_wgrad_kernel       dW_ih, dW_hh, db from the saved pre-activation gradients dG (reductions over t)
-//   lstm_dx_kernel          dx[t] = sum_d W_ih[d]^T dG[d][t]
+//   lstm_wgrad_dx_kernel    (r6: one launch) dW_ih, dW_hh, db from the saved pre-activation gradients dG (reductions over t: lstm_wgrad_body)
+//                           and dx[t] = sum_d W_ih[d]^T dG[d][t] (lstm_dx_body)
 #pragma once
 #include "common.hpp"
 
@@ -292,10 +292,8 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
 
 // dW_ih[d][r][c] = sum_t dG[d][t][r] x[t][c];  dW_hh[d][r][c] = sum_t dG[d][t][r] hprev[d][t][c];  db = sum_t dG[d][t][r]
 // grid (512/4, ndir), 512 threads = 4 gate rows x 128 columns.
-__global__ __launch_bounds__(512) void lstm_wgrad_kernel(const float *dG, const float *x, const float *out, LstmGrads g,
-                                                         int T, int ndir) {
-    const int d = blockIdx.y;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 7), c = threadIdx.x & 127;
+__device__ __forceinline__ void lstm_wgrad_body(const int bx, const int d, const float *dG, const float *x, const float *out, const LstmGrads &g, int T, int ndir) {
+    const int r = bx * 4 + (threadIdx.x >> 7), c = threadIdx.x & 127;
     const float *dg = dG + (long)d * T * LSTM_G + r;
     float ai = 0.f, ah = 0.f, ab = 0.f;
     // 32 time steps' loads in flight at a time, summed in time order (a step-at-a-time loop is a chain of T memory round trips;
@@ -332,10 +330,10 @@ __global__ __launch_bounds__(512) void lstm_wgrad_kernel(const float *dG, const 
 // dx[t][c] = (dx_add[t][c]) + sum_d sum_r dG[d][t][r] W_ih[d][r][c]; grid (T), 512 threads = 4 row quarters x 128 columns.  What a workgroup costs is
 // its chain of weight loads (W_ih comes from L2): every thread walks a quarter of the rows with 32 loads in flight, the four
 // partial sums meet in LDS in quarter order.  (128 threads with 16 loads in flight: 64 dependent round trips, 18.6 us at T = 125.)
-__global__ __launch_bounds__(512) void lstm_dx_kernel(const float *dG, LstmWeights w, float *dx, const float *dx_add, int T, int ndir) {
+__device__ __forceinline__ void lstm_dx_body(const int t, const float *dG, const LstmWeights &w, float *dx, const float *dx_add, int T, int ndir) {
     __shared__ float gsm[2 * LSTM_G];
     __shared__ float part[4][LSTM_H];
-    const int t = blockIdx.x, c = threadIdx.x & 127, k = threadIdx.x >> 7;
+    const int c = threadIdx.x & 127, k = threadIdx.x >> 7;
     const int R = ndir * LSTM_G;
     for (int e = threadIdx.x; e < R; e += 512) gsm[e] = dG[((long)(e / LSTM_G) * T + t) * LSTM_G + e % LSTM_G];
     __syncthreads();
@@ -353,4 +351,15 @@ __global__ __launch_bounds__(512) void lstm_dx_kernel(const float *dG, LstmWeigh
     __syncthreads();
     const float base = dx_add ? dx_add[(long)t * LSTM_H + c] : 0.f;   // (requested before the row walk would be nicer; it is one load)
     if (k == 0) dx[(long)t * LSTM_H + c] = base + ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+}
+
+// (r6) The two launches behind the backward recurrence in ONE: they read the same dG and do not depend on each other.  Workgroups [0, T) take the input
+// gradient's rows (what the encoder's backward waits for: dealt first), the next (LSTM_G / 4) x ndir the weight gradients' row quads -- 7.4 + 14.4 us of two
+// launches become the longer one's.  Same arithmetic per workgroup as the two kernels it replaces (bitwise).
+__global__ __launch_bounds__(512) void lstm_wgrad_dx_kernel(const float *dG, const float *x, const float *out, const LstmGrads g, const LstmWeights w, float *dx,
+                                                            const float *dx_add, const int T, const int ndir) {
+    const int b = blockIdx.x;
+    if (b < T) return lstm_dx_body(b, dG, w, dx, dx_add, T, ndir);
+    const int q = b - T;
+    lstm_wgrad_body(q % (LSTM_G / 4), q / (LSTM_G / 4), dG, x, out, g, T, ndir);
 }

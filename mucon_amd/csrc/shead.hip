@@ -110,8 +110,7 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *gates = dG + al64(per * LSTM_G);
     float *cells = gates + al64(per * LSTM_G);
     hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir);
-    hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(LSTM_G / 4, ndir), dim3(512), 0, s, dG, x, out, g, T, ndir);
-    hipLaunchKernelGGL(lstm_dx_kernel, dim3(T), dim3(512), 0, s, dG, w, d_x, d_x_add, T, ndir);
+    hipLaunchKernelGGL(lstm_wgrad_dx_kernel, dim3(T + (LSTM_G / 4) * ndir), dim3(512), 0, s, dG, x, out, g, w, d_x, d_x_add, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }

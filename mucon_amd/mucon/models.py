@@ -290,6 +290,7 @@ class MuCon(nn.Module):
         d_mem, d_hn, d_cn, _, _, _, *g_dec = F_.run_backward(F_._DecoderFn, c_dec, d_tlogp, d_lens)
         c_lstm.dx_accumulate = d_enc[0]                                 # the LSTM's input gradient is added onto the y-head's in its kernel
         _, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
+        c_enc.reuse_grads = True       # (r6) the optimizer step of the previous video is behind us: its gradient buffer and views serve again (ops._EncoderFn.backward)
         g_enc = F_.run_backward(F_._EncoderFn, c_enc, d_enc)[4:]
         for prm, g in zip(enc_params, g_enc):
             prm.grad = g

@@ -138,6 +138,9 @@ def _apply(fn, *args):
     return fn.forward(_NoGradCtx(), *args)
 
 
+_GRAD_BUFFERS = {}   # _EncoderFn.backward under ctx.reuse_grads: (parameter identities, layout) -> (flat buffer, per-parameter views, their struct, tail offset); <= 4 entries
+
+
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tape, spec, training, seed, *params):
@@ -173,8 +176,21 @@ class _EncoderFn(torch.autograd.Function):
         # (ctx.flat_extra floats of room behind them for the caller's other gradients -- ctx.flat_tail: then ONE collective on
         # one buffer reduces everything, with no gather copy)
         extra = int(getattr(ctx, "flat_extra", 0))
-        flat = torch.empty(sum(sizes) + extra, dtype=torch.float32, device=tape.device)
         ov = getattr(ctx, "dp_overlap", None)
+        # (r6) ctx.reuse_grads (the fused step paths, where the optimizer has consumed the previous step's gradients before this pass runs): the flat buffer,
+        # its ~50 per-parameter views and their ctypes struct are kept between steps -- building them is 0.13 ms of the host's 0.72 ms per one-video
+        # training step (tools/experiments/e2e_host_sections.py), which is bound by the host as much as by the GPU.  The pass writes every member.
+        reuse_key = None
+        if getattr(ctx, "reuse_grads", False):
+            reuse_key = (tuple(id(p) for p in params), tuple(sizes), extra, ov is not None, tape.device)
+            hit = _GRAD_BUFFERS.get(reuse_key)
+            if hit is not None:
+                flat, grads, cg, tail_at, _ = hit
+                ctx.flat_tail = flat[tail_at: tail_at + extra] if extra else flat[:0]
+                ctx.flat_rest_off = sizes[0] + sizes[1] + extra if ov is not None else 0
+                cp = _param_struct(("enc", len(ctx.spec.stages)), params, lambda ts: _pack_params(ctx.spec, ts))
+                return _EncoderFn._launch_backward(ctx, lib, tape, d_enc, cp, cg, ov, grads)
+        flat = torch.empty(sum(sizes) + extra, dtype=torch.float32, device=tape.device)
         # layout: [every parameter][extra] -- or, for the overlapped data-parallel step, [first_conv.weight, .bias][extra][the rest]: what is
         # final only at the pass's end (first_conv's gradients, the caller's tail) is one contiguous range, what is final at the event the other
         head = sizes[0] + sizes[1]
@@ -188,6 +204,14 @@ class _EncoderFn(torch.autograd.Function):
             grads.append(flat[off: off + p.numel()].view(p.shape))
             off += n
         cp, cg = _param_struct(("enc", len(ctx.spec.stages)), params, lambda ts: _pack_params(ctx.spec, ts)), _pack_params(ctx.spec, grads)
+        if reuse_key is not None:
+            if len(_GRAD_BUFFERS) >= 4:
+                _GRAD_BUFFERS.clear()
+            _GRAD_BUFFERS[reuse_key] = (flat, grads, cg, tail_at, list(params))   # (the parameters are held: their ids cannot be recycled while the entry lives)
+        return _EncoderFn._launch_backward(ctx, lib, tape, d_enc, cp, cg, ov, grads)
+
+    @staticmethod
+    def _launch_backward(ctx, lib, tape, d_enc, cp, cg, ov, grads):
         if ov is not None:
             # data-parallel step: (torch.cuda.Event, max workgroups) -- the event is recorded once every gradient but first_conv's is final, the
             # weight-gradient launches leave CUs free for RCCL (include/mucon_hip.h: mucon_encoder_bwd_overlap).  flat[ctx.flat_rest_off:] is what is
@@ -830,11 +854,17 @@ class FusedClipSGD:
         _, _, idx, tab, total, bufs = plan
         if not idx:
             return
+        last = self.__dict__.get("_last_grads")
+        if last is None or len(last) != len(grads):
+            last = [None] * len(grads)
+        self._last_grads = grads          # (held until the next step: an identity below means the very tensor the table was refreshed for)
         for k, i in enumerate(idx):
             g, p_ = grads[i], flat[i][0]
+            t = tab[k]
+            if g is last[i] and t.param == p_.data_ptr():
+                continue                  # (r6) the gradient tensor of the previous step again (the encoder's cached views) and the parameter where it was: the record stands
             if not g.is_contiguous() or not p_.is_contiguous():
                 raise _lib.MuconHipError("FusedClipSGD needs contiguous parameters and gradients")
-            t = tab[k]
             if t.n != p_.numel() or g.numel() != t.n or g.dtype != torch.float32 or p_.dtype != torch.float32:
                 # a parameter's storage was replaced by one of another size / type: the cached table is stale -- and so is every momentum buffer
                 # that no longer matches its parameter (id(p) is unchanged: the table would point the kernel at the old, smaller buffer)

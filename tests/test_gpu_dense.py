@@ -734,3 +734,46 @@ def test_deferred_head_reduction_equals_the_plain_call(B, T, C):
     for k, (a_, b_) in enumerate(zip(base, out)):
         assert torch.equal(a_, b_), k
     assert lib.mucon_head_bwd_flush() == 0       # nothing pending: a no-op
+
+
+def test_reused_gradient_buffers_hold_the_same_gradients():
+    """(r6) ctx.reuse_grads (the fused step paths): the flat gradient buffer, its per-parameter views and their struct are kept between steps.  The views of the
+    second pass ARE the first pass's tensors, every member is rewritten (a pass on other data gives that data's gradients), and they equal the fresh-buffer pass's
+    bit for bit; the fused optimizer, whose table skips a record whose gradient tensor is the previous step's, still applies the step of THIS gradient."""
+    import types
+    from mucon_amd import ops
+    from oracle import dense as od
+    B, T = 2, 1201
+    spec, ocfg = _spec({}), _ocfg({})
+    params_np = od.seeded_params(ocfg, 41)
+    names = ops.param_names(spec)
+    tapes = [torch.tensor(synth.tape(42 + k, B, T, 2048), device=DEV) for k in range(2)]
+    vs = [torch.tensor(synth.uniform_pm1(52 + k, (B, spec.out_length(T), 128)), device=DEV) for k in range(2)]
+
+    def run(reuse, k, P):
+        enc, ctx = ops.run_forward(ops._EncoderFn, tapes[k], spec, True, 7 + k, *P)
+        ctx.reuse_grads = reuse
+        return ops.run_backward(ops._EncoderFn, ctx, vs[k])[4:]
+
+    P = [p.detach() for p in _dev_params(params_np, names)]
+    fresh = [[g.clone() for g in run(False, k, P)] for k in range(2)]
+    first = run(True, 0, P)
+    kept = [g.clone() for g in first]
+    second = run(True, 1, P)
+    torch.cuda.synchronize()
+    assert all(a is b for a, b in zip(first, second))                       # the same tensors
+    for name, a_, b_, c_, d_ in zip(names, kept, fresh[0], second, fresh[1]):
+        assert torch.equal(a_, b_), name
+        assert torch.equal(c_, d_), name
+    # the optimizer over cached gradient tensors: two steps equal two steps over fresh ones
+    def train(reuse):
+        Q = [p.detach().clone() for p in _dev_params(params_np, names)]
+        opt = ops.FusedClipSGD([Q], 100.0, types.SimpleNamespace(param_groups=[{"lr": 0.01, "weight_decay": 0.005, "momentum": 0.0}]))
+        for k in range(2):
+            for p_, g_ in zip(Q, run(reuse, k, Q)):
+                p_.grad = g_
+            opt.step()
+        torch.cuda.synchronize()
+        return Q
+    for name, a_, b_ in zip(names, train(False), train(True)):
+        assert torch.equal(a_, b_), name

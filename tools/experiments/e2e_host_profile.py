@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mucon_amd import synth  # noqa: E402
 from mucon_amd.config import get_cfg_defaults, update_config  # noqa: E402
 from mucon_amd.core.datasets import Batch  # noqa: E402

@@ -6,11 +6,14 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 other=$1; shift
+legs="--no-viterbi"
+[ "${WITH_E2E:-0}" = "1" ] && legs=""     # WITH_E2E=1: the end-to-end / evaluation legs too
 for rnd in 1 2; do
   for t in "$other" .; do
-    (cd "$t" && python3 bench.py --steps 100 --warmup 10 --repeats 3 --no-viterbi --no-cpu-baseline --no-traffic "$@" 2>/dev/null) | python3 -c "
+    (cd "$t" && python3 bench.py --steps 100 --warmup 10 --repeats 3 $legs --no-cpu-baseline --no-traffic "$@" 2>/dev/null) | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('tree [%s]: ms_per_step %.4f  repeats %s  wgrad %.4f ms  first_conv %.4f ms' % ('$t', d['ms_per_step'], d['ms_per_step_repeats'], d['roofline']['avg_launch_ms'], d['roofline_first_conv_fwd']['avg_launch_ms']))"
+e = (d.get('end_to_end', {}).get('ms_per_video'), d.get('evaluation', {}).get('ms_per_video'), (d.get('dense_batch1') or {}).get('B1_T2000', {}).get('ms_per_step'))
+print('tree [%s]: ms_per_step %.4f  repeats %s  wgrad %.4f ms  first_conv %.4f ms' % ('$t', d['ms_per_step'], d['ms_per_step_repeats'], d['roofline']['avg_launch_ms'], d['roofline_first_conv_fwd']['avg_launch_ms']) + ('  e2e / eval / dense B=1 T=2000 ms: %s' % (e,) if e[0] is not None else ''))"
   done
 done
