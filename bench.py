@@ -660,6 +660,7 @@ def batch1_dense_legs(dev, spec, C, params, with_cpu=True):
             c_head.defer_reduce = os.environ.get("MUCON_BENCH_DEFER_HEAD", "1") == "1"
             d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
             wc.grad, bc.grad = d_w.view_as(wc), d_b
+            c_enc.reuse_grads = True      # (a one-video step is bound by the host as much as by the GPU: the gradient views are kept, as in MuCon.fused_train_step)
             for p_, g_ in zip(enc_params, ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]):
                 p_.grad = g_
             sgd.step()

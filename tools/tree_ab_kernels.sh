@@ -3,7 +3,7 @@
 #   bash tools/tree_ab_kernels.sh .r05_tree        (the frozen tree: tools/tree_ab.sh)
 # Prints every kernel's average duration (us) per run side by side (kernels that exist in one tree only show 0 in the other) and the sum over one step.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-other=$1
+other=$1; shift     # further arguments go to bench.py (e.g. --batch 1 --frames 2000: the one-video step's kernels)
 OUT=$R/gpurun_out/tree_ab_kernels
 rm -rf $OUT && mkdir -p $OUT
 i=0
@@ -11,7 +11,7 @@ for rnd in 1 2; do
   for t in "$R/$other" "$R"; do
     i=$((i+1))
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t$i -- python3 $t/bench.py --steps 100 --warmup 10 --repeats 1 --no-viterbi --no-cpu-baseline --no-calibration --no-traffic > $OUT/b$i.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t$i -- python3 $t/bench.py --steps 100 --warmup 10 --repeats 1 --no-viterbi --no-cpu-baseline --no-calibration --no-traffic "$@" > $OUT/b$i.log 2>&1
     cp $(ls $OUT/t$i/*/*kernel_stats.csv | head -1) $OUT/stats$i.csv
     rm -rf $OUT/t$i
   done
