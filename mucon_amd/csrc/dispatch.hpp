@@ -17,6 +17,7 @@ constexpr int kTnBatchKs = 2;           // the f32 batched launch runs 8-wave wo
 constexpr int kTnKs = 0;                // stand-alone f32 launches: 0 = k-split 2 for layer jobs, 1 for first_conv's
 constexpr int kTsMaxWorkgroups = 256;    // static-runs launch: persistent workgroups = min(CUs, this); the slab arena is sized for it
 constexpr int kReduceLanes = 4;         // slab lanes per workgroup of the batched slab reduction
+constexpr int kReduceChunks = 4;        // ... and 256-element chunks per workgroup of a pass of >= 1,024 chunks (r6)
 
 // ---- NT / two-stage layer kernels ---------------------------------------------------------------------------------------
 constexpr int kFirstConv8w = 1;         // first_conv forward on the f32 MFMA: 128-row tiles with 8 waves (0.160 -> 0.153 ms)

@@ -385,10 +385,13 @@ struct ReduceBatch {
     TsColTab ct;                        // the static-runs launch's columns (jobs with sched >= 0)
 };
 
-template <int G>
+// (r6) U consecutive 256-element chunks of a job per workgroup (U = 1: one).  The big pass of a training step is ~3,900 chunks whose workgroups live ~3 us, a
+// fifth of it the two scalar-memory round trips in front of the first load (argument block, then the job's record): with U = 4 a workgroup pays them once for four
+// chunks and keeps four times the loads in flight.  Chunk and slab-lane assignment per ELEMENT are unchanged: the same sums in the same order.
+template <int G, int U = 1>
 __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch rb) {
-    // a workgroup owns 256 consecutive elements of one job: 64 lanes x float4, G slab lanes
-    __shared__ f32x4 part[G][64];
+    // a workgroup owns U x 256 consecutive elements of one job: 64 lanes x float4, G slab lanes
+    __shared__ f32x4 part[G][U][64];
     // Which job this workgroup belongs to: the number of jobs that start at or before it.  All first blocks are read at once
     // (64 contiguous kernel-argument words, independent scalar loads) and compared in registers -- walking the table job by
     // job was a chain of up to ~50 dependent scalar-cache round trips in front of every workgroup's first load (2 - 4 us each:
@@ -398,70 +401,112 @@ __global__ __launch_bounds__(64 * G) void reduce_batch_kernel(const ReduceBatch 
     for (int k = 0; k < REDUCE_MAX_JOBS; ++k) ji += (int)blockIdx.x >= rb.first_block[k] ? 1 : 0;
     const ReduceJob &J = rb.j[ji];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int e = (((int)blockIdx.x - J.block0) * 64 + lane) * 4;   // ncols, coff, ld are multiples of 4
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int row = 0, col = 0;
+    f32x4 s[U];
+    int row[U], col[U], e[U];
     if (!J.vec) {  // odd shapes (e.g. a class count that is not a multiple of 4): element-wise
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ek = e + k;
-            if (ek < J.n_elems) {
-                const int r = ek / J.ncols, c = ek - r * J.ncols;
-                const float *p = J.slabs + (long)r * J.ld + J.coff + c;
-                float a = 0.f;
-                for (int i = g; i < J.nslabs; i += G) a += p[(long)i * J.slab_stride];
-                s[k] = a;
+        for (int u = 0; u < U; ++u) {
+            e[u] = ((((int)blockIdx.x - J.block0) * U + u) * 64 + lane) * 4;   // ncols, coff, ld are multiples of 4
+            s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            row[u] = col[u] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ek = e[u] + k;
+                if (ek < J.n_elems) {
+                    const int r = ek / J.ncols, c = ek - r * J.ncols;
+                    const float *p = J.slabs + (long)r * J.ld + J.coff + c;
+                    float a = 0.f;
+                    for (int i = g; i < J.nslabs; i += G) a += p[(long)i * J.slab_stride];
+                    s[u][k] = a;
+                }
             }
         }
-    } else if (e < J.n_elems) {
-        row = e / J.ncols;
-        col = e - row * J.ncols;
-        const float *p = J.slabs + (long)row * J.ld + J.coff + col;
-        int nslabs = J.nslabs;
-        long stride = J.slab_stride;
-        if (J.sched >= 0) {   // the static-runs launch's partial tiles: this lane's 256-column block of the job says where they are and how many
-            const int gcol = J.coff + col, cb = J.isbias ? (int)J.bcol : gcol >> 8;
-            nslabs = rb.ct.n[J.sched][cb];
-            stride = J.isbias ? 256 : 128 * 256;
-            p = (J.isbias ? rb.ct.bias + gcol : rb.ct.slabs + (long)row * 256 + (gcol & 255)) + (long)rb.ct.slab0[J.sched][cb] * stride;
+    } else {
+        const float *p[U];
+        int nsl[U];
+        long stride[U];
+        int nmax = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e[u] = ((((int)blockIdx.x - J.block0) * U + u) * 64 + lane) * 4;
+            s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ee = e[u] < J.n_elems ? e[u] : 0;     // (a chunk past the job's end: loads of element 0, nothing stored)
+            row[u] = ee / J.ncols;
+            col[u] = ee - row[u] * J.ncols;
+            p[u] = J.slabs + (long)row[u] * J.ld + J.coff + col[u];
+            nsl[u] = J.nslabs;
+            stride[u] = J.slab_stride;
+            if (J.sched >= 0) {   // the static-runs launch's partial tiles: this lane's 256-column block of the job says where they are and how many
+                const int gcol = J.coff + col[u], cb = J.isbias ? (int)J.bcol : gcol >> 8;
+                nsl[u] = rb.ct.n[J.sched][cb];
+                stride[u] = J.isbias ? 256 : 128 * 256;
+                p[u] = (J.isbias ? rb.ct.bias + gcol : rb.ct.slabs + (long)row[u] * 256 + (gcol & 255)) + (long)rb.ct.slab0[J.sched][cb] * stride[u];
+            }
+            if (e[u] >= J.n_elems) nsl[u] = 0;
+            nmax = max(nmax, nsl[u]);
         }
-        int i = g;
-        if (G >= 16) {   // few deep jobs (the y-head's 256 slabs): sixteen loads per lane in flight -- the pass is its chain of round trips
-            for (; i + 15 * G < nslabs; i += 16 * G) {
-                f32x4 v[16];
+        if (U == 1) {
+            int i = g;
+            if (G >= 16) {   // few deep jobs (the y-head's 256 slabs): sixteen loads per lane in flight -- the pass is its chain of round trips
+                for (; i + 15 * G < nsl[0]; i += 16 * G) {
+                    f32x4 v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * stride);
+                    for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const f32x4 *>(p[0] + (long)(i + G * q) * stride[0]);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
+                    for (int q = 0; q < 16; ++q) s[0] += v[q];
+                }
+            }
+            for (; i + 3 * G < nsl[0]; i += 4 * G) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(p[0] + (long)(i + G * q) * stride[0]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[0] += v[q];
+            }
+            for (; i < nsl[0]; i += G) s[0] += *reinterpret_cast<const f32x4 *>(p[0] + (long)i * stride[0]);
+        } else {
+            // one loop for the U chunks: every round requests four slabs per chunk (4 U loads in flight); a chunk with fewer slabs re-reads its last one and
+            // adds nothing (the loads are unconditional: a load behind a branch would make the compiler wait for everything in flight at the join)
+            for (int i = g; i < nmax; i += 4 * G) {
+                f32x4 v[U][4];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = min(i + G * q, max(nsl[u] - 1, 0));
+                        v[u][q] = *reinterpret_cast<const f32x4 *>(p[u] + (long)k * stride[u]);
+                    }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (i + G * q < nsl[u]) s[u] += v[u][q];
             }
         }
-        for (; i + 3 * G < nslabs; i += 4 * G) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(i + G * u) * stride);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s += v[u];
-        }
-        for (; i < nslabs; i += G) s += *reinterpret_cast<const f32x4 *>(p + (long)i * stride);
     }
     if (G > 1) {
-        part[g][lane] = s;
+#pragma unroll
+        for (int u = 0; u < U; ++u) part[g][u][lane] = s[u];
         __syncthreads();
     }
-    if (g == 0 && e < J.n_elems) {
-        f32x4 t = s;
+    if (g == 0) {
 #pragma unroll
-        for (int k = 1; k < G; ++k) t += part[k][lane];
-        if (!J.vec) {
+        for (int u = 0; u < U; ++u) {
+            if (e[u] >= J.n_elems) continue;
+            f32x4 t = s[u];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (e + k < J.n_elems) J.out[e + k] = t[k];
-        } else if (J.mode == 0) {
-            *reinterpret_cast<f32x4 *>(J.out + e) = t;
-        } else {
-            const int tap = col >> 7, i = col & 127;
+            for (int k = 1; k < G; ++k) t += part[k][u][lane];
+            if (!J.vec) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) J.out[(row * 128 + i + k) * 3 + tap] = t[k];
+                for (int k = 0; k < 4; ++k)
+                    if (e[u] + k < J.n_elems) J.out[e[u] + k] = t[k];
+            } else if (J.mode == 0) {
+                *reinterpret_cast<f32x4 *>(J.out + e[u]) = t;
+            } else {
+                const int tap = col[u] >> 7, i = col[u] & 127;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) J.out[(row[u] * 128 + i + k) * 3 + tap] = t[k];
+            }
         }
     }
 }

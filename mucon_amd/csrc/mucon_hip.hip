@@ -335,7 +335,21 @@ struct Reducer {
         // loads per thread is what their time is; the big pass (3,900 workgroups, <= 32 slabs) is bandwidth-bound and wants 4
         // ... and a pass whose jobs have one or two slabs (a batch-1 step: every time chunk is the whole video) is a copy:
         // one wave per workgroup, no exchange
-        switch (rb.nblocks <= 128 ? 16 : (max_slabs <= 2 ? 1 : kReduceLanes)) {
+        const int lanes = rb.nblocks <= 128 ? 16 : (max_slabs <= 2 ? 1 : kReduceLanes);
+        if (lanes == 4 && kReduceChunks > 1 && rb.nblocks >= 1024) {
+            // the big pass of a training step: kReduceChunks chunks per workgroup (gemm_tn.hpp: reduce_batch_kernel<G, U>) -- the jobs' first workgroups re-counted
+            int nb = 0;
+            for (int k = 0; k < rb.njobs; ++k) {
+                rb.j[k].block0 = nb;
+                rb.first_block[k] = nb;
+                nb += (rb.j[k].n_elems + 256 * kReduceChunks - 1) / (256 * kReduceChunks);
+            }
+            hipLaunchKernelGGL((reduce_batch_kernel<4, kReduceChunks>), dim3(nb), dim3(256), 0, stream, rb);
+            rb.njobs = 0;
+            rb.nblocks = 0;
+            return hipGetLastError();
+        }
+        switch (lanes) {
             case 1: hipLaunchKernelGGL(reduce_batch_kernel<1>, dim3(rb.nblocks), dim3(64), 0, stream, rb); break;
             case 2: hipLaunchKernelGGL(reduce_batch_kernel<2>, dim3(rb.nblocks), dim3(128), 0, stream, rb); break;
             case 4: hipLaunchKernelGGL(reduce_batch_kernel<4>, dim3(rb.nblocks), dim3(256), 0, stream, rb); break;
