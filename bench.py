@@ -1004,7 +1004,7 @@ def main():
                          "note": "achieved = algorithmic fp32 FLOP / launch time; peak = the kernel's own ceiling = 2.5 PFLOP/s dense bf16 MFMA / 6 "
                                  "(it issues 6 bf16 MFMA FLOP per algorithmic FLOP), so frac = frac_of_bf16_mfma_peak <= 1; "
                                  "frac_of_f32_mfma_peak prices the same FLOP against the 157.3 TFLOP/s f32-input MFMA peak a plain fp32 kernel is capped at",
-                         "rocprof_summary": "profiles/r05_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
+                         "rocprof_summary": "profiles/r06_kernel_stats_hotpath.csv (hot-path leg alone; the default command's summary "
                                             "mixes in the 10x smaller launches of the end-to-end leg)"},
             # first_conv forward: the kernel that streams the tape.  bf16 MFMA on exactly split fp32 operands
             # (csrc/gemm_split.hpp): its roof is HBM, the f32-MFMA roof (0.109 ms) no longer applies
