@@ -3,10 +3,10 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/e2e_prof
 rm -rf $OUT && mkdir -p $OUT
-python3 $R/tools/e2e_loop.py 40 2>&1 | tail -1 | cut -c1-120
+python3 $R/tools/experiments/e2e_loop.py 40 2>&1 | tail -1 | cut -c1-120
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/tools/e2e_loop.py 30 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/tools/experiments/e2e_loop.py 30 > $OUT/log.txt 2>&1
 cd $R
-python3 tools/e2e_trace_summary.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/summary.txt
+python3 tools/e2e_trace_summary.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) v > $OUT/summary.txt
 head -${1:-14} $OUT/summary.txt
 rm -rf $OUT/trace
