@@ -658,6 +658,7 @@ def batch1_dense_legs(dev, spec, C, params, with_cpu=True):
             enc, c_enc = ops.run_forward(ops._EncoderFn, tapes[i % n_tapes], spec, True, int(i), *enc_params)
             (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
             c_head.defer_reduce = os.environ.get("MUCON_BENCH_DEFER_HEAD", "1") == "1"
+            c_head.reuse_grads = True
             d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
             wc.grad, bc.grad = d_w.view_as(wc), d_b
             c_enc.reuse_grads = True      # (a one-video step is bound by the host as much as by the GPU: the gradient views are kept, as in MuCon.fused_train_step)
@@ -764,6 +765,7 @@ def main():
         tape = tapes[i % len(tapes)]
         enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, int(i) ^ rank_key, *enc_params)
         (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc2, bc, int(T), False, True)
+        c_head.reuse_grads = True
         c_head.defer_reduce = defer_head   # (r6) the y-head's slab sums ride in the encoder backward's first launch (mucon_head_bwd_defer): one launch fewer
         d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
         wc.grad, bc.grad = d_w.view_as(wc), d_b

@@ -282,6 +282,7 @@ class MuCon(nn.Module):
                                                 batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw, self._loss_tw)
         d_seg, d_sx, d_tlogp, d_len = c_loss.saved_tensors            # d main / d input, computed with the loss itself
         c_head.defer_reduce = True     # (r6) d_wc / d_bc are summed inside the encoder backward's first launch, which follows on this stream below
+        c_head.reuse_grads = c_dec.reuse_grads = c_lstm.reuse_grads = True   # (r6) the previous video's gradient tensors serve again: the optimizer step that consumed them is behind us
         if lc.smoothing.log_softmax_before:
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
         else:

@@ -138,6 +138,28 @@ def _apply(fn, *args):
     return fn.forward(_NoGradCtx(), *args)
 
 
+_PARAM_GRADS = {}     # _param_grads under ctx.reuse_grads: (tag, parameter identities) -> (gradient tensors, their struct or None, the parameters); <= 8 entries
+
+
+def _param_grads(ctx, tag, params, pack=None):
+    """Gradient tensors for `params` (+ their ctypes struct when `pack` is given).  Fresh ones, as autograd expects -- unless ctx.reuse_grads (the fused step
+    paths: the optimizer has consumed the previous step's gradients before this pass writes): then the tensors of the previous step serve again.  Besides the
+    allocations this keeps the fused optimizer's table identical step after step (no upload, ops.FusedClipSGD skips the unchanged records)."""
+    if not getattr(ctx, "reuse_grads", False):
+        grads = [torch.empty_like(w) for w in params]
+        return grads, (pack(grads) if pack else None)
+    key = (tag, tuple(id(w) for w in params))
+    hit = _PARAM_GRADS.get(key)
+    if hit is not None and all(g.shape == w.shape and g.device == w.device for g, w in zip(hit[0], params)):
+        return hit[0], hit[1]
+    grads = [torch.empty_like(w) for w in params]
+    st = pack(grads) if pack else None
+    if len(_PARAM_GRADS) >= 8:
+        _PARAM_GRADS.clear()
+    _PARAM_GRADS[key] = (grads, st, list(params))   # (the parameters are held: their ids cannot be recycled while the entry lives)
+    return grads, st
+
+
 _GRAD_BUFFERS = {}   # _EncoderFn.backward under ctx.reuse_grads: (parameter identities, layout) -> (flat buffer, per-parameter views, their struct, tail offset); <= 4 entries
 
 
@@ -451,8 +473,16 @@ class _HeadFn(torch.autograd.Function):
         dl = d_logits.contiguous() if (d_logits is not None and d_logits.numel() == B * Tf * C) else None
         dp = d_logp.contiguous() if (d_logp is not None and d_logp.numel() == B * Tf * C) else None
         d_enc = torch.empty_like(enc)
-        d_w = torch.empty_like(w)
-        d_b = torch.empty(C, dtype=torch.float32, device=enc.device)
+        hit = _PARAM_GRADS.get(("head", id(w))) if getattr(ctx, "reuse_grads", False) else None
+        if hit is not None and hit[0][0].shape == w.shape and hit[0][0].device == w.device:
+            d_w, d_b = hit[0]                     # (the fused step paths: the previous step's pair, see _param_grads)
+        else:
+            d_w = torch.empty_like(w)
+            d_b = torch.empty(C, dtype=torch.float32, device=enc.device)
+            if getattr(ctx, "reuse_grads", False):
+                if len(_PARAM_GRADS) >= 8:
+                    _PARAM_GRADS.clear()
+                _PARAM_GRADS[("head", id(w))] = ([d_w, d_b], None, [w])
         if getattr(ctx, "defer_reduce", False):
             # (r6) the fused step paths (bench.py, MuCon.fused_train_step), where the encoder's backward follows on this stream before anyone reads
             # d_w / d_b: their slab sums ride in that pass's first launch (include/mucon_hip.h: mucon_head_bwd_defer).  ctx keeps the workspace alive.
@@ -508,10 +538,10 @@ class _LstmFn(torch.autograd.Function):
         # x's shape): the kernel adds the LSTM's own into it instead of a separate element-wise launch
         acc = getattr(ctx, "dx_accumulate", None)
         d_x = acc if acc is not None else torch.empty_like(x)
-        grads = [torch.empty_like(w) for w in weights]
+        grads, cg = _param_grads(ctx, ("lstm", ndir), weights, lambda ts: _lstm_params(ts, ndir))
         _lib.check(lib.mucon_lstm_bwd(T, I, H, ndir, _lib.ptr(x), ctypes.byref(_param_struct(("lstm", ndir), weights, lambda ts: _lstm_params(ts, ndir))), _lib.ptr(out),
                                       _lib.ptr(d_out), _lib.ptr(d_hn), _lib.ptr(d_cn), _lib.ptr(d_x), _lib.ptr(acc),
-                                      ctypes.byref(_lstm_params(grads, ndir)), _lib.ptr(ctx.ws), ctx.nbytes,
+                                      ctypes.byref(cg), _lib.ptr(ctx.ws), ctx.nbytes,
                                       _lib.current_stream_ptr()), "mucon_lstm_bwd")
         return (d_x, None, *grads)
 
@@ -656,11 +686,11 @@ class _DecoderFn(torch.autograd.Function):
         d_logp = d_logp.contiguous() if d_logp is not None else None
         d_len = d_len.contiguous() if d_len is not None else None
         d_memory, d_hn, d_cn = torch.empty_like(memory), torch.empty_like(hn), torch.empty_like(cn)
-        grads = [torch.empty_like(w) for w in params]
+        grads, cg = _param_grads(ctx, ("dec",), params, _decoder_params)
         _lib.check(lib.mucon_decoder_bwd(ctypes.byref(ctx.cfg), ctx.n, ctypes.byref(_param_struct(("dec",), params, _decoder_params)), _lib.ptr(memory),
                                          _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(logp), _lib.ptr(d_logp), _lib.ptr(d_len),
                                          _lib.ptr(ctx.dropmask), _lib.ptr(d_memory), _lib.ptr(d_hn), _lib.ptr(d_cn),
-                                         ctypes.byref(_decoder_params(grads)), _lib.ptr(ctx.ws), ctx.nbytes,
+                                         ctypes.byref(cg), _lib.ptr(ctx.ws), ctx.nbytes,
                                          _lib.current_stream_ptr()), "mucon_decoder_bwd")
         return (d_memory, d_hn, d_cn, None, None, None, *grads)
 
