@@ -1138,6 +1138,10 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
             tail.nblocks = tail.nblocks0 + (hp.C + 255) / 256;
             tail_rows = (tail.nblocks + g.G - 1) / g.G;
             g_head_pending.pending = false;
+        } else if (g_head_pending.pending) {
+            // left on ANOTHER stream: not this pass's to take -- but nobody else may come for it either: finished now, on the stream it was left on
+            rc = mucon_head_bwd_flush();
+            if (rc != MUCON_OK) return rc;
         }
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(g.G, B + tail_rows), dim3(GN_THREADS), 0, s, g.z, g.denc, g.dz, g.stats, g.Tz, g.G, B, g, tail);
         HIPCHK(hipGetLastError());

@@ -735,6 +735,21 @@ def test_deferred_head_reduction_equals_the_plain_call(B, T, C):
         assert torch.equal(a_, b_), k
     assert lib.mucon_head_bwd_flush() == 0       # nothing pending: a no-op
 
+    # a pair left pending on ANOTHER stream than the encoder backward's: that pass does not take it, but finishes it (on the stream it was left on)
+    side = torch.cuda.Stream()
+    enc, c_enc = ops.run_forward(ops._EncoderFn, tape, spec, True, 5, *P)
+    (_, logp), c_head = ops.run_forward(ops._HeadFn, enc, wc, bc, T, False, True)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        c_head.defer_reduce = True
+        d_enc, d_w, d_b = ops.run_backward(ops._HeadFn, c_head, None, dlogp)[:3]
+    torch.cuda.synchronize()
+    g = ops.run_backward(ops._EncoderFn, c_enc, d_enc)[4:]
+    torch.cuda.synchronize()
+    assert torch.equal(d_w, base[1]) and torch.equal(d_b, base[2])
+    for k, (a_, b_) in enumerate(zip(base[3:], g)):
+        assert torch.equal(a_, b_), k
+
 
 def test_reused_gradient_buffers_hold_the_same_gradients():
     """(r6) ctx.reuse_grads (the fused step paths): the flat gradient buffer, its per-parameter views and their struct are kept between steps.  The views of the
