@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 8   /* 8: mucon_head_bwd_defer / mucon_head_bwd_flush (the y-head's slab reduction inside the encoder backward's first launch); 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 8   /* 8: mucon_head_bwd_defer / _flush (the y-head's slab reduction inside the encoder backward's first launch), mucon_decoder_bwd_defer / _flush (the decoder's weight-gradient outer products inside the LSTM backward's recurrence launch); 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -395,6 +395,14 @@ int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, const mucon
                       const float *memory, const float *hn, const float *cn, const float *logp, const float *d_logp,
                       const float *d_lengths, const float *dropmask, float *d_memory, float *d_hn, float *d_cn,
                       const mucon_decoder_params *d_params, void *workspace, size_t workspace_bytes, void *stream);
+/* ABI 8 (no reference counterpart: autograd runs each weight gradient as a launch of its own, reference src/mucon/trainers.py:131).  One-shot option of the
+ * NEXT mucon_decoder_bwd on this thread (enable != 0): that call writes d_memory / d_hn / d_cn and the two gradients its step loop produces (embedding, v) as
+ * always, but leaves the outer products that are every other tensor of d_params to the NEXT mucon_lstm_bwd on the same stream, which computes them in extra
+ * workgroups of its backward recurrence launch (two workgroups busy for ~89 us at Tz = 125: the sums cost the step nothing there; a launch of ~13 us otherwise).
+ * The same sums in the same order: bitwise the plain call's gradients.  d_params, the decoder's workspace and memory / hn / cn must stay valid until then.  Another
+ * mucon_decoder_bwd, a mucon_lstm_bwd on another stream, or mucon_decoder_bwd_flush finish a pending batch in a launch of its own. */
+int mucon_decoder_bwd_defer(int32_t enable);
+int mucon_decoder_bwd_flush(void);
 
 /* ---- the four MuCon losses, forward and gradients --------------------------------
  * Replaces MuCon.loss (reference src/mucon/models.py:376-565) together with project_lengths_softmax and

@@ -976,49 +976,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_bwd_kernel(DecDims dm, De
     }
 }
 
-// out[i][j] = sum_n A[n*lda + i] B[n*ldb + j];  bias[i] = sum_n A[n*lda + i]
-struct OuterJob {
-    const float *A, *B;
-    float *out, *bias, *bias2;
-    int lda, ldb, ra, cb, n, block0;
-};
-constexpr int DEC_MAXJOBS = 12;
-struct OuterBatch {
-    OuterJob job[DEC_MAXJOBS];
-    int njobs;
-};
-__global__ __launch_bounds__(256) void dec_outer_kernel(OuterBatch ob) {
-    int ji = 0;
-    while (ji + 1 < ob.njobs && (int)blockIdx.x >= ob.job[ji + 1].block0) ++ji;
-    const OuterJob &jb = ob.job[ji];
-    const long e = (long)(blockIdx.x - jb.block0) * 256 + threadIdx.x;
-    if (e >= (long)jb.ra * jb.cb) return;
-    const int i = (int)(e / jb.cb), j = (int)(e - (long)i * jb.cb);
-    float acc = 0.f, accb = 0.f;
-    // eight terms' loads in flight at a time, summed in order (dW1 sums over the Tz encoder states: a term-at-a-time loop is a
-    // chain of Tz memory round trips)
-    for (int n0 = 0; n0 < jb.n; n0 += 8) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int n = min(n0 + q, jb.n - 1);
-            av[q] = jb.A[(long)n * jb.lda + i];
-            bv[q] = jb.B[(long)n * jb.ldb + j];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (n0 + q < jb.n) {
-                acc += av[q] * bv[q];
-                accb += av[q];
-            }
-        }
-    }
-    jb.out[e] = acc;
-    if (j == 0) {
-        if (jb.bias) jb.bias[i] = accb;
-        if (jb.bias2) jb.bias2[i] = accb;
-    }
-}
+// (OuterJob / OuterBatch / dec_outer_body: lstm.hpp -- the batch can ride in the LSTM's backward recurrence launch, mucon_decoder_bwd_defer)
+__global__ __launch_bounds__(256) void dec_outer_kernel(OuterBatch ob) { dec_outer_body(ob, (int)blockIdx.x, (int)threadIdx.x); }
 
 // Per encoder state t (grid (Tz), 256 threads), summed over the S decoding steps in step order:
 //   d_mp[t][k]     = sum_s d_score[s][t] v[k] (1 - tanh^2(mp[t][k] + q[s][k]))        -> dl.mp (input of dW1's outer product)

@@ -179,6 +179,57 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The decoder's weight gradients as a batch of outer products (decoder.hpp: dec_outer_kernel).  Defined here because the batch
+// can ride in THIS header's backward recurrence launch (r6: mucon_decoder_bwd_defer): nobody waits for these sums before the
+// optimizer step, and that launch keeps two workgroups busy for ~89 us while the rest of the chip idles.
+//   out[i][j] = sum_n A[n*lda + i] B[n*ldb + j];  bias[i] = sum_n A[n*lda + i]
+// One thread per output element, no barriers: `block` / `tid` = a 256-thread block of the stand-alone launch.
+struct OuterJob {
+    const float *A, *B;
+    float *out, *bias, *bias2;
+    int lda, ldb, ra, cb, n, block0;
+};
+constexpr int DEC_MAXJOBS = 12;
+struct OuterBatch {
+    OuterJob job[DEC_MAXJOBS];
+    int njobs;
+    int nblocks;     // 256-thread blocks of the whole batch (0: nothing)
+};
+__device__ __forceinline__ void dec_outer_body(const OuterBatch &ob, const int block, const int tid) {
+    int ji = 0;
+    while (ji + 1 < ob.njobs && block >= ob.job[ji + 1].block0) ++ji;
+    const OuterJob &jb = ob.job[ji];
+    const long e = (long)(block - jb.block0) * 256 + tid;
+    if (e >= (long)jb.ra * jb.cb) return;
+    const int i = (int)(e / jb.cb), j = (int)(e - (long)i * jb.cb);
+    float acc = 0.f, accb = 0.f;
+    // eight terms' loads in flight at a time, summed in order (dW1 sums over the Tz encoder states: a term-at-a-time loop is a
+    // chain of Tz memory round trips)
+    for (int n0 = 0; n0 < jb.n; n0 += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = min(n0 + q, jb.n - 1);
+            av[q] = jb.A[(long)n * jb.lda + i];
+            bv[q] = jb.B[(long)n * jb.ldb + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (n0 + q < jb.n) {
+                acc += av[q] * bv[q];
+                accb += av[q];
+            }
+        }
+    }
+    jb.out[e] = acc;
+    if (j == 0) {
+        if (jb.bias) jb.bias[i] = accb;
+        if (jb.bias2) jb.bias2[i] = accb;
+    }
+}
+
+
 // grid (ndir), 512 threads.  dG [ndir][T][512]: gradient at the gate pre-activations (input of the weight / input gradients).
 // A ROW of 16 lanes (the unit DPP row operations work on) owns four hidden units j0 .. j0+3 (wave w: units 16w .. 16w+15)
 // in both roles of a step:
@@ -193,7 +244,12 @@ __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, Ls
 // 16-byte bank groups.
 __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, const float *out, const float *gates,
                                                              const float *cells, const float *d_out, const float *d_hn,
-                                                             const float *d_cn, float *dG, int T, int ndir) {
+                                                             const float *d_cn, float *dG, int T, int ndir, const OuterBatch ob) {
+    if ((int)blockIdx.x >= ndir) {   // (r6) a deferred batch of the decoder's outer products: two of its 256-thread blocks per workgroup
+        const int blk = ((int)blockIdx.x - ndir) * 2 + (int)(threadIdx.x >> 8);
+        if (blk < ob.nblocks) dec_outer_body(ob, blk, (int)(threadIdx.x & 255));
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float dgs[2][16 * LSTM_SEG];
     const int d = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

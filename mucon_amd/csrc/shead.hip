@@ -85,6 +85,29 @@ extern "C" int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     return MUCON_OK;
 }
 
+// One-shot option of the NEXT mucon_decoder_bwd call (mucon_decoder_bwd_defer), and what such a call leaves behind: the batch of outer products that are
+// the decoder's weight gradients, to ride in extra workgroups of the next mucon_lstm_bwd's recurrence launch on the same stream -- or taken by
+// mucon_decoder_bwd_flush (a launch of their own on the stream they were left on)
+static struct OuterPending {
+    bool armed = false, pending = false;
+    OuterBatch ob;
+    hipStream_t stream = nullptr;
+} g_outer_pending;
+
+extern "C" int mucon_decoder_bwd_defer(int32_t enable) {
+    g_outer_pending.armed = enable != 0;
+    return MUCON_OK;
+}
+
+extern "C" int mucon_decoder_bwd_flush(void) {
+    OuterPending &op = g_outer_pending;
+    if (!op.pending) return MUCON_OK;
+    op.pending = false;
+    if (op.ob.nblocks > 0) hipLaunchKernelGGL(dec_outer_kernel, dim3(op.ob.nblocks), dim3(256), 0, op.stream, op.ob);
+    SHIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
 extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, const float *x, const mucon_lstm_params *params,
                               const float *out, const float *d_out, const float *d_hn, const float *d_cn, float *d_x,
                               const float *d_x_add, const mucon_lstm_params *d_params, void *workspace, size_t workspace_bytes,
@@ -109,7 +132,19 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *dG = static_cast<float *>(workspace);
     float *gates = dG + al64(per * LSTM_G);
     float *cells = gates + al64(per * LSTM_G);
-    hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir);
+    // (r6) a batch of the decoder's outer products left pending on this stream rides in extra workgroups of the recurrence launch (two CUs busy for ~89 us)
+    OuterBatch ob;
+    ob.njobs = 0;
+    ob.nblocks = 0;
+    int extra = 0;
+    if (g_outer_pending.pending && g_outer_pending.stream == s) {
+        ob = g_outer_pending.ob;
+        extra = (ob.nblocks + 1) / 2;
+        g_outer_pending.pending = false;
+    } else if (g_outer_pending.pending) {
+        if ((rc = mucon_decoder_bwd_flush()) != MUCON_OK) return rc;   // left on another stream: finished there
+    }
+    hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir + extra), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir, ob);
     hipLaunchKernelGGL(lstm_wgrad_dx_kernel, dim3(T + (LSTM_G / 4) * ndir), dim3(512), 0, s, dG, x, out, g, w, d_x, d_x_add, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
@@ -270,6 +305,7 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     if (!params || !memory || !hn || !cn || !logp || !d_memory || !d_hn || !d_cn || !d_params || !workspace)
         return sfail(MUCON_E_ARG, "decoder: null pointer argument");
     if (workspace_bytes < mucon_decoder_workspace_bytes(cfg)) return sfail(MUCON_E_WORKSPACE, "decoder workspace too small");
+    if (g_outer_pending.pending && (rc = mucon_decoder_bwd_flush()) != MUCON_OK) return rc;   // an earlier deferred batch nobody took
     DecParams p, g;
     if ((rc = dec_params(p, params, "parameter")) != MUCON_OK) return rc;
     if ((rc = dec_params(g, d_params, "gradient")) != MUCON_OK) return rc;
@@ -318,7 +354,17 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
     job(L.dl.c0, DEC_D, DEC_D, cn, ME, ME, 1, g.co_w, g.co_b, nullptr);
     job(memory, ME, ME, L.dl.mp, DEC_D, DEC_D, Tz, g.w1, nullptr, nullptr);
     ob.njobs = nj;
+    ob.nblocks = blocks;
     hipLaunchKernelGGL(dec_attn_grad_kernel, dim3(Tz), dim3(256), 0, s, L.sv, L.dl, p.w1, p.v, d_memory, S, Tz, ME);   // before dW1's job
+    const bool defer = g_outer_pending.armed;
+    g_outer_pending.armed = false;
+    if (defer) {   // (mucon_decoder_bwd_defer) the weight gradients are left to the next mucon_lstm_bwd on this stream
+        g_outer_pending.ob = ob;
+        g_outer_pending.stream = s;
+        g_outer_pending.pending = true;
+        SHIPCHK(hipGetLastError());
+        return MUCON_OK;
+    }
     hipLaunchKernelGGL(dec_outer_kernel, dim3(blocks), dim3(256), 0, s, ob);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;

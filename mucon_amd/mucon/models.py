@@ -281,8 +281,10 @@ class MuCon(nn.Module):
         (main, parts), c_loss = F_.run_forward(F_._LossFn, seg, sx, tlogp, lens[:-1].contiguous(), self._loss_spec(), target.to(torch.int64),
                                                 batch.transcript_tf_target.to(torch.int64), self._loss_tmpl, self._loss_mw, self._loss_tw)
         d_seg, d_sx, d_tlogp, d_len = c_loss.saved_tensors            # d main / d input, computed with the loss itself
-        c_head.defer_reduce = True     # (r6) d_wc / d_bc are summed inside the encoder backward's first launch, which follows on this stream below
-        c_head.reuse_grads = c_dec.reuse_grads = c_lstm.reuse_grads = True   # (r6) the previous video's gradient tensors serve again: the optimizer step that consumed them is behind us
+        if getattr(self, "fused_step_deferrals", True):      # (an instance attribute set to False: the same step without them -- tests compare the two bit for bit)
+            c_head.defer_reduce = True     # (r6) d_wc / d_bc are summed inside the encoder backward's first launch, which follows on this stream below
+            c_dec.defer_outer = True       # (r6) the decoder's weight-gradient outer products ride in the LSTM backward's recurrence launch, which follows on this stream below
+            c_head.reuse_grads = c_dec.reuse_grads = c_lstm.reuse_grads = True   # (r6) the previous video's gradient tensors serve again: the optimizer step that consumed them is behind us
         if lc.smoothing.log_softmax_before:
             d_enc, d_wc, d_bc = F_.run_backward(F_._HeadFn, c_head, d_seg.unsqueeze(0), d_sx.unsqueeze(0))[:3]
         else:
@@ -291,7 +293,7 @@ class MuCon(nn.Module):
         d_mem, d_hn, d_cn, _, _, _, *g_dec = F_.run_backward(F_._DecoderFn, c_dec, d_tlogp, d_lens)
         c_lstm.dx_accumulate = d_enc[0]                                 # the LSTM's input gradient is added onto the y-head's in its kernel
         _, _, *g_lstm = F_.run_backward(F_._LstmFn, c_lstm, d_mem, d_hn.view(ndir, -1), d_cn.view(ndir, -1))
-        c_enc.reuse_grads = True       # (r6) the optimizer step of the previous video is behind us: its gradient buffer and views serve again (ops._EncoderFn.backward)
+        c_enc.reuse_grads = bool(getattr(self, "fused_step_deferrals", True))   # (r6) the optimizer step of the previous video is behind us: its gradient buffer and views serve again (ops._EncoderFn.backward)
         g_enc = F_.run_backward(F_._EncoderFn, c_enc, d_enc)[4:]
         for prm, g in zip(enc_params, g_enc):
             prm.grad = g

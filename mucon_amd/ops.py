@@ -687,6 +687,10 @@ class _DecoderFn(torch.autograd.Function):
         d_len = d_len.contiguous() if d_len is not None else None
         d_memory, d_hn, d_cn = torch.empty_like(memory), torch.empty_like(hn), torch.empty_like(cn)
         grads, cg = _param_grads(ctx, ("dec",), params, _decoder_params)
+        if getattr(ctx, "defer_outer", False):
+            # (r6) the fused step path, where the LSTM's backward follows on this stream before anyone reads the decoder's weight gradients: their outer
+            # products ride in that pass's recurrence launch (include/mucon_hip.h: mucon_decoder_bwd_defer).  ctx keeps the workspace alive.
+            _lib.check(lib.mucon_decoder_bwd_defer(1), "mucon_decoder_bwd_defer")
         _lib.check(lib.mucon_decoder_bwd(ctypes.byref(ctx.cfg), ctx.n, ctypes.byref(_param_struct(("dec",), params, _decoder_params)), _lib.ptr(memory),
                                          _lib.ptr(hn), _lib.ptr(cn), _lib.ptr(logp), _lib.ptr(d_logp), _lib.ptr(d_len),
                                          _lib.ptr(ctx.dropmask), _lib.ptr(d_memory), _lib.ptr(d_hn), _lib.ptr(d_cn),

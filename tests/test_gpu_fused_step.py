@@ -70,3 +70,41 @@ def test_trainer_takes_the_fused_step_and_matches():
     for n in finals[0]:
         a, b = finals[0][n].double(), finals[1][n].double()
         assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7, n
+
+
+def test_fused_step_deferrals_change_no_bit():
+    """(r6, ABI 8) MuCon.fused_train_step defers the y-head's slab sums into the encoder backward's first launch (mucon_head_bwd_defer) and the decoder's
+    weight-gradient outer products into the LSTM backward's recurrence launch (mucon_decoder_bwd_defer), and hands out the previous step's gradient tensors
+    again: the same step with all of that switched off (fused_step_deferrals = False) gives the same losses and EVERY gradient bit for bit, step after step
+    (three steps each, the second and third on reused tensors)."""
+    from test_gpu_model import make_batch, seeded_value
+    from mucon_amd import _lib
+    from mucon_amd.config import get_cfg_defaults, update_config
+    from mucon_amd.mucon.models import create_model
+    cfg = update_config(get_cfg_defaults(), [], [])
+    model = create_model(cfg, num_classes=48, max_decoding_steps=31, input_feature_size=2048)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(seeded_value(name, p.shape).astype(np.float32)))
+    model = model.cuda().train()
+    model.set_teacher_forcing(cfg.model.teacher_forcing)
+    batches = [make_batch(640, 5).to("cuda"), make_batch(901, 7).to("cuda"), make_batch(640, 5).to("cuda")]
+    runs = []
+    for deferrals in (True, False):
+        model.fused_step_deferrals = deferrals
+        steps = []
+        for k, batch in enumerate(batches):
+            model.zero_grad(set_to_none=True)
+            model._step = 41 + k
+            torch.manual_seed(7 + k)
+            loss, fo = model.fused_train_step(batch)
+            torch.cuda.synchronize()
+            steps.append((loss.main.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        runs.append(steps)
+    lib = _lib.load()
+    assert lib.mucon_decoder_bwd_flush() == 0 and lib.mucon_head_bwd_flush() == 0      # nothing left pending
+    for (la, ga), (lb, gb) in zip(*runs):
+        assert la == lb
+        assert set(ga) == set(gb)
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), n
