@@ -212,7 +212,10 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
  * (beside the GroupNorm backward: one launch fewer on the step's critical path, ~6 us at B = 8 x T = 4096) -- the same sums in the same order, bitwise the
  * d_w / d_b of the plain call.  d_w / d_b and the workspace must stay valid until then.  If another mucon_head_bwd comes first, or
  * mucon_head_bwd_flush is called, the pending sums are taken by a launch of their own on the stream they were left on.  Shapes the float4 sums do not
- * cover (C not a multiple of 4) are reduced at once as if the option were off. */
+ * cover (C not a multiple of 4) are reduced at once as if the option were off.
+ * enable bit 1 (enable = 3, H = 128 only): the z-level backward KERNEL waits as well -- for the next mucon_decoder_bwd on the same stream, whose eight-workgroup step
+ * loop (~65 us on eight CUs) runs it in extra workgroups; d_enc exists once that call has been enqueued (the LSTM's backward, which adds onto it, follows).  If no
+ * mucon_decoder_bwd comes, mucon_encoder_bwd / mucon_head_bwd_flush / the next mucon_head_bwd launch the kernel on its own.  Bitwise the plain call's results. */
 int mucon_head_bwd_defer(int32_t enable);
 int mucon_head_bwd_flush(void);
 

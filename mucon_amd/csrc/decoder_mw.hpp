@@ -25,6 +25,7 @@
 // arg-max itself, every workgroup the same bits.
 #pragma once
 #include "decoder.hpp"
+#include "head_body.hpp"
 
 constexpr int MW_G = 8;                       // workgroups
 constexpr int MW_T = 256;                     // threads each
@@ -471,7 +472,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_heads_bwd_kernel(DecDims 
 // grid MW_G, MW_T threads, dynamic LDS mw_bwd_lds_bytes(Tz); behind decoder_heads_bwd_kernel.
 __global__ __launch_bounds__(MW_T) void decoder_bwd_mw_kernel(DecDims dm, DecParams p, DecSaved sv, DecDeltas dl, const float *memory,
                                                              const float *dropmask, float *d_emb, float *d_v, float *d_hn, float *d_cn,
-                                                             unsigned long long *xbuf) {
+                                                             unsigned long long *xbuf, const HeadBwdArgs ha, const int hgx, const int hblocks) {
+    if ((int)blockIdx.x >= MW_G) {   // (r6) workgroups behind the eight: a deferred y-head backward (head_body.hpp), one of its 256-thread blocks each
+        const int hb = (int)blockIdx.x - MW_G;
+        if (hb < hblocks) head_bwd_z_body(ha, hb % hgx, hb / hgx, hgx, (int)threadIdx.x);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float mwb_dyn[];
     float *s_wih = mwb_dyn;                             // [64 gate rows: gate * 16 + unit][128]
     float *s_whh = s_wih + 64 * DEC_D;                  // [64][128]

@@ -45,6 +45,7 @@ struct HeadPending {
     hipStream_t stream = nullptr;
 };
 HeadPending g_head_pending;
+HeadKernelPending g_head_kernel_pending;   // (head_body.hpp) mucon_head_bwd_defer bit 1: the z-level backward kernel itself, left to the next mucon_decoder_bwd (shead.hip)
 int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (fixed since r6: was the knob TS_GROUP_ROWS)
 int g_ts_stagger = 1024;      // fixed since r6: was the knob TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
                               // (gemm_tn_split.hpp: ts_body_st); 0: every job on round 4's lock-step schedule
@@ -1121,6 +1122,11 @@ int mucon_encoder_bwd(const mucon_encoder_cfg *cfg, const mucon_encoder_params *
         g.use_relu = cfg->last_relu;
         g.drop = make_drop(cfg->seed, L, cfg->p_drop_last, cfg->training != 0);
         g.zero = reinterpret_cast<unsigned *>(ws + pl.sync);   // (the pass's first kernel: the words the later launches count in start at zero)
+        // (a deferred y-head backward KERNEL no mucon_decoder_bwd took: it must run before its sums are taken below)
+        if (g_head_kernel_pending.pending) {
+            rc = head_kernel_flush();
+            if (rc != MUCON_OK) return rc;
+        }
         // (r6) a y-head slab reduction left pending on this stream (mucon_head_bwd_defer) rides in extra rows of this launch's grid
         HeadReduceTail tail;
         memset(&tail, 0, sizeof(tail));
@@ -1515,11 +1521,21 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a.enc, a.w, a.dlogits, a.dlogp, a.logp_z, a.Tz, a.Tf, a.C, a.scale, a);
+    const bool defer = g_head_pending.armed && (C & 3) == 0 && ((C * H) & 3) == 0;   // (the tail sums float4 columns; other shapes reduce here)
+    const bool defer_kernel = defer && g_head_kernel_pending.armed && H == 128;
+    g_head_pending.armed = false;
+    g_head_kernel_pending.armed = false;
+    if (defer_kernel) {
+        // (mucon_head_bwd_defer bit 1) the kernel itself waits for the next mucon_decoder_bwd on this stream: d_enc and the partial sums exist once THAT call has been enqueued
+        HeadKernelPending &kp = g_head_kernel_pending;
+        kp.a = a;
+        kp.gx = zblocks;
+        kp.gy = B;
+        kp.stream = s;
+        kp.pending = true;
+    } else if (H == 128) hipLaunchKernelGGL(head_bwd_z_kernel, dim3(zblocks, B), dim3(256), 0, s, a.enc, a.w, a.dlogits, a.dlogp, a.logp_z, a.Tz, a.Tf, a.C, a.scale, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(zblocks, B), dim3(256), head_smem_bytes(H, C), s, a);
     HIPCHK(hipGetLastError());
-    const bool defer = g_head_pending.armed && (C & 3) == 0 && ((C * H) & 3) == 0;   // (the tail sums float4 columns; other shapes reduce here)
-    g_head_pending.armed = false;
     if (defer) {
         HeadPending &hp = g_head_pending;
         hp.pending = true;
@@ -1541,11 +1557,25 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
 }
 
 int mucon_head_bwd_defer(int32_t enable) {
-    g_head_pending.armed = enable != 0;
+    g_head_pending.armed = (enable & 1) != 0;
+    g_head_kernel_pending.armed = (enable & 3) == 3;   // (the kernel can only wait if its sums wait too)
+    return MUCON_OK;
+}
+
+// the z-level backward kernel a deferred mucon_head_bwd left behind and nobody took: launched now, on the stream it was left on
+int head_kernel_flush() {
+    HeadKernelPending &kp = g_head_kernel_pending;
+    if (!kp.pending) return MUCON_OK;
+    kp.pending = false;
+    const HeadBwdArgs &a = kp.a;
+    hipLaunchKernelGGL(head_bwd_z_kernel, dim3(kp.gx, kp.gy), dim3(256), 0, kp.stream, a.enc, a.w, a.dlogits, a.dlogp, a.logp_z, a.Tz, a.Tf, a.C, a.scale, a);
+    HIPCHK(hipGetLastError());
     return MUCON_OK;
 }
 
 int mucon_head_bwd_flush(void) {
+    int rc = head_kernel_flush();
+    if (rc != MUCON_OK) return rc;
     HeadPending &hp = g_head_pending;
     if (!hp.pending) return MUCON_OK;
     hp.pending = false;

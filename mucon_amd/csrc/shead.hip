@@ -8,12 +8,14 @@
 #include <string.h>
 
 #include "../../include/mucon_hip.h"
+#include "head_body.hpp"
 #include "lstm.hpp"
 #include "decoder.hpp"
 #include "decoder_mw.hpp"
 #include "loss.hpp"
 #include "optim.hpp"
 #include <vector>
+
 
 void mucon_internal_set_error(const char *msg);  // mucon_hip.hip: feeds mucon_last_error()
 
@@ -318,9 +320,22 @@ extern "C" int mucon_decoder_bwd(const mucon_decoder_cfg *cfg, int32_t n_steps, 
         // the heads for all steps (one workgroup; clears the exchange granules), then the step loop on eight workgroups (decoder_mw.hpp)
         hipLaunchKernelGGL(decoder_heads_bwd_kernel, dim3(S), dim3(DEC_THREADS), 0, s, dec_dims(cfg, S), p, L.sv, L.dl, logp, d_logp, d_lengths,
                            W(g.emb), L.xbuf, (int)MWB_X_WORDS);
-        hipLaunchKernelGGL(decoder_bwd_mw_kernel, dim3(MW_G), dim3(MW_T), mw_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
-                           dropmask, W(g.emb), W(g.v), d_hn, d_cn, L.xbuf);
+        // (r6) a y-head backward kernel left pending on this stream (mucon_head_bwd_defer, bit 1) rides in extra workgroups of the step loop's launch: same 256 threads
+        HeadBwdArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        int hgx = 1, hblocks = 0;
+        if (g_head_kernel_pending.pending && g_head_kernel_pending.stream == s) {
+            ha = g_head_kernel_pending.a;
+            hgx = g_head_kernel_pending.gx;
+            hblocks = g_head_kernel_pending.gx * g_head_kernel_pending.gy;
+            g_head_kernel_pending.pending = false;
+        } else if (g_head_kernel_pending.pending) {
+            if ((rc = head_kernel_flush()) != MUCON_OK) return rc;
+        }
+        hipLaunchKernelGGL(decoder_bwd_mw_kernel, dim3(MW_G + hblocks), dim3(MW_T), mw_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
+                           dropmask, W(g.emb), W(g.v), d_hn, d_cn, L.xbuf, ha, hgx, hblocks);
     } else {
+        if (g_head_kernel_pending.pending && (rc = head_kernel_flush()) != MUCON_OK) return rc;   // (the one-workgroup kernel has 1,024 threads: the pending kernel runs on its own)
         hipLaunchKernelGGL(decoder_bwd_kernel, dim3(1), dim3(DEC_THREADS), dec_bwd_lds_bytes(Tz), s, dec_dims(cfg, S), p, L.sv, L.dl, memory,
                            logp, d_logp, d_lengths, dropmask, d_memory, W(g.emb), W(g.v), d_hn, d_cn);
     }

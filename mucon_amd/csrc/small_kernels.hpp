@@ -3,6 +3,7 @@
 // log-softmax) forward/backward.  All activations are time-major [B][T][128] float32.
 #pragma once
 #include "common.hpp"
+#include "head_body.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Weight packing (per forward call; ~2 MB total, L2 resident afterwards).
@@ -472,28 +473,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const float *z_, con
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// y-head.  F.interpolate(mode="nearest") source index (models.py:574), computed as torch does:
-// scale = float(Tz)/float(Tf); src = min(int(floorf(i * scale)), Tz - 1).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int zmap(int i, float scale, int Tz) {
-    const int z = (int)floorf((float)i * scale);
-    return z < Tz - 1 ? z : Tz - 1;
-}
-// first frame i in [0, Tf] with zmap(i) >= z  (Tf when none)
-__device__ __forceinline__ int first_frame(int z, float scale, int Tz, int Tf) {
-    if (z <= 0) return 0;
-    if (z >= Tz) return Tf;
-    long guess = ((long)z * Tf) / Tz - 2;
-    int i = guess < 0 ? 0 : (int)guess;
-    while (i > 0 && zmap(i - 1, scale, Tz) >= z) --i;
-    while (i < Tf && zmap(i, scale, Tz) < z) ++i;
-    return i;
-}
-
 constexpr int HEAD_FB = 128;  // frames per workgroup (forward)
 constexpr int HEAD_ZC = 16;   // z rows per pass
-constexpr int HEAD_MAXC = 64; // classes supported by the LDS carve
 
 struct HeadFwdArgs {
     const float *enc;   // [B][Tz][H]
@@ -676,15 +657,6 @@ __global__ __launch_bounds__(256) void head_fwd_z_kernel(const float *enc_, cons
 }
 static inline size_t head_fwd_z_smem_bytes(int H) { return sizeof(float) * ((size_t)HF_Z * H + 2 * HF_Z * HEAD_MAXC); }
 
-struct HeadBwdArgs {
-    const float *enc, *w;          // [B][Tz][H], [C][H]
-    const float *dlogits, *dlogp;  // [B][Tf][C] or null
-    const float *logp_z;           // [B][Tz][C]
-    float *denc;                   // [B][Tz][H]
-    float *w_slabs, *b_slabs;      // [nblk][C][H], [nblk][C]
-    int Tz, Tf, H, C;
-    float scale;
-};
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -767,7 +739,6 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs a) {
 // themselves: thread (k = tid & 127, half = tid >> 7) reads its column of W straight from global (coalesced over k) for
 // d_enc, keeps its column of the encoding rows in registers for the weight-gradient partials, and the per-row class sums run
 // up shuffle trees.  30 -> ~14 us at B=8, T=4096.
-constexpr int HB_Z = 8;
 __global__ __launch_bounds__(256) void head_bwd_z_kernel(const float *enc_, const float *w_, const float *dlogits_, const float *dlogp_, const float *logp_z_, const int Tz_,
                                                          const int Tf_, const int C_, const float scale_, const HeadBwdArgs a_) {
     HeadBwdArgs a = a_;   // (leading scalars: see gn_fwd_kernel)
@@ -780,105 +751,7 @@ __global__ __launch_bounds__(256) void head_bwd_z_kernel(const float *enc_, cons
     a.Tf = Tf_;
     a.C = C_;
     a.scale = scale_;
-    __shared__ __attribute__((aligned(16))) float Es[HB_Z][128];
-    __shared__ float G1[HB_Z][HEAD_MAXC], G2[HB_Z][HEAD_MAXC], S2[HB_Z];
-    const int C = a.C;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int z0 = blockIdx.x * HB_Z;
-    const int nz = min(HB_Z, a.Tz - z0);
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int zi = tid >> 5, k4 = (tid & 31) * 4;   // 8 rows x 32 float4
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (zi < nz) v = *reinterpret_cast<const f32x4 *>(a.enc + ((long)b * a.Tz + z0 + zi) * 128 + k4);
-        *reinterpret_cast<f32x4 *>(&Es[zi][k4]) = v;
-    }
-    for (int o = tid; o < HB_Z * HEAD_MAXC; o += 256) {
-        const int zi = o >> 6, c = o & 63;
-        float g1 = 0.f, g2 = 0.f;
-        if (zi < nz && c < C) {
-            const int fa = first_frame(z0 + zi, a.scale, a.Tz, a.Tf);
-            const int fb = first_frame(z0 + zi + 1, a.scale, a.Tz, a.Tf);
-            // frames of the bin in order, eight loads in flight at a time (a bin has ~Tf/Tz frames)
-            const int nfr = fb - fa;
-            // (both arrays are read unconditionally, a missing one through the other's pointer with weight 0: a load behind a
-            // branch costs a branch and a full wait per element)
-            const float *p1 = a.dlogits ? a.dlogits : a.dlogp, *p2 = a.dlogp ? a.dlogp : a.dlogits;
-            const float w1 = a.dlogits ? 1.f : 0.f, w2 = a.dlogp ? 1.f : 0.f;
-            constexpr int HB_FRAMES = 16;   // (r5) frames of a bin requested at once (8: round 4 -- a bin of Tf / Tz = 16 frames was two dependent round trips)
-            for (int base = 0; base < nfr; base += HB_FRAMES) {
-                float v1[HB_FRAMES], v2[HB_FRAMES];
-#pragma unroll
-                for (int j = 0; j < HB_FRAMES; ++j) {
-                    const long gi = ((long)b * a.Tf + fa + min(base + j, nfr - 1)) * C + c;
-                    v1[j] = p1[gi];
-                    v2[j] = p2[gi];
-                }
-#pragma unroll
-                for (int j = 0; j < HB_FRAMES; ++j) {
-                    if (base + j < nfr) {
-                        g1 += v1[j];
-                        g2 += v2[j];
-                    }
-                }
-            }
-            g1 *= w1;
-            g2 *= w2;
-        }
-        G1[zi][c] = g1;
-        G2[zi][c] = g2;
-    }
-    // (r5) the saved log-probabilities of this thread's two rows are requested in front of the barrier (they were a round trip behind it)
-    float lpz[HB_Z / 4];
-#pragma unroll
-    for (int i = 0; i < HB_Z / 4; ++i) {
-        const int zi = (tid >> 6) + 4 * i, c = tid & 63;
-        lpz[i] = a.logp_z[((long)b * a.Tz + z0 + min(zi, nz - 1)) * C + min(c, C - 1)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < HB_Z / 4; ++i) {   // a wave per row: S2 = sum_c G2, then the log-softmax backward
-        const int zi = (tid >> 6) + 4 * i;
-        const int c = tid & 63;
-        float s = G2[zi][c];
-#pragma unroll
-        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        float d = G1[zi][c] + G2[zi][c];
-        if (zi < nz && c < C && s != 0.f) d -= expf(lpz[i]) * s;
-        G1[zi][c] = d;
-        if (c == 0) S2[zi] = s;
-    }
-    __syncthreads();
-    const int k = tid & 127, half = tid >> 7;
-    {   // d_enc[z][k] = sum_c dlogit[z][c] * W[c][k] for rows 4 half .. 4 half + 3
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) {
-            const float w = a.w[(long)c * 128 + k];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += G1[half * 4 + j][c] * w;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (half * 4 + j < nz) a.denc[((long)b * a.Tz + z0 + half * 4 + j) * 128 + k] = acc[j];
-    }
-    {   // partial dW[c][k] = sum_z dlogit[z][c] * enc[z][k] for classes c = half, half + 2, ...
-        float e[HB_Z];
-#pragma unroll
-        for (int zi = 0; zi < HB_Z; ++zi) e[zi] = Es[zi][k];
-        for (int c = half; c < C; c += 2) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int zi = 0; zi < HB_Z; ++zi) sacc += G1[zi][c] * e[zi];
-            a.w_slabs[(long)blk * C * 128 + c * 128 + k] = sacc;
-        }
-    }
-    if (tid < C) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int zi = 0; zi < HB_Z; ++zi) sacc += G1[zi][tid];
-        a.b_slabs[(long)blk * C + tid] = sacc;
-    }
+    head_bwd_z_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)threadIdx.x);   // (head_body.hpp)
 }
 
 static inline size_t head_smem_bytes(int H, int C) {

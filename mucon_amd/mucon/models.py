@@ -283,6 +283,7 @@ class MuCon(nn.Module):
         d_seg, d_sx, d_tlogp, d_len = c_loss.saved_tensors            # d main / d input, computed with the loss itself
         if getattr(self, "fused_step_deferrals", True):      # (an instance attribute set to False: the same step without them -- tests compare the two bit for bit)
             c_head.defer_reduce = True     # (r6) d_wc / d_bc are summed inside the encoder backward's first launch, which follows on this stream below
+            c_head.defer_kernel = True     # (r6) ... and the y-head's z-level backward kernel rides in the decoder backward's eight-workgroup launch, which follows on this stream below
             c_dec.defer_outer = True       # (r6) the decoder's weight-gradient outer products ride in the LSTM backward's recurrence launch, which follows on this stream below
             c_head.reuse_grads = c_dec.reuse_grads = c_lstm.reuse_grads = True   # (r6) the previous video's gradient tensors serve again: the optimizer step that consumed them is behind us
         if lc.smoothing.log_softmax_before:

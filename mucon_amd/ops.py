@@ -486,7 +486,8 @@ class _HeadFn(torch.autograd.Function):
         if getattr(ctx, "defer_reduce", False):
             # (r6) the fused step paths (bench.py, MuCon.fused_train_step), where the encoder's backward follows on this stream before anyone reads
             # d_w / d_b: their slab sums ride in that pass's first launch (include/mucon_hip.h: mucon_head_bwd_defer).  ctx keeps the workspace alive.
-            _lib.check(lib.mucon_head_bwd_defer(1), "mucon_head_bwd_defer")
+            # ctx.defer_kernel (MuCon.fused_train_step only): the z-level kernel itself waits for the decoder's backward, which follows on this stream there
+            _lib.check(lib.mucon_head_bwd_defer(3 if getattr(ctx, "defer_kernel", False) else 1), "mucon_head_bwd_defer")
             ctx.deferred = (d_w, d_b)
         _lib.check(lib.mucon_head_bwd(B, Tz, Tf, H, C, _lib.ptr(enc), _lib.ptr(w), _lib.ptr(dl), _lib.ptr(dp),
                                       _lib.ptr(d_enc), _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ctx.ws), ctx.nbytes,
