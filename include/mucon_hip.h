@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUCON_ABI_VERSION 8   /* 8: mucon_head_bwd_defer / _flush (the y-head's slab reduction inside the encoder backward's first launch), mucon_decoder_bwd_defer / _flush (the decoder's weight-gradient outer products inside the LSTM backward's recurrence launch); 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
+#define MUCON_ABI_VERSION 8   /* 8: mucon_head_bwd_defer / _flush (the y-head's slab reduction inside the encoder backward's first launch), mucon_decoder_bwd_defer / _flush (the decoder's weight-gradient outer products inside the LSTM backward's recurrence launch), mucon_head_fwd_defer / _flush (the y-head's forward inside the LSTM forward's recurrence launch); 7: the *_poisson Viterbi entries (length scores built on the device), group_norms [2 * n_groups] with sticky skipped-step counts; 5: label_format of the Viterbi entry points; 4: mucon_viterbi_job carries the emission pointer; mucon_viterbi_decode_host */
 #define MUCON_MAX_LAYERS 16
 
 #define MUCON_OK 0
@@ -200,6 +200,14 @@ size_t mucon_head_workspace_bytes(int32_t B, int32_t Tz, int32_t H, int32_t C);
 int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc,
                    const float *w, const float *b, float *logits, float *logp, void *workspace,
                    size_t workspace_bytes, void *stream);
+
+/* ABI 8 (no reference counterpart).  One-shot option of the NEXT mucon_head_fwd on this thread (enable != 0, H = 128): the call enqueues nothing; the NEXT
+ * mucon_lstm_fwd on the same stream runs the classifier in extra workgroups of its recurrence launch (two CUs busy for ~73 us at Tz = 125: ~9 us of launch off the
+ * step's critical path).  logits / logp and the workspace's saved rows exist once that call has been enqueued; enc, w, b and the outputs must stay valid until then.
+ * Another mucon_head_fwd, mucon_head_bwd, mucon_loss_fwd_bwd, a mucon_lstm_fwd on another stream, or mucon_head_fwd_flush launch a pending forward on its own.  Bitwise
+ * the plain call's results. */
+int mucon_head_fwd_defer(int32_t enable);
+int mucon_head_fwd_flush(void);
 
 /* d_logits / d_logp [B][Tf][C] (either may be NULL) -> d_enc [B][Tz][H], d_w [C][H], d_b [C]. */
 int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc,

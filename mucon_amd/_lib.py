@@ -124,6 +124,8 @@ SYMBOLS = {
     "mucon_head_bwd": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mucon_decoder_bwd_defer": (ctypes.c_int, [_i32]),
     "mucon_decoder_bwd_flush": (ctypes.c_int, []),
+    "mucon_head_fwd_defer": (ctypes.c_int, [_i32]),
+    "mucon_head_fwd_flush": (ctypes.c_int, []),
     "mucon_head_bwd_defer": (ctypes.c_int, [_i32]),
     "mucon_head_bwd_flush": (ctypes.c_int, []),
     "mucon_viterbi_job_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

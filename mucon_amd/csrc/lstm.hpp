@@ -16,6 +16,7 @@
 //                           and dx[t] = sum_d W_ih[d]^T dG[d][t] (lstm_dx_body)
 #pragma once
 #include "common.hpp"
+#include "head_body.hpp"
 
 constexpr int LSTM_H = 128;
 constexpr int LSTM_G = 4 * LSTM_H;  // 512 gate rows
@@ -113,7 +114,15 @@ __global__ __launch_bounds__(512) void lstm_inproj_kernel(const float *x, LstmWe
 // new h for everybody).
 constexpr int LSTM_SEG = 36;   // backward: pitch of the sixteen 32-float segments of the gate gradients in LDS
 __global__ __launch_bounds__(512) void lstm_recur_fwd_kernel(const float *Gx, LstmWeights w, float *out, float *gates,
-                                                             float *cells, float *hn, float *cn, int T, int ndir) {
+                                                             float *cells, float *hn, float *cn, int T, int ndir, const HeadFwdArgs ha, const int hgx, const int hblocks) {
+    if ((int)blockIdx.x >= ndir) {   // (r6) workgroups behind the directions: a deferred y-head forward (head_body.hpp, H = 128), two of its 256-thread blocks each
+        __shared__ __attribute__((aligned(16))) float hsm[2][HF_Z * 128 + 2 * HF_Z * HEAD_MAXC];
+        const int half = (int)(threadIdx.x >> 8);
+        const int blk = ((int)blockIdx.x - ndir) * 2 + half;
+        const bool active = blk < hblocks;
+        head_fwd_z_body(ha, hsm[half], active ? blk % hgx : 0, active ? blk / hgx : 0, (int)(threadIdx.x & 255), active);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float hs[2][LSTM_H];
     const int d = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -197,6 +206,7 @@ struct OuterBatch {
     int nblocks;     // 256-thread blocks of the whole batch (0: nothing)
 };
 __device__ __forceinline__ void dec_outer_body(const OuterBatch &ob, const int block, const int tid) {
+#pragma clang fp contract(off)   // (explicit fmaf only: both launches that inline this body must produce the same bits)
     int ji = 0;
     while (ji + 1 < ob.njobs && block >= ob.job[ji + 1].block0) ++ji;
     const OuterJob &jb = ob.job[ji];
@@ -217,7 +227,7 @@ __device__ __forceinline__ void dec_outer_body(const OuterBatch &ob, const int b
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (n0 + q < jb.n) {
-                acc += av[q] * bv[q];
+                acc = __builtin_fmaf(av[q], bv[q], acc);
                 accb += av[q];
             }
         }

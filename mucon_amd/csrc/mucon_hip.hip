@@ -45,6 +45,7 @@ struct HeadPending {
     hipStream_t stream = nullptr;
 };
 HeadPending g_head_pending;
+HeadFwdPending g_head_fwd_pending;        // (head_body.hpp) mucon_head_fwd_defer: the forward kernel, left to the next mucon_lstm_fwd (shead.hip)
 HeadKernelPending g_head_kernel_pending;   // (head_body.hpp) mucon_head_bwd_defer bit 1: the z-level backward kernel itself, left to the next mucon_decoder_bwd (shead.hip)
 int g_ts_group_rows = 1 << 30;    // ... a residual layer's groups: single videos when a video has at least this many rows, else the whole batch (fixed since r6: was the knob TS_GROUP_ROWS)
 int g_ts_stagger = 1024;      // fixed since r6: was the knob TS_STAGGER=n: the single-image weight-gradient jobs (first_conv's) with time chunks >= n steps on the staggered block schedule
@@ -1480,11 +1481,44 @@ int mucon_head_fwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
+    if (g_head_fwd_pending.pending) {   // an earlier deferred forward nobody took: launched now, on its own
+        rc = head_fwd_flush();
+        if (rc != MUCON_OK) return rc;
+    }
+    const bool defer = g_head_fwd_pending.armed && H == 128;
+    g_head_fwd_pending.armed = false;
+    if (defer) {
+        // (mucon_head_fwd_defer) the kernel waits for the next mucon_lstm_fwd on this stream: logits / logp / the saved z-level log-probs exist once THAT call has been enqueued
+        HeadFwdPending &fp = g_head_fwd_pending;
+        fp.a = a;
+        fp.gx = (Tz + HF_Z - 1) / HF_Z;
+        fp.gy = B;
+        fp.stream = s;
+        fp.pending = true;
+        return MUCON_OK;
+    }
     if (H % 16 == 0) hipLaunchKernelGGL(head_fwd_z_kernel, dim3((Tz + HF_Z - 1) / HF_Z, B), dim3(256), head_fwd_z_smem_bytes(H), s, a.enc, a.w, a.b, a.logp_z, a.Tz, a.H, a.C, a);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3((Tf + HEAD_FB - 1) / HEAD_FB, B), dim3(256), smem, s, a);
     HIPCHK(hipGetLastError());
     return MUCON_OK;
 }
+
+int mucon_head_fwd_defer(int32_t enable) {
+    g_head_fwd_pending.armed = enable != 0;
+    return MUCON_OK;
+}
+
+int head_fwd_flush() {
+    HeadFwdPending &fp = g_head_fwd_pending;
+    if (!fp.pending) return MUCON_OK;
+    fp.pending = false;
+    const HeadFwdArgs &a = fp.a;
+    hipLaunchKernelGGL(head_fwd_z_kernel, dim3(fp.gx, fp.gy), dim3(256), head_fwd_z_smem_bytes(a.H), fp.stream, a.enc, a.w, a.b, a.logp_z, a.Tz, a.H, a.C, a);
+    HIPCHK(hipGetLastError());
+    return MUCON_OK;
+}
+
+int mucon_head_fwd_flush(void) { return head_fwd_flush(); }
 
 int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, const float *enc, const float *w,
                    const float *d_logits, const float *d_logp, float *d_enc, float *d_w, float *d_b,
@@ -1493,6 +1527,10 @@ int mucon_head_bwd(int32_t B, int32_t Tz, int32_t Tf, int32_t H, int32_t C, cons
     if (rc != MUCON_OK) return rc;
     if (!enc || !w || !d_enc || !d_w || !d_b || !workspace) return fail(MUCON_E_ARG, "null pointer argument");
     if (workspace_bytes < mucon_head_workspace_bytes(B, Tz, H, C)) return fail(MUCON_E_WORKSPACE, "head workspace too small");
+    if (g_head_fwd_pending.pending) {   // a deferred FORWARD nobody took: this pass reads what it saves
+        rc = head_fwd_flush();
+        if (rc != MUCON_OK) return rc;
+    }
     if (g_head_pending.pending) {   // an earlier deferred reduction no encoder_bwd has taken: run it now, on its own stream
         rc = mucon_head_bwd_flush();
         if (rc != MUCON_OK) return rc;

@@ -82,7 +82,19 @@ extern "C" int mucon_lstm_fwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
     float *gates = Gx + al64(per * LSTM_G);
     float *cells = gates + al64(per * LSTM_G);
     hipLaunchKernelGGL(lstm_inproj_kernel, dim3((T + LSTM_IP_T - 1) / LSTM_IP_T, ndir), dim3(512), 0, s, x, w, Gx, T);
-    hipLaunchKernelGGL(lstm_recur_fwd_kernel, dim3(ndir), dim3(512), 0, s, Gx, w, out, gates, cells, hn, cn, T, ndir);
+    // (r6) a y-head forward left pending on this stream (mucon_head_fwd_defer) rides in extra workgroups of the recurrence launch: two of its 256-thread blocks each
+    HeadFwdArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    int hgx = 1, hblocks = 0;
+    if (g_head_fwd_pending.pending && g_head_fwd_pending.stream == s) {
+        ha = g_head_fwd_pending.a;
+        hgx = g_head_fwd_pending.gx;
+        hblocks = g_head_fwd_pending.gx * g_head_fwd_pending.gy;
+        g_head_fwd_pending.pending = false;
+    } else if (g_head_fwd_pending.pending) {
+        if ((rc = head_fwd_flush()) != MUCON_OK) return rc;   // left on another stream: finished there
+    }
+    hipLaunchKernelGGL(lstm_recur_fwd_kernel, dim3(ndir + (hblocks + 1) / 2), dim3(512), 0, s, Gx, w, out, gates, cells, hn, cn, T, ndir, ha, hgx, hblocks);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }
@@ -471,6 +483,10 @@ extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmen
     b.d_tlogp = d_transcript_logp;
     b.d_lengths = d_lengths;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_head_fwd_pending.pending) {   // (a deferred y-head forward nobody took: the losses read its outputs)
+        const int frc = head_fwd_flush();
+        if (frc != MUCON_OK) return frc;
+    }
     const int chunks = (cfg->T + LOSS_FB - 1) / LOSS_FB;
     hipLaunchKernelGGL(loss_acc_kernel, dim3(chunks), dim3(256), 0, s, d, b);
     hipLaunchKernelGGL(loss_mid_kernel, dim3(1), dim3(256), 0, s, d, b, chunks);

@@ -326,6 +326,7 @@ struct HeadReduceTail {
     int nblocks;     // of both jobs (0: nothing deferred)
 };
 __device__ __forceinline__ void head_reduce_tail(const HeadReduceTail &t, const int block) {
+#pragma clang fp contract(off)
     __shared__ f32x4 hpart[16][64];
     const int job = block >= t.nblocks0 ? 1 : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -476,14 +477,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const float *z_, con
 constexpr int HEAD_FB = 128;  // frames per workgroup (forward)
 constexpr int HEAD_ZC = 16;   // z rows per pass
 
-struct HeadFwdArgs {
-    const float *enc;   // [B][Tz][H]
-    const float *w, *b; // [C][H], [C]
-    float *logits, *logp;  // [B][Tf][C] or null
-    float *logp_z;      // [B][Tz][C]
-    int Tz, Tf, H, C;
-    float scale;
-};
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -544,7 +537,6 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
 // them.  Thread (class c = tid >> 2, k-quarter q = tid & 3) keeps its share of W[c] in registers straight from global (the four
 // lanes of a class read 64 contiguous bytes per step) and multiplies it with all HF_Z rows from LDS; the quarters meet by two
 // shuffles.  No W staging pass, no divisions: 22 -> ~8 us at B=8, T=4096 against the frame-organised kernel above.
-constexpr int HF_Z = 8;
 __global__ __launch_bounds__(256) void head_fwd_z_kernel(const float *enc_, const float *w_, const float *b_, float *logp_z_, const int Tz_, const int H_, const int C_,
                                                          const HeadFwdArgs a_) {
     HeadFwdArgs a = a_;   // (leading scalars: see gn_fwd_kernel)
@@ -556,104 +548,7 @@ __global__ __launch_bounds__(256) void head_fwd_z_kernel(const float *enc_, cons
     a.H = H_;
     a.C = C_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = a.H, C = a.C;
-    float *Es = smem;                      // [HF_Z][H]
-    float *Ls = Es + HF_Z * H;             // [HF_Z][MAXC] logits
-    float *Ps = Ls + HF_Z * HEAD_MAXC;     // [HF_Z][MAXC] log-probs
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int z0 = blockIdx.x * HF_Z;
-    const int nz = min(HF_Z, a.Tz - z0);
-    const int c = tid >> 2, q = tid & 3;
-    for (int e = tid * 4; e < nz * H; e += 1024)
-        *reinterpret_cast<f32x4 *>(Es + e) = *reinterpret_cast<const f32x4 *>(a.enc + ((long)b * a.Tz + z0) * H + e);
-    for (int e = nz * H + tid; e < HF_Z * H; e += 256) Es[e] = 0.f;
-    // (r5) H = 128: the thread's eight pieces of W are requested in front of the barrier, beside the rows' own trip (they were a second trip behind it)
-    const float *wr = a.w + (long)min(c, C - 1) * H;
-    f32x4 wpre[8];
-    const bool pre = H == 128;
-    if (pre) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wpre[i] = *reinterpret_cast<const f32x4 *>(wr + q * 4 + 16 * i);
-    }
-    __syncthreads();
-    float acc[HF_Z];
-#pragma unroll
-    for (int zi = 0; zi < HF_Z; ++zi) acc[zi] = 0.f;
-    if (c < C && pre) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = q * 4 + 16 * i;
-#pragma unroll
-            for (int zi = 0; zi < HF_Z; ++zi) {
-                const f32x4 ev = *reinterpret_cast<const f32x4 *>(Es + zi * H + k);
-                acc[zi] += (wpre[i][0] * ev[0] + wpre[i][1] * ev[1]) + (wpre[i][2] * ev[2] + wpre[i][3] * ev[3]);
-            }
-        }
-    } else if (c < C) {
-        for (int k = q * 4; k < H; k += 16) {
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k);
-#pragma unroll
-            for (int zi = 0; zi < HF_Z; ++zi) {
-                const f32x4 ev = *reinterpret_cast<const f32x4 *>(Es + zi * H + k);
-                acc[zi] += (wv[0] * ev[0] + wv[1] * ev[1]) + (wv[2] * ev[2] + wv[3] * ev[3]);
-            }
-        }
-    }
-#pragma unroll
-    for (int zi = 0; zi < HF_Z; ++zi) {
-        acc[zi] += __shfl_xor(acc[zi], 1);
-        acc[zi] += __shfl_xor(acc[zi], 2);
-    }
-    if (c < C && q == 0) {
-        const float bias = a.b[c];
-#pragma unroll
-        for (int zi = 0; zi < HF_Z; ++zi) Ls[zi * HEAD_MAXC + c] = acc[zi] + bias;
-    }
-    __syncthreads();
-    // log-softmax over the classes: a wave per z row, lane = class (C <= 64); the sum runs up a fixed shuffle tree
-    for (int zi = tid >> 6; zi < nz; zi += 4) {
-        const int cc = tid & 63;
-        const float x = cc < C ? Ls[zi * HEAD_MAXC + cc] : -INFINITY;
-        float m = x;
-#pragma unroll
-        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float s = cc < C ? expf(x - m) : 0.f;
-#pragma unroll
-        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (cc < C) {
-            const float lp = x - (m + logf(s));
-            Ps[zi * HEAD_MAXC + cc] = lp;
-            a.logp_z[((long)b * a.Tz + z0 + zi) * C + cc] = lp;
-        }
-    }
-    __syncthreads();
-    // the frames of these rows are contiguous: [first frame of z0, first frame of z0 + nz)
-    const int fa = first_frame(z0, a.scale, a.Tz, a.Tf), fb = first_frame(z0 + nz, a.scale, a.Tz, a.Tf);
-    if ((C & 3) == 0) {
-        // (r5) 16-byte pieces: thread (frame slot tid / (C / 4), piece tid % (C / 4)); 256 / 12 = 21 frames per pass at C = 48 -- seven passes
-        // for a workgroup's ~128 frames instead of 32 passes of 4-byte stores (a wave per frame, 48 of 64 lanes)
-        const int C4 = C >> 2, slots = 256 / C4;
-        const int slot = tid / C4, c4 = (tid - slot * C4) * 4;
-        if (slot < slots) {
-            for (int i = fa + slot; i < fb; i += slots) {
-                const int zi = zmap(i, a.scale, a.Tz) - z0;
-                const long gi = ((long)b * a.Tf + i) * C + c4;
-                if (a.logits) *reinterpret_cast<f32x4 *>(a.logits + gi) = *reinterpret_cast<const f32x4 *>(Ls + zi * HEAD_MAXC + c4);
-                if (a.logp) *reinterpret_cast<f32x4 *>(a.logp + gi) = *reinterpret_cast<const f32x4 *>(Ps + zi * HEAD_MAXC + c4);
-            }
-        }
-        return;
-    }
-    for (int i = fa + (tid >> 6); i < fb; i += 4) {   // a wave per frame, lane = class
-        const int cc = tid & 63;
-        const int zi = zmap(i, a.scale, a.Tz) - z0;
-        if (cc < C) {
-            const long gi = ((long)b * a.Tf + i) * C + cc;
-            if (a.logits) a.logits[gi] = Ls[zi * HEAD_MAXC + cc];
-            if (a.logp) a.logp[gi] = Ps[zi * HEAD_MAXC + cc];
-        }
-    }
+    head_fwd_z_body(a, smem, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, true);   // (head_body.hpp)
 }
 static inline size_t head_fwd_z_smem_bytes(int H) { return sizeof(float) * ((size_t)HF_Z * H + 2 * HF_Z * HEAD_MAXC); }
 

@@ -256,6 +256,13 @@ class MuCon(nn.Module):
         seed = self._dropout_seed()
         enc_params = self.ft.ordered_parameters() + [self.ft_last_gn.weight, self.ft_last_gn.bias]
         enc, c_enc = F_.run_forward(F_._EncoderFn, feats, self._encoder_spec(), True, int(seed), *enc_params)
+        # the y-head's forward in front of the s-head's (it only needs enc): (r6) its kernel then rides in the LSTM's forward recurrence launch, which follows on this
+        # stream (ops.DEFER_NEXT_HEAD_FORWARD -> mucon_head_fwd_defer); logits / logp are written by THAT launch and first read by the losses below
+        wc = self.conv_classifier.weight
+        F_.DEFER_NEXT_HEAD_FORWARD = bool(getattr(self, "fused_step_deferrals", True))
+        (logits, logp), c_head = F_.run_forward(F_._HeadFn, enc, wc.reshape(wc.shape[0], wc.shape[1]), self.conv_classifier.bias,
+                                                 int(Tf), True, True)
+        F_.DEFER_NEXT_HEAD_FORWARD = False
         lstm = self.fs_encoder_lstm
         lstm_w = list(lstm.parameters())
         ndir = 2 if lstm.bidirectional else 1
@@ -266,9 +273,6 @@ class MuCon(nn.Module):
         (tlogp, lens), c_dec = F_.run_forward(F_._DecoderFn, memory, h_n.reshape(-1), c_n.reshape(-1), batch.transcript_tf_input,
                                                mask, (int(steps), bool(self.teacher_forcing), False, int(self.EOS_token_id)),
                                                *dec_params)
-        wc = self.conv_classifier.weight
-        (logits, logp), c_head = F_.run_forward(F_._HeadFn, enc, wc.reshape(wc.shape[0], wc.shape[1]), self.conv_classifier.bias,
-                                                 int(Tf), True, True)
         seg = logits[0]
         sx = logp[0] if lc.smoothing.log_softmax_before else seg
         fo = MuConForwardOut(transcript=tlogp, lengths=lens[:-1], segmentation=seg)

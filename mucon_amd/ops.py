@@ -440,6 +440,9 @@ def linear_forward(tape: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor)
     return _LinearFn.apply(tape, weight.reshape(weight.shape[0], weight.shape[1]), bias)
 
 
+DEFER_NEXT_HEAD_FORWARD = False   # set by MuCon.fused_train_step in front of its y-head forward (a forward has no ctx to carry the wish)
+
+
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, w, b, Tf, want_logits, want_logp):
@@ -452,6 +455,12 @@ class _HeadFn(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         logits = torch.empty((B, Tf, C), dtype=torch.float32, device=enc.device) if want_logits else None
         logp = torch.empty((B, Tf, C), dtype=torch.float32, device=enc.device) if want_logp else None
+        global DEFER_NEXT_HEAD_FORWARD
+        if DEFER_NEXT_HEAD_FORWARD:
+            # (r6) MuCon.fused_train_step: the LSTM's forward follows on this stream before anyone reads the classifier's outputs -- the kernel rides in that
+            # pass's recurrence launch (include/mucon_hip.h: mucon_head_fwd_defer).  One-shot; the outputs below are written by THAT call.
+            DEFER_NEXT_HEAD_FORWARD = False
+            _lib.check(lib.mucon_head_fwd_defer(1), "mucon_head_fwd_defer")
         _lib.check(lib.mucon_head_fwd(B, Tz, Tf, H, C, _lib.ptr(enc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(logits),
                                       _lib.ptr(logp), _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
                    "mucon_head_fwd")
