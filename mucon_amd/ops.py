@@ -482,7 +482,9 @@ class _HeadFn(torch.autograd.Function):
         dl = d_logits.contiguous() if (d_logits is not None and d_logits.numel() == B * Tf * C) else None
         dp = d_logp.contiguous() if (d_logp is not None and d_logp.numel() == B * Tf * C) else None
         d_enc = torch.empty_like(enc)
-        hit = _PARAM_GRADS.get(("head", id(w))) if getattr(ctx, "reuse_grads", False) else None
+        # (keyed by the weight's ADDRESS and shape: the callers hand in a fresh [C, H] view of conv_classifier.weight every step, whose id() says nothing)
+        hkey = ("head", w.data_ptr(), tuple(w.shape), w.device)
+        hit = _PARAM_GRADS.get(hkey) if getattr(ctx, "reuse_grads", False) else None
         if hit is not None and hit[0][0].shape == w.shape and hit[0][0].device == w.device:
             d_w, d_b = hit[0]                     # (the fused step paths: the previous step's pair, see _param_grads)
         else:
@@ -491,7 +493,7 @@ class _HeadFn(torch.autograd.Function):
             if getattr(ctx, "reuse_grads", False):
                 if len(_PARAM_GRADS) >= 8:
                     _PARAM_GRADS.clear()
-                _PARAM_GRADS[("head", id(w))] = ([d_w, d_b], None, [w])
+                _PARAM_GRADS[hkey] = ([d_w, d_b], None, [w])
         if getattr(ctx, "defer_reduce", False):
             # (r6) the fused step paths (bench.py, MuCon.fused_train_step), where the encoder's backward follows on this stream before anyone reads
             # d_w / d_b: their slab sums ride in that pass's first launch (include/mucon_hip.h: mucon_head_bwd_defer).  ctx keeps the workspace alive.
