@@ -1,4 +1,4 @@
-// The four MuCon losses and their gradients in four launches.
+// The four MuCon losses and their gradients in three launches (four until r6: loss_mid_kernel is now a function of loss_grad_kernel).
 //   reference src/mucon/masks.py:8-74          project_lengths_softmax, create_masks (affine_grid + grid_sample)
 //   reference src/mucon/models.py:376-396      loss(): main = sum of multiplier * component
 //   reference src/mucon/models.py:398-412      smoothing loss (mse of consecutive rows, right side detached, clamp)
@@ -22,8 +22,8 @@
 //   loss_acc_kernel    T/32 wgs    : every workgroup derives the segment geometry itself (64 lanes of arithmetic; workgroup 0 also writes it out,
 //                                    with the transcript + length losses and their gradients: until r4 a launch of its own, loss_prep_kernel),
 //                                    then: masks of its 32 frames, partial windows / arithmetic sums / smoothing sums -> slabs
-//   loss_mid_kernel    1 workgroup : ordered slab reduction, per-segment log-softmax, the five loss values, d windows
-//   loss_grad_kernel   T/32 wgs    : d segmentation, d smoothing input, d mask -> partial d scale / d shift slabs
+//   loss_grad_kernel   T/32 wgs    : (loss_mid_body, every workgroup for itself: ordered slab reduction, per-segment log-softmax, the five loss values, d windows), then
+//                                    d segmentation, d smoothing input, d mask -> partial d scale / d shift slabs
 //   loss_fin_kernel    1 workgroup : ordered slab reduction, chain through the geometry and the softmax -> d lengths
 // Every reduction has a fixed order: results are bitwise reproducible.
 #pragma once
@@ -272,22 +272,46 @@ __global__ __launch_bounds__(256) void loss_acc_kernel(LossDims d, LossBufs b) {
     if (tid == 0) slab[N * M + 1] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// 1 workgroup, 256 threads
-__global__ __launch_bounds__(256) void loss_mid_kernel(LossDims d, LossBufs b, int chunks) {
-    __shared__ float s_win[LOSS_MAXN][LOSS_MAXM + 1];
-    __shared__ float s_seg_loss[LOSS_MAXN];
-    __shared__ float s_scal[2];
+// The step between the two passes over the frames -- the chunk partials summed in order, the per-segment windows' log-softmax and its gradient, the loss scalars -- as a
+// function every workgroup of loss_grad_kernel runs for itself (r6: it was a one-workgroup launch of its own, loss_mid_kernel, 10.8 us on the one-video step's critical path;
+// the sums are over T / 32 chunks of N x M + 2 floats: recomputing them per workgroup costs less than the launch).  Same arithmetic in the same order in every workgroup;
+// workgroup 0 (`write`) also leaves the results the later launch and the caller read (gwin, glwin, gsm, losses).  -> s_gwin (LDS) and the smoothing gradient's scale.
+__device__ __forceinline__ float loss_mid_body(const LossDims &d, const LossBufs &b, const int chunks, float (*s_win)[LOSS_MAXM + 1], float (*s_gwin)[LOSS_MAXM + 1],
+                                               float *s_seg_loss, float *s_scal, const bool write) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = d.N, M = d.M, stride = N * M + 2;
-    if (d.mucon_type == 0) {
-        for (int e = tid; e < N * M; e += 256) {
-            const float acc = loss_ordered_sum(b.slab + e, stride, chunks);
-            const int n = e / M, m = e - n * M;
-            s_win[n][m] = acc / b.geo[0 * LOSS_MAXN + n];
+    // a thread's elements (tid, tid + 256, ... of the N x M windows; the two scalars ride as elements N M, N M + 1) are summed TOGETHER, two at a time: their loads
+    // are independent, the chain of round trips is one element's (each element still adds its chunks in order)
+    const int nel = (d.mucon_type == 0 ? N * M : 0), first_scal = N * M;
+    for (int e0 = tid; e0 < N * M + 2; e0 += 512) {
+        const int e1 = e0 + 256;
+        const bool a0 = e0 < nel || e0 >= first_scal, a1 = e1 < N * M + 2 && (e1 < nel || e1 >= first_scal);
+        float acc0 = 0.f, acc1 = 0.f;
+        const float *p0 = b.slab + (a0 ? e0 : first_scal), *p1 = b.slab + (a1 ? e1 : first_scal);
+        constexpr int Q = 16;
+        for (int c0 = 0; c0 < chunks; c0 += Q) {
+            float v0[Q], v1[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const long o = (long)min(c0 + q, chunks - 1) * stride;
+                v0[q] = p0[o];
+                v1[q] = p1[o];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (c0 + q < chunks) {
+                    acc0 += v0[q];
+                    acc1 += v1[q];
+                }
         }
-    }
-    if (tid < 2) {  // arithmetic partials, smoothing partials
-        s_scal[tid] = loss_ordered_sum(b.slab + N * M + tid, stride, chunks);
+        if (a0) {
+            if (e0 >= first_scal) s_scal[e0 - first_scal] = acc0;
+            else s_win[e0 / M][e0 % M] = acc0 / b.geo[0 * LOSS_MAXN + e0 / M];
+        }
+        if (a1) {
+            if (e1 >= first_scal) s_scal[e1 - first_scal] = acc1;
+            else s_win[e1 / M][e1 % M] = acc1 / b.geo[0 * LOSS_MAXN + e1 / M];
+        }
     }
     __syncthreads();
     const float wsum = b.small[2];
@@ -308,17 +332,33 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(LossDims d, LossBufs b, i
             float gw = 0.f;
             if (lane < M) gw = (ex / se - (lane == tg ? 1.f : 0.f)) * (wt / wsum) * d.mul_mucon;
             const float gl = loss_wave_sum(lane < M ? gw * x : 0.f);
-            if (lane < M) b.gwin[n * M + lane] = gw / L;
+            if (lane < M) {
+                s_gwin[n][lane] = gw / L;
+                if (write) b.gwin[n * M + lane] = gw / L;
+            }
             if (lane == 0) {
                 s_seg_loss[n] = -wt * (s_win[n][tg] - lse);
-                b.glwin[n] = -gl / L;
+                if (write) b.glwin[n] = -gl / L;
             }
         }
-    } else {
+    } else if (write) {
         for (int e = tid; e < N; e += 256) b.glwin[e] = 0.f;
     }
     __syncthreads();
-    if (tid == 0) {
+    // (every thread: a handful of scalar operations on LDS values -- the smoothing gradient's scale is what the frames' pass needs)
+    const float cnt = (float)(d.T - 1) * (float)M;
+    float sm = s_scal[1] / cnt;
+    float gs = 2.f / cnt;
+    if (d.smoothing_clamp) {
+        if (sm < d.clamp_min) {
+            sm = d.clamp_min;
+            gs = 0.f;
+        } else if (sm > d.clamp_max) {
+            sm = d.clamp_max;
+            gs = 0.f;
+        }
+    }
+    if (write && tid == 0) {
         float mu;
         if (d.mucon_type == 0) {
             float acc = 0.f;
@@ -326,18 +366,6 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(LossDims d, LossBufs b, i
             mu = acc / wsum;
         } else {
             mu = s_scal[0] / (float)d.T;
-        }
-        const float cnt = (float)(d.T - 1) * (float)M;
-        float sm = s_scal[1] / cnt;
-        float gs = 2.f / cnt;
-        if (d.smoothing_clamp) {
-            if (sm < d.clamp_min) {
-                sm = d.clamp_min;
-                gs = 0.f;
-            } else if (sm > d.clamp_max) {
-                sm = d.clamp_max;
-                gs = 0.f;
-            }
         }
         b.gsm[0] = gs * d.mul_smoothing;
         const float tl = b.small[0], ll = b.small[1];
@@ -347,18 +375,23 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(LossDims d, LossBufs b, i
         b.losses[3] = mu;
         b.losses[4] = sm;
     }
+    return gs * d.mul_smoothing;
 }
 
 // grid (chunks), 256 threads
-__global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) {
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b, int chunks) {
     __shared__ float s_seg[LOSS_FB][LOSS_MAXM + 1];
     __shared__ float s_mask[LOSS_MAXN][LOSS_FB + 1];
     __shared__ float s_dmask[LOSS_MAXN][LOSS_FB + 1];   // d mask / d ix
     __shared__ float s_xb[LOSS_FB];
     __shared__ float s_lse[LOSS_FB];
     __shared__ float s_gwin[LOSS_MAXN][LOSS_MAXM + 1];
+    __shared__ float s_win[LOSS_MAXN][LOSS_MAXM + 1];
+    __shared__ float s_seg_loss[LOSS_MAXN];
+    __shared__ float s_scal[2];
     const int tid = threadIdx.x, t0 = blockIdx.x * LOSS_FB;
     const int T = d.T, M = d.M, N = d.N;
+    const float gs = loss_mid_body(d, b, chunks, s_win, s_gwin, s_seg_loss, s_scal, blockIdx.x == 0);   // (ends behind a barrier: s_gwin is complete)
     const int nf = min(LOSS_FB, T - t0);
     for (int e = tid; e < LOSS_FB * M; e += 256) {
         const int f = e / M, m = e - f * M;
@@ -372,8 +405,6 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
         s_dmask[n][f] = dv;
         if (n == 0) s_xb[f] = xb;
     }
-    if (d.mucon_type == 0)
-        for (int e = tid; e < N * M; e += 256) s_gwin[e / M][e % M] = b.gwin[e];
     __syncthreads();
     if (d.mucon_type == 1) {
         if (tid < LOSS_FB) {
@@ -386,7 +417,6 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossDims d, LossBufs b) 
         __syncthreads();
     }
     // d segmentation (+ the smoothing gradient on its own tensor)
-    const float gs = b.gsm[0];
     const float invT = d.mul_mucon / (float)T;
     for (int e = tid; e < nf * M; e += 256) {
         const int f = e / M, m = e - f * M;

@@ -489,8 +489,7 @@ extern "C" int mucon_loss_fwd_bwd(const mucon_loss_cfg *cfg, const float *segmen
     }
     const int chunks = (cfg->T + LOSS_FB - 1) / LOSS_FB;
     hipLaunchKernelGGL(loss_acc_kernel, dim3(chunks), dim3(256), 0, s, d, b);
-    hipLaunchKernelGGL(loss_mid_kernel, dim3(1), dim3(256), 0, s, d, b, chunks);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks), dim3(256), 0, s, d, b);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks), dim3(256), 0, s, d, b, chunks);   // (r6: every workgroup does the step between the two passes for itself, loss_mid_body)
     hipLaunchKernelGGL(loss_fin_kernel, dim3(1), dim3(64), 0, s, d, b, chunks);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;

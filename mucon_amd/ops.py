@@ -832,7 +832,7 @@ def losses_forward(segmentation: torch.Tensor, smoothing_input: torch.Tensor, tr
                    lengths: torch.Tensor, spec: LossSpec, mucon_target: torch.Tensor, transcript_target: torch.Tensor,
                    mask_template: torch.Tensor, mucon_class_weight: Optional[torch.Tensor] = None,
                    transcript_class_weight: Optional[torch.Tensor] = None):
-    """MuCon.loss for one video in four launches (reference models.py:376-565 + masks.py:8-74).
+    """MuCon.loss for one video in three launches (reference models.py:376-565 + masks.py:8-74).
 
     segmentation [T, M] logits; smoothing_input [T, M] (log-probs or the logits, per smoothing.log_softmax_before);
     transcript_logp [S, M+1]; lengths [N]; targets int64.  Returns (main, parts) with parts = [transcript, length, mucon,
