@@ -438,14 +438,19 @@ def eval_bench(dev, n_videos=32, rank=0, world=1, sync=None, allmax=None, T=2000
         sync = torch.cuda.synchronize
     ev.evaluate(rank, world)
     sync()
-    t0 = time.perf_counter()
-    res = ev.evaluate(rank, world)
-    sync()
-    dt = time.perf_counter() - t0
-    if allmax is not None:
-        dt = allmax(dt)                  # the slowest rank's time for the whole sharded pass
-    dt /= len(db)
-    out = {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3)}
+    # (r6) three timed passes, the median reported: a pass over these 32 videos is ~10 ms, and the second pass after process start still pays for the caching
+    # allocator's pools of the side streams growing (0.37 ms per video against 0.27 - 0.30 from the third pass on: a real test set is hundreds of videos)
+    passes = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = ev.evaluate(rank, world)
+        sync()
+        dt = time.perf_counter() - t0
+        if allmax is not None:
+            dt = allmax(dt)                  # the slowest rank's time for the whole sharded pass
+        passes.append(dt / len(db))
+    dt = sorted(passes)[1]
+    out = {"videos_per_s": round(1.0 / dt, 1), "ms_per_video": round(dt * 1e3, 3), "ms_per_video_passes": [round(x * 1e3, 3) for x in passes]}
     if world > 1 or allmax is not None:
         out.update({"n_gpus": world, "videos": len(db), "videos_per_rank": n_videos, "skipped_videos": int(res.get("skipped_videos", 0)),
                     "sharding": "video i on rank i mod world (MuConEvaluator.evaluate(rank, world)); metric accumulators all-reduced as one vector, per-video records "

@@ -206,15 +206,26 @@ class MuConEvaluator:
             start = cur.record_event()
             for st in streams:
                 st.wait_event(start)
-        for k, (i, batch) in enumerate(idxs):
-            if streams:
-                with torch.cuda.stream(streams[k % len(streams)]):
+        # (r6) the chunk's first forward validates the parameters (addresses, types, sizes); nothing between the forwards of a chunk can replace them
+        ef = None
+        if getattr(model, "fast_eval_forward", False):
+            from .eval_forward import for_model
+            ef = for_model(model)
+        try:
+            for k, (i, batch) in enumerate(idxs):
+                if ef is not None:
+                    ef.trusted = k > 0
+                if streams:
+                    with torch.cuda.stream(streams[k % len(streams)]):
+                        batch = batch.to(dev)
+                        out = model.forward_deferred(batch)
+                else:
                     batch = batch.to(dev)
                     out = model.forward_deferred(batch)
-            else:
-                batch = batch.to(dev)
-                out = model.forward_deferred(batch)
-            vids.append({"i": i, "batch": batch, "out": out})
+                vids.append({"i": i, "batch": batch, "out": out})
+        finally:
+            if ef is not None:
+                ef.trusted = False
         for st in streams:
             cur.wait_stream(st)
         # -- sync 1: how many words every video decoded, and which
