@@ -358,31 +358,40 @@ __global__ __launch_bounds__(512) void lstm_recur_bwd_kernel(LstmWeights w, cons
 
 // dW_ih[d][r][c] = sum_t dG[d][t][r] x[t][c];  dW_hh[d][r][c] = sum_t dG[d][t][r] hprev[d][t][c];  db = sum_t dG[d][t][r]
 // grid (512/4, ndir), 512 threads = 4 gate rows x 128 columns.
-__device__ __forceinline__ void lstm_wgrad_body(const int bx, const int d, const float *dG, const float *x, const float *out, const LstmGrads &g, int T, int ndir) {
-    const int r = bx * 4 + (threadIdx.x >> 7), c = threadIdx.x & 127;
-    const float *dg = dG + (long)d * T * LSTM_G + r;
+// (r6) x and the previous hidden states of LSTM_WG_T time steps are staged in LDS once per workgroup (coalesced 16-byte loads: ONE memory round trip per 64 steps; the
+// workgroup's four gradient rows beside them) and the sums run from LDS in time order -- the per-thread loop over 32 steps' worth of scattered loads was four dependent round
+// trips at T = 125 (14.4 us).  Same terms in the same order.
+constexpr int LSTM_WG_T = 64;    // (65 KB of LDS: two workgroups of the merged launch per CU -- the launch-wide dynamic allocation is also what the input-gradient workgroups reserve)
+constexpr size_t LSTM_WG_LDS_BYTES = sizeof(float) * (2 * LSTM_WG_T * LSTM_H + 4 * LSTM_WG_T);
+__device__ __forceinline__ void lstm_wgrad_body(const int bx, const int d, const float *dG, const float *x, const float *out, const LstmGrads &g, int T, int ndir, float *sm) {
+    float *xs = sm, *hs = sm + LSTM_WG_T * LSTM_H, *gs = hs + LSTM_WG_T * LSTM_H;   // [step][128], [step][128], [step][4 rows]
+    const int tid = threadIdx.x;
+    const int rq = tid >> 7, r = bx * 4 + rq, c = tid & 127;
     float ai = 0.f, ah = 0.f, ab = 0.f;
-    // 32 time steps' loads in flight at a time, summed in time order (a step-at-a-time loop is a chain of T memory round trips;
-    // eight at a time still 16 of them: 15.7 us at T = 125)
-    constexpr int WG_B = 32;
-    for (int s0 = 0; s0 < T; s0 += WG_B) {
-        float gv[WG_B], xv[WG_B], hv[WG_B];
-#pragma unroll
-        for (int j = 0; j < WG_B; ++j) {
-            const int s = min(s0 + j, T - 1);
-            const int t = d == 0 ? s : T - 1 - s;
+    for (int s0 = 0; s0 < T; s0 += LSTM_WG_T) {
+        const int ns = min(LSTM_WG_T, T - s0);
+        if (s0) __syncthreads();     // (the previous chunk's readers are done)
+        // step s of the sums is time t = s (forward direction) or T - 1 - s (backward); its "previous" state is out[t - 1] / out[t + 1]
+        for (int e = tid; e < ns * (LSTM_H / 4); e += 512) {
+            const int j = e >> 5, c4 = (e & 31) * 4;
+            const int sidx = s0 + j;
+            const int t = d == 0 ? sidx : T - 1 - sidx;
             const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, T - 1);
-            gv[j] = dg[(long)t * LSTM_G];
-            xv[j] = x[(long)t * LSTM_H + c];
-            hv[j] = out[(long)tp * (ndir * LSTM_H) + d * LSTM_H + c];
+            *reinterpret_cast<f32x4 *>(xs + j * LSTM_H + c4) = *reinterpret_cast<const f32x4 *>(x + (long)t * LSTM_H + c4);
+            *reinterpret_cast<f32x4 *>(hs + j * LSTM_H + c4) = *reinterpret_cast<const f32x4 *>(out + (long)tp * (ndir * LSTM_H) + d * LSTM_H + c4);
         }
-#pragma unroll
-        for (int j = 0; j < WG_B; ++j) {
-            if (s0 + j < T) {
-                ai += gv[j] * xv[j];
-                if (s0 + j > 0) ah += gv[j] * hv[j];
-                ab += gv[j];
-            }
+        for (int e = tid; e < ns * 4; e += 512) {
+            const int j = e >> 2, q = e & 3;
+            const int sidx = s0 + j;
+            const int t = d == 0 ? sidx : T - 1 - sidx;
+            gs[j * 4 + q] = dG[((long)d * T + t) * LSTM_G + bx * 4 + q];
+        }
+        __syncthreads();
+        for (int j = 0; j < ns; ++j) {
+            const float gv = gs[j * 4 + rq];
+            ai += gv * xs[j * LSTM_H + c];
+            if (s0 + j > 0) ah += gv * hs[j * LSTM_H + c];
+            ab += gv;
         }
     }
     g.w_ih[d][(long)r * LSTM_H + c] = ai;
@@ -424,8 +433,9 @@ __device__ __forceinline__ void lstm_dx_body(const int t, const float *dG, const
 // launches become the longer one's.  Same arithmetic per workgroup as the two kernels it replaces (bitwise).
 __global__ __launch_bounds__(512) void lstm_wgrad_dx_kernel(const float *dG, const float *x, const float *out, const LstmGrads g, const LstmWeights w, float *dx,
                                                             const float *dx_add, const int T, const int ndir) {
+    extern __shared__ __attribute__((aligned(16))) float wg_sm[];   // (the weight-gradient workgroups' staging tiles: LSTM_WG_LDS_BYTES)
     const int b = blockIdx.x;
     if (b < T) return lstm_dx_body(b, dG, w, dx, dx_add, T, ndir);
     const int q = b - T;
-    lstm_wgrad_body(q % (LSTM_G / 4), q / (LSTM_G / 4), dG, x, out, g, T, ndir);
+    lstm_wgrad_body(q % (LSTM_G / 4), q / (LSTM_G / 4), dG, x, out, g, T, ndir, wg_sm);
 }

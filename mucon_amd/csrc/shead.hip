@@ -159,7 +159,12 @@ extern "C" int mucon_lstm_bwd(int32_t T, int32_t I, int32_t H, int32_t ndir, con
         if ((rc = mucon_decoder_bwd_flush()) != MUCON_OK) return rc;   // left on another stream: finished there
     }
     hipLaunchKernelGGL(lstm_recur_bwd_kernel, dim3(ndir + extra), dim3(512), 0, s, w, out, gates, cells, d_out, d_hn, d_cn, dG, T, ndir, ob);
-    hipLaunchKernelGGL(lstm_wgrad_dx_kernel, dim3(T + (LSTM_G / 4) * ndir), dim3(512), 0, s, dG, x, out, g, w, d_x, d_x_add, T, ndir);
+    static bool wg_attr = false;
+    if (!wg_attr) {
+        SHIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_wgrad_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WG_LDS_BYTES));
+        wg_attr = true;
+    }
+    hipLaunchKernelGGL(lstm_wgrad_dx_kernel, dim3(T + (LSTM_G / 4) * ndir), dim3(512), LSTM_WG_LDS_BYTES, s, dG, x, out, g, w, d_x, d_x_add, T, ndir);
     SHIPCHK(hipGetLastError());
     return MUCON_OK;
 }
