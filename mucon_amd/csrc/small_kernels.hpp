@@ -252,19 +252,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const float *z_, flo
     const int nel = a.Tz * lpg;
     const float *zb = a.z + (long)b * a.Tz * 128 + g * cpg;
     float mean = 0.f, rstd = 1.f;
+    // (r6) a thread's first GN_KEEP elements stay in registers across the three passes (at Tz <= 1024 with one float4 column per group: all of them) -- each
+    // pass re-loading them was a memory round trip of its own in front of a block-wide sum; the same values in the same order
+    constexpr int GN_KEEP = 4;
+    f32x4 keep[GN_KEEP];
+#pragma unroll
+    for (int k = 0; k < GN_KEEP; ++k) {
+        const int e = min((int)threadIdx.x + k * GN_THREADS, nel - 1);
+        const int t = e / lpg, c = e - t * lpg;
+        keep[k] = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+    }
+    auto elem = [&](int e) {     // (elements beyond the kept ones: from memory, pass by pass)
+        const int t = e / lpg, c = e - t * lpg;
+        return *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+    };
     if (a.use_gn) {
         const float n = (float)a.Tz * (float)cpg;
         float s = 0.f;
-        for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
-            const int t = e / lpg, c = e - t * lpg;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+#pragma unroll
+        for (int k = 0; k < GN_KEEP; ++k)
+            if ((int)threadIdx.x + k * GN_THREADS < nel) s += (keep[k][0] + keep[k][1]) + (keep[k][2] + keep[k][3]);
+        for (int e = threadIdx.x + GN_KEEP * GN_THREADS; e < nel; e += GN_THREADS) {
+            const f32x4 v = elem(e);
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
         mean = gn_block_sum(s, red) / n;
         float q = 0.f;
-        for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
-            const int t = e / lpg, c = e - t * lpg;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+#pragma unroll
+        for (int k = 0; k < GN_KEEP; ++k)
+            if ((int)threadIdx.x + k * GN_THREADS < nel) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = keep[k][j] - mean;
+                    q += d * d;
+                }
+            }
+        for (int e = threadIdx.x + GN_KEEP * GN_THREADS; e < nel; e += GN_THREADS) {
+            const f32x4 v = elem(e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = v[k] - mean;
@@ -281,9 +305,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(const float *z_, flo
         }
     }
     float *eb = a.enc + (long)b * a.Tz * 128 + g * cpg;
-    for (int e = threadIdx.x; e < nel; e += GN_THREADS) {
+    int kk = 0;
+    for (int e = threadIdx.x; e < nel; e += GN_THREADS, ++kk) {
         const int t = e / lpg, c = e - t * lpg;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
+        f32x4 v = kk == 0 ? keep[0] : kk == 1 ? keep[1] : kk == 2 ? keep[2] : kk == 3 ? keep[3] : *reinterpret_cast<const f32x4 *>(zb + (long)t * 128 + c * 4);
         f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
         if (a.use_gn) {
             ga = *reinterpret_cast<const f32x4 *>(a.gamma + g * cpg + c * 4);
@@ -427,9 +452,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const float *z_, con
     const int col = threadIdx.x % lpg, slot = threadIdx.x / lpg, nslots = GN_THREADS / lpg;
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
-    for (int t = slot; t < a.Tz; t += nslots) {
+    // (r6) the first GB_KEEP rows of a thread keep their (x_hat, gradient at the GroupNorm output) in registers for the second pass (at Tz <= 512 with one
+    // float4 column per group: all of them): re-deriving them was two loads and a dropout hash per element behind the block-wide sums
+    constexpr int GB_KEEP = 2;
+    f32x4 kxh[GB_KEEP], kdg[GB_KEEP], kga[GB_KEEP];
+    int it = 0;
+    for (int t = slot; t < a.Tz; t += nslots, ++it) {
         f32x4 xh, dg, ga;
         dgn_at(t, col, xh, dg, ga);
+        if (it == 0) {
+            kxh[0] = xh;
+            kdg[0] = dg;
+            kga[0] = ga;
+        } else if (it == 1) {
+            kxh[1] = xh;
+            kdg[1] = dg;
+            kga[1] = ga;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             sg[k] += dg[k] * xh[k];
@@ -465,9 +504,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(const float *z_, con
         a.part[((long)b * 2 + which) * 128 + g * cpg + c] =
             (cred[which][0][c] + cred[which][1][c]) + (cred[which][2][c] + cred[which][3][c]);
     }
-    for (int t = slot; t < a.Tz; t += nslots) {
+    it = 0;
+    for (int t = slot; t < a.Tz; t += nslots, ++it) {
         f32x4 xh, dg, ga, o;
-        dgn_at(t, col, xh, dg, ga);
+        if (it == 0) {
+            xh = kxh[0];
+            dg = kdg[0];
+            ga = kga[0];
+        } else if (it == 1) {
+            xh = kxh[1];
+            dg = kdg[1];
+            ga = kga[1];
+        } else {
+            dgn_at(t, col, xh, dg, ga);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = rstd * (dg[k] * ga[k] - m1 - xh[k] * m2);
         *reinterpret_cast<f32x4 *>(ob + (long)t * 128 + col * 4) = o;
